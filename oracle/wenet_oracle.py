@@ -1,0 +1,711 @@
+"""CPU oracle for the WeNet Conformer-ASR inference hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a *restatement* of the reference
+algorithm (wenet-e2e/wenet, Python path) written as plain functions over a
+``state_dict`` (name -> fp32 tensor) and the parsed ``train.yaml`` dict.  It is
+imported only by ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` -- never by ``wenet_amd/`` (the product
+path), which fails loudly when its HIP library is missing.
+
+Pinning (see tests/test_oracle_vs_reference.py and tests/golden/):
+  * model + search: checked against the reference's own ``ASRModel.decode`` /
+    ``search.py`` imported unmodified from /root/reference (oracle/_ref_harness),
+    at the tiny fixture sizes committed under tests/golden/ and, when the
+    reference tree is present, at the full BASELINE configs;
+  * prefix beam search: additionally against the known-answer table of
+    runtime/core/test/ctc_prefix_beam_search_test.cc:29-72;
+  * fbank: against the reference's C++ frontend (runtime/core/frontend/fbank.h)
+    compiled from where it lies into oracle/_ref/ (oracle/Makefile), golden rows
+    committed in tests/golden/fbank_*.npz.  torchaudio.compliance.kaldi (the
+    Python path's third-party fbank, unpinned `torchaudio>=2.1.2`) is absent, so
+    the Python-side fbank parity is anchored on that C++ restatement.
+
+All arithmetic is fp32 like the reference default (wenet/bin/recognize.py:250);
+the prefix-beam bookkeeping uses Python floats (fp64) exactly like search.py.
+Citations are path:line under /root/reference/.
+"""
+import math
+from collections import defaultdict
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------
+# result record -- wenet/models/transformer/search.py:30-61
+
+
+class DecodeResult:
+
+    def __init__(self,
+                 tokens,
+                 score=0.0,
+                 confidence=0.0,
+                 tokens_confidence=None,
+                 times=None,
+                 nbest=None,
+                 nbest_scores=None,
+                 nbest_times=None,
+                 text=''):
+        self.tokens = tokens
+        self.score = score
+        self.confidence = confidence
+        self.tokens_confidence = tokens_confidence
+        self.times = times
+        self.nbest = nbest
+        self.nbest_scores = nbest_scores
+        self.nbest_times = nbest_times
+        self.text = text
+
+
+# --------------------------------------------------------------------------
+# features
+
+
+def _mel_scale(freq):  # runtime/core/frontend/fbank.h:196-213 (HTK)
+    return np.float32(1127.0) * np.log(
+        np.float32(1.0) + np.float32(freq) / np.float32(700.0),
+        dtype=np.float32)
+
+
+def mel_banks(num_bins=80, sample_rate=16000, fft_points=512, low_freq=20.0):
+    """HTK triangular filters, runtime/core/frontend/fbank.h:91-148.
+
+    Returns a dense (num_bins, fft_points//2) fp32 matrix (the reference stores
+    each row sparsely as (first_index, weights)).
+    """
+    num_fft_bins = fft_points // 2
+    fft_bin_width = np.float32(sample_rate) / np.float32(fft_points)
+    mel_low = _mel_scale(low_freq)
+    mel_high = _mel_scale(sample_rate / 2)
+    delta = (mel_high - mel_low) / np.float32(num_bins + 1)
+    out = np.zeros((num_bins, num_fft_bins), dtype=np.float32)
+    for b in range(num_bins):
+        left = np.float32(mel_low + np.float32(b) * delta)
+        center = np.float32(mel_low + np.float32(b + 1) * delta)
+        right = np.float32(mel_low + np.float32(b + 2) * delta)
+        for i in range(num_fft_bins):
+            mel = _mel_scale(fft_bin_width * np.float32(i))
+            if mel > left and mel < right:
+                if mel <= center:
+                    w = (mel - left) / (center - left)
+                else:
+                    w = (right - mel) / (right - center)
+                out[b, i] = np.float32(w)
+    return out
+
+
+def povey_window(frame_length=400):
+    """runtime/core/frontend/fbank.h:150-156."""
+    a = 2.0 * math.pi / (frame_length - 1)
+    i = np.arange(frame_length, dtype=np.float64)
+    return np.power(0.5 - 0.5 * np.cos(a * i), 0.85).astype(np.float32)
+
+
+def fbank(waveform: np.ndarray,
+          num_mel_bins: int = 80,
+          frame_length: int = 400,
+          frame_shift: int = 160,
+          sample_rate: int = 16000) -> np.ndarray:
+    """Kaldi-compatible log-mel fbank of ONE utterance.
+
+    `waveform` is float in [-1, 1] as `torchaudio.load` returns; it is scaled by
+    1<<15 exactly like wenet/dataset/processor.py:245 before the Kaldi recipe
+    (dither 0, energy_floor 0, povey window, snip_edges, remove DC, pre-emphasis
+    0.97, 512-point FFT, HTK mel 20 Hz..Nyquist, log floor FLT_EPSILON), restated
+    from runtime/core/frontend/fbank.h:250-327.  -> (T, num_mel_bins) fp32.
+    """
+    wave = waveform.astype(np.float32) * np.float32(1 << 15)
+    n = wave.shape[0]
+    if n < frame_length:
+        return np.zeros((0, num_mel_bins), dtype=np.float32)
+    num_frames = 1 + (n - frame_length) // frame_shift
+    fft_points = 1 << int(math.ceil(math.log2(frame_length)))
+    idx = (np.arange(num_frames)[:, None] * frame_shift +
+           np.arange(frame_length)[None, :])
+    data = wave[idx]  # (T, 400)
+    # remove DC offset (fbank.h:272-277); float accumulation
+    mean = data.sum(axis=1, dtype=np.float32) / np.float32(frame_length)
+    data = data - mean[:, None]
+    # pre-emphasis (fbank.h:221-226)
+    pre = np.empty_like(data)
+    pre[:, 1:] = data[:, 1:] - np.float32(0.97) * data[:, :-1]
+    pre[:, 0] = data[:, 0] - np.float32(0.97) * data[:, 0]
+    pre = pre * povey_window(frame_length)[None, :]
+    padded = np.zeros((num_frames, fft_points), dtype=np.float32)
+    padded[:, :frame_length] = pre
+    spec = np.fft.rfft(padded.astype(np.float64), axis=1)
+    power = (spec.real**2 + spec.imag**2)[:, :fft_points // 2].astype(
+        np.float32)  # fbank.h:292-294 keeps bins [0, N/2)
+    banks = mel_banks(num_mel_bins, sample_rate, fft_points)
+    mel = power @ banks.T
+    mel = np.maximum(mel, np.finfo(np.float32).eps)  # fbank.h:306
+    return np.log(mel).astype(np.float32)
+
+
+def padding(feats: List[np.ndarray]) -> Tuple[torch.Tensor, torch.Tensor, List[int]]:
+    """wenet/dataset/processor.py:526-577 (feature part): sort by length
+    descending, zero-pad to (B, Tmax, F); returns (padded, lengths, order)."""
+    lens = torch.tensor([f.shape[0] for f in feats], dtype=torch.int32)
+    order = torch.argsort(lens, descending=True)
+    sorted_feats = [torch.as_tensor(feats[i]) for i in order]
+    padded = torch.nn.utils.rnn.pad_sequence(sorted_feats,
+                                             batch_first=True,
+                                             padding_value=0)
+    return padded, lens[order], order.tolist()
+
+
+# --------------------------------------------------------------------------
+# masks -- wenet/utils/mask.py
+
+
+def make_pad_mask(lengths: torch.Tensor, max_len: int = 0) -> torch.Tensor:
+    """wenet/utils/mask.py:201-227: True at padded positions."""
+    max_len = max_len if max_len > 0 else int(lengths.max().item())
+    seq = torch.arange(0, max_len, dtype=torch.int64)
+    return seq.unsqueeze(0) >= lengths.to(torch.int64).unsqueeze(-1)
+
+
+def subsequent_chunk_mask(size: int, chunk_size: int,
+                          num_left_chunks: int = -1) -> torch.Tensor:
+    """wenet/utils/mask.py:88-123."""
+    i = torch.arange(size)
+    ending = torch.clamp((i // chunk_size + 1) * chunk_size, max=size)
+    if num_left_chunks < 0:
+        start = torch.zeros_like(i)
+    else:
+        start = torch.clamp((i // chunk_size - num_left_chunks) * chunk_size,
+                            min=0)
+    j = torch.arange(size).unsqueeze(0)
+    return (j >= start.unsqueeze(1)) & (j < ending.unsqueeze(1))
+
+
+def subsequent_mask(size: int) -> torch.Tensor:
+    """wenet/utils/mask.py:51-85: lower-triangular (size, size) bool."""
+    a = torch.arange(size)
+    return a.unsqueeze(0) <= a.unsqueeze(1)
+
+
+def add_optional_chunk_mask(xs, masks, use_dynamic_chunk, decoding_chunk_size,
+                            static_chunk_size, num_decoding_left_chunks):
+    """wenet/utils/mask.py:126-198, decode-time branches only
+    (decoding_chunk_size != 0 is asserted by ASRModel.decode,
+    asr_model.py:310, so the random training branch is unreachable)."""
+    if use_dynamic_chunk:
+        max_len = xs.size(1)
+        if decoding_chunk_size < 0:
+            chunk_size, num_left = max_len, -1
+        else:
+            assert decoding_chunk_size > 0
+            chunk_size, num_left = decoding_chunk_size, num_decoding_left_chunks
+        cm = subsequent_chunk_mask(xs.size(1), chunk_size, num_left)
+        return masks & cm.unsqueeze(0)
+    if static_chunk_size > 0:
+        cm = subsequent_chunk_mask(xs.size(1), static_chunk_size,
+                                   num_decoding_left_chunks)
+        return masks & cm.unsqueeze(0)
+    return masks
+
+
+# --------------------------------------------------------------------------
+# encoder building blocks
+
+
+def global_cmvn(x, mean, istd):
+    """wenet/models/transformer/cmvn.py:36-47."""
+    return (x - mean) * istd
+
+
+def positional_encoding_table(d_model: int, max_len: int = 5000):
+    """wenet/models/transformer/embedding.py:47-56 (the `pe` buffer)."""
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(
+        torch.arange(0, d_model, 2, dtype=torch.float32) *
+        -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.unsqueeze(0)
+
+
+def conv2d_subsampling4(x, x_mask, sd, pfx, d_model):
+    """wenet/models/transformer/subsampling.py:203-228 +
+    RelPositionalEncoding.forward embedding.py:134-147."""
+    x = x.unsqueeze(1)
+    x = F.relu(F.conv2d(x, sd[pfx + 'conv.0.weight'], sd[pfx + 'conv.0.bias'],
+                        stride=2))
+    x = F.relu(F.conv2d(x, sd[pfx + 'conv.2.weight'], sd[pfx + 'conv.2.bias'],
+                        stride=2))
+    b, c, t, f = x.size()
+    x = F.linear(x.transpose(1, 2).contiguous().view(b, t, c * f),
+                 sd[pfx + 'out.0.weight'], sd[pfx + 'out.0.bias'])
+    pe = sd.get(pfx + 'pos_enc.pe')
+    if pe is None:
+        pe = positional_encoding_table(d_model)
+    x = x * math.sqrt(d_model)
+    pos_emb = pe[:, 0:x.size(1)]
+    return x, pos_emb, x_mask[:, :, 2::2][:, :, 2::2]
+
+
+def layer_norm(x, sd, pfx, eps=1e-5):
+    return F.layer_norm(x, (x.size(-1), ), sd[pfx + 'weight'],
+                        sd[pfx + 'bias'], eps)
+
+
+def feed_forward(x, sd, pfx, activation):
+    """wenet/models/transformer/positionwise_feed_forward.py:50-58."""
+    return F.linear(activation(F.linear(x, sd[pfx + 'w_1.weight'],
+                                        sd[pfx + 'w_1.bias'])),
+                    sd[pfx + 'w_2.weight'], sd[pfx + 'w_2.bias'])
+
+
+def _forward_attention(value, scores, mask, sd, pfx, h, d_k):
+    """wenet/models/transformer/attention.py:133-178."""
+    if mask.size(-1) > 0:
+        m = mask.unsqueeze(-3).eq(0)
+        m = m[..., :scores.size(-1)]
+        scores = scores.masked_fill(m, -float('inf'))
+        attn = torch.softmax(scores.float(), dim=-1).masked_fill(m, 0.0)
+    else:
+        attn = torch.softmax(scores.float(), dim=-1)
+    x = torch.matmul(attn, value)
+    x = x.transpose(-3, -2).contiguous()
+    x = x.view(x.size()[:-2] + (h * d_k, ))
+    return F.linear(x, sd[pfx + 'linear_out.weight'],
+                    sd[pfx + 'linear_out.bias'])
+
+
+def _qkv(query, key, value, sd, pfx, h):
+    """wenet/models/transformer/attention.py:109-131 (head-first views)."""
+    def proj(name, x):
+        y = F.linear(x, sd[pfx + name + '.weight'], sd.get(pfx + name + '.bias'))
+        y = y.view(y.size()[:-1] + (h, y.size(-1) // h))
+        return y.transpose(-3, -2)
+    return proj('linear_q', query), proj('linear_k', key), proj('linear_v', value)
+
+
+def rel_pos_mha(x, mask, pos_emb, sd, pfx, h):
+    """RelPositionMultiHeadedAttention.forward,
+    wenet/models/transformer/attention.py:364-438 (non-sdpa path, no cache;
+    rel_shift is disabled in the reference, :407-409)."""
+    d_k = x.size(-1) // h
+    q, k, v = _qkv(x, x, x, sd, pfx, h)
+    q = q.transpose(1, 2)  # (b, t, h, d_k)
+    p = F.linear(pos_emb, sd[pfx + 'linear_pos.weight'])
+    p = p.view(pos_emb.size(0), -1, h, d_k).transpose(1, 2)
+    q_u = (q + sd[pfx + 'pos_bias_u']).transpose(1, 2)
+    q_v = (q + sd[pfx + 'pos_bias_v']).transpose(1, 2)
+    matrix_bd = torch.matmul(q_v, p.transpose(-2, -1))
+    matrix_ac = torch.matmul(q_u, k.transpose(-2, -1))
+    scores = (matrix_ac + matrix_bd) / math.sqrt(d_k)
+    return _forward_attention(v, scores, mask, sd, pfx, h, d_k)
+
+
+def mha(query, key, value, mask, sd, pfx, h):
+    """MultiHeadedAttention.forward / MultiHeadedCrossAttention.forward without
+    caches, wenet/models/transformer/attention.py:247-304,456-520."""
+    d_k = query.size(-1) // h
+    q, k, v = _qkv(query, key, value, sd, pfx, h)
+    scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(d_k)
+    return _forward_attention(v, scores, mask, sd, pfx, h, d_k)
+
+
+def conv_module(x, mask_pad, sd, pfx, kernel_size, causal, activation):
+    """ConvolutionModule.forward, wenet/models/transformer/convolution.py:98-153
+    with cnn_module_norm='layer_norm' and no streaming cache."""
+    x = x.transpose(1, 2)
+    if mask_pad.size(2) > 0:
+        x = x.masked_fill(~mask_pad, 0.0)
+    lorder = kernel_size - 1 if causal else 0
+    if lorder > 0:
+        x = F.pad(x, (lorder, 0), 'constant', 0.0)
+    x = F.conv1d(x, sd[pfx + 'pointwise_conv1.weight'],
+                 sd[pfx + 'pointwise_conv1.bias'])
+    x = F.glu(x, dim=1)
+    c = x.size(1)
+    x = F.conv1d(x, sd[pfx + 'depthwise_conv.weight'],
+                 sd[pfx + 'depthwise_conv.bias'],
+                 padding=0 if causal else (kernel_size - 1) // 2, groups=c)
+    x = x.transpose(1, 2)
+    x = activation(F.layer_norm(x, (c, ), sd[pfx + 'norm.weight'],
+                                sd[pfx + 'norm.bias'], 1e-5))
+    x = x.transpose(1, 2)
+    x = F.conv1d(x, sd[pfx + 'pointwise_conv2.weight'],
+                 sd[pfx + 'pointwise_conv2.bias'])
+    if mask_pad.size(2) > 0:
+        x = x.masked_fill(~mask_pad, 0.0)
+    return x.transpose(1, 2)
+
+
+def conformer_layer(x, mask, pos_emb, mask_pad, sd, pfx, h, kernel_size,
+                    causal):
+    """ConformerEncoderLayer.forward, encoder_layer.py:188-265
+    (normalize_before=True, macaron style, ff_scale 0.5, swish = SiLU per
+    wenet/utils/class_utils.py:42)."""
+    act = F.silu
+    residual = x
+    x = residual + 0.5 * feed_forward(
+        layer_norm(x, sd, pfx + 'norm_ff_macaron.'), sd,
+        pfx + 'feed_forward_macaron.', act)
+    residual = x
+    x = residual + rel_pos_mha(layer_norm(x, sd, pfx + 'norm_mha.'), mask,
+                               pos_emb, sd, pfx + 'self_attn.', h)
+    residual = x
+    x = residual + conv_module(layer_norm(x, sd, pfx + 'norm_conv.'), mask_pad,
+                               sd, pfx + 'conv_module.', kernel_size, causal,
+                               act)
+    residual = x
+    x = residual + 0.5 * feed_forward(layer_norm(x, sd, pfx + 'norm_ff.'), sd,
+                                      pfx + 'feed_forward.', act)
+    return layer_norm(x, sd, pfx + 'norm_final.')
+
+
+def encoder_forward(configs: dict,
+                    sd: Dict[str, torch.Tensor],
+                    xs: torch.Tensor,
+                    xs_lens: torch.Tensor,
+                    decoding_chunk_size: int = -1,
+                    num_decoding_left_chunks: int = -1,
+                    return_layers: bool = False):
+    """BaseEncoder.forward for a ConformerEncoder,
+    wenet/models/transformer/encoder.py:122-181 -> (xs (B,T',d), masks (B,1,T'))."""
+    ec = configs['encoder_conf']
+    d = ec.get('output_size', 256)
+    h = ec.get('attention_heads', 4)
+    nblocks = ec.get('num_blocks', 6)
+    ksize = ec.get('cnn_module_kernel', 15)
+    causal = ec.get('causal', False)
+    T = xs.size(1)
+    masks = ~make_pad_mask(xs_lens, T).unsqueeze(1)
+    if 'encoder.global_cmvn.mean' in sd:
+        xs = global_cmvn(xs, sd['encoder.global_cmvn.mean'],
+                         sd['encoder.global_cmvn.istd'])
+    xs, pos_emb, masks = conv2d_subsampling4(xs, masks, sd, 'encoder.embed.', d)
+    mask_pad = masks
+    chunk_masks = add_optional_chunk_mask(
+        xs, masks, ec.get('use_dynamic_chunk', False), decoding_chunk_size,
+        ec.get('static_chunk_size', 0), num_decoding_left_chunks)
+    layers = [xs]
+    for i in range(nblocks):
+        xs = conformer_layer(xs, chunk_masks, pos_emb, mask_pad, sd,
+                             f'encoder.encoders.{i}.', h, ksize, causal)
+        layers.append(xs)
+    xs = layer_norm(xs, sd, 'encoder.after_norm.')
+    if return_layers:
+        return xs, masks, layers
+    return xs, masks
+
+
+# --------------------------------------------------------------------------
+# CTC head and searches
+
+
+def ctc_logprobs(sd, encoder_out, blank_penalty: float = 0.0,
+                 blank_id: int = 0):
+    """ASRModel.ctc_logprobs asr_model.py:254-265 / CTC.log_softmax ctc.py:73-81."""
+    logits = F.linear(encoder_out, sd['ctc.ctc_lo.weight'],
+                      sd['ctc.ctc_lo.bias'])
+    if blank_penalty > 0.0:
+        logits[:, :, blank_id] -= blank_penalty
+    return logits.log_softmax(dim=2)
+
+
+def remove_duplicates_and_blank(hyp: List[int], blank_id: int = 0) -> List[int]:
+    """wenet/utils/ctc_utils.py:23-33."""
+    new_hyp = []
+    cur = 0
+    while cur < len(hyp):
+        if hyp[cur] != blank_id:
+            new_hyp.append(hyp[cur])
+        prev = cur
+        while cur < len(hyp) and hyp[cur] == hyp[prev]:
+            cur += 1
+    return new_hyp
+
+
+def ctc_greedy_search(ctc_probs, ctc_lens, blank_id: int = 0):
+    """wenet/models/transformer/search.py:109-124."""
+    batch_size, maxlen = ctc_probs.shape[0], ctc_probs.size(1)
+    _, topk_index = ctc_probs.topk(1, dim=2)
+    topk_index = topk_index.view(batch_size, maxlen)
+    mask = make_pad_mask(ctc_lens, maxlen)
+    topk_index = topk_index.masked_fill(mask, blank_id)
+    return [
+        DecodeResult(remove_duplicates_and_blank(hyp.tolist(), blank_id))
+        for hyp in topk_index
+    ]
+
+
+def log_add(*args) -> float:
+    """wenet/utils/common.py:302-310."""
+    if all(a == -float('inf') for a in args):
+        return -float('inf')
+    a_max = max(args)
+    lsp = math.log(sum(math.exp(a - a_max) for a in args))
+    return a_max + lsp
+
+
+class PrefixScore:
+    """wenet/models/transformer/search.py:64-106 (context graph omitted: it is
+    None on this path)."""
+    __slots__ = ('s', 'ns', 'v_s', 'v_ns', 'cur_token_prob', 'times_s',
+                 'times_ns')
+
+    def __init__(self, s=float('-inf'), ns=float('-inf'), v_s=float('-inf'),
+                 v_ns=float('-inf')):
+        self.s, self.ns, self.v_s, self.v_ns = s, ns, v_s, v_ns
+        self.cur_token_prob = float('-inf')
+        self.times_s = []
+        self.times_ns = []
+
+    def score(self):
+        return log_add(self.s, self.ns)
+
+    def viterbi_score(self):
+        return self.v_s if self.v_s > self.v_ns else self.v_ns
+
+    def times(self):
+        return self.times_s if self.v_s > self.v_ns else self.times_ns
+
+
+def ctc_prefix_beam_search(ctc_probs, ctc_lens, beam_size: int,
+                           blank_id: int = 0) -> List[DecodeResult]:
+    """wenet/models/transformer/search.py:127-249 with context_graph=None.
+
+    Iteration order is the reference's: top-k tokens in torch.topk order
+    (descending log-prob), then `cur_hyps` in beam order; `next_hyps` keeps dict
+    insertion order and Python's stable sort breaks score ties by it.
+    """
+    results = []
+    for i in range(ctc_probs.shape[0]):
+        ctc_prob = ctc_probs[i]
+        num_t = int(ctc_lens[i])
+        cur_hyps = [(tuple(), PrefixScore(s=0.0, ns=-float('inf'), v_s=0.0,
+                                          v_ns=0.0))]
+        for t in range(0, num_t):
+            logp = ctc_prob[t]
+            next_hyps = defaultdict(lambda: PrefixScore())
+            _, top_k_index = logp.topk(beam_size)
+            for u in top_k_index:
+                u = u.item()
+                prob = logp[u].item()
+                for prefix, ps in cur_hyps:
+                    last = prefix[-1] if len(prefix) > 0 else None
+                    if u == blank_id:
+                        nx = next_hyps[prefix]
+                        nx.s = log_add(nx.s, ps.score() + prob)
+                        nx.v_s = ps.viterbi_score() + prob
+                        nx.times_s = ps.times().copy()
+                    elif u == last:
+                        n1 = next_hyps[prefix]
+                        n1.ns = log_add(n1.ns, ps.ns + prob)
+                        if n1.v_ns < ps.v_ns + prob:
+                            n1.v_ns = ps.v_ns + prob
+                            if n1.cur_token_prob < prob:
+                                n1.cur_token_prob = prob
+                                n1.times_ns = ps.times_ns.copy()
+                                n1.times_ns[-1] = t
+                        n2 = next_hyps[prefix + (u, )]
+                        n2.ns = log_add(n2.ns, ps.s + prob)
+                        if n2.v_ns < ps.v_s + prob:
+                            n2.v_ns = ps.v_s + prob
+                            n2.cur_token_prob = prob
+                            n2.times_ns = ps.times_s.copy()
+                            n2.times_ns.append(t)
+                    else:
+                        nx = next_hyps[prefix + (u, )]
+                        nx.ns = log_add(nx.ns, ps.score() + prob)
+                        if nx.v_ns < ps.viterbi_score() + prob:
+                            nx.v_ns = ps.viterbi_score() + prob
+                            nx.cur_token_prob = prob
+                            nx.times_ns = ps.times().copy()
+                            nx.times_ns.append(t)
+            next_hyps = sorted(next_hyps.items(), key=lambda x: x[1].score(),
+                               reverse=True)
+            cur_hyps = next_hyps[:beam_size]
+        nbest = [y[0] for y in cur_hyps]
+        nbest_scores = [y[1].score() for y in cur_hyps]
+        nbest_times = [y[1].times() for y in cur_hyps]
+        results.append(
+            DecodeResult(tokens=nbest[0], score=nbest_scores[0],
+                         times=nbest_times[0], nbest=nbest,
+                         nbest_scores=nbest_scores, nbest_times=nbest_times))
+    return results
+
+
+# --------------------------------------------------------------------------
+# attention decoder + rescoring
+
+
+def _decoder_forward(configs, sd, pfx, nblocks, memory, memory_mask, ys_in_pad,
+                     ys_in_lens):
+    """TransformerDecoder.forward decoder.py:146-201 + DecoderLayer.forward
+    decoder_layer.py:68-153 (normalize_before, relu FFN, abs-pos embedding
+    embedding.py:58-76: x*sqrt(d)+pe)."""
+    dc = configs['decoder_conf']
+    h = dc.get('attention_heads', 4)
+    d = memory.size(-1)
+    maxlen = ys_in_pad.size(1)
+    tgt_mask = ~make_pad_mask(ys_in_lens, maxlen).unsqueeze(1)
+    tgt_mask = tgt_mask & subsequent_mask(maxlen).unsqueeze(0)
+    pe = sd.get(pfx + 'embed.1.pe')
+    if pe is None:
+        pe = positional_encoding_table(d)
+    x = F.embedding(ys_in_pad, sd[pfx + 'embed.0.weight']) * math.sqrt(d) + \
+        pe[:, :maxlen]
+    for j in range(nblocks):
+        lp = f'{pfx}decoders.{j}.'
+        residual = x
+        xn = layer_norm(x, sd, lp + 'norm1.')
+        x = residual + mha(xn, xn, xn, tgt_mask, sd, lp + 'self_attn.', h)
+        residual = x
+        xn = layer_norm(x, sd, lp + 'norm2.')
+        x = residual + mha(xn, memory, memory, memory_mask, sd,
+                           lp + 'src_attn.', h)
+        residual = x
+        x = residual + feed_forward(layer_norm(x, sd, lp + 'norm3.'), sd,
+                                    lp + 'feed_forward.', F.relu)
+    x = layer_norm(x, sd, pfx + 'after_norm.')
+    return F.linear(x, sd[pfx + 'output_layer.weight'],
+                    sd[pfx + 'output_layer.bias'])
+
+
+def is_bidirectional(configs) -> bool:
+    return configs.get('decoder', 'bitransformer') == 'bitransformer'
+
+
+def forward_attention_decoder(configs, sd, hyps, hyps_lens, encoder_out,
+                              reverse_weight: float = 0.0, sos: int = 2,
+                              eos: int = 2):
+    """ASRModel.forward_attention_decoder asr_model.py:453-547."""
+    assert encoder_out.size(0) == 1
+    num_hyps = hyps.size(0)
+    encoder_out = encoder_out.repeat(num_hyps, 1, 1)
+    encoder_mask = torch.ones(num_hyps, 1, encoder_out.size(1),
+                              dtype=torch.bool)
+    r_hyps_lens = hyps_lens - 1
+    r_hyps = hyps[:, 1:]
+    max_len = torch.max(r_hyps_lens)
+    index_range = torch.arange(0, max_len, 1)
+    seq_len_expand = r_hyps_lens.unsqueeze(1)
+    seq_mask = seq_len_expand > index_range
+    index = (seq_len_expand - 1) - index_range
+    index = index * seq_mask
+    r_hyps = torch.gather(r_hyps, 1, index)
+    r_hyps = torch.where(seq_mask, r_hyps, eos)
+    r_hyps = torch.cat([hyps[:, 0:1], r_hyps], dim=1)
+    dc = configs['decoder_conf']
+    if is_bidirectional(configs):
+        lp, nl = 'decoder.left_decoder.', dc.get('num_blocks', 6)
+    else:
+        lp, nl = 'decoder.', dc.get('num_blocks', 6)
+    decoder_out = _decoder_forward(configs, sd, lp, nl, encoder_out,
+                                   encoder_mask, hyps, hyps_lens)
+    decoder_out = F.log_softmax(decoder_out, dim=-1)
+    r_decoder_out = torch.tensor(0.0)
+    if is_bidirectional(configs) and reverse_weight > 0.0:
+        r_decoder_out = _decoder_forward(configs, sd, 'decoder.right_decoder.',
+                                         dc.get('r_num_blocks', 0), encoder_out,
+                                         encoder_mask, r_hyps, hyps_lens)
+    r_decoder_out = F.log_softmax(r_decoder_out, dim=-1)
+    return decoder_out, r_decoder_out
+
+
+def attention_rescoring(configs, sd, ctc_prefix_results, encoder_outs,
+                        encoder_lens, ctc_weight: float = 0.0,
+                        reverse_weight: float = 0.0, sos: int = 2,
+                        eos: int = 2, ignore_id: int = -1):
+    """wenet/models/transformer/search.py:374-458 (non-whisper branch)."""
+    results = []
+    for b in range(encoder_outs.shape[0]):
+        encoder_out = encoder_outs[b, :int(encoder_lens[b]), :].unsqueeze(0)
+        hyps = ctc_prefix_results[b].nbest
+        ctc_scores = ctc_prefix_results[b].nbest_scores
+        hyps_lens = torch.tensor([len(h) for h in hyps], dtype=torch.long)
+        maxl = int(hyps_lens.max()) if len(hyps) else 0
+        # pad_sequence(..., ignore_id) then add_sos_eos (common.py:113-155):
+        # ys_in = [sos] + hyp, padded with eos.
+        ys_in = torch.full((len(hyps), maxl + 1), eos, dtype=torch.long)
+        ys_in[:, 0] = sos
+        for i, h in enumerate(hyps):
+            if len(h):
+                ys_in[i, 1:1 + len(h)] = torch.tensor(h, dtype=torch.long)
+        hyps_lens = hyps_lens + 1
+        decoder_out, r_decoder_out = forward_attention_decoder(
+            configs, sd, ys_in, hyps_lens, encoder_out, reverse_weight, sos,
+            eos)
+        best_score, best_index = -float('inf'), 0
+        confidences, tokens_confidences, all_scores = [], [], []
+        for i, hyp in enumerate(hyps):
+            score = 0.0
+            tc = []
+            for j, w in enumerate(hyp):
+                s = decoder_out[i][j][w]
+                score += s
+                tc.append(math.exp(s))
+            score += decoder_out[i][len(hyp)][eos]
+            if reverse_weight > 0 and r_decoder_out.dim() > 0:
+                r_score = 0.0
+                for j, w in enumerate(hyp):
+                    s = r_decoder_out[i][len(hyp) - j - 1][w]
+                    r_score += s
+                    tc[j] = (tc[j] + math.exp(s)) / 2
+                r_score += r_decoder_out[i][len(hyp)][eos]
+                score = score * (1 - reverse_weight) + r_score * reverse_weight
+            confidences.append(math.exp(score / (len(hyp) + 1)))
+            score += ctc_scores[i] * ctc_weight
+            all_scores.append(float(score))
+            if score > best_score:
+                best_score = score.item()
+                best_index = i
+            tokens_confidences.append(tc)
+        r = DecodeResult(hyps[best_index], best_score,
+                         confidence=confidences[best_index],
+                         times=ctc_prefix_results[b].nbest_times[best_index],
+                         tokens_confidence=tokens_confidences[best_index])
+        r.all_scores = all_scores  # oracle-only extra: every hypothesis' score
+        results.append(r)
+    return results
+
+
+def special_symbols(configs):
+    """sos/eos as ASRModel.__init__ resolves them (asr_model.py:52-60): from
+    tokenizer_conf.special_tokens if present, else vocab_size-1."""
+    vocab = configs['output_dim']
+    st = (configs.get('tokenizer_conf') or {}).get('special_tokens') or {}
+    return st.get('<sos>', vocab - 1), st.get('<eos>', vocab - 1)
+
+
+def decode(configs, sd, methods, speech, speech_lengths, beam_size: int = 1,
+           decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1,
+           ctc_weight: float = 0.0, reverse_weight: float = 0.0,
+           blank_id: int = 0, blank_penalty: float = 0.0):
+    """ASRModel.decode asr_model.py:267-343 (methods: ctc_greedy_search,
+    ctc_prefix_beam_search, attention_rescoring)."""
+    assert speech.shape[0] == speech_lengths.shape[0]
+    assert decoding_chunk_size != 0
+    with torch.no_grad():
+        encoder_out, encoder_mask = encoder_forward(configs, sd, speech,
+                                                    speech_lengths,
+                                                    decoding_chunk_size,
+                                                    num_decoding_left_chunks)
+        encoder_lens = encoder_mask.squeeze(1).sum(1)
+        ctc_probs = ctc_logprobs(sd, encoder_out, blank_penalty, blank_id)
+        sos, eos = special_symbols(configs)
+        results = {}
+        if 'ctc_greedy_search' in methods:
+            results['ctc_greedy_search'] = ctc_greedy_search(
+                ctc_probs, encoder_lens, blank_id)
+        if 'ctc_prefix_beam_search' in methods:
+            results['ctc_prefix_beam_search'] = ctc_prefix_beam_search(
+                ctc_probs, encoder_lens, beam_size, blank_id)
+        if 'attention_rescoring' in methods:
+            pre = results.get('ctc_prefix_beam_search')
+            if pre is None:
+                pre = ctc_prefix_beam_search(ctc_probs, encoder_lens, beam_size,
+                                             blank_id)
+            results['attention_rescoring'] = attention_rescoring(
+                configs, sd, pre, encoder_out, encoder_lens, ctc_weight,
+                reverse_weight, sos, eos)
+    return results

@@ -1,0 +1,33 @@
+"""Helpers to load the committed reference fixtures (tests/golden/*.npz,
+written by oracle/gen_golden.py from the real reference)."""
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def case_names(prefix=''):
+    return sorted(
+        os.path.basename(p)[:-4]
+        for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + '*.npz'))
+        if not os.path.basename(p).startswith('fbank'))
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    meta = json.loads(bytes(z['meta']).decode('utf8'))
+    arrays = {k: z[k] for k in z.files if k != 'meta'}
+    return meta, arrays
+
+
+def build_inputs(meta):
+    """Regenerate (configs, state_dict, feats, lens) of a golden case."""
+    from wenet_amd import synthetic as S
+    configs = S.make_configs(meta['config'])
+    sd = S.make_state_dict(configs, meta['wseed'])
+    feats, lens = S.make_features(meta['batch'], tuple(meta['frames']),
+                                  seed=meta['fseed'])
+    return configs, sd, feats, lens

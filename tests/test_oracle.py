@@ -1,0 +1,144 @@
+"""CPU tests that pin the oracle (oracle/wenet_oracle.py):
+  * against the reference's own known-answer table for CTC prefix beam search
+    (runtime/core/test/ctc_prefix_beam_search_test.cc:29-72),
+  * against the mask docstring examples (wenet/utils/mask.py:109-113,212-216),
+  * against the committed outputs of the real reference (tests/golden/),
+  * and, when /root/reference is present, against the live reference.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import needs_reference
+from golden_util import build_inputs, case_names, load_case
+from oracle import wenet_oracle as O
+
+
+def test_prefix_beam_known_answer():
+    data = torch.tensor([[0.25, 0.40, 0.35], [0.40, 0.35, 0.25],
+                         [0.10, 0.50, 0.40]]).log().unsqueeze(0)
+    r = O.ctc_prefix_beam_search(data, torch.tensor([3]), 3)[0]
+    assert [list(x) for x in r.nbest] == [[2, 1], [1, 2], [1]]
+    np.testing.assert_allclose(np.exp(r.nbest_scores),
+                               [0.2185, 0.1550, 0.1525], rtol=1e-5)
+    assert r.nbest_times == [[0, 2], [0, 2], [2]]
+
+
+def test_mask_examples():
+    m = O.subsequent_chunk_mask(4, 2).int().tolist()
+    assert m == [[1, 1, 0, 0], [1, 1, 0, 0], [1, 1, 1, 1], [1, 1, 1, 1]]
+    p = O.make_pad_mask(torch.tensor([5, 3, 2])).int().tolist()
+    assert p == [[0, 0, 0, 0, 0], [0, 0, 0, 1, 1], [0, 0, 1, 1, 1]]
+
+
+def test_greedy_collapse():
+    assert O.remove_duplicates_and_blank([0, 1, 1, 0, 1, 2, 2, 0]) == [1, 1, 2]
+
+
+def _check_against_meta(meta, arrays, res, enc, enc_lens, logp):
+    np.testing.assert_array_equal(enc_lens.numpy(), arrays['enc_lens'])
+    for b, n in enumerate(arrays['enc_lens']):
+        np.testing.assert_allclose(enc[b, :n].numpy(), arrays['enc_out'][b, :n],
+                                   rtol=0, atol=2e-5)
+    k = arrays['ctc_topk_idx'].shape[-1]
+    topv, _ = logp.topk(k, dim=-1)
+    for b, n in enumerate(arrays['enc_lens']):
+        np.testing.assert_allclose(topv[b, :n].numpy(),
+                                   arrays['ctc_topk_val'][b, :n], atol=2e-4)
+    for b in range(meta['batch']):
+        assert res['ctc_greedy_search'][b].tokens == meta['greedy'][b]
+        p = res['ctc_prefix_beam_search'][b]
+        g = meta['prefix'][b]
+        assert [list(x) for x in p.nbest] == g['nbest']
+        assert [list(x) for x in p.nbest_times] == g['nbest_times']
+        np.testing.assert_allclose(p.nbest_scores, g['nbest_scores'],
+                                   rtol=0, atol=1e-3)
+        r = res['attention_rescoring'][b]
+        gr = meta['rescoring'][b]
+        assert list(r.tokens) == gr['tokens']
+        assert abs(r.score - gr['score']) < 1e-3
+        assert abs(r.confidence - gr['confidence']) < 1e-4
+        np.testing.assert_allclose(r.tokens_confidence,
+                                   gr['tokens_confidence'], atol=1e-4)
+        assert list(r.times) == gr['times']
+
+
+@pytest.mark.parametrize('name', case_names())
+def test_oracle_matches_committed_reference_outputs(name):
+    meta, arrays = load_case(name)
+    configs, sd, feats, lens = build_inputs(meta)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        enc, mask = O.encoder_forward(configs, sd, feats, lens, meta['chunk'],
+                                      meta['left'])
+        enc_lens = mask.squeeze(1).sum(1)
+        logp = O.ctc_logprobs(sd, enc)
+    res = O.decode(configs, sd, ['ctc_greedy_search', 'ctc_prefix_beam_search',
+                                 'attention_rescoring'], feats, lens,
+                   beam_size=meta['beam'], decoding_chunk_size=meta['chunk'],
+                   num_decoding_left_chunks=meta['left'],
+                   ctc_weight=meta['ctc_weight'],
+                   reverse_weight=meta['reverse_weight'])
+    _check_against_meta(meta, arrays, res, enc, enc_lens, logp)
+
+
+@needs_reference
+@pytest.mark.parametrize('config', ['tiny_causal', 'tiny_sym', 'aishell_u2pp'])
+def test_synthetic_state_dict_matches_reference_names(config):
+    import argparse
+    import copy
+    from oracle import _ref_harness
+    from wenet_amd import synthetic as S
+    _ref_harness.install()
+    from wenet.utils.init_model import init_model
+    configs = S.make_configs(config)
+    sd = S.make_state_dict(configs, 0)
+    rc = copy.deepcopy(configs)
+    rc['cmvn'] = None
+    model, _ = init_model(argparse.Namespace(), rc)
+    ref = model.state_dict()
+    extra = {'encoder.global_cmvn.mean', 'encoder.global_cmvn.istd'}
+    assert set(ref.keys()) | extra == set(sd.keys())
+    for k, v in ref.items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    np.testing.assert_array_equal(ref['encoder.embed.pos_enc.pe'].numpy(),
+                                  sd['encoder.embed.pos_enc.pe'].numpy())
+
+
+@needs_reference
+@pytest.mark.parametrize('config,chunk,left,beam', [
+    ('tiny_causal', -1, -1, 7), ('tiny_causal', 3, 1, 2), ('tiny_sym', -1, -1, 4),
+    ('tiny_sym', 5, -1, 3)])
+def test_oracle_matches_live_reference(config, chunk, left, beam):
+    from oracle import _ref_harness, gen_golden
+    from wenet_amd import synthetic as S
+    _ref_harness.install()
+    configs = S.make_configs(config)
+    sd = S.make_state_dict(configs, 3)
+    model = gen_golden.build_reference_model(configs, sd)
+    feats, lens = S.make_features(4, (50, 220), seed=21)
+    methods = ['ctc_greedy_search', 'ctc_prefix_beam_search',
+               'attention_rescoring']
+    rw = 0.4 if configs['decoder'] == 'bitransformer' else 0.0
+    with torch.no_grad():
+        ref = model.decode(methods, feats, lens, beam_size=beam,
+                           decoding_chunk_size=chunk,
+                           num_decoding_left_chunks=left, ctc_weight=0.4,
+                           reverse_weight=rw)
+    got = O.decode(configs, sd, methods, feats, lens, beam_size=beam,
+                   decoding_chunk_size=chunk, num_decoding_left_chunks=left,
+                   ctc_weight=0.4, reverse_weight=rw)
+    for b in range(4):
+        assert ref['ctc_greedy_search'][b].tokens == \
+            got['ctc_greedy_search'][b].tokens
+        rp, gp = ref['ctc_prefix_beam_search'][b], \
+            got['ctc_prefix_beam_search'][b]
+        assert [list(x) for x in rp.nbest] == [list(x) for x in gp.nbest]
+        assert rp.nbest_scores == gp.nbest_scores  # same fp64 arithmetic
+        assert rp.nbest_times == gp.nbest_times
+        rr, gr = ref['attention_rescoring'][b], got['attention_rescoring'][b]
+        assert list(rr.tokens) == list(gr.tokens)
+        assert abs(rr.score - gr.score) < 1e-5
+        assert abs(rr.confidence - gr.confidence) < 1e-6
