@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds per second (RTF^-1) of the 12-layer
+Conformer decode path on MI355X (BASELINE.json `metric`).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one `ASRModel.decode()` pass over one batch of synthetic fbank
+features that are already resident in HBM: BASELINE.json configs[1]
+(AIShell u2++ Conformer 12L/4h/256d, batch 32 x ~10 s, ctc_prefix_beam_search,
+beam 10) on every GPU (weak scaling: the global batch is 32 x N utterances,
+sorted by length and dealt round-robin; results are gathered with one RCCL
+all_gather inside the timed region).  Weights are random-init (sharpened CTC
+head, wenet_amd/synthetic.py), inputs synthetic.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     : the FFN w_1 GEMM (fp32 MFMA), achieved = algorithmic FLOP of
+                 its launches / their HIP-event durations inside the timed
+                 region, peak 157.3 TF (MI355X_MICROARCH.md);
+  cpu_baseline : the oracle (torch-CPU restatement of the reference decode,
+                 kind "port") timed on this box's host cores on a bounded
+                 sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
+CONFIG = 'aishell_u2pp'
+BATCH_PER_GPU = 32
+FRAMES = (800, 1200)  # 8..12 s of 10 ms frames, mean ~10 s
+BEAM = 10
+METHOD = 'ctc_prefix_beam_search'
+
+
+def audio_seconds(n_frames) -> float:
+    # snip_edges framing: samples = (T - 1) * 160 + 400 at 16 kHz
+    return float(sum(((int(t) - 1) * 160 + 400) / 16000.0 for t in n_frames))
+
+
+def cpu_baseline(configs, sd, feats, lens):
+    """Oracle decode (same method / beam) on a bounded sample, all host cores."""
+    from oracle import wenet_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    n = min(8, feats.shape[0])
+    f = feats[:n, :int(lens[:n].max())].contiguous()
+    l = lens[:n]
+    O.decode(configs, sd, [METHOD], f[:1], l[:1], beam_size=BEAM)  # warm-up
+    reps, t0 = 0, time.time()
+    while True:
+        O.decode(configs, sd, [METHOD], f, l, beam_size=BEAM)
+        reps += 1
+        if time.time() - t0 > 12.0 or reps >= 3:
+            break
+    dt = (time.time() - t0) / reps
+    return {
+        'value': round(audio_seconds(l.tolist()) / dt, 2),
+        'unit': 'audio_s/s',
+        'cores': torch.get_num_threads(),
+        'kind': 'port',
+        'sample': f'{n} utterances of the same batch ({audio_seconds(l.tolist()):.0f} s '
+                  f'audio), {METHOD} beam {BEAM}, oracle/wenet_oracle.py '
+                  f'(torch-CPU fp32 + Python prefix beam), mean of {reps} runs',
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with '
+                         f'--nproc-per-node {args.gpus} (WORLD_SIZE={world})')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=device)
+
+    from wenet_amd import _lib, dist as wdist, synthetic as S
+    from wenet_amd.model import ASRModel
+    configs = S.make_configs(CONFIG)
+    sd = S.make_state_dict(configs, 0)
+    model = ASRModel(configs, sd, device=device)
+
+    # global batch, sharded by length (weak scaling: 32 utterances per GPU)
+    gfeats, glens = S.make_features(BATCH_PER_GPU * world, FRAMES, seed=1234)
+    mine = wdist.shard_indices(glens.tolist(), world, rank)
+    lens = glens[mine]
+    feats = gfeats[mine, :int(lens.max())].contiguous()
+    feats_dev = feats.to(device)
+    total_audio = audio_seconds(glens.tolist())
+    max_tok = 256
+
+    def step():
+        res = model.decode([METHOD], feats_dev, lens, beam_size=BEAM)[METHOD]
+        rec = wdist.pack_results(mine, [r.tokens for r in res],
+                                 [r.score for r in res], BATCH_PER_GPU, max_tok,
+                                 device)
+        return wdist.gather_results(rec, world)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    L = _lib.lib()
+    _lib.check(L.wn_profile_enable(model._h, 1), 'profile')
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    n_launch, ms, flops = ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
+    _lib.check(L.wn_profile_collect(model._h, ctypes.byref(n_launch),
+                                    ctypes.byref(ms), ctypes.byref(flops)),
+               'profile')
+    _lib.check(L.wn_profile_enable(model._h, 0), 'profile')
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert len(out) == BATCH_PER_GPU * world, 'result gather lost utterances'
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_audio * args.steps / dt
+        achieved = (flops.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
+        enc_rows = int(sum(max(0, (int(t) - 7) // 4 + 1) for t in lens.tolist()))
+        line = {
+            'metric': 'audio-seconds/sec (RTF^-1), 12L Conformer fbank80, '
+                      'ctc_prefix_beam_search',
+            'value': round(value, 1),
+            'unit': 'audio_s/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'BASELINE.json configs[1]: AIShell u2++ conformer '
+                            '12L/4head/256d fbank80, batch 32 x ~10 s per GPU '
+                            '(8-12 s ragged), ctc_prefix_beam_search beam 10, '
+                            'features resident in HBM, random-init weights',
+                'global_batch': BATCH_PER_GPU * world,
+                'audio_seconds_per_step': round(total_audio, 1),
+                'encoder_frames_per_gpu': enc_rows,
+                'parallelism': f'utterance-sharded x{world}, one all_gather of results',
+            },
+            'roofline': {
+                'bound': 'mfma',
+                'kernel': 'gemm_f32_kernel<128,128,2,2,SiLU> (FFN w_1, '
+                          f'M={enc_rows} N=2048 K=256)',
+                'achieved': round(achieved, 2),
+                'peak': FP32_MFMA_PEAK_TFLOPS,
+                'unit': 'TFLOP/s',
+                'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                'launches': n_launch.value,
+                'avg_launch_us': round(ms.value * 1e3 / max(n_launch.value, 1), 2),
+                'traffic': None,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline(configs, sd, feats, lens)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

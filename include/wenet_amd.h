@@ -1,0 +1,191 @@
+/* libwenet_amd -- C ABI of the MI355X-native Conformer-ASR inference path.
+ *
+ * The reference (wenet-e2e/wenet) has NO operator / FFI boundary on this path:
+ * `ASRModel.decode()` (wenet/models/transformer/asr_model.py:267-343) calls
+ * torch.nn modules and the pure-Python functions of
+ * wenet/models/transformer/search.py.  This header is the boundary a
+ * maintainer would bind instead (ctypes stub in INTEGRATION.md); every entry
+ * point names the reference function(s) it replaces.  The only C-ABI precedent
+ * in the reference is the streaming recogniser runtime/core/api/wenet_api.h:27-108
+ * (opaque handle, int status); the same style is kept here, but batch-oriented
+ * and tensor-in / tensor-out.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error; wn_last_error() gives
+ *    the thread-local message;
+ *  - `*_dev` pointers are device (HBM) pointers owned by the caller (e.g. a
+ *    torch-ROCm tensor's data_ptr()); `*_host` pointers are host memory;
+ *  - `stream` is a hipStream_t (0 = default stream).  Launches are
+ *    asynchronous; functions that fill host outputs synchronise `stream`
+ *    before returning;
+ *  - the library owns the weights and a workspace arena that grows on demand;
+ *    one wn_model per process/GPU (one process per GPU for multi-GPU);
+ *  - all arithmetic is fp32 (fp64 for the prefix-beam bookkeeping, like the
+ *    reference's Python floats); tokens / lengths are int32.
+ */
+#ifndef WENET_AMD_H_
+#define WENET_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wn_model wn_model;
+
+/* Parsed train.yaml (wenet/utils/init_model.py:100-181 reads the same keys). */
+typedef struct {
+  int32_t feat_dim;          /* input_dim, 80 */
+  int32_t d_model;           /* encoder_conf.output_size */
+  int32_t n_heads;           /* encoder_conf.attention_heads (d_model/n_heads must be 64) */
+  int32_t ffn_dim;           /* encoder_conf.linear_units */
+  int32_t n_layers;          /* encoder_conf.num_blocks */
+  int32_t cnn_kernel;        /* encoder_conf.cnn_module_kernel */
+  int32_t causal;            /* encoder_conf.causal */
+  int32_t use_dynamic_chunk; /* encoder_conf.use_dynamic_chunk */
+  int32_t static_chunk_size; /* encoder_conf.static_chunk_size */
+  int32_t vocab;             /* output_dim */
+  int32_t has_cmvn;
+  int32_t dec_heads;         /* decoder_conf.attention_heads */
+  int32_t dec_ffn_dim;       /* decoder_conf.linear_units */
+  int32_t dec_layers;        /* decoder_conf.num_blocks (left-to-right) */
+  int32_t dec_r_layers;      /* decoder_conf.r_num_blocks; 0 if not bitransformer */
+  int32_t bidirectional;     /* decoder == 'bitransformer' */
+  int32_t sos, eos;          /* asr_model.py:59-62 */
+  int32_t max_pos;           /* positional table length (5000) */
+  float norm_eps;            /* 1e-5 */
+} wn_config;
+
+/* One entry of the reference state_dict (fp32, host memory, C-contiguous). */
+typedef struct {
+  const char* name;
+  const float* data;
+  int64_t numel;
+} wn_tensor;
+
+const char* wn_last_error(void);
+const char* wn_version(void);
+
+/* Build a model from a reference state_dict; replaces
+ * init_model + load_checkpoint + model.to(device)
+ * (wenet/utils/init_model.py:184, wenet/utils/checkpoint.py:26-43,
+ *  wenet/cli/model.py:109).  Weights are re-laid-out for the kernels. */
+int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
+                    int32_t n_weights, int32_t device, wn_model** out);
+void wn_model_destroy(wn_model* m);
+
+/* A weight-less handle that only owns a workspace: enough for
+ * wn_set_ctc_probs + the two CTC searches, i.e. for calling the reference's
+ * free functions search.ctc_greedy_search / ctc_prefix_beam_search on a
+ * caller-provided (B, T, V) log-prob tensor. */
+int wn_workspace_create(int32_t device, wn_model** out);
+
+/* ---- features ---------------------------------------------------------- */
+/* compute_fbank (wenet/dataset/processor.py:226-256 -> kaldi.fbank with
+ * num_mel_bins, 25 ms / 10 ms, dither 0, povey window; arithmetic restated
+ * from runtime/core/frontend/fbank.h:250-327) + padding
+ * (processor.py:526-577, without the sort).  pcm_dev holds the B waveforms
+ * back to back, float in [-1, 1]; sample_off_host has B+1 entries.
+ * feats_dev is (B, max_frames, feat_dim), zero padded.
+ * n_frames_host receives 1 + (n - 400) / 160 per utterance. */
+int wn_fbank(wn_model* m, const float* pcm_dev, const int64_t* sample_off_host,
+             int32_t B, float* feats_dev, int32_t max_frames,
+             int32_t* n_frames_host, void* stream);
+
+/* ---- encoder ------------------------------------------------------------ */
+/* ASRModel._forward_encoder / BaseEncoder.forward (asr_model.py:216-239,
+ * encoder.py:122-181): GlobalCMVN, Conv2dSubsampling4, rel-pos encoding,
+ * chunk mask, n_layers x ConformerEncoderLayer, after_norm.
+ * feats_dev: (B, T, feat_dim) padded; feat_lens_host: B lengths.
+ * decoding_chunk_size / num_left_chunks as in the reference (<0: full).
+ * enc_lens_host (B) receives the subsampled lengths.  If enc_out_dev != NULL
+ * it receives the padded (B, T', d_model) output, T' = ((T-1)/2-1)/2, rows
+ * past each length zero-filled (the reference leaves unspecified values
+ * there).  The packed encoder output stays resident in the model's workspace
+ * as the "current batch" for the wn_ctc_* / wn_rescore calls below. */
+int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host,
+              int32_t B, int32_t T, int32_t decoding_chunk_size,
+              int32_t num_left_chunks, float* enc_out_dev,
+              int32_t* enc_lens_host, void* stream);
+
+/* Use caller-provided padded encoder output (B, Tp, d_model) + lengths as the
+ * current batch (for the reference's free functions that take encoder_out). */
+int wn_set_encoder_out(wn_model* m, const float* enc_out_dev,
+                       const int32_t* enc_lens_host, int32_t B, int32_t Tp,
+                       void* stream);
+
+/* ---- CTC ---------------------------------------------------------------- */
+/* ASRModel.ctc_logprobs (asr_model.py:254-265): Linear(d->V) + log_softmax
+ * over the current batch, with top-k per frame (k = max(1, beam)) kept in the
+ * workspace for the searches.  If logp_dev != NULL the full padded
+ * (B, Tp, V) log-prob tensor is also written (rows past the length zeroed). */
+int wn_ctc_logprobs(wn_model* m, int32_t topk, int32_t blank_id,
+                    float blank_penalty, float* logp_dev, int32_t Tp,
+                    void* stream);
+
+/* Use caller-provided padded log-probs (B, Tp, V) + lengths as the current
+ * CTC posteriors (for search.ctc_greedy_search / ctc_prefix_beam_search called
+ * directly on a tensor); computes the per-frame top-k without re-normalising. */
+int wn_set_ctc_probs(wn_model* m, const float* logp_dev,
+                     const int32_t* lens_host, int32_t B, int32_t Tp,
+                     int32_t V, int32_t topk, void* stream);
+
+/* ctc_greedy_search (search.py:109-124): tokens_host is (B, max_len) int32,
+ * tok_lens_host (B). max_len must be >= the longest subsampled length. */
+int wn_ctc_greedy_search(wn_model* m, int32_t blank_id, int32_t* tokens_host,
+                         int32_t* tok_lens_host, int32_t max_len, void* stream);
+
+/* ctc_prefix_beam_search (search.py:127-249, context_graph=None).  Outputs,
+ * all host: n_hyps (B); hyp_lens, hyp_tlens (B, beam); hyp_tokens, hyp_times
+ * (B, beam, max_len); hyp_scores (B, beam) fp64.  The n-best list also stays
+ * on the device for wn_attention_rescoring. */
+int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
+                              int32_t* n_hyps_host, int32_t* hyp_lens_host,
+                              int32_t* hyp_tlens_host, int32_t* hyp_tokens_host,
+                              int32_t* hyp_times_host, double* hyp_scores_host,
+                              int32_t max_len, void* stream);
+
+/* ---- attention rescoring ------------------------------------------------- */
+/* attention_rescoring + ASRModel.forward_attention_decoder
+ * (search.py:374-458, asr_model.py:453-547) for ALL utterances and hypotheses
+ * of the current batch in one pass (the reference loops utterance by
+ * utterance).  hyps given on the host as produced by the prefix beam search:
+ * n_hyps (B), hyp_lens (B, beam), hyp_tokens (B, beam, max_len).
+ * Outputs (host): l2r_logp, r2l_logp (B, beam, max_len + 1): log-prob of each
+ * hypothesis token then of <eos> under the left-to-right decoder, and of the
+ * reversed sequence under the right-to-left decoder (zeros when
+ * reverse_weight == 0 or the model has no right decoder). */
+int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
+                           const int32_t* hyp_lens_host,
+                           const int32_t* hyp_tokens_host, int32_t max_len,
+                           float reverse_weight, float* l2r_logp_host,
+                           float* r2l_logp_host, void* stream);
+
+/* ---- raw operators (used by the parity tests and by other hosts) ---------- */
+/* C[M,N] = resid + alpha * act(A[M,K] * W[N,K]^T + bias); act: 0 none,
+ * 1 SiLU, 2 ReLU.  fp32 on v_mfma_f32_32x32x2_f32. */
+int wn_op_gemm(const float* A_dev, const float* W_dev, const float* bias_dev,
+               const float* resid_dev, float* C_dev, int32_t M, int32_t N,
+               int32_t K, float alpha, int32_t act, void* stream);
+int wn_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev,
+                    float* y_dev, int32_t M, int32_t D, float eps, void* stream);
+
+/* Measurement hook for bench.py: bracket every launch of the dominant kernel
+ * (the FFN w_1 GEMM, positionwise_feed_forward.py:58) with HIP events on the
+ * launch stream.  wn_profile_collect waits for them and returns the number of
+ * launches, their summed duration and their summed algorithmic FLOPs
+ * (2*M*N*K each) since the last enable/collect. */
+int wn_profile_enable(wn_model* m, int32_t on);
+int wn_profile_collect(wn_model* m, int32_t* n_launches, double* total_ms,
+                       double* total_flops);
+
+/* Test hook: "n_layers" = run only the first n encoder layers (-1: all),
+ * "skip_after_norm" = 1 leaves out encoder.after_norm; lets the parity tests
+ * compare every ConformerEncoderLayer output with the oracle. */
+int wn_debug_set(wn_model* m, const char* key, int32_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WENET_AMD_H_ */

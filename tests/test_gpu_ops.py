@@ -1,0 +1,113 @@
+"""GPU operator tests: each HIP kernel family against a plain torch fp32
+reference of the same op (run on the box's CPU)."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _gemm(A, W, bias=None, resid=None, alpha=1.0, act=0):
+    from wenet_amd import _lib
+    L = _lib.lib()
+    M, K = A.shape
+    N = W.shape[0]
+    C = torch.empty((M, N), dtype=torch.float32, device='cuda')
+    _lib.check(L.wn_op_gemm(_ptr(A), _ptr(W), _ptr(bias), _ptr(resid), _ptr(C),
+                            M, N, K, alpha, act,
+                            torch.cuda.current_stream().cuda_stream), 'gemm')
+    torch.cuda.synchronize()
+    return C
+
+
+@pytest.mark.parametrize('M,N,K', [
+    (128, 128, 32), (1, 1, 32), (77, 67, 64), (300, 256, 256),
+    (7936, 2048, 256), (7936, 256, 2048), (513, 4233, 256), (2000, 768, 256),
+    (129, 130, 2432)])
+def test_gemm_plain_asymmetric(M, N, K):
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)  # asymmetric operands (transpose check)
+    ref = A.double() @ W.double().T
+    got = _gemm(A.cuda(), W.cuda()).cpu().double()
+    err = (got - ref).abs().max().item()
+    scale = (A.abs().double() @ W.abs().double().T).max().item()
+    assert err <= 2e-6 * scale, (err, scale)
+
+
+def test_gemm_identity_detects_transposed_store():
+    K = 64
+    A = torch.eye(K)
+    W = torch.arange(96 * K, dtype=torch.float32).reshape(96, K) / 100.0
+    got = _gemm(A.cuda(), W.cuda()).cpu()
+    torch.testing.assert_close(got, W.T.contiguous(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('act', [0, 1, 2])
+@pytest.mark.parametrize('use_resid', [False, True])
+def test_gemm_epilogues(act, use_resid):
+    g = torch.Generator().manual_seed(act * 2 + int(use_resid))
+    M, N, K = 333, 200, 96
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g) if use_resid else None
+    y = A @ W.T + bias
+    if act == 1:
+        y = torch.nn.functional.silu(y)
+    elif act == 2:
+        y = torch.relu(y)
+    y = 0.5 * y
+    if use_resid:
+        y = y + resid
+    got = _gemm(A.cuda(), W.cuda(), bias.cuda(),
+                resid.cuda() if use_resid else None, 0.5, act).cpu()
+    torch.testing.assert_close(got, y, rtol=1e-5, atol=2e-5)
+
+
+def test_gemm_in_place_residual():
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 257, 256, 512
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+    x = torch.randn(M, N, generator=g)
+    from wenet_amd import _lib
+    xc = x.cuda()
+    Ac, Wc = A.cuda(), W.cuda()
+    _lib.check(_lib.lib().wn_op_gemm(Ac.data_ptr(), Wc.data_ptr(), None,
+                                     xc.data_ptr(), xc.data_ptr(), M, N, K,
+                                     1.0, 0, None), 'gemm')
+    torch.cuda.synchronize()
+    torch.testing.assert_close(xc.cpu(), x + A @ W.T, rtol=1e-5, atol=5e-5)
+
+
+def test_gemm_rejects_bad_k():
+    from wenet_amd import _lib
+    A = torch.zeros(4, 30, device='cuda')
+    W = torch.zeros(4, 30, device='cuda')
+    C = torch.zeros(4, 4, device='cuda')
+    st = _lib.lib().wn_op_gemm(A.data_ptr(), W.data_ptr(), None, None,
+                               C.data_ptr(), 4, 4, 30, 1.0, 0, None)
+    assert st != 0 and b'multiple of 32' in _lib.lib().wn_last_error()
+
+
+@pytest.mark.parametrize('D', [64, 128, 256, 512])
+def test_layernorm(D):
+    from wenet_amd import _lib
+    g = torch.Generator().manual_seed(D)
+    M = 1001
+    x = torch.randn(M, D, generator=g) * 3 + 1
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (D, ), w, b, 1e-5)
+    xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+    y = torch.empty_like(xc)
+    _lib.check(_lib.lib().wn_op_layernorm(xc.data_ptr(), wc.data_ptr(),
+                                          bc.data_ptr(), y.data_ptr(), M, D,
+                                          1e-5, None), 'ln')
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-5, atol=2e-5)

@@ -1,0 +1,270 @@
+"""GPU parity tests: the HIP path (through the C ABI) against
+  * the committed outputs of the real reference (tests/golden/), and
+  * the CPU oracle on the same seeded inputs,
+stage by stage (encoder, CTC log-probs, greedy, prefix beam, rescoring,
+fbank) and end to end.
+
+Tolerances (fp32 path, different summation order than torch-CPU):
+  encoder output       |err| <= 2e-3 on unit-variance activations
+  CTC log-probs        |err| <= 5e-3 (logits are sharpened x12)
+  greedy tokens        identical wherever the oracle's top-1 margin > 2e-2
+  prefix-beam scores   |err| <= 2e-3, rescoring scores |err| <= 1e-3 * (L+1)
+Bit-exact (same log-prob tensor fed to both): greedy tokens, n-best token
+lists, n-best time stamps; fp64 n-best scores to 1e-9.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import build_inputs, case_names, load_case
+from gpu_util import cached_model, compare_nbest, frame_margins
+
+pytestmark = pytest.mark.gpu
+
+METHODS = ['ctc_greedy_search', 'ctc_prefix_beam_search', 'attention_rescoring']
+
+
+def _oracle():
+    from oracle import wenet_oracle as O
+    return O
+
+
+@pytest.mark.parametrize('name', case_names())
+def test_golden_case(name):
+    meta, arrays = load_case(name)
+    configs, sd, model = cached_model(meta['config'], meta['wseed'])
+    _, _, feats, lens = build_inputs(meta)
+    enc, mask = model._forward_encoder(feats.cuda(), lens, meta['chunk'],
+                                       meta['left'])
+    enc_lens = mask.squeeze(1).sum(1).cpu().numpy()
+    np.testing.assert_array_equal(enc_lens, arrays['enc_lens'])
+    enc = enc.cpu().numpy()
+    for b, n in enumerate(arrays['enc_lens']):
+        err = np.abs(enc[b, :n] - arrays['enc_out'][b, :n]).max()
+        assert err < 2e-3, (name, b, err)
+    logp = model.ctc_logprobs(torch.from_numpy(enc).cuda(),
+                              encoder_lens=torch.from_numpy(enc_lens))
+    k = arrays['ctc_topk_idx'].shape[-1]
+    topv = logp.topk(k, dim=-1).values.cpu().numpy()
+    for b, n in enumerate(arrays['enc_lens']):
+        assert np.abs(topv[b, :n] - arrays['ctc_topk_val'][b, :n]).max() < 5e-3
+    res = model.decode(METHODS, feats.cuda(), lens, beam_size=meta['beam'],
+                       decoding_chunk_size=meta['chunk'],
+                       num_decoding_left_chunks=meta['left'],
+                       ctc_weight=meta['ctc_weight'],
+                       reverse_weight=meta['reverse_weight'])
+    ref_margin = arrays['ctc_topk_val'][..., 0] - arrays['ctc_topk_val'][..., 1]
+    for b in range(meta['batch']):
+        n = arrays['enc_lens'][b]
+        if ref_margin[b, :n].min() > 2e-2:
+            assert res['ctc_greedy_search'][b].tokens == meta['greedy'][b]
+        g = meta['prefix'][b]
+        compare_nbest(res['ctc_prefix_beam_search'][b], g['nbest'],
+                      g['nbest_scores'], g['nbest_times'], what=f'{name}[{b}]')
+        r, gr = res['attention_rescoring'][b], meta['rescoring'][b]
+        if list(r.tokens) == gr['tokens']:
+            tol = 1e-3 * (len(gr['tokens']) + 1)
+            assert abs(r.score - gr['score']) < tol, (name, b, r.score, gr['score'])
+            np.testing.assert_allclose(r.tokens_confidence,
+                                       gr['tokens_confidence'], atol=2e-3)
+
+
+@pytest.mark.parametrize('config,B,frames,chunk,left', [
+    ('tiny_causal', 7, (30, 260), -1, -1),
+    ('tiny_causal', 5, (30, 260), 8, 1),
+    ('tiny_sym', 6, (7, 180), -1, -1),
+    ('aishell_u2pp', 4, (400, 700), 16, -1),
+])
+def test_encoder_layers_vs_oracle(config, B, frames, chunk, left):
+    """Every ConformerEncoderLayer output against the oracle (wn_debug_set)."""
+    from wenet_amd import _lib, synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=77)
+    with torch.no_grad():
+        ref, mask, layers = O.encoder_forward(configs, sd, feats, lens, chunk,
+                                              left, return_layers=True)
+    ref_lens = mask.squeeze(1).sum(1).numpy()
+    L = _lib.lib()
+    try:
+        for n in range(len(layers)):
+            _lib.check(L.wn_debug_set(model._h, b'n_layers', n), 'dbg')
+            _lib.check(L.wn_debug_set(model._h, b'skip_after_norm', 1), 'dbg')
+            enc, m = model._forward_encoder(feats.cuda(), lens, chunk, left)
+            enc = enc.cpu()
+            for b in range(B):
+                nb = int(ref_lens[b])
+                err = (enc[b, :nb] - layers[n][b, :nb]).abs().max().item() \
+                    if nb else 0.0
+                scale = max(layers[n][b, :nb].abs().max().item(), 1.0) if nb else 1.0
+                assert err < 1e-3 * scale, (config, 'layer', n, 'utt', b, err)
+    finally:
+        L.wn_debug_set(model._h, b'n_layers', -1)
+        L.wn_debug_set(model._h, b'skip_after_norm', 0)
+    enc, m = model._forward_encoder(feats.cuda(), lens, chunk, left)
+    np.testing.assert_array_equal(m.squeeze(1).sum(1).cpu().numpy(), ref_lens)
+    for b in range(B):
+        nb = int(ref_lens[b])
+        if nb:
+            assert (enc[b, :nb].cpu() - ref[b, :nb]).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize('V,T,B,beam', [(67, 40, 5, 4), (4233, 120, 3, 10),
+                                        (101, 33, 4, 1), (5002, 64, 2, 16),
+                                        (300, 3, 3, 8)])
+def test_search_free_functions_bit_exact(V, T, B, beam):
+    """Same (B,T,V) log-prob tensor into the oracle's Python search and the
+    GPU search: token lists, n-best order and time stamps must be identical."""
+    from wenet_amd import search as S
+    O = _oracle()
+    g = torch.Generator().manual_seed(V + T)
+    logits = torch.randn(B, T, V, generator=g) * 3.0
+    logits[..., 0] += 6.0  # blank-heavy like a real CTC model
+    # repeat frames so the "repeat" / "merge" branches are exercised
+    for t in range(1, T, 3):
+        logits[:, t] = logits[:, t - 1] + 0.05 * torch.randn(B, V, generator=g)
+    logp = logits.log_softmax(-1)
+    lens = torch.randint(max(1, T // 2), T + 1, (B, ), generator=g)
+    lens[0] = T
+    ref_g = O.ctc_greedy_search(logp, lens)
+    got_g = S.ctc_greedy_search(logp.cuda(), lens)
+    for b in range(B):
+        assert got_g[b].tokens == ref_g[b].tokens
+    ref_p = O.ctc_prefix_beam_search(logp, lens, beam)
+    got_p = S.ctc_prefix_beam_search(logp.cuda(), lens, beam)
+    for b in range(B):
+        assert [list(x) for x in got_p[b].nbest] == \
+            [list(x) for x in ref_p[b].nbest], b
+        assert [list(x) for x in got_p[b].nbest_times] == \
+            [list(x) for x in ref_p[b].nbest_times], b
+        np.testing.assert_allclose(got_p[b].nbest_scores,
+                                   ref_p[b].nbest_scores, rtol=0, atol=1e-9)
+        assert list(got_p[b].tokens) == list(ref_p[b].tokens)
+        assert got_p[b].times == ref_p[b].times
+
+
+def test_prefix_beam_known_answer_gpu():
+    """runtime/core/test/ctc_prefix_beam_search_test.cc:29-72 on the GPU."""
+    from wenet_amd import search as S
+    data = torch.tensor([[0.25, 0.40, 0.35], [0.40, 0.35, 0.25],
+                         [0.10, 0.50, 0.40]]).log().unsqueeze(0)
+    r = S.ctc_prefix_beam_search(data.cuda(), torch.tensor([3]), 3)[0]
+    assert [list(x) for x in r.nbest] == [[2, 1], [1, 2], [1]]
+    np.testing.assert_allclose(np.exp(r.nbest_scores),
+                               [0.2185, 0.1550, 0.1525], rtol=1e-5)
+    assert r.nbest_times == [[0, 2], [0, 2], [2]]
+
+
+def test_zero_length_and_short_utterances():
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('tiny_causal', 0)
+    feats, _ = S.make_features(4, 60, seed=3)
+    lens = torch.tensor([60, 7, 6, 10], dtype=torch.int32)  # 6 -> no frames
+    ref = O.decode(configs, sd, METHODS[:2], feats, lens, beam_size=3)
+    got = model.decode(METHODS[:2], feats.cuda(), lens, beam_size=3)
+    for b in range(4):
+        assert got['ctc_greedy_search'][b].tokens == \
+            ref['ctc_greedy_search'][b].tokens
+        rp, gp = ref['ctc_prefix_beam_search'][b], got['ctc_prefix_beam_search'][b]
+        assert len(gp.nbest) == len(rp.nbest)
+        assert list(gp.tokens) == list(rp.tokens)
+
+
+def test_rescoring_vs_oracle_on_same_hyps():
+    """Feed the ORACLE's encoder output and n-best lists to the GPU rescoring:
+    isolates the decoder path; scores within 1e-3."""
+    from wenet_amd import search as S, synthetic as SY
+    O = _oracle()
+    for config, rw in [('tiny_causal', 0.3), ('tiny_sym', 0.0),
+                       ('aishell_u2pp', 0.4)]:
+        configs, sd, model = cached_model(config, 0)
+        feats, lens = SY.make_features(3, (200, 330), seed=19)
+        with torch.no_grad():
+            enc, mask = O.encoder_forward(configs, sd, feats, lens)
+            enc_lens = mask.squeeze(1).sum(1)
+            logp = O.ctc_logprobs(sd, enc)
+        pre = O.ctc_prefix_beam_search(logp, enc_lens, 6)
+        sos, eos = O.special_symbols(configs)
+        ref = O.attention_rescoring(configs, sd, pre, enc, enc_lens, 0.5, rw,
+                                    sos, eos)
+        got = S.attention_rescoring(model, pre, enc.cuda(), enc_lens, 0.5, rw)
+        for b in range(3):
+            np.testing.assert_allclose(got[b].all_scores, ref[b].all_scores,
+                                       rtol=0, atol=1e-3)
+            assert list(got[b].tokens) == list(ref[b].tokens)
+            assert abs(got[b].confidence - ref[b].confidence) < 1e-4
+
+
+def test_end_to_end_vs_oracle_ragged_batch():
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('aishell_u2pp', 0)
+    feats, lens = S.make_features(6, (300, 520), seed=101)
+    ref = O.decode(configs, sd, METHODS, feats, lens, beam_size=10,
+                   ctc_weight=0.5, reverse_weight=0.3)
+    got = model.decode(METHODS, feats.cuda(), lens, beam_size=10,
+                       ctc_weight=0.5, reverse_weight=0.3)
+    with torch.no_grad():
+        enc, mask = O.encoder_forward(configs, sd, feats, lens)
+        margins = frame_margins(O.ctc_logprobs(sd, enc))
+    enc_lens = mask.squeeze(1).sum(1)
+    for b in range(6):
+        if margins[b, :enc_lens[b]].min() > 2e-2:
+            assert got['ctc_greedy_search'][b].tokens == \
+                ref['ctc_greedy_search'][b].tokens
+        rp = ref['ctc_prefix_beam_search'][b]
+        compare_nbest(got['ctc_prefix_beam_search'][b], rp.nbest,
+                      rp.nbest_scores, rp.nbest_times, what=f'e2e[{b}]')
+        if list(got['attention_rescoring'][b].tokens) == \
+                list(ref['attention_rescoring'][b].tokens):
+            L = len(ref['attention_rescoring'][b].tokens)
+            assert abs(got['attention_rescoring'][b].score -
+                       ref['attention_rescoring'][b].score) < 1e-3 * (L + 1)
+
+
+def test_padding_invariance_property():
+    """Size-independent property: an utterance decodes identically whether it
+    is alone or padded inside a ragged batch (the packed layout never lets pad
+    frames leak)."""
+    from wenet_amd import synthetic as S
+    configs, sd, model = cached_model('tiny_sym', 0)
+    feats, lens = S.make_features(5, (60, 300), seed=8)
+    full = model.decode(METHODS[:2], feats.cuda(), lens, beam_size=4)
+    for b in range(5):
+        n = int(lens[b])
+        one = model.decode(METHODS[:2], feats[b:b + 1, :n].cuda(), lens[b:b + 1],
+                           beam_size=4)
+        assert one['ctc_greedy_search'][0].tokens == \
+            full['ctc_greedy_search'][b].tokens
+        assert list(one['ctc_prefix_beam_search'][0].tokens) == \
+            list(full['ctc_prefix_beam_search'][b].tokens)
+
+
+def test_fbank_vs_oracle():
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('tiny_sym', 0)
+    waves = [S.make_audio(n, seed=i) for i, n in enumerate([16000, 5000, 399, 24321])]
+    feats, nfr = model.compute_fbank(waves)
+    feats = feats.cpu().numpy()
+    for i, w in enumerate(waves):
+        ref = O.fbank(w)
+        assert int(nfr[i]) == ref.shape[0]
+        if ref.shape[0]:
+            err = np.abs(feats[i, :ref.shape[0]] - ref)
+            # log-mel of fp32 FFTs: a few low-energy bins carry the error
+            assert np.percentile(err, 99) < 2e-3 and err.max() < 5e-2, \
+                (i, np.percentile(err, 99), err.max())
+        assert np.all(feats[i, ref.shape[0]:] == 0)
+
+
+def test_rejects_cpu_tensors_and_chunk_zero():
+    configs, sd, model = cached_model('tiny_sym', 0)
+    from wenet_amd import search as S
+    with pytest.raises(RuntimeError):
+        S.ctc_greedy_search(torch.zeros(1, 4, 8), torch.tensor([4]))
+    feats = torch.zeros(1, 40, 80)
+    with pytest.raises(AssertionError):
+        model.decode(['ctc_greedy_search'], feats.cuda(), torch.tensor([40]),
+                     decoding_chunk_size=0)

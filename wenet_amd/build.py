@@ -1,0 +1,79 @@
+"""Build libwenet_amd.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m wenet_amd.build          # incremental
+    python -m wenet_amd.build --force
+
+hipcc cross-compiles without a GPU; the .so lands next to this file so that it
+travels with the source tree (it is git-ignored, not gpurun-ignored).
+"""
+import concurrent.futures
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, '..', 'build', 'obj')
+LIB = os.path.join(HERE, 'libwenet_amd.so')
+SOURCES = ['gemm.hip', 'encoder_kernels.hip', 'ctc.hip', 'fbank.hip',
+           'model.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+         '-fno-gpu-rdc', '-Wno-unused-result']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), shutil.which('hipcc'),
+              '/opt/rocm/bin/hipcc'):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def _stamp(paths):
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        with open(p, 'rb') as f:
+            h.update(p.encode())
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
+               if f.endswith('.h')]
+    headers.append(os.path.join(HERE, '..', 'include', 'wenet_amd.h'))
+    stamp_file = os.path.join(OBJ, 'stamp')
+    stamp = _stamp(headers + [os.path.join(CSRC, s) for s in SOURCES])
+    if (not force and os.path.exists(LIB) and os.path.exists(stamp_file)
+            and open(stamp_file).read() == stamp):
+        return LIB
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, src.replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {src}:\n{r.stderr}')
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB
+           ] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stderr}')
+    with open(stamp_file, 'w') as f:
+        f.write(stamp)
+    if verbose:
+        print(f'built {LIB} ({os.path.getsize(LIB) // 1024} KiB)')
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,89 @@
+// Shared declarations for libwenet_amd (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+namespace wn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const std::string& msg);
+#define WN_STR2(x) #x
+#define WN_STR(x) WN_STR2(x)
+#define WN_HIP(expr)                                                         \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      ::wn::set_error(std::string(__FILE__ ":" WN_STR(__LINE__) ": ") +      \
+                      #expr + " -> " + hipGetErrorString(_e));               \
+      return -2;                                                             \
+    }                                                                        \
+  } while (0)
+#define WN_CHECK(cond, msg)                                                  \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      ::wn::set_error(std::string(__FILE__ ":" WN_STR(__LINE__) ": ") +      \
+                      (msg));                                                \
+      return -1;                                                             \
+    }                                                                        \
+  } while (0)
+#define WN_TRY(expr)                                                         \
+  do {                                                                       \
+    int _r = (expr);                                                         \
+    if (_r != 0) return _r;                                                  \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float silu_f(float x) {
+  return x / (1.0f + expf(-x));
+}
+__device__ __forceinline__ float sigmoid_f(float x) {
+  return 1.0f / (1.0f + expf(-x));
+}
+#endif
+
+// ---- GEMM -----------------------------------------------------------------
+// C[M,N] = epilogue(A[M,K] * W[N,K]^T), fp32 in / fp32 accumulate on
+// v_mfma_f32_32x32x2_f32.  All pointers are device pointers.
+enum GemmAct { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+
+struct GemmArgs {
+  const float* A = nullptr;  // [M, lda] (plain) or gathered (a_row_off)
+  const float* W = nullptr;  // [N, K] row-major (torch Linear layout)
+  const float* bias = nullptr;   // [N] or null
+  const float* resid = nullptr;  // [M, ldr] or null: C = resid + alpha*act(..)
+  float* C = nullptr;            // [M, ldc]
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldc = 0, ldr = 0;
+  float alpha = 1.0f;
+  int act = ACT_NONE;
+  bool glu = false;  // W rows permuted [32 a | 32 gate] per 64; C has N/2 cols
+  // implicit 3x3/stride-2 conv A operand (subsampling conv2): element (row,k)
+  // lives at A[a_row_off[row] + (tap/3)*conv_sy + (tap%3)*conv_sx + k%conv_C],
+  // tap = k / conv_C.
+  const int64_t* a_row_off = nullptr;
+  int conv_C = 0;
+  int64_t conv_sy = 0, conv_sx = 0;
+};
+
+int gemm_f32(const GemmArgs& a, hipStream_t stream);
+
+}  // namespace wn

@@ -1,0 +1,437 @@
+// HBM-bound / LDS-staged encoder kernels: LayerNorm, CMVN + first subsampling
+// conv, the depthwise-conv core of the Conformer conv module, and the
+// relative-position multi-head attention (online softmax, fp32 MFMA).
+#include "kernels.h"
+
+namespace wn {
+
+namespace {
+
+// ===========================================================================
+// LayerNorm -- torch.nn.LayerNorm(d, eps) as used by encoder_layer.py:166-184.
+// One wave per row; the row lives in registers (E = D/64 values per lane),
+// two-pass mean / variance, wave-shuffle reductions, 16-byte accesses.
+template <int E>
+struct RowRegs {
+  static constexpr int VEC = E >= 4 ? 4 : E;
+  float v[E];
+  __device__ __forceinline__ static int index(int lane, int e) {
+    return (e / VEC) * 64 * VEC + lane * VEC + (e % VEC);
+  }
+  __device__ __forceinline__ void load(const float* p, int lane) {
+    if constexpr (VEC == 4) {
+#pragma unroll
+      for (int j = 0; j < E / 4; ++j) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(p + j * 256 + lane * 4);
+        v[j * 4 + 0] = t[0]; v[j * 4 + 1] = t[1];
+        v[j * 4 + 2] = t[2]; v[j * 4 + 3] = t[3];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = p[index(lane, e)];
+    }
+  }
+  __device__ __forceinline__ void store(float* p, int lane) const {
+    if constexpr (VEC == 4) {
+#pragma unroll
+      for (int j = 0; j < E / 4; ++j) {
+        f32x4 t = {v[j * 4 + 0], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]};
+        *reinterpret_cast<f32x4*>(p + j * 256 + lane * 4) = t;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) p[index(lane, e)] = v[e];
+    }
+  }
+};
+
+template <int E>
+__device__ __forceinline__ void ln_inplace(RowRegs<E>& r, const float* w,
+                                           const float* b, int lane,
+                                           float eps) {
+  constexpr int D = E * 64;
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) s += r.v[e];
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const float d = r.v[e] - mean;
+    q += d * d;
+  }
+  const float var = wave_sum(q) * (1.0f / D);
+  const float rstd = 1.0f / sqrtf(var + eps);
+  RowRegs<E> ww, bb;
+  ww.load(w, lane);
+  bb.load(b, lane);
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    r.v[e] = (r.v[e] - mean) * rstd * ww.v[e] + bb.v[e];
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ w,
+    const float* __restrict__ b, float* __restrict__ y, int ldy, int M,
+    float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  RowRegs<E> r;
+  r.load(x + (int64_t)row * ldx, lane);
+  ln_inplace<E>(r, w, b, lane, eps);
+  r.store(y + (int64_t)row * ldy, lane);
+}
+
+// ===========================================================================
+// GlobalCMVN (cmvn.py:36-47) + Conv2d(1, C, 3, stride 2) + ReLU
+// (subsampling.py:188-190).  One block per (utterance, T1 frame): the three
+// normalised input rows sit in LDS, threads sweep (f1, c) with c fastest so
+// the channels-last output row is written in full 16-byte segments.
+__global__ __launch_bounds__(256) void cmvn_conv1_kernel(Conv1Args a) {
+  const int b = blockIdx.y;
+  const int t1 = blockIdx.x;
+  if (t1 >= a.t1_len[b]) return;
+  __shared__ float xin[3][128];
+  const float* src = a.feats + ((int64_t)b * a.T + 2 * t1) * a.F;
+  for (int i = threadIdx.x; i < 3 * a.F; i += 256) {
+    const int r = i / a.F, f = i % a.F;
+    float v = src[r * a.F + f];
+    if (a.mean) v = (v - a.mean[f]) * a.istd[f];
+    xin[r][f] = v;
+  }
+  __syncthreads();
+  float* dst = a.out + (int64_t)(a.t1_off[b] + t1) * a.F1 * a.C;
+  const int total = a.F1 * a.C;
+  for (int o = threadIdx.x; o < total; o += 256) {
+    const int f1 = o / a.C, c = o % a.C;
+    // accumulation order = (ky, kx) row-major, like a direct conv loop
+    float acc = a.bias[c];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        acc = fmaf(a.w[(ky * 3 + kx) * a.C + c], xin[ky][2 * f1 + kx], acc);
+    dst[o] = fmaxf(acc, 0.f);
+  }
+}
+
+// ===========================================================================
+// Depthwise Conv1d over time + LayerNorm(channels) + SiLU, the middle of
+// ConvolutionModule.forward (convolution.py:119-146).  One wave per output
+// frame, channels in registers.  A neighbour frame outside the utterance is
+// what the reference would have read there:
+//   t < 0           : causal -> GLU(pointwise_conv1(0)) = cpad (the K-1 left
+//                     pad happens BEFORE pointwise_conv1, :122-124);
+//                     symmetric -> 0 (Conv1d zero padding)
+//   len <= t < Tmax : cpad (masked_fill(~mask_pad, 0) before pointwise_conv1)
+//   t >= Tmax       : 0 (symmetric Conv1d zero padding past the tensor end)
+template <int E>
+__global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const int u = a.row_utt[row];
+  if (u < 0) return;
+  const int off = a.off[u], len = a.len[u];
+  const int t = row - off;
+  if (t >= len) return;
+  const int lpad = a.causal ? a.K - 1 : (a.K - 1) / 2;
+  RowRegs<E> acc, cp;
+  acc.load(a.bias, lane);
+  cp.load(a.cpad, lane);
+  for (int k = 0; k < a.K; ++k) {
+    const int tt = t + k - lpad;
+    RowRegs<E> wk;
+    wk.load(a.wt + (int64_t)k * (E * 64), lane);
+    if (tt >= 0 && tt < len) {
+      RowRegs<E> xv;
+      xv.load(a.x + (int64_t)(off + tt) * a.ldx, lane);
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc.v[e] = fmaf(wk.v[e], xv.v[e], acc.v[e]);
+    } else if ((tt < 0 && a.causal) || (tt >= len && tt < a.t_max)) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc.v[e] = fmaf(wk.v[e], cp.v[e], acc.v[e]);
+    }
+  }
+  ln_inplace<E>(acc, a.ln_w, a.ln_b, lane, a.eps);
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc.v[e] = silu_f(acc.v[e]);
+  acc.store(a.y + (int64_t)row * a.ldy, lane);
+}
+
+// ===========================================================================
+// Attention.  Replaces RelPositionMultiHeadedAttention.forward /
+// MultiHeadedAttention.forward_attention (attention.py:133-178,364-438) and
+// the decoder's self / cross attention.  No (T x T) score tensor ever reaches
+// HBM.
+//
+// One block = NW waves, each wave owns 32 query rows of one (sequence, head).
+// Per 32-key tile, K (and the projected position rows P) are staged in LDS and
+// the TRANSPOSED score tile S^T = K (Q+u)^T + P (Q+v)^T is produced with
+// v_mfma_f32_32x32x2_f32: lane l then holds, for ITS query (l & 31), the 16
+// keys (r&3)+8(r>>2)+4(l>>5), r = 0..15.  Row max / sum are 15 in-lane ops plus
+// one exchange with lane^32, and -- the point of the transposed form -- the
+// probabilities are already in the A-operand layout of the P.V MFMA: step s
+// consumes register p[s] directly against the V rows key(s, lane>>5).
+constexpr int KT = 32;          // keys per tile
+constexpr int KSTR = 68;        // LDS row stride (floats): 64 + 4 pad
+
+template <int NW, bool RELPOS>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
+  const int s = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (NW * 32);
+  const int qlen = a.q_len[s];
+  if (q0 >= qlen) return;
+  const int kvlen = a.kv_len[s];
+  const int qoff = a.q_off[s], kvoff = a.kv_off[s];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, li = lane & 31;
+
+  __shared__ __attribute__((aligned(16))) float sK[KT * KSTR];
+  __shared__ __attribute__((aligned(16))) float sP[RELPOS ? KT * KSTR : 4];
+  __shared__ __attribute__((aligned(16))) float sV[KT * KSTR];
+
+  // ---- this lane's query row ---------------------------------------------
+  const int qi = q0 + wave * 32 + li;
+  const int qc = qi < qlen ? qi : qlen - 1;
+  f32x4 qu[8], qv[8];
+  {
+    const float* qp = a.Q + (int64_t)(qoff + qc) * a.ldq + h * 64 + hi * 4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      f32x4 q = *reinterpret_cast<const f32x4*>(qp + kk * 8);
+      if (RELPOS) {
+        const f32x4 bu = *reinterpret_cast<const f32x4*>(
+            a.bias_u + h * 64 + kk * 8 + hi * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(
+            a.bias_v + h * 64 + kk * 8 + hi * 4);
+        qu[kk] = q + bu;
+        qv[kk] = q + bv;
+      } else {
+        qu[kk] = q;
+      }
+    }
+  }
+  // key window of this query: [jmin, jmax)
+  int jmin = 0, jmax = kvlen;
+  if (a.mask_mode == 1) {
+    jmax = min(kvlen, qi + 1);
+  } else if (a.mask_mode == 2) {
+    const int c = qi / a.chunk_size;
+    jmax = min(kvlen, (c + 1) * a.chunk_size);
+    if (a.left_chunks >= 0) jmin = max((c - a.left_chunks) * a.chunk_size, 0);
+  }
+  // key range of the whole block (uniform)
+  int blo = 0, bhi = kvlen;
+  {
+    const int qlast = min(q0 + NW * 32, qlen) - 1;
+    if (a.mask_mode == 1) {
+      bhi = min(kvlen, qlast + 1);
+    } else if (a.mask_mode == 2) {
+      bhi = min(kvlen, (qlast / a.chunk_size + 1) * a.chunk_size);
+      if (a.left_chunks >= 0)
+        blo = max((q0 / a.chunk_size - a.left_chunks) * a.chunk_size, 0);
+    }
+  }
+  const int t_lo = blo / KT, t_hi = (bhi + KT - 1) / KT;
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+
+  for (int kt = t_lo; kt < t_hi; ++kt) {
+    const int j0 = kt * KT;
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage K / P / V tiles: 32 rows x 16 float4 each -------------------
+    for (int c = tid; c < KT * 16; c += NW * 64) {
+      const int r = c >> 4, c4 = c & 15;
+      int j = j0 + r;
+      if (j > kvlen - 1) j = kvlen - 1;
+      const int64_t grow = kvoff + j;
+      *reinterpret_cast<f32x4*>(sK + r * KSTR + c4 * 4) =
+          *reinterpret_cast<const f32x4*>(a.K + grow * a.ldk + h * 64 + c4 * 4);
+      *reinterpret_cast<f32x4*>(sV + r * KSTR + c4 * 4) =
+          *reinterpret_cast<const f32x4*>(a.V + grow * a.ldv + h * 64 + c4 * 4);
+      if (RELPOS)
+        *reinterpret_cast<f32x4*>(sP + r * KSTR + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(a.P + (int64_t)j * a.ldp + h * 64 +
+                                            c4 * 4);
+    }
+    __syncthreads();
+
+    // ---- S^T tile -------------------------------------------------------------
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    const float* kf = sK + li * KSTR + hi * 4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const f32x4 fk = *reinterpret_cast<const f32x4*>(kf + kk * 8);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        sc = __builtin_amdgcn_mfma_f32_32x32x2f32(fk[t], qu[kk][t], sc, 0, 0, 0);
+    }
+    if (RELPOS) {
+      const float* pf = sP + li * KSTR + hi * 4;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const f32x4 fp = *reinterpret_cast<const f32x4*>(pf + kk * 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          sc = __builtin_amdgcn_mfma_f32_32x32x2f32(fp[t], qv[kk][t], sc, 0, 0,
+                                                    0);
+      }
+    }
+    // ---- online softmax on this lane's query -----------------------------------
+    float tmax = -1e30f;
+    bool ok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      ok[r] = (j >= jmin) && (j < jmax);
+      sc[r] *= a.scale;
+      if (ok[r]) tmax = fmaxf(tmax, sc[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = ok[r] ? expf(sc[r] - m_new) : 0.f;
+      sc[r] = p;
+      psum += p;
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    // rescale the running output: its rows are queries (r&3)+8(r>>2)+4hi
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * hi, 64);
+        o0[r] *= ar;
+        o1[r] *= ar;
+      }
+    }
+    // ---- O += P V ----------------------------------------------------------------
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int key = (st & 3) + 8 * (st >> 2) + 4 * hi;
+      const float v0 = sV[key * KSTR + li];
+      const float v1 = sV[key * KSTR + 32 + li];
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[st], v0, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[st], v1, o1, 0, 0, 0);
+    }
+  }
+  // ---- normalise and store -------------------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;  // fully-masked row -> 0
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    const float ir = __shfl(inv, qr, 64);
+    const int qrow = q0 + wave * 32 + qr;
+    if (qrow < qlen) {
+      float* op = a.O + (int64_t)(qoff + qrow) * a.ldo + h * 64;
+      op[li] = o0[r] * ir;
+      op[32 + li] = o1[r] * ir;
+    }
+  }
+}
+
+__global__ void copy_rows_kernel(const float* src, int lds, const int* src_rows,
+                                 float* dst, int ldd, const int* dst_rows,
+                                 int n_rows, int D4) {
+  const int r = blockIdx.x;
+  if (r >= n_rows) return;
+  const int sr = src_rows ? src_rows[r] : r;
+  const int dr = dst_rows ? dst_rows[r] : r;
+  if (sr < 0 || dr < 0) return;
+  const f32x4* s = reinterpret_cast<const f32x4*>(src + (int64_t)sr * lds);
+  f32x4* d = reinterpret_cast<f32x4*>(dst + (int64_t)dr * ldd);
+  for (int i = threadIdx.x; i < D4; i += blockDim.x) d[i] = s[i];
+}
+
+}  // namespace
+
+int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
+              int ldy, int M, int D, float eps, hipStream_t s) {
+  WN_CHECK(M > 0, "layernorm: empty");
+  WN_CHECK(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: row stride % 4");
+  dim3 g(cdiv(M, 4)), t(256);
+#define WN_LN(E)                                                             \
+  case E * 64:                                                               \
+    hipLaunchKernelGGL(layernorm_kernel<E>, g, t, 0, s, x, ldx, w, b, y, ldy, \
+                       M, eps);                                              \
+    break;
+  switch (D) {
+    WN_LN(1) WN_LN(2) WN_LN(4) WN_LN(8) WN_LN(12) WN_LN(16) WN_LN(20)
+    default:
+      set_error("layernorm: unsupported width " + std::to_string(D));
+      return -1;
+  }
+#undef WN_LN
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+int cmvn_conv1_relu(const Conv1Args& a, hipStream_t s) {
+  WN_CHECK(a.F <= 128, "conv1: feature dim > 128");
+  WN_CHECK(a.max_t1 > 0 && a.B > 0, "conv1: empty");
+  hipLaunchKernelGGL(cmvn_conv1_kernel, dim3(a.max_t1, a.B), dim3(256), 0, s,
+                     a);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+int dwconv_ln_silu(const DwConvArgs& a, hipStream_t s) {
+  dim3 g(cdiv(a.M, 4)), t(256);
+#define WN_DW(E)                                              \
+  case E * 64:                                                \
+    hipLaunchKernelGGL(dwconv_kernel<E>, g, t, 0, s, a);      \
+    break;
+  switch (a.D) {
+    WN_DW(1) WN_DW(2) WN_DW(4) WN_DW(8) WN_DW(12) WN_DW(16) WN_DW(20)
+    default:
+      set_error("dwconv: unsupported width " + std::to_string(a.D));
+      return -1;
+  }
+#undef WN_DW
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+int attention(const AttnArgs& a, hipStream_t s) {
+  WN_CHECK(a.n_seq > 0 && a.n_heads > 0 && a.max_q_len > 0, "attention: empty");
+  WN_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0,
+           "attention: strides must be multiples of 4 floats");
+  WN_CHECK(a.mask_mode != 2 || a.chunk_size > 0, "attention: chunk size");
+  constexpr int NW = 2;
+  dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 64);
+  if (a.P)
+    hipLaunchKernelGGL((attention_kernel<NW, true>), g, t, 0, s, a);
+  else
+    hipLaunchKernelGGL((attention_kernel<NW, false>), g, t, 0, s, a);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+int copy_rows(const float* src, int lds, const int* src_rows, float* dst,
+              int ldd, const int* dst_rows, int n_rows, int D, hipStream_t s) {
+  if (n_rows <= 0) return 0;
+  WN_CHECK(D % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0, "copy_rows: % 4");
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(n_rows), dim3(64), 0, s, src, lds,
+                     src_rows, dst, ldd, dst_rows, n_rows, D / 4);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+int fill_zero(void* p, size_t bytes, hipStream_t s) {
+  WN_HIP(hipMemsetAsync(p, 0, bytes, s));
+  return 0;
+}
+
+}  // namespace wn

@@ -1,0 +1,291 @@
+// fp32 GEMM on CDNA4 matrix cores: C = epi(A[M,K] * W[N,K]^T).
+//
+// This is the kernel family that carries ~98 % of the encoder's FLOPs (FFN,
+// QKV / out projections, pointwise convs, CTC head, decoder projections and the
+// implicit-GEMM 3x3/s2 subsampling conv).  It replaces the torch.nn.Linear /
+// Conv calls of wenet/models/transformer/{positionwise_feed_forward.py:50-58,
+// attention.py:109-131,176, convolution.py:138,148, subsampling.py:188-226}.
+//
+// Design (gfx950):
+//  * v_mfma_f32_32x32x2_f32: exact fp32 multiply / fp32 accumulate (bitwise an
+//    fmaf chain), 64 FLOP/clk/SIMD = 157.3 TF chip peak.  The reference runs
+//    fp32, and greedy-token identity / 1e-3 rescoring parity need fp32.
+//  * 256 threads = 4 waves in a WGM x WGN grid; each wave owns MT x NT 32x32
+//    accumulator tiles (64 acc VGPRs for the 128x128 block).
+//  * K tile = 32 floats.  A and W tiles are staged global -> VGPR -> LDS with a
+//    36-float row stride: a wave's ds_read_b128 (lane = row, 16 B of k) then
+//    hits 16 distinct 16-B slots per 16-lane service group -> conflict-free.
+//    One 16-B LDS read feeds 4 MFMAs (lanes 0-31 carry k..k+3, lanes 32-63
+//    k+4..k+7; any k pairing is legal as long as A and W agree).
+//  * double-buffered LDS, one barrier per K tile; global loads for tile t+1
+//    are issued before the MFMAs of tile t.
+//  * XCD-aware block order: the N tiles of one M panel run on the same XCD so
+//    the A panel is fetched into one L2, not eight.
+//  * epilogue fused: bias, SiLU/ReLU, alpha, residual add, GLU.
+#include "common.h"
+
+namespace wn {
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_STRIDE = 36;  // floats
+
+template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
+          bool CONV>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m,
+                                                        int tiles_n) {
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int A_CHUNKS = BM * 8 / 256;  // float4 chunks per thread
+  constexpr int B_CHUNKS = BN * 8 / 256;
+  static_assert(WGM * WGN == 4, "4 waves per block");
+  static_assert(!GLU || NT == 2, "GLU epilogue needs a 64-wide wave tile");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TILE = (BM + BN) * LDS_STRIDE;  // floats per buffer: A then W
+
+  // ---- XCD-aware tile assignment (bijective for any grid size) -----------
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8;
+    const int xcd = bid % 8, slot = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn_ = wave % WGN;
+
+  // ---- per-thread global load descriptors --------------------------------
+  const float* a_ptr[A_CHUNKS];
+  int a_lds[A_CHUNKS];
+#pragma unroll
+  for (int i = 0; i < A_CHUNKS; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c >> 3, kc = c & 7;
+    int grow = m0 + row;
+    if (grow > p.M - 1) grow = p.M - 1;
+    if (CONV) {
+      a_ptr[i] = p.A + p.a_row_off[grow] + kc * 4;
+    } else {
+      a_ptr[i] = p.A + (int64_t)grow * p.lda + kc * 4;
+    }
+    a_lds[i] = row * LDS_STRIDE + kc * 4;
+  }
+  const float* b_ptr[B_CHUNKS];
+  int b_lds[B_CHUNKS];
+#pragma unroll
+  for (int i = 0; i < B_CHUNKS; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c >> 3, kc = c & 7;
+    int grow = n0 + row;
+    if (grow > p.N - 1) grow = p.N - 1;
+    b_ptr[i] = p.W + (int64_t)grow * p.K + kc * 4;
+    b_lds[i] = row * LDS_STRIDE + kc * 4;
+  }
+
+  f32x4 ra[A_CHUNKS], rb[B_CHUNKS];
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+    int64_t aoff = k0;
+    if (CONV) {
+      const int tap = k0 / p.conv_C;
+      aoff = (int64_t)(tap / 3) * p.conv_sy + (int64_t)(tap % 3) * p.conv_sx +
+             (k0 - tap * p.conv_C);
+    }
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i)
+      ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + aoff);
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i)
+      rb[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + k0);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i)
+      *reinterpret_cast<f32x4*>(smem + buf * TILE + a_lds[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i)
+      *reinterpret_cast<f32x4*>(smem + buf * TILE + BM * LDS_STRIDE +
+                                b_lds[i]) = rb[i];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nk = p.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  // LDS fragment addresses: row = lane & 31, k sub-block = lane >> 5.
+  const int frag_off = (lane & 31) * LDS_STRIDE + (lane >> 5) * 4;
+  const int a_frag = (wm * WTM) * LDS_STRIDE + frag_off;
+  const int b_frag = (wn_ * WTN) * LDS_STRIDE + frag_off;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const float* cA = smem + cur * TILE + a_frag;
+    const float* cB = smem + cur * TILE + BM * LDS_STRIDE + b_frag;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        fa[i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * LDS_STRIDE +
+                                                kk * 8);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        fb[j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LDS_STRIDE +
+                                                kk * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------
+  // C/D layout of the 32x32 MFMA: col = lane & 31,
+  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  const int col_in = lane & 31;
+  const int row_hi = (lane >> 5) * 4;
+  if (GLU) {
+    const int ncol_out = p.N / 2;
+    const int cbase = n0 + wn_ * WTN;  // permuted column of the 'a' half
+    const int ca = cbase + col_in, cg = cbase + 32 + col_in;
+    const int cout = cbase / 2 + col_in;
+    const bool cok = cg < p.N;
+    const float ba = (p.bias && cok) ? p.bias[ca] : 0.0f;
+    const float bg = (p.bias && cok) ? p.bias[cg] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
+        if (row < p.M && cok) {
+          const float a = acc[i][0][r] + ba;
+          const float g = acc[i][1][r] + bg;
+          p.C[(int64_t)row * p.ldc + cout] = a * sigmoid_f(g);
+        }
+      }
+    }
+    (void)ncol_out;
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn_ * WTN + j * 32 + col_in;
+    const bool cok = col < p.N;
+    const float b = (p.bias && cok) ? p.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
+        if (row < p.M && cok) {
+          float v = acc[i][j][r] + b;
+          if (ACT == ACT_SILU) v = silu_f(v);
+          if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+          v *= p.alpha;
+          if (RESID) v += p.resid[(int64_t)row * p.ldr + col];
+          p.C[(int64_t)row * p.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
+          bool CONV>
+int launch(const GemmArgs& a, hipStream_t stream) {
+  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
+  const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
+  auto kern = gemm_f32_kernel<BM, BN, WGM, WGN, ACT, RESID, GLU, CONV>;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, a,
+                     tiles_m, tiles_n);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int BM, int BN, int WGM, int WGN, bool CONV>
+int dispatch_epi(const GemmArgs& a, hipStream_t s) {
+  const bool resid = a.resid != nullptr;
+  if (a.glu) {
+    if constexpr (BN / WGN == 64 && !CONV) {
+      return launch<BM, BN, WGM, WGN, ACT_NONE, false, true, false>(a, s);
+    } else {
+      set_error("gemm: GLU epilogue needs a 64-wide wave tile");
+      return -1;
+    }
+  }
+  switch (a.act) {
+    case ACT_NONE:
+      return resid ? launch<BM, BN, WGM, WGN, ACT_NONE, true, false, CONV>(a, s)
+                   : launch<BM, BN, WGM, WGN, ACT_NONE, false, false, CONV>(a, s);
+    case ACT_SILU:
+      if constexpr (!CONV)
+        return resid ? launch<BM, BN, WGM, WGN, ACT_SILU, true, false, false>(a, s)
+                     : launch<BM, BN, WGM, WGN, ACT_SILU, false, false, false>(a, s);
+      break;
+    case ACT_RELU:
+      return resid ? launch<BM, BN, WGM, WGN, ACT_RELU, true, false, CONV>(a, s)
+                   : launch<BM, BN, WGM, WGN, ACT_RELU, false, false, CONV>(a, s);
+  }
+  set_error("gemm: unsupported epilogue");
+  return -1;
+}
+
+}  // namespace
+
+int gemm_f32(const GemmArgs& a, hipStream_t stream) {
+  WN_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
+  WN_CHECK(a.K % BK == 0, "gemm: K must be a multiple of 32");
+  WN_CHECK(a.A && a.W && a.C, "gemm: null operand");
+  const bool conv = a.a_row_off != nullptr;
+  if (conv) {
+    WN_CHECK(a.conv_C % BK == 0 && a.K == 9 * a.conv_C,
+             "gemm(conv): K must be 9*C with C % 32 == 0");
+  } else {
+    WN_CHECK(a.lda % 4 == 0, "gemm: lda must be a multiple of 4 floats");
+  }
+  if (a.glu) WN_CHECK(a.N % 64 == 0, "gemm(GLU): N must be a multiple of 64");
+  // Tile choice: the 128x128 block is the efficient one (64 MFMAs per wave per
+  // K tile between barriers); fall back to 64-row / 64x64 blocks when the
+  // problem would otherwise leave most of the 256 CUs idle.
+  const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
+  const int64_t t64x128 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 128);
+  if (conv) {
+    if (t128 >= 384) return dispatch_epi<128, 128, 2, 2, true>(a, stream);
+    return dispatch_epi<64, 128, 2, 2, true>(a, stream);
+  }
+  if (t128 >= 384) return dispatch_epi<128, 128, 2, 2, false>(a, stream);
+  if (t64x128 >= 256 || a.glu)
+    return dispatch_epi<64, 128, 2, 2, false>(a, stream);
+  return dispatch_epi<64, 64, 2, 2, false>(a, stream);
+}
+
+}  // namespace wn

@@ -1,0 +1,115 @@
+// Launch wrappers of the non-GEMM kernels of libwenet_amd.
+#pragma once
+#include "common.h"
+
+namespace wn {
+
+// y[r,:] = LayerNorm(x[r,:]) * w + b, one wave per row; D in {64..1024, %64}.
+int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
+              int ldy, int M, int D, float eps, hipStream_t s);
+
+// GlobalCMVN + Conv2d(1->C,3,stride 2) + ReLU over the padded (B,T,F) frame
+// tensor, written packed channels-last: out[(t1_off[b]+t1)*F1 + f1][c].
+struct Conv1Args {
+  const float* feats;    // (B, T, F) padded
+  const float* mean;     // [F] or null (no CMVN)
+  const float* istd;     // [F]
+  const float* w;        // [9][C]  (tap-major, reordered from (C,1,3,3))
+  const float* bias;     // [C]
+  float* out;            // [sum T1_b][F1][C]
+  const int* t1_off;     // [B] packed row offset (in T1 frames)
+  const int* t1_len;     // [B] number of T1 frames to produce
+  int B, T, F, F1, C, max_t1;
+};
+int cmvn_conv1_relu(const Conv1Args& a, hipStream_t s);
+
+// Depthwise conv over time + LayerNorm(channels) + SiLU (the middle of
+// ConvolutionModule.forward).  x is the GLU output [rows][D].
+struct DwConvArgs {
+  const float* x; int ldx;
+  const float* wt;      // [K][D] tap-major depthwise weights
+  const float* bias;    // [D]
+  const float* cpad;    // [D] value of a padded (masked / left-pad) frame
+  const float* ln_w; const float* ln_b;
+  float* y; int ldy;
+  const int* row_utt;   // [M] utterance of each row (-1: skip)
+  const int* off;       // [B] first row of utterance
+  const int* len;       // [B] valid frames
+  int M, D, K, causal, t_max;  // t_max: padded length T' of the batch
+  float eps;
+};
+int dwconv_ln_silu(const DwConvArgs& a, hipStream_t s);
+
+// Multi-head attention with online softmax (d_k = 64).  Optional relative
+// position term: score = ((q+u).k + (q+v).p) * scale.
+struct AttnArgs {
+  const float* Q; const float* K; const float* V;
+  int ldq, ldk, ldv;
+  const float* P = nullptr; int ldp = 0;      // [T][h*64] projected pos table
+  const float* bias_u = nullptr; const float* bias_v = nullptr;  // [h][64]
+  float* O; int ldo;
+  const int* q_off; const int* q_len;   // [n_seq]
+  const int* kv_off; const int* kv_len; // [n_seq]
+  int n_seq, n_heads, max_q_len;
+  int mask_mode = 0;   // 0: keys < kv_len; 1: causal; 2: chunk window
+  int chunk_size = 0, left_chunks = -1;
+  float scale = 0.125f;
+};
+int attention(const AttnArgs& a, hipStream_t s);
+
+// CTC head tail: per row log-softmax statistics + top-k (descending, lower
+// index first on ties) (+ optionally the full log-prob row).
+struct CtcRowArgs {
+  const float* logits; int ld;    // [M][V]
+  int M, V, k;
+  int blank; float blank_penalty;
+  float* topk_val;   // [M][k] log-probs
+  int* topk_idx;     // [M][k]
+  float* logp;       // [M][ld_out] or null
+  int ld_out;
+};
+int ctc_logsoftmax_topk(const CtcRowArgs& a, hipStream_t s);
+
+// Greedy collapse (ctc_greedy_search): per utterance remove repeats + blanks.
+int ctc_greedy_collapse(const int* top1, int top1_stride, const int* off,
+                        const int* len, int B, int blank, int* out_tokens,
+                        int out_stride, int* out_lens, hipStream_t s);
+
+// CTC prefix beam search, one workgroup per utterance.
+struct PrefixBeamArgs {
+  const float* topk_val; const int* topk_idx; int k;  // [rows][k]
+  const int* off; const int* len; int B;
+  int beam, blank, max_len;
+  // node pools (device scratch): see prefix_beam.hip
+  int* pool; int64_t pool_stride;  // ints per utterance
+  // outputs
+  int* n_hyps;          // [B]
+  int* hyp_lens;        // [B][beam]
+  int* hyp_tlens;       // [B][beam] length of the times list
+  int* hyp_tokens;      // [B][beam][max_len]
+  int* hyp_times;       // [B][beam][max_len]
+  double* hyp_scores;   // [B][beam]
+};
+int64_t prefix_beam_pool_ints(int max_len, int beam);
+int ctc_prefix_beam(const PrefixBeamArgs& a, hipStream_t s);
+
+// Kaldi fbank (see fbank.hip).
+struct FbankArgs {
+  const float* pcm;          // all utterances back to back, float in [-1, 1]
+  const int64_t* sample_off; // [B] first sample of each utterance (device)
+  const int* n_frames;       // [B] (device)
+  int B, max_frames, n_mel;
+  const float* window;       // [400] povey
+  const float* twiddle;      // [256][2] cos, -sin of 2*pi*k/512
+  const int* mel_start; const int* mel_len; const int* mel_off;  // [n_mel]
+  const float* mel_w;        // CSR weights
+  float* feats;              // (B, max_frames, n_mel)
+};
+int fbank_kaldi(const FbankArgs& a, hipStream_t s);
+
+// rows scatter/gather helpers
+int copy_rows(const float* src, int lds, const int* src_rows, float* dst,
+              int ldd, const int* dst_rows, int n_rows, int D, hipStream_t s);
+int fill_zero(void* p, size_t bytes, hipStream_t s);
+
+}  // namespace wn

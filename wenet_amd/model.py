@@ -1,0 +1,449 @@
+"""`ASRModel` / `load_model` with the reference's API surface, running on
+libwenet_amd's HIP kernels.
+
+Mirrors (reference file:line):
+  * wenet.load_model(model_dir, device)          wenet/cli/model.py:71-110
+  * ASRModel.decode(methods, speech, lens, ...)  wenet/models/transformer/asr_model.py:267-343
+  * ASRModel.transcribe(wav)                     asr_model.py:345-358
+  * ASRModel._forward_encoder / ctc_logprobs     asr_model.py:216-239, 254-265
+  * sos_symbol / eos_symbol / subsampling_rate / right_context /
+    is_bidirectional_decoder                     asr_model.py:360-383, 443-451
+
+torch is used only as the tensor container (device memory, streams) and to read
+`final.pt`.  There is no CPU path: everything below raises if the HIP library
+is missing or the tensors are not on a GPU.
+"""
+import ctypes
+import json
+import math
+import os
+import wave
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from wenet_amd import _lib
+from wenet_amd.search import (DecodeResult, _greedy, _prefix_beam,
+                              _require_cuda, _stream_ptr, rescore_from_logps)
+
+_SUPPORTED = ('ctc_greedy_search', 'ctc_prefix_beam_search',
+              'attention_rescoring')
+
+
+def config_from_yaml(configs: dict) -> _lib.WnConfig:
+    """train.yaml dict -> wn_config (keys as init_model.py:100-181 reads them)."""
+    ec = configs['encoder_conf']
+    dc = configs.get('decoder_conf') or {}
+    if configs.get('encoder', 'conformer') != 'conformer':
+        raise NotImplementedError('only the Conformer encoder is accelerated')
+    checks = dict(input_layer='conv2d', pos_enc_layer_type='rel_pos',
+                  selfattention_layer_type='rel_selfattn',
+                  activation_type='swish', cnn_module_norm='layer_norm',
+                  normalize_before=True, use_cnn_module=True,
+                  macaron_style=True)
+    defaults = dict(input_layer='conv2d', pos_enc_layer_type='rel_pos',
+                    selfattention_layer_type='rel_selfattn',
+                    activation_type='swish', cnn_module_norm='batch_norm',
+                    normalize_before=True, use_cnn_module=True,
+                    macaron_style=True)
+    for k, v in checks.items():
+        got = ec.get(k, defaults[k])
+        if got != v:
+            raise NotImplementedError(
+                f'encoder_conf.{k}={got!r} is outside the accelerated path '
+                f'(needs {v!r})')
+    vocab = configs['output_dim']
+    st = (configs.get('tokenizer_conf') or {}).get('special_tokens')
+    sos = vocab - 1 if st is None else st.get('<sos>', vocab - 1)
+    eos = vocab - 1 if st is None else st.get('<eos>', vocab - 1)
+    dec_type = configs.get('decoder', 'bitransformer')
+    bidir = dec_type == 'bitransformer'
+    c = _lib.WnConfig()
+    c.feat_dim = configs['input_dim']
+    c.d_model = ec.get('output_size', 256)
+    c.n_heads = ec.get('attention_heads', 4)
+    c.ffn_dim = ec.get('linear_units', 2048)
+    c.n_layers = ec.get('num_blocks', 6)
+    c.cnn_kernel = ec.get('cnn_module_kernel', 15)
+    c.causal = int(bool(ec.get('causal', False)))
+    c.use_dynamic_chunk = int(bool(ec.get('use_dynamic_chunk', False)))
+    c.static_chunk_size = ec.get('static_chunk_size', 0)
+    c.vocab = vocab
+    c.has_cmvn = int(configs.get('cmvn', None) == 'global_cmvn')
+    c.dec_heads = dc.get('attention_heads', 4)
+    c.dec_ffn_dim = dc.get('linear_units', 2048)
+    c.dec_layers = dc.get('num_blocks', 6) if dec_type is not None else 0
+    c.dec_r_layers = dc.get('r_num_blocks', 0) if bidir else 0
+    c.bidirectional = int(bidir)
+    c.sos, c.eos = sos, eos
+    c.max_pos = 5000
+    c.norm_eps = ec.get('norm_eps', 1e-5)
+    return c
+
+
+def load_cmvn(cmvn_file: str, is_json: bool):
+    """wenet/utils/cmvn.py:21-93 -> (mean, istd) float64 arrays."""
+    if is_json:
+        with open(cmvn_file) as f:
+            st = json.load(f)
+        means, variance, count = st['mean_stat'], st['var_stat'], st['frame_num']
+    else:
+        with open(cmvn_file) as f:
+            arr = f.read().split()
+        assert arr[0] == '[' and arr[-2] == '0' and arr[-1] == ']'
+        dim = int((len(arr) - 2 - 2) / 2)
+        means = [float(x) for x in arr[1:dim + 1]]
+        count = float(arr[dim + 1])
+        variance = [float(x) for x in arr[dim + 2:2 * dim + 2]]
+    means = list(means)
+    variance = list(variance)
+    for i in range(len(means)):
+        means[i] /= count
+        variance[i] = variance[i] / count - means[i] * means[i]
+        if variance[i] < 1.0e-20:
+            variance[i] = 1.0e-20
+        variance[i] = 1.0 / math.sqrt(variance[i])
+    return np.array(means), np.array(variance)
+
+
+class _Tokenizer:
+    """id -> symbol table from units.txt; `detokenize` like
+    wenet/text/base_tokenizer.py:14 + char/bpe tokenizers (join the symbols;
+    sentencepiece's word-boundary mark becomes a space)."""
+
+    def __init__(self, units_file: str):
+        self.id2sym = {}
+        with open(units_file, 'r', encoding='utf8') as f:
+            for line in f:
+                arr = line.strip().split()
+                if len(arr) == 2:
+                    self.id2sym[int(arr[1])] = arr[0]
+
+    def detokenize(self, ids: List[int]) -> Tuple[str, List[str]]:
+        tokens = [self.id2sym.get(int(i), '<unk>') for i in ids]
+        text = ''.join(tokens).replace('▁', ' ').strip()
+        return text, tokens
+
+
+class ASRModel:
+    """GPU-resident Conformer CTC/attention model with the reference's
+    inference API."""
+
+    default_decode_method = 'attention_rescoring'  # asr_model.py:40
+
+    def __init__(self, configs: dict, state_dict: Dict[str, torch.Tensor],
+                 device='cuda'):
+        self.configs = configs
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError(
+                'wenet_amd.ASRModel needs a GPU device (MI355X); there is no '
+                'CPU fallback -- use the reference for CPU decoding')
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self._cfg = config_from_yaml(configs)
+        self.vocab_size = self._cfg.vocab
+        self.sos, self.eos = self._cfg.sos, self._cfg.eos
+        self.ignore_id = -1
+        mc = configs.get('model_conf') or {}
+        self.ctc_weight = mc.get('ctc_weight', 0.5)
+        self.reverse_weight = mc.get('reverse_weight', 0.0)
+        self.special_tokens = (configs.get('tokenizer_conf') or {}).get(
+            'special_tokens')
+        L = _lib.lib()
+        arrs, tensors = [], (_lib.WnTensor * len(state_dict))()
+        for i, (k, v) in enumerate(state_dict.items()):
+            a = np.ascontiguousarray(
+                v.detach().to('cpu', torch.float32).numpy()
+                if isinstance(v, torch.Tensor) else np.asarray(v, np.float32))
+            arrs.append(a)
+            tensors[i].name = k.encode('utf8')
+            tensors[i].data = _lib.f32p(a)
+            tensors[i].numel = a.size
+        h = ctypes.c_void_p()
+        _lib.check(
+            L.wn_model_create(ctypes.byref(self._cfg), tensors,
+                              len(state_dict), self.device.index,
+                              ctypes.byref(h)), 'wn_model_create')
+        self._h = h.value
+        self._L = L
+        self._last_prefix_raw = None
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            try:
+                self._L.wn_model_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # torch.nn.Module-flavoured no-ops so reference driver code keeps working
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device).type != 'cuda':
+            raise RuntimeError('wenet_amd models live on the GPU only')
+        return self
+
+    # ---- exported symbols ------------------------------------------------
+    def subsampling_rate(self) -> int:  # asr_model.py:360-365
+        return 4
+
+    def right_context(self) -> int:  # asr_model.py:367-371 (Conv2dSubsampling4)
+        return 6
+
+    def sos_symbol(self) -> int:
+        return self.sos
+
+    def eos_symbol(self) -> int:
+        return self.eos
+
+    def is_bidirectional_decoder(self) -> bool:
+        return bool(self._cfg.bidirectional)
+
+    # ---- stages ----------------------------------------------------------
+    def _prep(self, speech: torch.Tensor, speech_lengths: torch.Tensor):
+        assert speech.shape[0] == speech_lengths.shape[0]
+        speech = speech.detach().to(self.device, torch.float32).contiguous()
+        lens = speech_lengths.detach().cpu().numpy().astype(np.int32)
+        return speech, lens
+
+    def _encode(self, speech, lens, chunk, left, want_out: bool):
+        B, T, F = speech.shape
+        assert F == self._cfg.feat_dim, 'feature dimension mismatch'
+        Tp = ((T - 1) // 2 - 1) // 2
+        enc_lens = np.zeros((B, ), dtype=np.int32)
+        out = None
+        if want_out:
+            out = torch.empty((B, Tp, self._cfg.d_model), dtype=torch.float32,
+                              device=self.device)
+        _lib.check(
+            self._L.wn_encode(self._h, speech.data_ptr(), _lib.i32p(lens), B,
+                              T, chunk, left,
+                              out.data_ptr() if out is not None else None,
+                              _lib.i32p(enc_lens), _stream_ptr(self.device)),
+            'wn_encode')
+        return out, enc_lens, Tp
+
+    def _forward_encoder(self, speech, speech_lengths,
+                         decoding_chunk_size: int = -1,
+                         num_decoding_left_chunks: int = -1,
+                         simulate_streaming: bool = False):
+        """asr_model.py:216-239 -> (encoder_out (B,T',d), encoder_mask (B,1,T'))."""
+        if simulate_streaming and decoding_chunk_size > 0:
+            raise NotImplementedError(
+                'forward_chunk_by_chunk (cache-based streaming) is not on the '
+                'accelerated path; use the chunk-mask decode')
+        speech, lens = self._prep(speech, speech_lengths)
+        out, enc_lens, Tp = self._encode(speech, lens, decoding_chunk_size,
+                                         num_decoding_left_chunks, True)
+        mask = (torch.arange(Tp, device=self.device).unsqueeze(0) <
+                torch.as_tensor(enc_lens, device=self.device).unsqueeze(1))
+        return out, mask.unsqueeze(1)
+
+    def _set_encoder_out(self, encoder_out: torch.Tensor, encoder_lens):
+        _require_cuda(encoder_out, '_set_encoder_out')
+        enc = encoder_out.detach().to(torch.float32).contiguous()
+        lens = torch.as_tensor(encoder_lens).detach().cpu().numpy().astype(
+            np.int32)
+        B, Tp, d = enc.shape
+        assert d == self._cfg.d_model
+        _lib.check(
+            self._L.wn_set_encoder_out(self._h, enc.data_ptr(),
+                                       _lib.i32p(lens), B, Tp,
+                                       _stream_ptr(self.device)),
+            'wn_set_encoder_out')
+        return B, Tp
+
+    def ctc_logprobs(self, encoder_out: torch.Tensor,
+                     blank_penalty: float = 0.0, blank_id: int = 0,
+                     encoder_lens=None):
+        """asr_model.py:254-265 -> (B, T', V) log-probs in HBM."""
+        B, Tp, _ = encoder_out.shape
+        if encoder_lens is None:
+            encoder_lens = torch.full((B, ), Tp, dtype=torch.int32)
+        self._set_encoder_out(encoder_out, encoder_lens)
+        out = torch.empty((B, Tp, self.vocab_size), dtype=torch.float32,
+                          device=self.device)
+        _lib.check(
+            self._L.wn_ctc_logprobs(self._h, 1, blank_id, blank_penalty,
+                                    out.data_ptr(), Tp,
+                                    _stream_ptr(self.device)),
+            'wn_ctc_logprobs')
+        return out
+
+    def _rescore(self, ctc_prefix_results: List[DecodeResult],
+                 ctc_weight: float, reverse_weight: float):
+        B = len(ctc_prefix_results)
+        beam = max(max(len(r.nbest) for r in ctc_prefix_results), 1)
+        max_len = max(
+            max((len(h) for h in r.nbest), default=0)
+            for r in ctc_prefix_results)
+        max_len = max(max_len, 1)
+        n_hyps = np.zeros((B, ), dtype=np.int32)
+        hyp_lens = np.zeros((B, beam), dtype=np.int32)
+        hyp_tokens = np.zeros((B, beam, max_len), dtype=np.int32)
+        for b, r in enumerate(ctc_prefix_results):
+            n_hyps[b] = len(r.nbest)
+            for i, h in enumerate(r.nbest):
+                hyp_lens[b, i] = len(h)
+                hyp_tokens[b, i, :len(h)] = np.asarray(h, dtype=np.int32)
+        l2r = np.zeros((B, beam, max_len + 1), dtype=np.float32)
+        r2l = np.zeros((B, beam, max_len + 1), dtype=np.float32)
+        _lib.check(
+            self._L.wn_attention_rescoring(
+                self._h, beam, _lib.i32p(n_hyps), _lib.i32p(hyp_lens),
+                _lib.i32p(hyp_tokens), max_len, float(reverse_weight),
+                _lib.f32p(l2r), _lib.f32p(r2l), _stream_ptr(self.device)),
+            'wn_attention_rescoring')
+        use_r2l = bool(self._cfg.bidirectional and self._cfg.dec_r_layers > 0)
+        return rescore_from_logps(
+            [r.nbest for r in ctc_prefix_results],
+            [r.nbest_scores for r in ctc_prefix_results],
+            [r.nbest_times for r in ctc_prefix_results], l2r, r2l, ctc_weight,
+            reverse_weight, use_r2l)
+
+    # ---- the drop-in entry point -----------------------------------------
+    def decode(self,
+               methods: List[str],
+               speech: torch.Tensor,
+               speech_lengths: torch.Tensor,
+               beam_size: int = 1,
+               decoding_chunk_size: int = -1,
+               num_decoding_left_chunks: int = -1,
+               ctc_weight: float = 0.0,
+               simulate_streaming: bool = False,
+               reverse_weight: float = 0.0,
+               context_graph=None,
+               blank_id: int = 0,
+               blank_penalty: float = 0.0,
+               length_penalty: float = 0.0,
+               infos: Dict[str, List[str]] = None
+               ) -> Dict[str, List[DecodeResult]]:
+        """asr_model.py:267-343."""
+        assert speech.shape[0] == speech_lengths.shape[0]
+        assert decoding_chunk_size != 0
+        for mth in methods:
+            if mth == 'attention':
+                raise NotImplementedError(
+                    "'attention' (autoregressive beam search) is not on the "
+                    'accelerated path yet (SURVEY.md section 8f)')
+        if context_graph is not None:
+            raise NotImplementedError('context biasing is not accelerated')
+        if simulate_streaming and decoding_chunk_size > 0:
+            raise NotImplementedError('simulate_streaming is not accelerated')
+        speech, lens = self._prep(speech, speech_lengths)
+        B = speech.shape[0]
+        _, enc_lens, Tp = self._encode(speech, lens, decoding_chunk_size,
+                                       num_decoding_left_chunks, False)
+        need_beam = ('ctc_prefix_beam_search' in methods
+                     or 'attention_rescoring' in methods)
+        k = beam_size if need_beam else 1
+        _lib.check(
+            self._L.wn_ctc_logprobs(self._h, k, blank_id, blank_penalty, None,
+                                    Tp, _stream_ptr(self.device)),
+            'wn_ctc_logprobs')
+        results = {}
+        max_len = int(enc_lens.max()) if B > 0 else 0
+        if 'ctc_greedy_search' in methods:
+            results['ctc_greedy_search'] = _greedy(self._h, B, max_len,
+                                                   blank_id, self.device)
+        prefix = None
+        if need_beam:
+            prefix, self._last_prefix_raw = _prefix_beam(
+                self._h, B, max_len, beam_size, blank_id, self.device)
+            if 'ctc_prefix_beam_search' in methods:
+                results['ctc_prefix_beam_search'] = prefix
+        if 'attention_rescoring' in methods:
+            results['attention_rescoring'] = self._rescore(
+                prefix, ctc_weight, reverse_weight)
+        return results
+
+    # older WeNet releases exposed decode() as recognize()
+    def recognize(self, *args, **kwargs):
+        return self.decode(*args, **kwargs)
+
+    # ---- features + single-file CLI path -----------------------------------
+    def compute_fbank(self, waveforms: List[np.ndarray]
+                      ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """processor.compute_fbank + padding for a list of float waveforms in
+        [-1, 1] (16 kHz) -> ((B, Tmax, F) features in HBM, lengths)."""
+        B = len(waveforms)
+        offs = np.zeros((B + 1, ), dtype=np.int64)
+        for i, w in enumerate(waveforms):
+            offs[i + 1] = offs[i] + len(w)
+        pcm = torch.from_numpy(
+            np.concatenate([np.asarray(w, np.float32) for w in waveforms])
+        ).to(self.device)
+        nfr = [0 if len(w) < 400 else 1 + (len(w) - 400) // 160
+               for w in waveforms]
+        tmax = max(max(nfr), 1)
+        feats = torch.empty((B, tmax, self._cfg.feat_dim), dtype=torch.float32,
+                            device=self.device)
+        n_frames = np.zeros((B, ), dtype=np.int32)
+        _lib.check(
+            self._L.wn_fbank(self._h, pcm.data_ptr(), _lib.i64p(offs), B,
+                             feats.data_ptr(), tmax, _lib.i32p(n_frames),
+                             _stream_ptr(self.device)), 'wn_fbank')
+        return feats, torch.from_numpy(n_frames.copy())
+
+    def compute_feature(self, wav_file: str) -> torch.Tensor:
+        """cli/model.py:59-66: decode_wav -> (resample) -> compute_fbank."""
+        wav = read_wav(wav_file)
+        feats, lens = self.compute_fbank([wav])
+        return feats[0, :int(lens[0])]
+
+    def transcribe(self, wav: str) -> DecodeResult:
+        """asr_model.py:345-358 (decode defaults: beam_size=1, ctc_weight=0)."""
+        assert hasattr(self, 'tokenizer')
+        speech = self.compute_feature(wav)
+        speech_lengths = torch.tensor([speech.size(0)])
+        results = self.decode([self.default_decode_method],
+                              speech.unsqueeze(0), speech_lengths)
+        result = results[self.default_decode_method][0]
+        result.text = self.tokenizer.detokenize(result.tokens)[0]
+        return result
+
+
+def read_wav(path: str) -> np.ndarray:
+    """16-bit PCM wav -> mono float32 in [-1, 1) like torchaudio.load
+    (processor.py:141-148); 16 kHz only (resampling is not accelerated)."""
+    with wave.open(path, 'rb') as w:
+        assert w.getsampwidth() == 2, 'only 16-bit PCM wav is supported'
+        sr, nch = w.getframerate(), w.getnchannels()
+        data = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    if sr != 16000:
+        raise NotImplementedError('only 16 kHz audio is supported')
+    if nch > 1:
+        data = data.reshape(-1, nch)[:, 0]
+    return (data.astype(np.float32) / 32768.0)
+
+
+def load_model(model_name_or_path: str, device='cuda') -> ASRModel:
+    """wenet/cli/model.py:71-110 for a local model directory holding
+    train.yaml, final.pt, units.txt and (optionally) global_cmvn."""
+    import yaml
+    model_dir = model_name_or_path
+    for f in ('train.yaml', 'final.pt', 'units.txt'):
+        if not os.path.exists(os.path.join(model_dir, f)):
+            raise FileNotFoundError(
+                f'Required file {f} not found in {model_dir}')
+    with open(os.path.join(model_dir, 'train.yaml'), 'r') as fin:
+        configs = yaml.load(fin, Loader=yaml.FullLoader)
+    sd = torch.load(os.path.join(model_dir, 'final.pt'), map_location='cpu',
+                    mmap=True)
+    sd = dict(sd)
+    if configs.get('cmvn') == 'global_cmvn' and \
+            'encoder.global_cmvn.mean' not in sd:
+        cmvn_file = os.path.join(model_dir, 'global_cmvn')
+        if not os.path.exists(cmvn_file):
+            cmvn_file = configs['cmvn_conf']['cmvn_file']
+        mean, istd = load_cmvn(cmvn_file, configs['cmvn_conf']['is_json_cmvn'])
+        sd['encoder.global_cmvn.mean'] = torch.from_numpy(mean).float()
+        sd['encoder.global_cmvn.istd'] = torch.from_numpy(istd).float()
+    model = ASRModel(configs, sd, device)
+    model.tokenizer = _Tokenizer(os.path.join(model_dir, 'units.txt'))
+    return model

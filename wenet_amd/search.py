@@ -1,0 +1,213 @@
+"""Search functions with the reference's names and signatures
+(wenet/models/transformer/search.py:30-61,109,127,374), backed by the HIP
+kernels of libwenet_amd (csrc/ctc.hip, csrc/model.hip).
+
+`ctc_greedy_search` / `ctc_prefix_beam_search` take a (B, T, V) log-prob tensor
+resident in HBM and return `DecodeResult`s; the per-frame top-k, the blank /
+repeat collapse and the whole prefix-beam bookkeeping run on the GPU (fp64 like
+the reference's Python floats).  `attention_rescoring` runs every hypothesis of
+every utterance through the attention decoder(s) in ONE batched pass and then
+replays the reference's scalar fp32 score arithmetic on the handful of gathered
+log-probs.
+"""
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from wenet_amd import _lib
+
+
+class DecodeResult:
+    """wenet/models/transformer/search.py:30-61 (same fields)."""
+
+    def __init__(self,
+                 tokens: List[int],
+                 score: float = 0.0,
+                 confidence: float = 0.0,
+                 tokens_confidence: List[float] = None,
+                 times: List[int] = None,
+                 nbest: List[List[int]] = None,
+                 nbest_scores: List[float] = None,
+                 nbest_times: List[List[int]] = None,
+                 text: str = ''):
+        self.tokens = tokens
+        self.score = score
+        self.confidence = confidence
+        self.tokens_confidence = tokens_confidence
+        self.times = times
+        self.nbest = nbest
+        self.nbest_scores = nbest_scores
+        self.nbest_times = nbest_times
+        self.text = text
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _Workspace:
+    """Weight-less wn_model handle per device for the free functions."""
+    _by_device: Dict[int, int] = {}
+
+    @classmethod
+    def handle(cls, device: torch.device) -> int:
+        idx = device.index if device.index is not None else \
+            torch.cuda.current_device()
+        if idx not in cls._by_device:
+            import ctypes
+            h = ctypes.c_void_p()
+            _lib.check(_lib.lib().wn_workspace_create(idx, ctypes.byref(h)),
+                       'wn_workspace_create')
+            cls._by_device[idx] = h.value
+        return cls._by_device[idx]
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f'{what}: wenet_amd runs on the GPU only (got a {t.device} tensor); '
+            'there is no CPU fallback')
+
+
+def _set_probs(ctc_probs: torch.Tensor, ctc_lens: torch.Tensor, topk: int):
+    _require_cuda(ctc_probs, 'ctc search')
+    assert ctc_probs.dim() == 3
+    probs = ctc_probs.detach().to(torch.float32).contiguous()
+    B, T, V = probs.shape
+    lens = ctc_lens.detach().cpu().numpy().astype(np.int32)
+    h = _Workspace.handle(probs.device)
+    _lib.check(
+        _lib.lib().wn_set_ctc_probs(h, probs.data_ptr(), _lib.i32p(lens), B, T,
+                                    V, topk, _stream_ptr(probs.device)),
+        'wn_set_ctc_probs')
+    return h, B, T, probs
+
+
+def _greedy(handle: int, B: int, max_len: int, blank_id: int,
+            device) -> List[DecodeResult]:
+    max_len = max(max_len, 1)
+    tokens = np.zeros((B, max_len), dtype=np.int32)
+    lens = np.zeros((B, ), dtype=np.int32)
+    _lib.check(
+        _lib.lib().wn_ctc_greedy_search(handle, blank_id, _lib.i32p(tokens),
+                                        _lib.i32p(lens), max_len,
+                                        _stream_ptr(device)),
+        'wn_ctc_greedy_search')
+    return [DecodeResult(tokens[b, :lens[b]].tolist()) for b in range(B)]
+
+
+def _prefix_beam(handle: int, B: int, max_len: int, beam_size: int,
+                 blank_id: int, device):
+    max_len = max(max_len, 1)
+    n_hyps = np.zeros((B, ), dtype=np.int32)
+    hyp_lens = np.zeros((B, beam_size), dtype=np.int32)
+    hyp_tlens = np.zeros((B, beam_size), dtype=np.int32)
+    hyp_tokens = np.zeros((B, beam_size, max_len), dtype=np.int32)
+    hyp_times = np.zeros((B, beam_size, max_len), dtype=np.int32)
+    hyp_scores = np.zeros((B, beam_size), dtype=np.float64)
+    _lib.check(
+        _lib.lib().wn_ctc_prefix_beam_search(
+            handle, beam_size, blank_id, _lib.i32p(n_hyps),
+            _lib.i32p(hyp_lens), _lib.i32p(hyp_tlens), _lib.i32p(hyp_tokens),
+            _lib.i32p(hyp_times), _lib.f64p(hyp_scores), max_len,
+            _stream_ptr(device)), 'wn_ctc_prefix_beam_search')
+    results = []
+    for b in range(B):
+        n = int(n_hyps[b])
+        nbest = [tuple(hyp_tokens[b, i, :hyp_lens[b, i]].tolist())
+                 for i in range(n)]
+        nbest_scores = [float(hyp_scores[b, i]) for i in range(n)]
+        nbest_times = [hyp_times[b, i, :hyp_tlens[b, i]].tolist()
+                       for i in range(n)]
+        results.append(
+            DecodeResult(tokens=nbest[0], score=nbest_scores[0],
+                         times=nbest_times[0], nbest=nbest,
+                         nbest_scores=nbest_scores, nbest_times=nbest_times))
+    raw = dict(n_hyps=n_hyps, hyp_lens=hyp_lens, hyp_tokens=hyp_tokens,
+               max_len=max_len)
+    return results, raw
+
+
+def ctc_greedy_search(ctc_probs: torch.Tensor,
+                      ctc_lens: torch.Tensor,
+                      blank_id: int = 0) -> List[DecodeResult]:
+    """search.py:109-124 on a (B, T, V) log-prob tensor in HBM."""
+    h, B, T, _keep = _set_probs(ctc_probs, ctc_lens, 1)
+    return _greedy(h, B, T, blank_id, ctc_probs.device)
+
+
+def ctc_prefix_beam_search(ctc_probs: torch.Tensor,
+                           ctc_lens: torch.Tensor,
+                           beam_size: int,
+                           context_graph=None,
+                           blank_id: int = 0) -> List[DecodeResult]:
+    """search.py:127-249 on a (B, T, V) log-prob tensor in HBM."""
+    if context_graph is not None:
+        raise NotImplementedError(
+            'context biasing (ContextGraph) is outside the accelerated path')
+    h, B, T, _keep = _set_probs(ctc_probs, ctc_lens, beam_size)
+    return _prefix_beam(h, B, T, beam_size, blank_id, ctc_probs.device)[0]
+
+
+def rescore_from_logps(hyps_per_utt, ctc_scores_per_utt, times_per_utt,
+                       l2r: np.ndarray, r2l: np.ndarray, ctc_weight: float,
+                       reverse_weight: float, use_r2l: bool
+                       ) -> List[DecodeResult]:
+    """The scalar tail of attention_rescoring (search.py:424-457), replayed
+    with the reference's dtypes: the per-token log-probs are fp32 tensor
+    elements, `score` accumulates in fp32 left to right, Python-float operands
+    are rounded to fp32 when they meet the fp32 tensor."""
+    f32 = np.float32
+    results = []
+    for b, hyps in enumerate(hyps_per_utt):
+        best_score = -float('inf')
+        best_index = 0
+        confidences, tokens_confidences, all_scores = [], [], []
+        for i, hyp in enumerate(hyps):
+            L = len(hyp)
+            s_l = l2r[b, i, :L + 1].astype(f32)
+            score = f32(0.0)
+            for j in range(L):
+                score = f32(score + s_l[j])
+            tc = [math.exp(float(s_l[j])) for j in range(L)]
+            score = f32(score + s_l[L])
+            if reverse_weight > 0 and use_r2l:
+                s_r = r2l[b, i, :L + 1].astype(f32)
+                r_score = f32(0.0)
+                for j in range(L):
+                    s = s_r[L - j - 1]
+                    r_score = f32(r_score + s)
+                    tc[j] = (tc[j] + math.exp(float(s))) / 2
+                r_score = f32(r_score + s_r[L])
+                score = f32(f32(score * f32(1 - reverse_weight)) +
+                            f32(r_score * f32(reverse_weight)))
+            confidences.append(math.exp(float(f32(score / f32(L + 1)))))
+            score = f32(score + f32(ctc_scores_per_utt[b][i] * ctc_weight))
+            all_scores.append(float(score))
+            if float(score) > best_score:
+                best_score = float(score)
+                best_index = i
+            tokens_confidences.append(tc)
+        r = DecodeResult(hyps[best_index], best_score,
+                         confidence=confidences[best_index],
+                         times=times_per_utt[b][best_index],
+                         tokens_confidence=tokens_confidences[best_index])
+        r.all_scores = all_scores  # extra: score of every hypothesis
+        results.append(r)
+    return results
+
+
+def attention_rescoring(model,
+                        ctc_prefix_results: List[DecodeResult],
+                        encoder_outs: torch.Tensor,
+                        encoder_lens: torch.Tensor,
+                        ctc_weight: float = 0.0,
+                        reverse_weight: float = 0.0,
+                        infos: Optional[dict] = None) -> List[DecodeResult]:
+    """search.py:374-458.  `model` is a wenet_amd ASRModel; `encoder_outs` is
+    the padded (B, T', d) encoder output in HBM."""
+    _require_cuda(encoder_outs, 'attention_rescoring')
+    model._set_encoder_out(encoder_outs, encoder_lens)
+    return model._rescore(ctc_prefix_results, ctc_weight, reverse_weight)
