@@ -145,7 +145,23 @@ __device__ __forceinline__ double log_add2(double a, double b) {
   return m + log(exp(a - m) + exp(b - m));
 }
 
+// Prefix identity is the token sequence (the reference keys a dict by the
+// tuple).  A physical node id is NOT an identity: a prefix that left the beam
+// can be re-created later as a new node while its old children are still
+// alive.  Every prefix therefore carries a 64-bit hash of its token sequence
+// (chained splitmix64), and all "is this the same prefix / is this its parent"
+// tests compare hashes.
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 prefix_hash(u64 h, int tok) {
+  u64 z = h ^ ((u64)(tok + 1) * 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+constexpr u64 ROOT_HASH = 0x243F6A8885A308D3ull;
+
 struct Hyp {  // one beam member
+  u64 hash, par_hash;
   int node, last, par;
   int ts, tns;  // heads of times_s / times_ns lists (0 = empty list)
   double s, ns, vs, vns;
@@ -154,6 +170,7 @@ struct Hyp {  // one beam member
 };
 
 struct Entry {
+  u64 hash, par_hash;
   double s, ns, vs, vns, score;
   int seq;
   int key_node;          // >=0: existing prefix node; -1: new child
@@ -185,6 +202,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(PrefixBeamArgs a) {
     n_parent[0] = -1; n_token[0] = -1; n_depth[0] = 0;
     t_prev[0] = 0; t_val[0] = -1;
     Hyp h;
+    h.hash = ROOT_HASH; h.par_hash = 0;
     h.node = 0; h.last = -1; h.par = -1; h.ts = 0; h.tns = 0;
     h.s = 0.0; h.ns = NEG_INF; h.vs = 0.0; h.vns = 0.0;  // search.py:144-147
     h.score = 0.0; h.vit = 0.0; h.tim = 0;
@@ -209,6 +227,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(PrefixBeamArgs a) {
       E.s = NEG_INF; E.ns = NEG_INF; E.vs = NEG_INF; E.vns = NEG_INF;
       E.ts = 0; E.tns_src = 0; E.tns_op = 0;
       E.key_node = -1; E.par_node = -1; E.token = -1; E.seq = 0x7fffffff;
+      E.hash = 0; E.par_hash = 0;
       if (e < nb) {
         // ---- unchanged prefix K = H[r] -----------------------------------
         const int r = e;
@@ -221,6 +240,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(PrefixBeamArgs a) {
         if (qb >= 0 || ql >= 0) {
           E.valid = 1;
           E.key_node = K.node; E.par_node = K.par; E.token = K.last;
+          E.hash = K.hash; E.par_hash = K.par_hash;
           int seq = 0x7fffffff;
           if (qb >= 0) {
             const double p = lp[qb];
@@ -234,7 +254,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(PrefixBeamArgs a) {
             const int u = K.last;
             int rp = -1;
             for (int j = 0; j < nb; ++j)
-              if (H[j].node == K.par) rp = j;
+              if (H[j].hash == K.par_hash) rp = j;
             const double xa = K.ns + p, va = K.vns + p;
             seq = min(seq, (ql * nb + r) * 2);
             double v = NEG_INF, ctp = NEG_INF;
@@ -270,9 +290,10 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(PrefixBeamArgs a) {
         const int r = (e - nb) / beam, q = (e - nb) % beam;
         const Hyp P = H[r];
         const int u = tok[q];
+        const u64 ch = prefix_hash(P.hash, u);
         bool merged = false;
         for (int j = 0; j < nb; ++j)
-          if (H[j].par == P.node && H[j].last == u) merged = true;
+          if (H[j].hash == ch) merged = true;
         if (u != a.blank && !merged) {
           const double p = lp[q];
           double x, v; int tb, sub;
@@ -282,6 +303,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(PrefixBeamArgs a) {
           E.ns = x;
           if (v > NEG_INF) { E.vns = v; E.tns_src = tb; E.tns_op = 1; }
           E.key_node = -1; E.par_node = P.node; E.token = u;
+          E.hash = ch; E.par_hash = P.hash;
           E.seq = (q * nb + r) * 2 + sub;
         }
       }
@@ -315,6 +337,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(PrefixBeamArgs a) {
           n_depth[slot] = n_depth[E.par_node] + 1;
         }
         h.par = E.par_node; h.last = E.token;
+        h.hash = E.hash; h.par_hash = E.par_hash;
         h.s = E.s; h.ns = E.ns; h.vs = E.vs; h.vns = E.vns;
         h.ts = E.ts;
         if (E.tns_op == 1) {
