@@ -95,6 +95,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tune', default='',
+                    help='experiments: comma list of key=value for wn_tune_set')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -112,6 +114,9 @@ def main():
                                 device_id=device)
 
     from wenet_amd import _lib, dist as wdist, synthetic as S
+    for kv in filter(None, args.tune.split(',')):
+        k, v = kv.split('=')
+        _lib.check(_lib.lib().wn_tune_set(k.encode(), int(v)), 'tune')
     from wenet_amd.model import ASRModel
     configs = S.make_configs(CONFIG)
     sd = S.make_state_dict(configs, 0)
@@ -192,7 +197,7 @@ def main():
             },
             'roofline': {
                 'bound': 'mfma',
-                'kernel': 'gemm_f32_kernel<128,128,2,2,SiLU> (FFN w_1, '
+                'kernel': 'gemm_f32_kernel<128,128,2x4 waves,SiLU> (FFN w_1, '
                           f'M={enc_rows} N=2048 K=256)',
                 'achieved': round(achieved, 2),
                 'peak': FP32_MFMA_PEAK_TFLOPS,

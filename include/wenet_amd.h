@@ -185,6 +185,11 @@ int wn_profile_collect(wn_model* m, int32_t* n_launches, double* total_ms,
  * compare every ConformerEncoderLayer output with the oracle. */
 int wn_debug_set(wn_model* m, const char* key, int32_t value);
 
+/* Process-wide kernel tuning knob for A/B measurements (tools/bench_gemm.py):
+ * "gemm_variant" (bit mask of experimental code paths), "gemm_tile" (force a
+ * block tile).  Defaults (0) are the shipped configuration. */
+int wn_tune_set(const char* key, int32_t value);
+
 #ifdef __cplusplus
 }
 #endif

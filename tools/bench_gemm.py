@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""GEMM micro-benchmark over the shapes of BASELINE config 2 (AIShell 256d,
+B=32 x ~10 s -> M = 7932 encoder rows), through the C ABI (wn_op_gemm).
+
+    python tools/bench_gemm.py [--reps 30] [--only w1] [--variants 0,1]
+
+Prints TFLOP/s per shape and variant (variants = wn_tune_set("gemm_variant")),
+interleaved within one process.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wenet_amd import _lib  # noqa: E402
+
+M = 7932
+SHAPES = {
+    # name: (M, N, K, act, resid)
+    'w1': (M, 2048, 256, 1, False),
+    'w2': (M, 256, 2048, 0, True),
+    'qkv': (M, 768, 256, 0, False),
+    'out': (M, 256, 256, 0, True),
+    'ctc': (M, 4233, 256, 0, False),
+    'sub_out': (M, 256, 4864, 0, False),
+    'w1_512': (M, 2048, 512, 1, False),
+    'w2_512': (M, 512, 2048, 0, True),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=30)
+    ap.add_argument('--only', default='')
+    ap.add_argument('--variants', default='0')
+    ap.add_argument('--tiles', default='0')
+    args = ap.parse_args()
+    L = _lib.lib()
+    dev = torch.device('cuda', 0)
+    variants = [(int(t), int(v)) for t in args.tiles.split(',')
+                for v in args.variants.split(',')]
+    names = [n for n in SHAPES if not args.only or n in args.only.split(',')]
+    out = {}
+    for name in names:
+        m, n, k, act, resid = SHAPES[name]
+        g = torch.Generator().manual_seed(1)
+        A = (torch.rand(m, k, generator=g) * 2 - 1).to(dev)
+        W = ((torch.rand(n, k, generator=g) * 2 - 1) * 0.1).to(dev)
+        bias = torch.rand(n, generator=g).to(dev)
+        R = torch.rand(m, n, generator=g).to(dev) if resid else None
+        C = torch.empty(m, n, device=dev)
+
+        def run():
+            _lib.check(L.wn_op_gemm(A.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                                    R.data_ptr() if resid else None,
+                                    C.data_ptr(), m, n, k, 1.0, act, None), name)
+        res = {}
+        for rnd in range(3):
+            for v in variants:
+                L.wn_tune_set(b'gemm_tile', v[0])
+                L.wn_tune_set(b'gemm_variant', v[1])
+                for _ in range(3):
+                    run()
+                torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / args.reps
+                res.setdefault(v, []).append(us)
+        for v in variants:
+            us = min(res[v])
+            tf = 2.0 * m * n * k / us / 1e6
+            print(f'{name:8s} M={m} N={n} K={k} tile/variant {v}: {us:8.2f} us  '
+                  f'{tf:6.1f} TF/s  (rounds {[round(x, 1) for x in res[v]]})', flush=True)
+            out[f'{name}/t{v[0]}v{v[1]}'] = dict(us=us, tflops=tf)
+    L.wn_tune_set(b'gemm_tile', 0)
+    L.wn_tune_set(b'gemm_variant', 0)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

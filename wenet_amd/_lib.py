@@ -32,7 +32,7 @@ EXPORTS = [
     'wn_ctc_logprobs', 'wn_set_ctc_probs', 'wn_ctc_greedy_search',
     'wn_ctc_prefix_beam_search', 'wn_attention_rescoring', 'wn_op_gemm',
     'wn_op_layernorm', 'wn_debug_set', 'wn_profile_enable',
-    'wn_profile_collect',
+    'wn_profile_collect', 'wn_tune_set',
 ]
 
 _lib = None
@@ -73,6 +73,7 @@ def lib():
     L.wn_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]
     L.wn_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
     L.wn_debug_set.argtypes = [vp, c_char_p, i32]
+    L.wn_tune_set.argtypes = [c_char_p, i32]
     L.wn_profile_enable.argtypes = [vp, i32]
     L.wn_profile_collect.argtypes = [vp, pi32, pf64, pf64]
     for n in EXPORTS:

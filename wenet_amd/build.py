@@ -68,6 +68,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stderr}')
+    # every kernel stub must resolve: dlopen with RTLD_NOW in a child process
+    r = subprocess.run([sys.executable, '-c',
+                        f'import ctypes, os; ctypes.CDLL({LIB!r}, mode=os.RTLD_NOW)'],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'{LIB} does not load:\n{r.stderr[-2000:]}')
     with open(stamp_file, 'w') as f:
         f.write(stamp)
     if verbose:

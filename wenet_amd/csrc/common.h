@@ -86,4 +86,10 @@ struct GemmArgs {
 
 int gemm_f32(const GemmArgs& a, hipStream_t stream);
 
+// Tuning knobs (wn_tune_set): experiments / A-B runs only, defaults are the
+// shipped configuration.
+extern int g_gemm_variant;  // bit mask, see gemm.hip
+extern int g_gemm_tile_conv, g_gemm_tile_glu;
+extern int g_gemm_tile;     // 0 auto, else force a block configuration (gemm.hip)
+
 }  // namespace wn

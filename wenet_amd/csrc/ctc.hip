@@ -138,13 +138,6 @@ constexpr int MAXB = 16;
 constexpr int MAXE = MAXB + MAXB * MAXB;
 constexpr double NEG_INF = -HUGE_VAL;
 
-__device__ __forceinline__ double log_add2(double a, double b) {
-  // wenet/utils/common.py:302-310 for two arguments
-  if (a == NEG_INF && b == NEG_INF) return NEG_INF;
-  const double m = a > b ? a : b;
-  return m + log(exp(a - m) + exp(b - m));
-}
-
 // Prefix identity is the token sequence (the reference keys a dict by the
 // tuple).  A physical node id is NOT an identity: a prefix that left the beam
 // can be re-created later as a new node while its old children are still
@@ -160,223 +153,305 @@ __device__ __forceinline__ u64 prefix_hash(u64 h, int tok) {
 }
 constexpr u64 ROOT_HASH = 0x243F6A8885A308D3ull;
 
-struct Hyp {  // one beam member
-  u64 hash, par_hash;
-  int node, last, par;
-  int ts, tns;  // heads of times_s / times_ns lists (0 = empty list)
-  double s, ns, vs, vns;
-  double score, vit;  // score() and viterbi_score()
-  int tim;            // times() head
+// Latency design (the search is T' dependent steps per utterance; nothing
+// here is bandwidth- or FLOP-bound):
+//  * one workgroup per utterance with one THREAD per entry (beam + beam^2 <=
+//    272): an entry lives in its thread's registers from evaluation to the
+//    write of the new beam member; only (score, seq) go through LDS for the
+//    rank;
+//  * the beam is a structure of arrays in LDS, double buffered; every loop
+//    over the beam is a broadcast LDS read;
+//  * the stable rank is wave-parallel: lanes hold the entries j, a wave walks
+//    its share of the entries e, and v_cmp + s_bcnt1 on the 64-bit compare mask
+//    counts the entries that beat e -- 8 waves share the beam^2 x beam^2
+//    comparison instead of one 110-iteration loop per thread;
+//  * three barriers per frame, all LDS-only (s_waitcnt lgkmcnt(0) + s_barrier):
+//    a __syncthreads() would also drain vmcnt, i.e. expose the HBM round trip
+//    of the node-pool stores and of the top-k prefetch in every frame;
+//  * the per-frame top-k (token, log-prob) pairs are staged through LDS 32
+//    frames at a time, fetched one chunk ahead;
+//  * the node pools are write-only inside the loop (depth and the
+//    predecessor of the times_ns head travel with the beam member);
+//  * log_add(a, b) = max + log(exp(a-max) + exp(b-max)): the max term is
+//    exp(0) = 1 exactly and a -inf term adds exp(-inf) = 0 exactly, so the
+//    fp64 exp / log run only for real merges -- bit-identical shortcuts.
+struct HypSoA {  // the beam, structure of arrays
+  u64 hash[MAXB], par_hash[MAXB];
+  double s[MAXB], ns[MAXB], vs[MAXB], vns[MAXB];
+  double score[MAXB], vit[MAXB];  // score() and viterbi_score()
+  int node[MAXB], last[MAXB], par[MAXB], depth[MAXB];
+  int ts[MAXB], tns[MAXB], tnsp[MAXB];  // times_s / times_ns heads (0 = empty
+                                        // list), predecessor of the tns head
+  int tim[MAXB];                        // times() head
 };
 
-struct Entry {
-  u64 hash, par_hash;
-  double s, ns, vs, vns, score;
-  int seq;
-  int key_node;          // >=0: existing prefix node; -1: new child
-  int par_node, token;   // for a new child
-  int ts;                // times_s head
-  int tns_src, tns_op;   // 0 empty, 1 append t, 2 replace last with t, 3 share
-  int valid;
-};
+__device__ __forceinline__ double log_add2_fast(double a, double b) {
+  const double m = a > b ? a : b;
+  const double n = a > b ? b : a;
+  if (n == NEG_INF) return m;  // covers (-inf, -inf) -> -inf too
+  return m + log(1.0 + exp(n - m));
+}
 
-__global__ __launch_bounds__(256) void prefix_beam_kernel(PrefixBeamArgs a) {
+// Workgroup barrier that orders LDS traffic only (global loads / stores stay
+// in flight across it).
+__device__ __forceinline__ void barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+constexpr int PB_CHUNK = 32;  // frames of top-k staged per LDS buffer
+constexpr int PB_THREADS = 512;
+constexpr int PB_WAVES = PB_THREADS / 64;
+constexpr int PB_CHUNKS = (MAXE + 63) / 64;
+
+__global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int T = a.len[b], off = a.off[b];
   const int beam = a.beam;
-  __shared__ Hyp hyp[2][MAXB];
-  __shared__ Entry ent[MAXE];
-  __shared__ int tok[MAXB];
-  __shared__ double lp[MAXB];
-  __shared__ int s_nb, s_nvalid;
+  __shared__ HypSoA hyp[2];
+  __shared__ double e_score[MAXE];
+  __shared__ int e_seq[MAXE];
+  __shared__ int e_rank[MAXE];
+  __shared__ int s_nvalid[2];
+  __shared__ int tok[2][PB_CHUNK][MAXB];
+  __shared__ float lp[2][PB_CHUNK][MAXB];
 
   const int cap = a.max_len * beam + 1;
   int* pool = a.pool + (int64_t)b * a.pool_stride;
   int* n_parent = pool;            // prefix nodes
   int* n_token = pool + cap;
-  int* n_depth = pool + 2 * cap;
-  int* t_prev = pool + 3 * cap;    // time nodes
-  int* t_val = pool + 4 * cap;
+  int* t_prev = pool + 2 * cap;    // time nodes
+  int* t_val = pool + 3 * cap;
 
   if (tid == 0) {
-    n_parent[0] = -1; n_token[0] = -1; n_depth[0] = 0;
+    n_parent[0] = -1; n_token[0] = -1;
     t_prev[0] = 0; t_val[0] = -1;
-    Hyp h;
-    h.hash = ROOT_HASH; h.par_hash = 0;
-    h.node = 0; h.last = -1; h.par = -1; h.ts = 0; h.tns = 0;
-    h.s = 0.0; h.ns = NEG_INF; h.vs = 0.0; h.vns = 0.0;  // search.py:144-147
-    h.score = 0.0; h.vit = 0.0; h.tim = 0;
-    hyp[0][0] = h;
-    s_nb = 1;
+    HypSoA& h = hyp[0];
+    h.hash[0] = ROOT_HASH; h.par_hash[0] = 0;
+    h.node[0] = 0; h.last[0] = -1; h.par[0] = -1; h.depth[0] = 0;
+    h.ts[0] = 0; h.tns[0] = 0; h.tnsp[0] = 0; h.tim[0] = 0;
+    h.s[0] = 0.0; h.ns[0] = NEG_INF; h.vs[0] = 0.0; h.vns[0] = 0.0;  // search.py:144-147
+    h.score[0] = 0.0; h.vit[0] = 0.0;
+    s_nvalid[0] = 0; s_nvalid[1] = 0;
+  }
+  {  // top-k chunk 0
+    const int f = tid / beam, q = tid - f * beam;
+    if (f < PB_CHUNK && f < T) {
+      tok[0][f][q] = a.topk_idx[(int64_t)(off + f) * a.k + q];
+      lp[0][f][q] = a.topk_val[(int64_t)(off + f) * a.k + q];
+    }
   }
   __syncthreads();
 
-  int cur = 0;
+  // Entry slots are fixed for the whole search so that no index arithmetic
+  // (integer division by `beam`) sits in the frame loop, and the two kinds of
+  // entries never share a wave (no divergent double pass):
+  //   slot r           (wave 0, lanes < MAXB) : unchanged prefix H[r]
+  //   slot MAXB + r*beam + q  (waves 1..)     : extension H[r] + topk[q]
+  const int x_r = tid >= 64 ? (tid - 64) / beam : 0;
+  const int x_q = tid >= 64 ? (tid - 64) - x_r * beam : 0;
+  const int my_slot = tid < MAXB ? tid : (tid >= 64 ? MAXB + (tid - 64) : 0x7fffffff);
+  const int nx_f = tid / beam, nx_q = tid - nx_f * beam;
+
+  int cur = 0, nb = 1;
   for (int t = 0; t < T; ++t) {
-    const int nb = s_nb;
-    const Hyp* H = hyp[cur];
-    if (tid < beam) {
-      tok[tid] = a.topk_idx[(int64_t)(off + t) * a.k + tid];
-      lp[tid] = (double)a.topk_val[(int64_t)(off + t) * a.k + tid];
+    const HypSoA& H = hyp[cur];
+    const int* tk = tok[(t / PB_CHUNK) & 1][t % PB_CHUNK];
+    const float* lq = lp[(t / PB_CHUNK) & 1][t % PB_CHUNK];
+    // first frame of a chunk: fetch the NEXT chunk now, park it in LDS at the
+    // end of this frame (its buffer was last read in the previous frame)
+    int nx_tok = 0;
+    float nx_lp = 0.f;
+    const int nx_t = (t / PB_CHUNK + 1) * PB_CHUNK + nx_f;
+    const bool nx_on = (t % PB_CHUNK == 0) && nx_f < PB_CHUNK && nx_t < T;
+    if (nx_on) {
+      nx_tok = a.topk_idx[(int64_t)(off + nx_t) * a.k + nx_q];
+      nx_lp = a.topk_val[(int64_t)(off + nx_t) * a.k + nx_q];
     }
-    __syncthreads();
-    const int n_ent = nb + nb * beam;
-    for (int e = tid; e < n_ent; e += 256) {
-      Entry E;
-      E.valid = 0;
-      E.s = NEG_INF; E.ns = NEG_INF; E.vs = NEG_INF; E.vns = NEG_INF;
-      E.ts = 0; E.tns_src = 0; E.tns_op = 0;
-      E.key_node = -1; E.par_node = -1; E.token = -1; E.seq = 0x7fffffff;
-      E.hash = 0; E.par_hash = 0;
-      if (e < nb) {
-        // ---- unchanged prefix K = H[r] -----------------------------------
-        const int r = e;
-        const Hyp K = H[r];
-        int qb = -1, ql = -1;
-        for (int q = 0; q < beam; ++q) {
-          if (tok[q] == a.blank) qb = q;
-          if (K.last >= 0 && tok[q] == K.last) ql = q;
+    const int n_ent = MAXB + nb * beam;  // slots in use (with holes)
+    // ---- this thread's entry ----------------------------------------------
+    int valid = 0;
+    double Es = NEG_INF, Ens = NEG_INF, Evs = NEG_INF, Evns = NEG_INF;
+    int Ets = 0, Etns_src = 0, Etns_op = 0, Etnsp = 0;  // op: 0 empty, 1 append t, 2 replace last
+    int Ekey = -1, Epar = -1, Etoken = -1, Edepth = 0, seq = 0x7fffffff;
+    u64 Ehash = 0, Eparh = 0;
+    if (tid < nb) {
+      // ---- unchanged prefix K = H[r] ------------------------------------------
+      const int r = tid;
+      const int Klast = H.last[r];
+      Ehash = H.hash[r]; Eparh = H.par_hash[r];
+      int qb = -1, ql = -1, rp = -1;
+#pragma unroll
+      for (int q = 0; q < MAXB; ++q) {
+        const int u = tk[q];
+        if (q < beam && u == a.blank) qb = q;
+        if (q < beam && Klast >= 0 && u == Klast) ql = q;
+      }
+#pragma unroll
+      for (int j = 0; j < MAXB; ++j) {
+        const u64 hj = H.hash[j];
+        if (j < nb && hj == Eparh) rp = j;
+      }
+      if (qb >= 0 || ql >= 0) {
+        valid = 1;
+        Ekey = H.node[r]; Epar = H.par[r]; Etoken = Klast; Edepth = H.depth[r];
+        if (qb >= 0) {
+          const double p = (double)lq[qb];
+          Es = H.score[r] + p;       // log_add(-inf, x) == x
+          Evs = H.vit[r] + p;
+          Ets = H.tim[r];
+          seq = min(seq, (qb * nb + r) * 2);
         }
-        if (qb >= 0 || ql >= 0) {
-          E.valid = 1;
-          E.key_node = K.node; E.par_node = K.par; E.token = K.last;
-          E.hash = K.hash; E.par_hash = K.par_hash;
-          int seq = 0x7fffffff;
-          if (qb >= 0) {
-            const double p = lp[qb];
-            E.s = K.score + p;       // log_add(-inf, x) == x
-            E.vs = K.vit + p;
-            E.ts = K.tim;
-            seq = min(seq, (qb * nb + r) * 2);
-          }
-          if (ql >= 0) {
-            const double p = lp[ql];
-            const int u = K.last;
-            int rp = -1;
-            for (int j = 0; j < nb; ++j)
-              if (H[j].hash == K.par_hash) rp = j;
-            const double xa = K.ns + p, va = K.vns + p;
-            seq = min(seq, (ql * nb + r) * 2);
-            double v = NEG_INF, ctp = NEG_INF;
-            int tsrc = 0, top = 0;
-            if (rp < 0) {
-              E.ns = xa;
-              if (v < va) { v = va; tsrc = K.tns; top = 2; }
-            } else {
-              const Hyp P = H[rp];
-              double xb, vb; int tb, sub;
-              if (P.last == u) { xb = P.s + p; vb = P.vs + p; tb = P.ts; sub = 1; }
-              else { xb = P.score + p; vb = P.vit + p; tb = P.tim; sub = 0; }
-              seq = min(seq, (ql * nb + rp) * 2 + sub);
-              if (r < rp) {          // hyp K is visited before its parent
-                E.ns = log_add2(xa, xb);
-                if (v < va) { v = va; ctp = p; tsrc = K.tns; top = 2; }
-                if (v < vb) { v = vb; ctp = p; tsrc = tb; top = 1; }
-              } else {               // parent first
-                E.ns = log_add2(xb, xa);
-                if (v < vb) { v = vb; ctp = p; tsrc = tb; top = 1; }
-                if (v < va) {
-                  v = va;
-                  if (ctp < p) { ctp = p; tsrc = K.tns; top = 2; }
-                }
+        if (ql >= 0) {
+          const double p = (double)lq[ql];
+          const int u = Klast;
+          const double xa = H.ns[r] + p, va = H.vns[r] + p;
+          const int Ktns = H.tns[r];
+          Etnsp = H.tnsp[r];
+          seq = min(seq, (ql * nb + r) * 2);
+          double v = NEG_INF, ctp = NEG_INF;
+          int tsrc = 0, top = 0;
+          if (rp < 0) {
+            Ens = xa;
+            if (v < va) { v = va; tsrc = Ktns; top = 2; }
+          } else {
+            double xb, vb; int tb, sub;
+            if (H.last[rp] == u) { xb = H.s[rp] + p; vb = H.vs[rp] + p; tb = H.ts[rp]; sub = 1; }
+            else { xb = H.score[rp] + p; vb = H.vit[rp] + p; tb = H.tim[rp]; sub = 0; }
+            seq = min(seq, (ql * nb + rp) * 2 + sub);
+            Ens = log_add2_fast(xa, xb);
+            if (r < rp) {          // hyp K is visited before its parent
+              if (v < va) { v = va; ctp = p; tsrc = Ktns; top = 2; }
+              if (v < vb) { v = vb; ctp = p; tsrc = tb; top = 1; }
+            } else {               // parent first
+              if (v < vb) { v = vb; ctp = p; tsrc = tb; top = 1; }
+              if (v < va) {
+                v = va;
+                if (ctp < p) { ctp = p; tsrc = Ktns; top = 2; }
               }
             }
-            E.vns = v; E.tns_src = tsrc; E.tns_op = top;
           }
-          E.seq = seq;
-        }
-      } else {
-        // ---- extension P + u ---------------------------------------------
-        const int r = (e - nb) / beam, q = (e - nb) % beam;
-        const Hyp P = H[r];
-        const int u = tok[q];
-        const u64 ch = prefix_hash(P.hash, u);
-        bool merged = false;
-        for (int j = 0; j < nb; ++j)
-          if (H[j].hash == ch) merged = true;
-        if (u != a.blank && !merged) {
-          const double p = lp[q];
-          double x, v; int tb, sub;
-          if (u == P.last) { x = P.s + p; v = P.vs + p; tb = P.ts; sub = 1; }
-          else { x = P.score + p; v = P.vit + p; tb = P.tim; sub = 0; }
-          E.valid = 1;
-          E.ns = x;
-          if (v > NEG_INF) { E.vns = v; E.tns_src = tb; E.tns_op = 1; }
-          E.key_node = -1; E.par_node = P.node; E.token = u;
-          E.hash = ch; E.par_hash = P.hash;
-          E.seq = (q * nb + r) * 2 + sub;
+          Evns = v; Etns_src = tsrc; Etns_op = top;
         }
       }
-      E.score = log_add2(E.s, E.ns);
-      ent[e] = E;
+    } else if (tid >= 64 && x_r < nb) {
+      // ---- extension P + u ----------------------------------------------------
+      const int r = x_r, q = x_q;
+      const int u = tk[q];
+      const u64 Ph = H.hash[r];
+      const u64 ch = prefix_hash(Ph, u);
+      bool merged = false;
+#pragma unroll
+      for (int j = 0; j < MAXB; ++j) {
+        const u64 hj = H.hash[j];
+        if (j < nb && hj == ch) merged = true;
+      }
+      if (u != a.blank && !merged) {
+        const double p = (double)lq[q];
+        double x, v; int tb, sub;
+        if (u == H.last[r]) { x = H.s[r] + p; v = H.vs[r] + p; tb = H.ts[r]; sub = 1; }
+        else { x = H.score[r] + p; v = H.vit[r] + p; tb = H.tim[r]; sub = 0; }
+        valid = 1;
+        Ens = x;
+        if (v > NEG_INF) { Evns = v; Etns_src = tb; Etns_op = 1; }
+        Ekey = -1; Epar = H.node[r]; Etoken = u; Edepth = H.depth[r] + 1;
+        Ehash = ch; Eparh = Ph;
+        seq = (q * nb + r) * 2 + sub;
+      }
     }
-    __syncthreads();
+    const double Escore = log_add2_fast(Es, Ens);
+    if (my_slot < n_ent) {
+      e_score[my_slot] = valid ? Escore : NEG_INF;
+      e_seq[my_slot] = valid ? seq : 0x7fffffff;
+    }
+    {
+      const unsigned long long vm = __ballot(valid);
+      if (lane == 0 && vm) atomicAdd(&s_nvalid[t & 1], __popcll(vm));
+    }
+    barrier_lds();
+    const int n_valid = s_nvalid[t & 1];
     // ---- second beam prune: stable sort by score desc, keep `beam` -----------
-    if (tid == 0) s_nvalid = 0;
-    __syncthreads();
-    Hyp* Hn = hyp[cur ^ 1];
-    for (int e = tid; e < n_ent; e += 256) {
-      const Entry E = ent[e];
-      if (!E.valid) continue;
-      atomicAdd(&s_nvalid, 1);
-      int rank = 0;
-      for (int j = 0; j < n_ent; ++j) {
-        if (!ent[j].valid) continue;
-        const double sj = ent[j].score;
-        if (sj > E.score || (sj == E.score && ent[j].seq < E.seq)) ++rank;
+    // rank(e) = #{ j : score_j > score_e or (score_j == score_e and seq_j < seq_e) }
+    {
+      const int n_chunks = (n_ent + 63) >> 6;
+      double sj[PB_CHUNKS];
+      int qj[PB_CHUNKS];
+#pragma unroll
+      for (int c = 0; c < PB_CHUNKS; ++c) {
+        const int j = c * 64 + lane;
+        const bool in = c < n_chunks && j < n_ent;
+        sj[c] = in ? e_score[j] : NEG_INF;
+        qj[c] = in ? e_seq[j] : 0x7fffffff;
       }
-      if (rank < beam) {
-        Hyp h;
-        const int slot = 1 + t * beam + rank;
-        if (E.key_node >= 0) {
-          h.node = E.key_node;
-        } else {
-          h.node = slot;
-          n_parent[slot] = E.par_node;
-          n_token[slot] = E.token;
-          n_depth[slot] = n_depth[E.par_node] + 1;
+      for (int e = wave; e < n_ent; e += PB_WAVES) {
+        const double se = e_score[e];
+        const int qe = e_seq[e];
+        int r = 0;
+#pragma unroll
+        for (int c = 0; c < PB_CHUNKS; ++c) {
+          if (c < n_chunks) {
+            const bool beats = (sj[c] > se) || (sj[c] == se && qj[c] < qe);
+            r += __popcll(__ballot(beats));
+          }
         }
-        h.par = E.par_node; h.last = E.token;
-        h.hash = E.hash; h.par_hash = E.par_hash;
-        h.s = E.s; h.ns = E.ns; h.vs = E.vs; h.vns = E.vns;
-        h.ts = E.ts;
-        if (E.tns_op == 1) {
-          t_prev[slot] = E.tns_src; t_val[slot] = t; h.tns = slot;
-        } else if (E.tns_op == 2) {
-          t_prev[slot] = t_prev[E.tns_src]; t_val[slot] = t; h.tns = slot;
-        } else {
-          h.tns = 0;
-        }
-        h.score = E.score;
-        h.vit = h.vs > h.vns ? h.vs : h.vns;   // search.py:87-88
-        h.tim = h.vs > h.vns ? h.ts : h.tns;   // search.py:90-91
-        Hn[rank] = h;
+        if (lane == 0) e_rank[e] = r;
       }
     }
-    __threadfence_block();
-    __syncthreads();
-    if (tid == 0) s_nb = min(beam, s_nvalid);
+    barrier_lds();
+    if (tid == 0) s_nvalid[(t + 1) & 1] = 0;
+    if (valid) {
+      const int rank = e_rank[my_slot];
+      if (rank < beam) {
+        HypSoA& Hn = hyp[cur ^ 1];
+        const int slot = 1 + t * beam + rank;
+        int node = Ekey;
+        if (Ekey < 0) {
+          node = slot;
+          n_parent[slot] = Epar;
+          n_token[slot] = Etoken;
+        }
+        int tns = 0, tnsp = 0;
+        if (Etns_op == 1) {
+          t_prev[slot] = Etns_src; t_val[slot] = t; tns = slot; tnsp = Etns_src;
+        } else if (Etns_op == 2) {
+          t_prev[slot] = Etnsp; t_val[slot] = t; tns = slot; tnsp = Etnsp;
+        }
+        Hn.node[rank] = node; Hn.par[rank] = Epar; Hn.last[rank] = Etoken;
+        Hn.depth[rank] = Edepth;
+        Hn.hash[rank] = Ehash; Hn.par_hash[rank] = Eparh;
+        Hn.s[rank] = Es; Hn.ns[rank] = Ens; Hn.vs[rank] = Evs; Hn.vns[rank] = Evns;
+        Hn.ts[rank] = Ets; Hn.tns[rank] = tns; Hn.tnsp[rank] = tnsp;
+        Hn.score[rank] = Escore;
+        Hn.vit[rank] = Evs > Evns ? Evs : Evns;   // search.py:87-88
+        Hn.tim[rank] = Evs > Evns ? Ets : tns;    // search.py:90-91
+      }
+    }
+    if (nx_on) {
+      tok[(t / PB_CHUNK + 1) & 1][nx_f][nx_q] = nx_tok;
+      lp[(t / PB_CHUNK + 1) & 1][nx_f][nx_q] = nx_lp;
+    }
+    nb = min(beam, n_valid);
     cur ^= 1;
-    __syncthreads();
+    barrier_lds();
   }
+  __syncthreads();  // node-pool stores visible to the emitting threads
 
   // ---- emit the n-best list -------------------------------------------------
-  const int nb = s_nb;
   if (tid == 0) a.n_hyps[b] = nb;
   if (tid < beam) {
     const int64_t o = (int64_t)b * beam + tid;
     if (tid < nb) {
-      const Hyp h = hyp[cur][tid];
-      const int L = n_depth[h.node];
+      const HypSoA& h = hyp[cur];
+      const int L = h.depth[tid];
       a.hyp_lens[o] = L;
-      a.hyp_scores[o] = h.score;
-      int* tk = a.hyp_tokens + o * a.max_len;
-      int node = h.node;
-      for (int i = L - 1; i >= 0; --i) { tk[i] = n_token[node]; node = n_parent[node]; }
+      a.hyp_scores[o] = h.score[tid];
+      int* tkn = a.hyp_tokens + o * a.max_len;
+      int node = h.node[tid];
+      for (int i = L - 1; i >= 0; --i) { tkn[i] = n_token[node]; node = n_parent[node]; }
       int n_t = 0;
-      for (int x = h.tim; x != 0; x = t_prev[x]) ++n_t;
+      for (int x = h.tim[tid]; x != 0; x = t_prev[x]) ++n_t;
       int* tm = a.hyp_times + o * a.max_len;
-      int x = h.tim;
+      int x = h.tim[tid];
       for (int i = n_t - 1; i >= 0; --i) { tm[i] = t_val[x]; x = t_prev[x]; }
       a.hyp_tlens[o] = n_t;  // == L, or 0 for a never-set list
     } else {
@@ -417,7 +492,7 @@ int ctc_greedy_collapse(const int* top1, int top1_stride, const int* off,
 }
 
 int64_t prefix_beam_pool_ints(int max_len, int beam) {
-  return 5 * ((int64_t)max_len * beam + 1);
+  return 4 * ((int64_t)max_len * beam + 1);
 }
 
 int ctc_prefix_beam(const PrefixBeamArgs& a, hipStream_t s) {
@@ -425,7 +500,9 @@ int ctc_prefix_beam(const PrefixBeamArgs& a, hipStream_t s) {
   WN_CHECK(a.beam >= 1 && a.beam <= MAXB,
            "prefix beam: beam_size must be in [1, 16]");
   WN_CHECK(a.k == a.beam, "prefix beam: top-k width must equal the beam");
-  hipLaunchKernelGGL(prefix_beam_kernel, dim3(a.B), dim3(256), 0, s, a);
+  static_assert(64 + MAXB * MAXB <= PB_THREADS, "one thread per entry");
+  static_assert(PB_CHUNK * MAXB <= PB_THREADS, "one thread per staged top-k pair");
+  hipLaunchKernelGGL(prefix_beam_kernel, dim3(a.B), dim3(PB_THREADS), 0, s, a);
   WN_HIP(hipGetLastError());
   return 0;
 }

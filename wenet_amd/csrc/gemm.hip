@@ -26,20 +26,31 @@
 
 namespace wn {
 
+int g_gemm_variant = 0;
+int g_gemm_tile = 0;
+int g_gemm_tile_conv = 0;
+int g_gemm_tile_glu = 0;
+
 namespace {
+
+__device__ __forceinline__ float silu_fast(float x) {
+  // x * sigmoid(x) on v_exp_f32 / v_rcp_f32 (each ~1 ulp)
+  return x * __frcp_rn(1.0f + __expf(-x));
+}
 
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = 36;  // floats
 
 template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
           bool CONV>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m,
-                                                        int tiles_n) {
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
+    GemmArgs p, int tiles_m, int tiles_n, int variant) {
+  constexpr int NTHR = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
-  constexpr int A_CHUNKS = BM * 8 / 256;  // float4 chunks per thread
-  constexpr int B_CHUNKS = BN * 8 / 256;
-  static_assert(WGM * WGN == 4, "4 waves per block");
+  constexpr int A_CHUNKS = BM * 8 / NTHR;  // float4 chunks per thread
+  constexpr int B_CHUNKS = BN * 8 / NTHR;
+  static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1 && MT >= 1 && NT >= 1, "tile");
   static_assert(!GLU || NT == 2, "GLU epilogue needs a 64-wide wave tile");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TILE = (BM + BN) * LDS_STRIDE;  // floats per buffer: A then W
@@ -59,13 +70,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m,
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WGN, wn_ = wave % WGN;
-
   // ---- per-thread global load descriptors --------------------------------
   const float* a_ptr[A_CHUNKS];
   int a_lds[A_CHUNKS];
 #pragma unroll
   for (int i = 0; i < A_CHUNKS; ++i) {
-    const int c = tid + 256 * i;
+    const int c = tid + NTHR * i;
     const int row = c >> 3, kc = c & 7;
     int grow = m0 + row;
     if (grow > p.M - 1) grow = p.M - 1;
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m,
   int b_lds[B_CHUNKS];
 #pragma unroll
   for (int i = 0; i < B_CHUNKS; ++i) {
-    const int c = tid + 256 * i;
+    const int c = tid + NTHR * i;
     const int row = c >> 3, kc = c & 7;
     int grow = n0 + row;
     if (grow > p.N - 1) grow = p.N - 1;
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m,
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    if (kt + 1 < nk && !(variant & 8)) gload(kt + 1);
     const float* cA = smem + cur * TILE + a_frag;
     const float* cB = smem + cur * TILE + BM * LDS_STRIDE + b_frag;
 #pragma unroll
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m,
   // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
   const int col_in = lane & 31;
   const int row_hi = (lane >> 5) * 4;
-  if (GLU) {
+  if constexpr (GLU) {
     const int ncol_out = p.N / 2;
     const int cbase = n0 + wn_ * WTN;  // permuted column of the 'a' half
     const int ca = cbase + col_in, cg = cbase + 32 + col_in;
@@ -176,17 +186,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m,
     const float bg = (p.bias && cok) ? p.bias[cg] : 0.0f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+      const int row0 = m0 + wm * WTM + i * 32 + row_hi;
+      float* cp = p.C + (int64_t)row0 * p.ldc + cout;
+      float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
-        if (row < p.M && cok) {
-          const float a = acc[i][0][r] + ba;
-          const float g = acc[i][1][r] + bg;
-          p.C[(int64_t)row * p.ldc + cout] = a * sigmoid_f(g);
-        }
+        const float a = acc[i][0][r] + ba;
+        const float g = acc[i][1][r] + bg;
+        v[r] = (variant & 1) ? a * sigmoid_f(g)
+                             : a * __frcp_rn(1.0f + __expf(-g));
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (row0 + dr < p.M && cok) cp[dr * p.ldc] = v[r];
       }
     }
     (void)ncol_out;
+    return;
+  }
+  // Values first (no branches, so the 16 results of a tile overlap their
+  // exp / rcp latencies), then the stores; only the ragged last tiles pay for
+  // per-row predicates.
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);  // block-uniform
+  if (variant & 4) {  // ablation: no epilogue (accumulators stay live)
+    if (p.alpha == 123456.0f) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p.C[r + lane] = acc[i][j][r];
+    }
     return;
   }
 #pragma unroll
@@ -196,16 +227,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m,
     const float b = (p.bias && cok) ? p.bias[col] : 0.0f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+      const int row0 = m0 + wm * WTM + i * 32 + row_hi;
+      float* cp = p.C + (int64_t)row0 * p.ldc + col;
+      const float* rp = RESID ? p.resid + (int64_t)row0 * p.ldr + col : nullptr;
+      float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
-        if (row < p.M && cok) {
-          float v = acc[i][j][r] + b;
-          if (ACT == ACT_SILU) v = silu_f(v);
-          if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
-          v *= p.alpha;
-          if (RESID) v += p.resid[(int64_t)row * p.ldr + col];
-          p.C[(int64_t)row * p.ldc + col] = v;
+        float x = acc[i][j][r] + b;
+        if (ACT == ACT_SILU) x = (variant & 1) ? silu_f(x) : silu_fast(x);
+        if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
+        v[r] = x * p.alpha;
+      }
+      if (full) {
+        if (RESID) {
+          float rr[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rr[r] = rp[((r & 3) + 8 * (r >> 2)) * p.ldr];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += rr[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cp[((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (row0 + dr < p.M && cok) {
+            float x = v[r];
+            if (RESID) x += rp[dr * p.ldr];
+            cp[dr * p.ldc] = x;
+          }
         }
       }
     }
@@ -225,8 +276,8 @@ int launch(const GemmArgs& a, hipStream_t stream) {
                                (int)lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, a,
-                     tiles_m, tiles_n);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WGM * WGN * 64), lds,
+                     stream, a, tiles_m, tiles_n, g_gemm_variant);
   WN_HIP(hipGetLastError());
   return 0;
 }
@@ -273,19 +324,40 @@ int gemm_f32(const GemmArgs& a, hipStream_t stream) {
     WN_CHECK(a.lda % 4 == 0, "gemm: lda must be a multiple of 4 floats");
   }
   if (a.glu) WN_CHECK(a.N % 64 == 0, "gemm(GLU): N must be a multiple of 64");
-  // Tile choice: the 128x128 block is the efficient one (64 MFMAs per wave per
-  // K tile between barriers); fall back to 64-row / 64x64 blocks when the
-  // problem would otherwise leave most of the 256 CUs idle.
+  // Tile choice (measured on M = 7932 rows, profiles/): 8 waves per block hide
+  // the barrier / LDS latency of the short K loops better than 4; the block
+  // shrinks with the problem so that the grid still covers the 256 CUs.
+  //   1: 128x128, 2x4 waves   2: 128x128, 4x2 waves (64-wide wave tile: GLU)
+  //   3: 64x128, 2x4 waves    4: 64x128, 2x2 waves (GLU)   5: 64x64, 2x2 waves
+  //   6: 128x128, 2x2 waves
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
   const int64_t t64x128 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 128);
-  if (conv) {
-    if (t128 >= 384) return dispatch_epi<128, 128, 2, 2, true>(a, stream);
-    return dispatch_epi<64, 128, 2, 2, true>(a, stream);
+  int cfg;
+  if (a.glu) cfg = t128 >= 224 ? 2 : 4;
+  else if (conv) cfg = t128 >= 384 ? 6 : 4;  // K = 9C: the 4-wave block wins
+  else if (t128 >= 384) cfg = 1;
+  else if (t64x128 >= 384) cfg = 3;
+  else cfg = 5;
+  const int forced = a.glu ? g_gemm_tile_glu : conv ? g_gemm_tile_conv : g_gemm_tile;
+  if (forced > 0) {
+    const int t = forced;
+    const bool ok = a.glu ? (t == 2 || t == 4)
+                          : conv ? (t == 1 || t == 2 || t == 4 || t == 6)
+                                 : (t >= 1 && t <= 6);
+    if (ok) cfg = t;
   }
-  if (t128 >= 384) return dispatch_epi<128, 128, 2, 2, false>(a, stream);
-  if (t64x128 >= 256 || a.glu)
-    return dispatch_epi<64, 128, 2, 2, false>(a, stream);
-  return dispatch_epi<64, 64, 2, 2, false>(a, stream);
+  switch (cfg) {
+    case 1: return conv ? dispatch_epi<128, 128, 2, 4, true>(a, stream)
+                        : dispatch_epi<128, 128, 2, 4, false>(a, stream);
+    case 2: return conv ? dispatch_epi<128, 128, 4, 2, true>(a, stream)
+                        : dispatch_epi<128, 128, 4, 2, false>(a, stream);
+    case 3: return dispatch_epi<64, 128, 2, 4, false>(a, stream);
+    case 4: return conv ? dispatch_epi<64, 128, 2, 2, true>(a, stream)
+                        : dispatch_epi<64, 128, 2, 2, false>(a, stream);
+    case 5: return dispatch_epi<64, 64, 2, 2, false>(a, stream);
+    default: return conv ? dispatch_epi<128, 128, 2, 2, true>(a, stream)
+                         : dispatch_epi<128, 128, 2, 2, false>(a, stream);
+  }
 }
 
 }  // namespace wn

@@ -766,6 +766,17 @@ int wn_debug_set(wn_model* m, const char* key, int32_t value) {
   return 0;
 }
 
+int wn_tune_set(const char* key, int32_t value) {
+  WN_CHECK(key, "wn_tune_set: null key");
+  const std::string k(key);
+  if (k == "gemm_variant") g_gemm_variant = value;
+  else if (k == "gemm_tile") g_gemm_tile = value;
+  else if (k == "gemm_tile_conv") g_gemm_tile_conv = value;
+  else if (k == "gemm_tile_glu") g_gemm_tile_glu = value;
+  else { set_error("wn_tune_set: unknown key " + k); return -1; }
+  return 0;
+}
+
 int wn_workspace_create(int32_t device, wn_model** out) {
   WN_CHECK(out, "wn_workspace_create: null argument");
   WN_HIP(hipSetDevice(device));
