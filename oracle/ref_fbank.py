@@ -1,0 +1,38 @@
+"""ctypes binding of oracle/_ref/libref_fbank.so -- the REFERENCE's own C++
+fbank (runtime/core/frontend/fbank.h) built by oracle/Makefile.  Test
+infrastructure only."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, '_ref', 'libref_fbank.so')
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+_lib = None
+
+
+def ref_fbank(waveform: np.ndarray, num_bins: int = 80, sample_rate: int = 16000,
+              frame_length: int = 400, frame_shift: int = 160) -> np.ndarray:
+    """`waveform` float in [-1, 1]; scaled by 1 << 15 like
+    wenet/dataset/processor.py:245 before the reference recipe."""
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.ref_fbank.restype = ctypes.c_int
+        _lib.ref_fbank.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_int]
+    w = np.ascontiguousarray(waveform.astype(np.float32) * np.float32(1 << 15))
+    n = w.shape[0]
+    max_frames = max(1, 1 + max(0, n - frame_length) // frame_shift)
+    out = np.zeros((max_frames, num_bins), dtype=np.float32)
+    got = _lib.ref_fbank(w.ctypes.data, n, num_bins, sample_rate, frame_length,
+                         frame_shift, out.ctypes.data, max_frames)
+    assert got >= 0, 'ref_fbank: output buffer too small'
+    return out[:got]

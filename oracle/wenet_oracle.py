@@ -7,7 +7,7 @@ imported only by ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` -- never by ``wenet_amd/`` (the product
 path), which fails loudly when its HIP library is missing.
 
-Pinning (see tests/test_oracle_vs_reference.py and tests/golden/):
+Pinning (see tests/test_oracle.py and tests/golden/):
   * model + search: checked against the reference's own ``ASRModel.decode`` /
     ``search.py`` imported unmodified from /root/reference (oracle/_ref_harness),
     at the tiny fixture sizes committed under tests/golden/ and, when the

@@ -1,0 +1,79 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the utterance sharding + the one
+result all_gather of wenet_amd/dist.py (the same code bench.py runs over RCCL).
+The decode itself is GPU-only; here every rank fabricates its shard's results
+with a deterministic function of the global utterance index, so the test checks
+the partition (every utterance exactly once, balanced) and the gather."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _fake_result(gi: int):
+    n = 3 + gi % 5
+    return [(gi * 7 + k) % 4233 for k in range(n)], -0.25 * gi - 1.0
+
+
+def _worker(rank: int, world: int, port: int, lengths, out_dir: str):
+    from wenet_amd import dist as wdist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        mine = wdist.shard_indices(lengths, world, rank)
+        toks, scores = zip(*[_fake_result(g) for g in mine]) if mine else ((), ())
+        per_rank = (len(lengths) + world - 1) // world
+        rec = wdist.pack_results(mine, toks, scores, per_rank, 16, 'cpu')
+        res = wdist.gather_results(rec, world)
+        np.save(os.path.join(out_dir, f'rank{rank}.npy'),
+                np.array([[g, len(t), s] + t + [0] * (16 - len(t)) for g, t, s in res],
+                         dtype=np.float64))
+        np.save(os.path.join(out_dir, f'mine{rank}.npy'), np.array(mine))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize('n_utts', [64, 37])
+def test_two_rank_gloo_shard_and_gather(tmp_path, n_utts):
+    rng = np.random.Generator(np.random.PCG64(5))
+    lengths = rng.integers(800, 1201, size=n_utts).tolist()
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), lengths, str(tmp_path)),
+             nprocs=world, join=True)
+    mine = [np.load(tmp_path / f'mine{r}.npy').tolist() for r in range(world)]
+    # a partition: every utterance on exactly one rank, sizes within one
+    assert sorted(mine[0] + mine[1]) == list(range(n_utts))
+    assert abs(len(mine[0]) - len(mine[1])) <= 1
+    # balanced audio: the snake deal keeps the sums within one utterance
+    s0, s1 = (sum(lengths[i] for i in m) for m in mine)
+    assert abs(s0 - s1) <= max(lengths)
+    # every rank holds the full, ordered result set after the one all_gather
+    for r in range(world):
+        got = np.load(tmp_path / f'rank{r}.npy')
+        assert got.shape[0] == n_utts
+        for gi in range(n_utts):
+            toks, score = _fake_result(gi)
+            assert int(got[gi, 0]) == gi and int(got[gi, 1]) == len(toks)
+            assert got[gi, 3:3 + len(toks)].astype(int).tolist() == toks
+            assert abs(got[gi, 2] - np.float32(score)) < 1e-6
+
+
+def test_shard_indices_single_rank_is_identity_order():
+    from wenet_amd import dist as wdist
+    lengths = [5, 9, 7]
+    assert wdist.shard_indices(lengths, 1, 0) == [1, 2, 0]

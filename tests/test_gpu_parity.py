@@ -288,6 +288,33 @@ def test_fbank_vs_oracle():
         assert np.all(feats[i, ref.shape[0]:] == 0)
 
 
+def test_fbank_vs_reference_cpp_golden():
+    """wn_fbank against the committed outputs of the reference's own C++ fbank
+    (tests/golden/fbank_*.npz, oracle/gen_golden_fbank.py)."""
+    import glob
+    import json
+    import os
+    from wenet_amd import synthetic as S
+    configs, sd, model = cached_model('tiny_sym', 0)
+    metas, refs, waves = [], [], []
+    for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden',
+                                           'fbank_*.npz'))):
+        z = np.load(p)
+        meta = json.loads(bytes(z['meta']).decode())
+        metas.append(meta)
+        refs.append(z['feats'])
+        waves.append(S.make_audio(meta['samples'], seed=meta['seed']))
+    assert len(waves) >= 4
+    feats, nfr = model.compute_fbank(waves)
+    feats = feats.cpu().numpy()
+    for i, ref in enumerate(refs):
+        assert int(nfr[i]) == ref.shape[0] == metas[i]['frames']
+        if ref.shape[0]:
+            err = np.abs(feats[i, :ref.shape[0]] - ref)
+            assert np.percentile(err, 99) < 2e-3 and err.max() < 5e-2, \
+                (metas[i]['case'], np.percentile(err, 99), err.max())
+
+
 def test_rejects_cpu_tensors_and_chunk_zero():
     configs, sd, model = cached_model('tiny_sym', 0)
     from wenet_amd import search as S

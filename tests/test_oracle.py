@@ -16,6 +16,48 @@ from golden_util import build_inputs, case_names, load_case
 from oracle import wenet_oracle as O
 
 
+def _fbank_cases():
+    import glob
+    import json
+    import os
+    out = []
+    for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden',
+                                           'fbank_*.npz'))):
+        z = np.load(p)
+        out.append((json.loads(bytes(z['meta']).decode()), z['feats']))
+    return out
+
+
+def test_fbank_matches_reference_cpp_golden():
+    """oracle fbank vs the committed outputs of the reference's own C++ fbank
+    (runtime/core/frontend/fbank.h built by oracle/Makefile,
+    oracle/gen_golden_fbank.py)."""
+    from wenet_amd import synthetic as S
+    cases = _fbank_cases()
+    assert len(cases) >= 4
+    for meta, ref in cases:
+        w = S.make_audio(meta['samples'], seed=meta['seed'])
+        assert abs(float(np.sum(w.astype(np.float64))) - meta['wave_sum']) < 1e-6
+        got = O.fbank(w)
+        assert got.shape == ref.shape == (meta['frames'], 80)
+        if ref.size:
+            # fp32 radix-2 FFT (reference) vs fp64 rfft (oracle), in log-mel
+            assert np.abs(got - ref).max() < 5e-4
+
+
+def test_fbank_matches_live_reference_cpp():
+    from oracle import ref_fbank
+    if not ref_fbank.available():
+        pytest.skip('oracle/_ref/libref_fbank.so not built (make -C oracle)')
+    from wenet_amd import synthetic as S
+    for n, seed in [(8000, 21), (401, 22), (33333, 23)]:
+        w = S.make_audio(n, seed=seed)
+        ref = ref_fbank.ref_fbank(w)
+        got = O.fbank(w)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 5e-4
+
+
 def test_prefix_beam_known_answer():
     data = torch.tensor([[0.25, 0.40, 0.35], [0.40, 0.35, 0.25],
                          [0.10, 0.50, 0.40]]).log().unsqueeze(0)
