@@ -168,6 +168,10 @@ int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host
 int wn_op_gemm(const float* A_dev, const float* W_dev, const float* bias_dev,
                const float* resid_dev, float* C_dev, int32_t M, int32_t N,
                int32_t K, float alpha, int32_t act, void* stream);
+/* out[i] = log_add(a[i], b[i]) (wenet/utils/common.py:302-310) in fp64 with the
+ * routine the prefix beam search uses. */
+int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,
+                  int32_t n, void* stream);
 int wn_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev,
                     float* y_dev, int32_t M, int32_t D, float eps, void* stream);
 

@@ -1,0 +1,73 @@
+"""CPU checks of the drop-in boundary: libwenet_amd.so loads without a GPU and
+exports every symbol include/wenet_amd.h declares (no compute calls here), the
+Python binding lists the same set, and argument validation that needs no device
+fails with the documented status / message."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'wenet_amd.h')
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(wn_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_declares_the_documented_entry_points():
+    syms = _declared_symbols()
+    for s in ('wn_model_create', 'wn_model_destroy', 'wn_fbank', 'wn_encode',
+              'wn_ctc_logprobs', 'wn_ctc_greedy_search',
+              'wn_ctc_prefix_beam_search', 'wn_attention_rescoring',
+              'wn_last_error'):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from wenet_amd import _lib, build
+    build.build(force=False, verbose=False)
+    assert os.path.exists(_lib.LIB_PATH)
+    L = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for s in declared:
+        assert hasattr(L, s), f'{s} declared in include/wenet_amd.h but not exported'
+    assert sorted(_lib.EXPORTS) == declared, \
+        'wenet_amd/_lib.py EXPORTS and include/wenet_amd.h disagree'
+    assert b'gfx950' in L.wn_version()
+
+
+def test_argument_validation_without_a_device():
+    from wenet_amd import _lib
+    L = _lib.lib()
+    # null arguments are rejected before any HIP call
+    assert L.wn_model_create(None, None, 0, 0, None) == -1
+    assert b'null' in L.wn_last_error()
+    assert L.wn_tune_set(b'no_such_knob', 1) == -1
+    assert b'unknown key' in L.wn_last_error()
+    assert L.wn_tune_set(b'gemm_tile', 0) == 0
+
+
+def test_product_path_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under wenet_amd/ may import,
+    call or link it."""
+    pkg = os.path.join(ROOT, 'wenet_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f), errors='replace').read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, re.M), f
+                assert 'wenet_oracle' not in text, f
+
+
+def test_model_refuses_cpu_device():
+    import torch
+    from wenet_amd import synthetic as S
+    from wenet_amd.model import ASRModel
+    configs = S.make_configs('tiny_sym')
+    with pytest.raises(RuntimeError):
+        ASRModel(configs, {}, device='cpu')

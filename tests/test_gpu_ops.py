@@ -111,3 +111,42 @@ def test_layernorm(D):
                                           1e-5, None), 'ln')
     torch.cuda.synchronize()
     torch.testing.assert_close(y.cpu(), ref, rtol=1e-5, atol=2e-5)
+
+
+def test_log_add_matches_reference_formula():
+    """wn_op_log_add (the prefix beam search's fp64 log_add) against
+    wenet/utils/common.py:302-310 evaluated with Python floats."""
+    from wenet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(7))
+    n = 20000
+    a = -rng.random(n) * 60.0
+    # gaps from 1e-12 to 60, both orders, plus the special cases
+    gap = rng.random(n) * 10.0 ** rng.integers(-12, 2, size=n)
+    b = a - gap
+    swap = rng.random(n) < 0.5
+    a, b = np.where(swap, b, a), np.where(swap, a, b)
+    a[:6] = [-np.inf, -np.inf, -3.5, 0.0, -1.0, -40.0]
+    b[:6] = [-np.inf, -2.25, -np.inf, 0.0, -38.5, -2.0]
+    ta = torch.from_numpy(a).cuda()
+    tb = torch.from_numpy(b).cuda()
+    to = torch.empty_like(ta)
+    _lib.check(L.wn_op_log_add(_ptr(ta), _ptr(tb), _ptr(to), n,
+                               torch.cuda.current_stream().cuda_stream), 'log_add')
+    got = to.cpu().numpy()
+
+    def ref(x, y):
+        if x == -math.inf and y == -math.inf:
+            return -math.inf
+        m = max(x, y)
+        return m + math.log(math.exp(x - m) + math.exp(y - m))
+    want = np.array([ref(float(x), float(y)) for x, y in zip(a, b)])
+    assert got[0] == -np.inf and got[1] == -2.25 and got[2] == -3.5
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    err = np.abs(got[fin] - want[fin])
+    # the result is a_max + log(...): its rounding error scales with the larger
+    # of |a_max| and |result| (a_max ~ -log(...) cancels to a small result)
+    scale = np.maximum(np.abs(want[fin]), np.abs(np.maximum(a, b)[fin]))
+    ulp = np.spacing(np.maximum(scale, 1e-300))
+    assert (err <= 4 * ulp).all(), (err / ulp).max()

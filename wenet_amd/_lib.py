@@ -31,7 +31,7 @@ EXPORTS = [
     'wn_workspace_create', 'wn_fbank', 'wn_encode', 'wn_set_encoder_out',
     'wn_ctc_logprobs', 'wn_set_ctc_probs', 'wn_ctc_greedy_search',
     'wn_ctc_prefix_beam_search', 'wn_attention_rescoring', 'wn_op_gemm',
-    'wn_op_layernorm', 'wn_debug_set', 'wn_profile_enable',
+    'wn_op_layernorm', 'wn_op_log_add', 'wn_debug_set', 'wn_profile_enable',
     'wn_profile_collect', 'wn_tune_set',
 ]
 
@@ -72,6 +72,7 @@ def lib():
                                          POINTER(f32), POINTER(f32), vp]
     L.wn_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]
     L.wn_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
+    L.wn_op_log_add.argtypes = [vp, vp, vp, i32, vp]
     L.wn_debug_set.argtypes = [vp, c_char_p, i32]
     L.wn_tune_set.argtypes = [c_char_p, i32]
     L.wn_profile_enable.argtypes = [vp, i32]

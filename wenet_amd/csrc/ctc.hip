@@ -185,11 +185,72 @@ struct HypSoA {  // the beam, structure of arrays
   int tim[MAXB];                        // times() head
 };
 
+// exp(d) for d in [-37, 0]: k = rint(d log2 e), r = d - k ln2 (two-part),
+// degree-13 Taylor on |r| <= 0.347 (truncation 4e-18), scaled by 2^k.
+__device__ __forceinline__ double exp_m37_0(double d) {
+  const double k = rint(d * 1.4426950408889634);
+  double r = fma(k, -6.93147180369123816490e-01, d);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;           // 1/13!
+  p = fma(p, r, 2.08767569878681e-09);         // 1/12!
+  p = fma(p, r, 2.505210838544172e-08);        // 1/11!
+  p = fma(p, r, 2.755731922398589e-07);        // 1/10!
+  p = fma(p, r, 2.7557319223985893e-06);       // 1/9!
+  p = fma(p, r, 2.48015873015873e-05);         // 1/8!
+  p = fma(p, r, 1.984126984126984e-04);        // 1/7!
+  p = fma(p, r, 1.388888888888889e-03);        // 1/6!
+  p = fma(p, r, 8.333333333333333e-03);        // 1/5!
+  p = fma(p, r, 4.1666666666666664e-02);       // 1/4!
+  p = fma(p, r, 1.6666666666666666e-01);       // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
+
+// log(s) for s in [1, 2]: s = 2^e * m, m in [0.7071, 1.4142], f = m - 1
+// (exact), z = f / (2 + f), log m = 2 atanh z = 2z (1 + w/3 + ... + w^9/19),
+// w = z^2 <= 0.0295 (truncation 2e-17).
+__device__ __forceinline__ double log_1_2(double s) {
+  const bool hi = s > 1.4142135623730951;
+  const double m = hi ? s * 0.5 : s;
+  const double f = m - 1.0;
+  const double z = f / (2.0 + f);
+  const double w = z * z;
+  double q = 5.2631578947368418e-02;           // 1/19
+  q = fma(q, w, 5.8823529411764705e-02);       // 1/17
+  q = fma(q, w, 6.6666666666666666e-02);       // 1/15
+  q = fma(q, w, 7.6923076923076927e-02);       // 1/13
+  q = fma(q, w, 9.0909090909090912e-02);       // 1/11
+  q = fma(q, w, 1.1111111111111110e-01);       // 1/9
+  q = fma(q, w, 1.4285714285714285e-01);       // 1/7
+  q = fma(q, w, 2.0000000000000001e-01);       // 1/5
+  q = fma(q, w, 3.3333333333333331e-01);       // 1/3
+  const double z2 = z + z;
+  const double r = fma(z2 * w, q, z2);
+  return hi ? r + 6.9314718055994529e-01 : r;
+}
+
+// log_add (wenet/utils/common.py:302-310) of two values:
+//   a_max + log(exp(a - a_max) + exp(b - a_max)).
+// The a_max term is exp(0) = 1 exactly, a -inf term adds exp(-inf) = 0 exactly
+// and below d = -37 the sum rounds to 1.0 (log -> 0), so those cases return
+// a_max bit-identically to the reference; otherwise 1 + exp(d) and its log are
+// evaluated with the two short fp64 kernels above (<= 2 ulp each; measured
+// against math.log / math.exp in tests/test_gpu_ops.py) instead of the generic
+// library exp / log: the search is bound by the length of this dependent
+// chain, not by throughput.
 __device__ __forceinline__ double log_add2_fast(double a, double b) {
   const double m = a > b ? a : b;
   const double n = a > b ? b : a;
-  if (n == NEG_INF) return m;  // covers (-inf, -inf) -> -inf too
-  return m + log(1.0 + exp(n - m));
+  const double d = n - m;          // <= 0, or NaN for (-inf, -inf)
+  if (!(d >= -37.0)) return m;     // covers n == -inf and (-inf, -inf) -> -inf
+  return m + log_1_2(1.0 + exp_m37_0(d));
+}
+
+__global__ void log_add_kernel(const double* a, const double* b, double* o, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = log_add2_fast(a[i], b[i]);
 }
 
 // Workgroup barrier that orders LDS traffic only (global loads / stores stay
@@ -201,11 +262,17 @@ __device__ __forceinline__ void barrier_lds() {
 constexpr int PB_CHUNK = 32;  // frames of top-k staged per LDS buffer
 constexpr int PB_THREADS = 512;
 constexpr int PB_WAVES = PB_THREADS / 64;
-constexpr int PB_CHUNKS = (MAXE + 63) / 64;
+constexpr int PB_CHUNKS = (MAXE + 63) / 64;  // 5: beam up to 16
 
+// NCH = 64-entry chunks the rank pass scans: compile-time so that the pass has
+// no per-chunk branches (2 covers beam <= 10, the default of every recipe).
+template <int NCH>
 __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  // wave-uniform values must be PROVABLY uniform (SGPRs) or every loop on
+  // them is compiled as a divergent, exec-masked loop
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = a.len[b], off = a.off[b];
   const int beam = a.beam;
   __shared__ HypSoA hyp[2];
@@ -213,6 +280,8 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
   __shared__ int e_seq[MAXE];
   __shared__ int e_rank[MAXE];
   __shared__ int s_nvalid[2];
+  __shared__ int s_claim[2][MAXB];
+  __shared__ int s_tie[2];
   __shared__ int tok[2][PB_CHUNK][MAXB];
   __shared__ float lp[2][PB_CHUNK][MAXB];
 
@@ -233,7 +302,9 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
     h.s[0] = 0.0; h.ns[0] = NEG_INF; h.vs[0] = 0.0; h.vns[0] = 0.0;  // search.py:144-147
     h.score[0] = 0.0; h.vit[0] = 0.0;
     s_nvalid[0] = 0; s_nvalid[1] = 0;
+    s_tie[0] = 0; s_tie[1] = 0;
   }
+  if (tid < 2 * MAXB) s_claim[tid / MAXB][tid % MAXB] = 0;
   {  // top-k chunk 0
     const int f = tid / beam, q = tid - f * beam;
     if (f < PB_CHUNK && f < T) {
@@ -253,8 +324,11 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
   const int my_slot = tid < MAXB ? tid : (tid >= 64 ? MAXB + (tid - 64) : 0x7fffffff);
   const int nx_f = tid / beam, nx_q = tid - nx_f * beam;
 
+  const bool dbg = a.dbg_cycles != nullptr && b == 0 && tid == 0;
+  long long c_eval = 0, c_rank = 0, c_sel = 0;
   int cur = 0, nb = 1;
   for (int t = 0; t < T; ++t) {
+    const long long c0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
     const HypSoA& H = hyp[cur];
     const int* tk = tok[(t / PB_CHUNK) & 1][t % PB_CHUNK];
     const float* lq = lp[(t / PB_CHUNK) & 1][t % PB_CHUNK];
@@ -280,18 +354,25 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
       const int r = tid;
       const int Klast = H.last[r];
       Ehash = H.hash[r]; Eparh = H.par_hash[r];
+      // all LDS reads first and unconditional (slots >= beam / nb hold stale
+      // values and are masked in the compares): one LDS round trip for the
+      // whole scan instead of one per iteration
       int qb = -1, ql = -1, rp = -1;
+      int tq[MAXB];
+      u64 hh[MAXB];
+#pragma unroll
+      for (int q = 0; q < MAXB; ++q) tq[q] = tk[q];
+#pragma unroll
+      for (int j = 0; j < MAXB; ++j) hh[j] = H.hash[j];
 #pragma unroll
       for (int q = 0; q < MAXB; ++q) {
-        const int u = tk[q];
-        if (q < beam && u == a.blank) qb = q;
-        if (q < beam && Klast >= 0 && u == Klast) ql = q;
+        const bool inb = q < beam;
+        qb = (inb & (tq[q] == a.blank)) ? q : qb;
+        ql = (inb & (Klast >= 0) & (tq[q] == Klast)) ? q : ql;
       }
 #pragma unroll
-      for (int j = 0; j < MAXB; ++j) {
-        const u64 hj = H.hash[j];
-        if (j < nb && hj == Eparh) rp = j;
-      }
+      for (int j = 0; j < MAXB; ++j)
+        rp = ((j < nb) & (hh[j] == Eparh)) ? j : rp;
       if (qb >= 0 || ql >= 0) {
         valid = 1;
         Ekey = H.node[r]; Epar = H.par[r]; Etoken = Klast; Edepth = H.depth[r];
@@ -340,12 +421,12 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
       const int u = tk[q];
       const u64 Ph = H.hash[r];
       const u64 ch = prefix_hash(Ph, u);
+      u64 hh[MAXB];
+#pragma unroll
+      for (int j = 0; j < MAXB; ++j) hh[j] = H.hash[j];  // unconditional, see above
       bool merged = false;
 #pragma unroll
-      for (int j = 0; j < MAXB; ++j) {
-        const u64 hj = H.hash[j];
-        if (j < nb && hj == ch) merged = true;
-      }
+      for (int j = 0; j < MAXB; ++j) merged |= (j < nb) & (hh[j] == ch);
       if (u != a.blank && !merged) {
         const double p = (double)lq[q];
         double x, v; int tb, sub;
@@ -369,36 +450,68 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
       if (lane == 0 && vm) atomicAdd(&s_nvalid[t & 1], __popcll(vm));
     }
     barrier_lds();
-    const int n_valid = s_nvalid[t & 1];
+    const long long c1 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    const int n_valid = __builtin_amdgcn_readfirstlane(s_nvalid[t & 1]);
     // ---- second beam prune: stable sort by score desc, keep `beam` -----------
     // rank(e) = #{ j : score_j > score_e or (score_j == score_e and seq_j < seq_e) }
-    {
-      const int n_chunks = (n_ent + 63) >> 6;
-      double sj[PB_CHUNKS];
-      int qj[PB_CHUNKS];
+    // Fast pass: count only score_j > score_e (one v_cmp + s_bcnt1 per 64
+    // entries).  That is the exact rank of every entry whose score is unique;
+    // entries that tie get the same number, so a tie inside the kept range
+    // shows up as two claims on one rank -> that frame reruns the exact pass.
+    auto rank_pass = [&](const bool exact) {
+      double sj[NCH];
+      int qj[NCH];
 #pragma unroll
-      for (int c = 0; c < PB_CHUNKS; ++c) {
+      for (int c = 0; c < NCH; ++c) {
         const int j = c * 64 + lane;
-        const bool in = c < n_chunks && j < n_ent;
+        const bool in = j < n_ent;
         sj[c] = in ? e_score[j] : NEG_INF;
         qj[c] = in ? e_seq[j] : 0x7fffffff;
       }
-      for (int e = wave; e < n_ent; e += PB_WAVES) {
-        const double se = e_score[e];
-        const int qe = e_seq[e];
+      // this wave ranks the slots e = wave + 8*it; lane `it` fetches slot e's
+      // key once, the loop broadcasts it with v_readlane (no LDS round trip
+      // per iteration) and lane `it` keeps the result
+      const int e_l = wave + PB_WAVES * lane;
+      const bool e_in = e_l < n_ent;
+      const double se_v = e_in ? e_score[e_l] : NEG_INF;
+      const int qe_v = e_in ? e_seq[e_l] : 0x7fffffff;
+      const int se_lo = __double2loint(se_v), se_hi = __double2hiint(se_v);
+      const int n_it = (n_ent - wave + PB_WAVES - 1) / PB_WAVES;
+      int my_r = 0;
+#pragma unroll 4
+      for (int it = 0; it < n_it; ++it) {
+        const double se = __hiloint2double(__builtin_amdgcn_readlane(se_hi, it),
+                                           __builtin_amdgcn_readlane(se_lo, it));
+        const int qe = __builtin_amdgcn_readlane(qe_v, it);
         int r = 0;
 #pragma unroll
-        for (int c = 0; c < PB_CHUNKS; ++c) {
-          if (c < n_chunks) {
-            const bool beats = (sj[c] > se) || (sj[c] == se && qj[c] < qe);
+        for (int c = 0; c < NCH; ++c) {
+          if (exact) {
+            // bitwise on purpose: no short-circuit branches in the loop
+            const bool beats = (sj[c] > se) | ((sj[c] == se) & (qj[c] < qe));
             r += __popcll(__ballot(beats));
+          } else {
+            r += __popcll(__ballot(sj[c] > se));
           }
         }
-        if (lane == 0) e_rank[e] = r;
+        if (lane == it) my_r = r;
       }
-    }
+      if (e_in) {
+        e_rank[e_l] = my_r;
+        if (!exact && qe_v != 0x7fffffff && my_r < beam) {
+          if (atomicAdd(&s_claim[t & 1][my_r], 1) != 0) s_tie[t & 1] = 1;
+        }
+      }
+    };
+    rank_pass(false);
     barrier_lds();
-    if (tid == 0) s_nvalid[(t + 1) & 1] = 0;
+    if (__builtin_amdgcn_readfirstlane(s_tie[t & 1])) {
+      rank_pass(true);
+      barrier_lds();
+    }
+    const long long c2 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    if (tid < MAXB) s_claim[(t + 1) & 1][tid] = 0;
+    if (tid == 0) { s_nvalid[(t + 1) & 1] = 0; s_tie[(t + 1) & 1] = 0; }
     if (valid) {
       const int rank = e_rank[my_slot];
       if (rank < beam) {
@@ -433,7 +546,12 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
     nb = min(beam, n_valid);
     cur ^= 1;
     barrier_lds();
+    if (dbg) {
+      const long long c3 = __builtin_amdgcn_s_memtime();
+      c_eval += c1 - c0; c_rank += c2 - c1; c_sel += c3 - c2;
+    }
   }
+  const long long c_loop_end = dbg ? __builtin_amdgcn_s_memtime() : 0;
   __syncthreads();  // node-pool stores visible to the emitting threads
 
   // ---- emit the n-best list -------------------------------------------------
@@ -445,20 +563,39 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
       const int L = h.depth[tid];
       a.hyp_lens[o] = L;
       a.hyp_scores[o] = h.score[tid];
+      // The token list and the time list are walked in ONE loop (two
+      // independent chains of dependent loads overlap).  times() is either
+      // never set (head 0) or has one entry per token; anything else falls
+      // back to the two-pass walk.
       int* tkn = a.hyp_tokens + o * a.max_len;
-      int node = h.node[tid];
-      for (int i = L - 1; i >= 0; --i) { tkn[i] = n_token[node]; node = n_parent[node]; }
-      int n_t = 0;
-      for (int x = h.tim[tid]; x != 0; x = t_prev[x]) ++n_t;
       int* tm = a.hyp_times + o * a.max_len;
+      int node = h.node[tid];
       int x = h.tim[tid];
-      for (int i = n_t - 1; i >= 0; --i) { tm[i] = t_val[x]; x = t_prev[x]; }
+      const bool has_t = x != 0;
+      int cnt = 0;
+      for (int i = L - 1; i >= 0; --i) {
+        tkn[i] = n_token[node];
+        node = n_parent[node];
+        if (x != 0) { tm[i] = t_val[x]; x = t_prev[x]; ++cnt; }
+      }
+      int n_t = has_t ? L : 0;
+      if (has_t && (x != 0 || cnt != L)) {  // not one time per token: recount
+        n_t = 0;
+        for (int y = h.tim[tid]; y != 0; y = t_prev[y]) ++n_t;
+        int y = h.tim[tid];
+        for (int i = n_t - 1; i >= 0; --i) { tm[i] = t_val[y]; y = t_prev[y]; }
+      }
       a.hyp_tlens[o] = n_t;  // == L, or 0 for a never-set list
     } else {
       a.hyp_lens[o] = 0;
       a.hyp_tlens[o] = 0;
       a.hyp_scores[o] = NEG_INF;
     }
+  }
+  if (dbg) {
+    a.dbg_cycles[0] = c_eval; a.dbg_cycles[1] = c_rank; a.dbg_cycles[2] = c_sel;
+    a.dbg_cycles[3] = T;
+    a.dbg_cycles[4] = __builtin_amdgcn_s_memtime() - c_loop_end;
   }
 }
 
@@ -491,6 +628,14 @@ int ctc_greedy_collapse(const int* top1, int top1_stride, const int* off,
   return 0;
 }
 
+int log_add_pairs(const double* a, const double* b, double* out, int n,
+                  hipStream_t s) {
+  WN_CHECK(n > 0 && a && b && out, "log_add: bad argument");
+  hipLaunchKernelGGL(log_add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, b, out, n);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
 int64_t prefix_beam_pool_ints(int max_len, int beam) {
   return 4 * ((int64_t)max_len * beam + 1);
 }
@@ -502,7 +647,10 @@ int ctc_prefix_beam(const PrefixBeamArgs& a, hipStream_t s) {
   WN_CHECK(a.k == a.beam, "prefix beam: top-k width must equal the beam");
   static_assert(64 + MAXB * MAXB <= PB_THREADS, "one thread per entry");
   static_assert(PB_CHUNK * MAXB <= PB_THREADS, "one thread per staged top-k pair");
-  hipLaunchKernelGGL(prefix_beam_kernel, dim3(a.B), dim3(PB_THREADS), 0, s, a);
+  if (MAXB + a.beam * a.beam <= 128)
+    hipLaunchKernelGGL(prefix_beam_kernel<2>, dim3(a.B), dim3(PB_THREADS), 0, s, a);
+  else
+    hipLaunchKernelGGL(prefix_beam_kernel<PB_CHUNKS>, dim3(a.B), dim3(PB_THREADS), 0, s, a);
   WN_HIP(hipGetLastError());
   return 0;
 }

@@ -89,8 +89,14 @@ struct PrefixBeamArgs {
   int* hyp_tokens;      // [B][beam][max_len]
   int* hyp_times;       // [B][beam][max_len]
   double* hyp_scores;   // [B][beam]
+  // optional phase timing of workgroup 0 (s_memtime cycles, summed over
+  // frames): [0] eval, [1] rank, [2] select/write, [3] frames, [4] emit
+  long long* dbg_cycles = nullptr;
 };
 int64_t prefix_beam_pool_ints(int max_len, int beam);
+// out[i] = log_add(a[i], b[i]) with the search's own fp64 routine (parity test)
+int log_add_pairs(const double* a, const double* b, double* out, int n,
+                  hipStream_t s);
 int ctc_prefix_beam(const PrefixBeamArgs& a, hipStream_t s);
 
 // Kaldi fbank (see fbank.hip).

@@ -2,6 +2,8 @@
 // the encoder / CTC / search / rescoring launch sequences and the C ABI
 // (include/wenet_amd.h).
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -209,6 +211,7 @@ struct wn_model {
   bool ctc_valid = false;
   DevBuf logits, topk_val, topk_idx;
   // searches
+  DevBuf pb_dbg;
   DevBuf g_tok, g_len, pb_pool, pb_nh, pb_len, pb_tlen, pb_tok, pb_tim, pb_score;
   // rescoring
   DevBuf r_tok, r_rtok, r_pos, r_tgt, r_rtgt, r_qoff, r_qlen, r_kvoff, r_kvlen;
@@ -1052,7 +1055,20 @@ int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
   a.n_hyps = m->pb_nh.as<int>(); a.hyp_lens = m->pb_len.as<int>();
   a.hyp_tlens = m->pb_tlen.as<int>(); a.hyp_tokens = m->pb_tok.as<int>();
   a.hyp_times = m->pb_tim.as<int>(); a.hyp_scores = m->pb_score.as<double>();
+  static const bool pb_dbg = getenv("WN_PB_CYCLES") != nullptr;  // debugging aid
+  if (pb_dbg) {
+    WN_TRY(m->pb_dbg.ensure(8 * sizeof(long long)));
+    a.dbg_cycles = m->pb_dbg.as<long long>();
+  }
   WN_TRY(ctc_prefix_beam(a, s));
+  if (pb_dbg) {
+    long long h[5];
+    WN_HIP(hipMemcpyAsync(h, a.dbg_cycles, sizeof(h), hipMemcpyDeviceToHost, s));
+    WN_HIP(hipStreamSynchronize(s));
+    fprintf(stderr, "[wn] prefix beam wg0: frames %lld, cycles/frame eval %.0f rank %.0f "
+            "select %.0f; emit %lld cycles\n", h[3], (double)h[0] / h[3],
+            (double)h[1] / h[3], (double)h[2] / h[3], h[4]);
+  }
   WN_HIP(hipMemcpyAsync(n_hyps_host, a.n_hyps, B * sizeof(int), hipMemcpyDeviceToHost, s));
   WN_HIP(hipMemcpyAsync(hyp_lens_host, a.hyp_lens, nb * sizeof(int), hipMemcpyDeviceToHost, s));
   WN_HIP(hipMemcpyAsync(hyp_tlens_host, a.hyp_tlens, nb * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1220,6 +1236,11 @@ int wn_op_gemm(const float* A, const float* W, const float* bias,
   g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N;
   g.alpha = alpha; g.act = act;
   return gemm_f32(g, (hipStream_t)stream);
+}
+
+int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,
+                  int32_t n, void* stream) {
+  return log_add_pairs(a_dev, b_dev, out_dev, n, (hipStream_t)stream);
 }
 
 int wn_op_layernorm(const float* x, const float* w, const float* b, float* y,
