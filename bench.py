@@ -95,6 +95,9 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='decodes kept in flight per GPU (wenet_amd/pipeline.py); '
+                         '1 = plain back-to-back ASRModel.decode() calls')
     ap.add_argument('--tune', default='',
                     help='experiments: comma list of key=value for wn_tune_set')
     args = ap.parse_args()
@@ -131,12 +134,25 @@ def main():
     total_audio = audio_seconds(glens.tolist())
     max_tok = 256
 
-    def step():
-        res = model.decode([METHOD], feats_dev, lens, beam_size=BEAM)[METHOD]
+    from wenet_amd.pipeline import DecodePipeline
+    pipe = DecodePipeline(model, n_streams=max(1, args.streams))
+
+    def finish(res):
         rec = wdist.pack_results(mine, [r.tokens for r in res],
                                  [r.score for r in res], BATCH_PER_GPU, max_tok,
                                  device)
         return wdist.gather_results(rec, world)
+
+    def run_steps(n):
+        """n decode passes over the batch, `--streams` of them in flight; the
+        per-step result gather (one all_gather) stays on the main thread, in
+        step order."""
+        futs = [pipe.submit([METHOD], feats_dev, lens, beam_size=BEAM)
+                for _ in range(n)]
+        out = None
+        for f in futs:
+            out = finish(f.result()[METHOD])
+        return out
 
     def barrier():
         if world > 1:
@@ -144,21 +160,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
+    out = run_steps(args.warmup)
     L = _lib.lib()
-    _lib.check(L.wn_profile_enable(model._h, 1), 'profile')
+    for mdl in pipe.models:
+        _lib.check(L.wn_profile_enable(mdl._h, 1), 'profile')
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     n_launch, ms, flops = ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
-    _lib.check(L.wn_profile_collect(model._h, ctypes.byref(n_launch),
-                                    ctypes.byref(ms), ctypes.byref(flops)),
-               'profile')
-    _lib.check(L.wn_profile_enable(model._h, 0), 'profile')
+    tot_launch, tot_ms, tot_flops = 0, 0.0, 0.0
+    for mdl in pipe.models:
+        _lib.check(L.wn_profile_collect(mdl._h, ctypes.byref(n_launch),
+                                        ctypes.byref(ms), ctypes.byref(flops)),
+                   'profile')
+        _lib.check(L.wn_profile_enable(mdl._h, 0), 'profile')
+        tot_launch += n_launch.value
+        tot_ms += ms.value
+        tot_flops += flops.value
+    n_launch.value, ms.value, flops.value = tot_launch, tot_ms, tot_flops
+    pipe.close()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -194,6 +216,7 @@ def main():
                 'audio_seconds_per_step': round(total_audio, 1),
                 'encoder_frames_per_gpu': enc_rows,
                 'parallelism': f'utterance-sharded x{world}, one all_gather of results',
+                'decodes_in_flight_per_gpu': max(1, args.streams),
             },
             'roofline': {
                 'bound': 'mfma',

@@ -75,6 +75,12 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
                     int32_t n_weights, int32_t device, wn_model** out);
 void wn_model_destroy(wn_model* m);
 
+/* A second handle on the same (immutable, shared) weights with its own
+ * workspace and current batch: one handle per in-flight batch lets a host keep
+ * several batches running on different streams (wenet_amd/pipeline.py).
+ * Handles may be used from different host threads, one thread per handle. */
+int wn_model_clone(const wn_model* src, wn_model** out);
+
 /* A weight-less handle that only owns a workspace: enough for
  * wn_set_ctc_probs + the two CTC searches, i.e. for calling the reference's
  * free functions search.ctc_greedy_search / ctc_prefix_beam_search on a

@@ -324,3 +324,30 @@ def test_rejects_cpu_tensors_and_chunk_zero():
     with pytest.raises(AssertionError):
         model.decode(['ctc_greedy_search'], feats.cuda(), torch.tensor([40]),
                      decoding_chunk_size=0)
+
+
+def test_pipeline_two_streams_matches_sequential_decode():
+    """wenet_amd.pipeline.DecodePipeline (2 decodes in flight on cloned
+    workspace handles) returns exactly what back-to-back decode() calls do."""
+    from wenet_amd import synthetic as S
+    from wenet_amd.pipeline import DecodePipeline
+    configs, sd, model = cached_model('tiny_causal', 0)
+    batches = []
+    for i in range(5):
+        feats, lens = S.make_features(3 + i % 2, (40, 160), seed=100 + i)
+        batches.append((feats.cuda(), lens))
+    kw = dict(beam_size=4, ctc_weight=0.5, reverse_weight=0.3)
+    seq = [model.decode(METHODS, f, l, **kw) for f, l in batches]
+    with DecodePipeline(model, n_streams=2) as pipe:
+        par = pipe.decode_many(METHODS, batches, **kw)
+        par2 = pipe.decode_many(METHODS, batches[::-1], **kw)[::-1]
+    for got_all in (par, par2):
+        for want, got in zip(seq, got_all):
+            for m in METHODS:
+                assert len(want[m]) == len(got[m])
+                for a, b in zip(want[m], got[m]):
+                    assert list(a.tokens) == list(b.tokens)
+                    assert a.score == b.score
+                    if a.nbest is not None:
+                        assert [list(x) for x in a.nbest] == [list(x) for x in b.nbest]
+                        assert list(a.nbest_scores) == list(b.nbest_scores)

@@ -188,7 +188,8 @@ using namespace wn;
 struct wn_model {
   wn_config cfg;
   int device = 0;
-  DevBuf weights;                        // one slab for every weight
+  // immutable after create, shared by wn_model_clone()d handles
+  std::shared_ptr<DevBuf> weights = std::make_shared<DevBuf>();  // one slab for every weight
   std::map<std::string, const float*> w; // name -> device pointer
   // re-laid-out subsampling weights
   const float* conv1_w = nullptr; const float* conv1_b = nullptr;
@@ -199,7 +200,7 @@ struct wn_model {
   Linear ctc;
   std::vector<EncLayer> layers;
   Decoder left, right;
-  DevBuf pos_tabs;
+  std::shared_ptr<DevBuf> pos_tabs = std::make_shared<DevBuf>();
 
   // ---- current batch ----------------------------------------------------
   int B = 0, Tp = 0, rows = 0;          // rows of the encoder-output layout
@@ -229,7 +230,8 @@ struct wn_model {
   // fbank tables
   const float* fb_window = nullptr; const float* fb_twiddle = nullptr;
   const float* fb_mel_w = nullptr;
-  DevBuf fb_tab_i, fb_off, fb_nfr;
+  std::shared_ptr<DevBuf> fb_tab_i = std::make_shared<DevBuf>();
+  DevBuf fb_off, fb_nfr;
 
   int F1() const { return (cfg.feat_dim - 1) / 2; }
   int F2() const { return (F1() - 1) / 2; }
@@ -636,10 +638,10 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
     }
   }
   // ---- upload ---------------------------------------------------------------
-  WN_TRY(m->weights.ensure(hs.data.size() * sizeof(float)));
-  WN_HIP(hipMemcpy(m->weights.p, hs.data.data(), hs.data.size() * sizeof(float),
+  WN_TRY(m->weights->ensure(hs.data.size() * sizeof(float)));
+  WN_HIP(hipMemcpy(m->weights->p, hs.data.data(), hs.data.size() * sizeof(float),
                    hipMemcpyHostToDevice));
-  const float* base = m->weights.as<float>();
+  const float* base = m->weights->as<float>();
   for (auto& kv : hs.at) m->w[kv.first] = base + kv.second.first;
   auto W = [&](const std::string& n) { return m->w.at(n); };
   auto LIN = [&](const std::string& p, int o, int i, bool bias = true) {
@@ -663,14 +665,14 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
     tab.insert(tab.end(), mel_start.begin(), mel_start.end());
     tab.insert(tab.end(), mel_len.begin(), mel_len.end());
     tab.insert(tab.end(), mel_off.begin(), mel_off.end());
-    WN_TRY(m->fb_tab_i.ensure(tab.size() * sizeof(int)));
-    WN_HIP(hipMemcpy(m->fb_tab_i.p, tab.data(), tab.size() * sizeof(int),
+    WN_TRY(m->fb_tab_i->ensure(tab.size() * sizeof(int)));
+    WN_HIP(hipMemcpy(m->fb_tab_i->p, tab.data(), tab.size() * sizeof(int),
                      hipMemcpyHostToDevice));
   }
   m->after_norm = NORM("encoder.after_norm");
   m->ctc = LIN("ctc.ctc_lo", V, d);
   m->layers.resize(c.n_layers);
-  WN_TRY(m->pos_tabs.ensure((size_t)c.n_layers * c.max_pos * d * sizeof(float)));
+  WN_TRY(m->pos_tabs->ensure((size_t)c.n_layers * c.max_pos * d * sizeof(float)));
   for (int i = 0; i < c.n_layers; ++i) {
     const std::string p = "encoder.encoders." + std::to_string(i);
     EncLayer& L = m->layers[i];
@@ -696,7 +698,7 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
     L.cpad = W(p + ".cpad");
     // p = linear_pos(pos_emb) depends on weights only (attention.py:395-396):
     // project the whole table once instead of per batch and layer.
-    L.pos_tab = m->pos_tabs.as<float>() + (size_t)i * c.max_pos * d;
+    L.pos_tab = m->pos_tabs->as<float>() + (size_t)i * c.max_pos * d;
     Linear lp; lp.w = L.pos_w; lp.b = nullptr; lp.out = d; lp.in = d;
     WN_TRY(linear(lp, m->pe, d, L.pos_tab, d, c.max_pos, 0));
   }
@@ -733,6 +735,31 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
 }
 
 void wn_model_destroy(wn_model* m) { delete m; }
+
+int wn_model_clone(const wn_model* src, wn_model** out) {
+  WN_CHECK(src && out, "wn_model_clone: null argument");
+  WN_HIP(hipSetDevice(src->device));
+  std::unique_ptr<wn_model> m(new wn_model());
+  m->cfg = src->cfg;
+  m->device = src->device;
+  // weights, projected position tables and fbank tables are read-only: share
+  m->weights = src->weights;
+  m->pos_tabs = src->pos_tabs;
+  m->fb_tab_i = src->fb_tab_i;
+  m->w = src->w;
+  m->conv1_w = src->conv1_w; m->conv1_b = src->conv1_b;
+  m->conv2 = src->conv2; m->sub_out = src->sub_out;
+  m->cmvn_mean = src->cmvn_mean; m->cmvn_istd = src->cmvn_istd;
+  m->pe = src->pe;
+  m->after_norm = src->after_norm;
+  m->ctc = src->ctc;
+  m->layers = src->layers;
+  m->left = src->left; m->right = src->right;
+  m->fb_window = src->fb_window; m->fb_twiddle = src->fb_twiddle;
+  m->fb_mel_w = src->fb_mel_w;
+  *out = m.release();
+  return 0;
+}
 
 int wn_profile_enable(wn_model* m, int32_t on) {
   WN_CHECK(m, "wn_profile_enable: null model");
@@ -1274,7 +1301,7 @@ int wn_fbank(wn_model* m, const float* pcm_dev, const int64_t* sample_off_host,
   a.pcm = pcm_dev; a.sample_off = m->fb_off.as<int64_t>();
   a.n_frames = m->fb_nfr.as<int>(); a.B = B; a.max_frames = max_frames;
   a.n_mel = m->cfg.feat_dim; a.window = m->fb_window; a.twiddle = m->fb_twiddle;
-  const int* tab = m->fb_tab_i.as<int>();
+  const int* tab = m->fb_tab_i->as<int>();
   a.mel_start = tab; a.mel_len = tab + a.n_mel; a.mel_off = tab + 2 * a.n_mel;
   a.mel_w = m->fb_mel_w; a.feats = feats_dev;
   return fbank_kaldi(a, s);

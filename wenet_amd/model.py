@@ -170,6 +170,20 @@ class ASRModel:
         self._L = L
         self._last_prefix_raw = None
 
+    def clone(self) -> 'ASRModel':
+        """A second model object on the SAME device weights with its own
+        workspace (wn_model_clone): one per in-flight batch
+        (wenet_amd/pipeline.py)."""
+        other = object.__new__(ASRModel)
+        other.__dict__.update({k: v for k, v in self.__dict__.items()
+                               if k not in ('_h', '_last_prefix_raw')})
+        h = ctypes.c_void_p()
+        _lib.check(self._L.wn_model_clone(self._h, ctypes.byref(h)),
+                   'wn_model_clone')
+        other._h = h.value
+        other._last_prefix_raw = None
+        return other
+
     def __del__(self):
         h = getattr(self, '_h', None)
         if h:
@@ -324,6 +338,18 @@ class ASRModel:
                infos: Dict[str, List[str]] = None
                ) -> Dict[str, List[DecodeResult]]:
         """asr_model.py:267-343."""
+        st = self._decode_begin(methods, speech, speech_lengths, beam_size,
+                                decoding_chunk_size, num_decoding_left_chunks,
+                                simulate_streaming, context_graph, blank_id,
+                                blank_penalty)
+        return self._decode_end(st, ctc_weight, reverse_weight)
+
+    def _decode_begin(self, methods, speech, speech_lengths, beam_size=1,
+                      decoding_chunk_size=-1, num_decoding_left_chunks=-1,
+                      simulate_streaming=False, context_graph=None, blank_id=0,
+                      blank_penalty=0.0):
+        """First half of decode(): argument checks, then the encoder and the
+        CTC head are queued on the current stream (no host sync)."""
         assert speech.shape[0] == speech_lengths.shape[0]
         assert decoding_chunk_size != 0
         for mth in methods:
@@ -346,13 +372,21 @@ class ASRModel:
             self._L.wn_ctc_logprobs(self._h, k, blank_id, blank_penalty, None,
                                     Tp, _stream_ptr(self.device)),
             'wn_ctc_logprobs')
+        return dict(methods=methods, B=B, enc_lens=enc_lens, need_beam=need_beam,
+                    beam_size=beam_size, blank_id=blank_id, speech=speech)
+
+    def _decode_end(self, st, ctc_weight=0.0, reverse_weight=0.0):
+        """Second half of decode(): the searches (+ rescoring) and the result
+        records; synchronises the stream."""
+        methods, B, enc_lens = st['methods'], st['B'], st['enc_lens']
+        beam_size, blank_id = st['beam_size'], st['blank_id']
         results = {}
         max_len = int(enc_lens.max()) if B > 0 else 0
         if 'ctc_greedy_search' in methods:
             results['ctc_greedy_search'] = _greedy(self._h, B, max_len,
                                                    blank_id, self.device)
         prefix = None
-        if need_beam:
+        if st['need_beam']:
             prefix, self._last_prefix_raw = _prefix_beam(
                 self._h, B, max_len, beam_size, blank_id, self.device)
             if 'ctc_prefix_beam_search' in methods:

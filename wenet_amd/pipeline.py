@@ -1,0 +1,95 @@
+"""Keep several batches in flight on one GPU.
+
+`ASRModel.decode()` is synchronous like the reference's
+(asr_model.py:267-343): it returns Python results, so it ends with a
+device-to-host copy and a stream sync.  Within ONE batch the CTC prefix beam
+search is T' dependent steps on 32 workgroups while the other ~220 CUs idle,
+and the host cannot queue the next batch's ~200 launches until the results are
+back.  `DecodePipeline` runs `n_streams` decodes concurrently, each on its own
+HIP stream and its own workspace handle (`wn_model_clone`: the weights are
+shared), so the search / result copy of batch i overlaps the encoder of batch
+i+1.  The encoders themselves are chained with HIP events (encoder i+1 starts
+on the GPU when encoder i has finished): the MFMA-bound GEMMs of two batches
+never share the chip -- they would only slow each other -- while the
+latency-bound search always has a full encoder to hide under.  Results are
+identical to `ASRModel.decode()`: every batch runs the same kernels in the same
+order on its stream.
+
+One host thread per stream drives the C ABI (ctypes drops the GIL inside the
+calls); the reference's own multi-process sharding (tools/decode.sh:65-83) is
+the precedent for running independent decodes side by side.
+"""
+import concurrent.futures
+import queue
+import threading
+from typing import List
+
+import torch
+
+from wenet_amd.model import ASRModel
+
+
+class DecodePipeline:
+
+    def __init__(self, model: ASRModel, n_streams: int = 2):
+        assert n_streams >= 1
+        self.device = model.device
+        self.models: List[ASRModel] = [model] + [model.clone()
+                                                 for _ in range(n_streams - 1)]
+        self.streams = [torch.cuda.Stream(device=self.device)
+                        for _ in range(n_streams)]
+        self._free = queue.SimpleQueue()
+        for i in range(n_streams):
+            self._free.put(i)
+        self._pool = concurrent.futures.ThreadPoolExecutor(
+            max_workers=n_streams, thread_name_prefix='wn-decode')
+        # encoder chain: launch order == execution order of the encoders
+        self._enc_lock = threading.Lock()
+        self._enc_done = None
+
+    def _run(self, ready: torch.cuda.Event, methods, speech, speech_lengths, kw):
+        i = self._free.get()
+        try:
+            torch.cuda.set_device(self.device)
+            stream = self.streams[i]
+            stream.wait_event(ready)  # inputs produced on the caller's stream
+            kw = dict(kw)
+            ctc_weight = kw.pop('ctc_weight', 0.0)
+            reverse_weight = kw.pop('reverse_weight', 0.0)
+            kw.pop('length_penalty', None)
+            kw.pop('infos', None)
+            with torch.cuda.stream(stream):
+                with self._enc_lock:
+                    if self._enc_done is not None:
+                        stream.wait_event(self._enc_done)
+                    st = self.models[i]._decode_begin(methods, speech,
+                                                      speech_lengths, **kw)
+                    done = torch.cuda.Event()
+                    done.record(stream)
+                    self._enc_done = done
+                return self.models[i]._decode_end(st, ctc_weight, reverse_weight)
+        finally:
+            self._free.put(i)
+
+    def submit(self, methods, speech: torch.Tensor, speech_lengths: torch.Tensor,
+               **kw) -> concurrent.futures.Future:
+        """Queue one `decode()`; returns a Future of its result dict."""
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        return self._pool.submit(self._run, ready, methods, speech,
+                                 speech_lengths, kw)
+
+    def decode_many(self, methods, batches, **kw):
+        """decode() every (speech, speech_lengths) of `batches`, results in
+        order."""
+        futs = [self.submit(methods, s, l, **kw) for s, l in batches]
+        return [f.result() for f in futs]
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
