@@ -33,7 +33,6 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(CtcRowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float srow[];
   __shared__ float red[8];
   __shared__ VI redvi[4];
-  __shared__ VI chosen;
   const int row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* x = a.logits + (int64_t)row * a.ld;
@@ -58,34 +57,38 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(CtcRowArgs a) {
     float* o = a.logp + (int64_t)row * a.ld_out;
     for (int i = tid; i < a.V; i += 256) o[i] = (srow[i] - mx) - lsum;
   }
-  VI prev;
-  prev.v = INFINITY;
-  prev.i = -1;
-  for (int r = 0; r < a.k; ++r) {
+  // top-k: every thread keeps the best of ITS strided elements; a round is one
+  // block arg-max over those 256 candidates, after which only the winner's
+  // owner rescans its V/256 elements (taken ones are overwritten with NaN,
+  // which no comparison selects).  Order: larger value first, lower index on
+  // ties (strict > while scanning indices upwards).
+  __syncthreads();  // all reads of srow for the log-prob row are done
+  auto local_best = [&]() {
     VI best;
     best.v = -INFINITY;
     best.i = 0x7fffffff;
     for (int i = tid; i < a.V; i += 256) {
       const float v = srow[i];
-      if (v < prev.v || (v == prev.v && i > prev.i)) {
-        VI c;
-        c.v = v;
-        c.i = i;
-        best = vi_better(best, c);
-      }
+      if (v > best.v || (v == best.v && i < best.i)) { best.v = v; best.i = i; }
     }
-    best = vi_wave(best);
+    return best;
+  };
+  VI mine = local_best();
+  for (int r = 0; r < a.k; ++r) {
+    VI best = vi_wave(mine);
     if (lane == 0) redvi[wave] = best;
     __syncthreads();
+    const VI b = vi_better(vi_better(redvi[0], redvi[1]),
+                           vi_better(redvi[2], redvi[3]));
     if (tid == 0) {
-      VI b = vi_better(vi_better(redvi[0], redvi[1]),
-                       vi_better(redvi[2], redvi[3]));
-      chosen = b;
       a.topk_val[(int64_t)row * a.k + r] = (b.v - mx) - lsum;
       a.topk_idx[(int64_t)row * a.k + r] = b.i;
     }
-    __syncthreads();
-    prev = chosen;
+    if (b.i < a.V && (b.i & 255) == tid) {  // owner: retire it, find the next
+      srow[b.i] = __builtin_nanf("");
+      mine = local_best();
+    }
+    __syncthreads();  // redvi reusable
   }
 }
 

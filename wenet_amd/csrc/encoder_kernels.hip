@@ -84,6 +84,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   r.store(y + (int64_t)row * ldy, lane);
 }
 
+// y1 = LN(x; w1, b1); y2 = LN(y1; w2, b2): norm_final of layer i followed by
+// norm_ff_macaron of layer i+1 (encoder_layer.py:263 -> :220) in one pass.
+template <int E>
+__global__ __launch_bounds__(256) void layernorm2_kernel(
+    const float* __restrict__ x, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2,
+    const float* __restrict__ b2, float* __restrict__ y1,
+    float* __restrict__ y2, int M, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  constexpr int D = E * 64;
+  RowRegs<E> r;
+  r.load(x + (int64_t)row * D, lane);
+  ln_inplace<E>(r, w1, b1, lane, eps);
+  r.store(y1 + (int64_t)row * D, lane);
+  ln_inplace<E>(r, w2, b2, lane, eps);
+  r.store(y2 + (int64_t)row * D, lane);
+}
+
 // ===========================================================================
 // GlobalCMVN (cmvn.py:36-47) + Conv2d(1, C, 3, stride 2) + ReLU
 // (subsampling.py:188-190).  One block per (utterance, T1 frame): the three
@@ -103,17 +123,24 @@ __global__ __launch_bounds__(256) void cmvn_conv1_kernel(Conv1Args a) {
   }
   __syncthreads();
   float* dst = a.out + (int64_t)(a.t1_off[b] + t1) * a.F1 * a.C;
-  const int total = a.F1 * a.C;
-  for (int o = threadIdx.x; o < total; o += 256) {
-    const int f1 = o / a.C, c = o % a.C;
-    // accumulation order = (ky, kx) row-major, like a direct conv loop
-    float acc = a.bias[c];
+  // one output channel per thread: its 9 taps + bias stay in registers, the
+  // input taps are wave-uniform LDS broadcasts, the store is one coalesced
+  // row of C floats per f1
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    float w[9];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int k = 0; k < 9; ++k) w[k] = a.w[k * a.C + c];
+    const float bias = a.bias[c];
+    for (int f1 = 0; f1 < a.F1; ++f1) {
+      // accumulation order = (ky, kx) row-major, like a direct conv loop
+      float acc = bias;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
-        acc = fmaf(a.w[(ky * 3 + kx) * a.C + c], xin[ky][2 * f1 + kx], acc);
-    dst[o] = fmaxf(acc, 0.f);
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          acc = fmaf(w[ky * 3 + kx], xin[ky][2 * f1 + kx], acc);
+      dst[f1 * a.C + c] = fmaxf(acc, 0.f);
+    }
   }
 }
 
@@ -168,7 +195,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs a) {
 // HBM.
 //
 // One block = NW waves, each wave owns 32 query rows of one (sequence, head).
-// Per 32-key tile, K (and the projected position rows P) are staged in LDS and
+// Per 32-key tile, K, V (and the projected position rows P) are staged
+// global -> registers -> LDS one tile ahead (double-buffered LDS, one barrier
+// per tile: the load latency hides under the previous tile's MFMAs) and
 // the TRANSPOSED score tile S^T = K (Q+u)^T + P (Q+v)^T is produced with
 // v_mfma_f32_32x32x2_f32: lane l then holds, for ITS query (l & 31), the 16
 // keys (r&3)+8(r>>2)+4(l>>5), r = 0..15.  Row max / sum are 15 in-lane ops plus
@@ -189,9 +218,10 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, li = lane & 31;
 
-  __shared__ __attribute__((aligned(16))) float sK[KT * KSTR];
-  __shared__ __attribute__((aligned(16))) float sP[RELPOS ? KT * KSTR : 4];
-  __shared__ __attribute__((aligned(16))) float sV[KT * KSTR];
+  // double-buffered K / V / P tiles: [buf][matrix][KT * KSTR]
+  constexpr int NMAT = RELPOS ? 3 : 2;
+  constexpr int MAT = KT * KSTR;
+  __shared__ __attribute__((aligned(16))) float stile[2 * NMAT * MAT];
 
   // ---- this lane's query row ---------------------------------------------
   const int qi = q0 + wave * 32 + li;
@@ -242,25 +272,51 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
 
-  for (int kt = t_lo; kt < t_hi; ++kt) {
+  // ---- tile staging: global -> registers (issued a whole tile ahead, so the
+  // HBM / L2 latency hides under the previous tile's MFMAs) -> LDS.
+  constexpr int NCH = KT * 16 / (NW * 64);  // float4 chunks per thread and matrix
+  f32x4 rK[NCH], rV[NCH], rP[RELPOS ? NCH : 1];
+  auto gload = [&](int kt) {
     const int j0 = kt * KT;
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K / P / V tiles: 32 rows x 16 float4 each -------------------
-    for (int c = tid; c < KT * 16; c += NW * 64) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * (NW * 64);
       const int r = c >> 4, c4 = c & 15;
       int j = j0 + r;
       if (j > kvlen - 1) j = kvlen - 1;
       const int64_t grow = kvoff + j;
-      *reinterpret_cast<f32x4*>(sK + r * KSTR + c4 * 4) =
-          *reinterpret_cast<const f32x4*>(a.K + grow * a.ldk + h * 64 + c4 * 4);
-      *reinterpret_cast<f32x4*>(sV + r * KSTR + c4 * 4) =
-          *reinterpret_cast<const f32x4*>(a.V + grow * a.ldv + h * 64 + c4 * 4);
+      rK[i] = *reinterpret_cast<const f32x4*>(a.K + grow * a.ldk + h * 64 + c4 * 4);
+      rV[i] = *reinterpret_cast<const f32x4*>(a.V + grow * a.ldv + h * 64 + c4 * 4);
       if (RELPOS)
-        *reinterpret_cast<f32x4*>(sP + r * KSTR + c4 * 4) =
-            *reinterpret_cast<const f32x4*>(a.P + (int64_t)j * a.ldp + h * 64 +
-                                            c4 * 4);
+        rP[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)j * a.ldp + h * 64 +
+                                                c4 * 4);
     }
-    __syncthreads();
+  };
+  auto lstore = [&](int buf) {
+    float* base = stile + buf * NMAT * MAT;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * (NW * 64);
+      const int r = c >> 4, c4 = c & 15;
+      *reinterpret_cast<f32x4*>(base + r * KSTR + c4 * 4) = rK[i];
+      *reinterpret_cast<f32x4*>(base + MAT + r * KSTR + c4 * 4) = rV[i];
+      if (RELPOS)
+        *reinterpret_cast<f32x4*>(base + 2 * MAT + r * KSTR + c4 * 4) = rP[i];
+    }
+  };
+  if (t_lo < t_hi) {
+    gload(t_lo);
+    lstore(0);
+  }
+  __syncthreads();
+
+  for (int kt = t_lo; kt < t_hi; ++kt) {
+    const int j0 = kt * KT;
+    const int cur = (kt - t_lo) & 1;
+    const float* sK = stile + cur * NMAT * MAT;
+    const float* sV = sK + MAT;
+    const float* sP = sK + 2 * MAT;
+    if (kt + 1 < t_hi) gload(kt + 1);
 
     // ---- S^T tile -------------------------------------------------------------
     f32x16 sc;
@@ -297,11 +353,11 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = expf(m_run - m_new);
+    const float alpha = __expf(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = ok[r] ? expf(sc[r] - m_new) : 0.f;
+      const float p = ok[r] ? __expf(sc[r] - m_new) : 0.f;
       sc[r] = p;
       psum += p;
     }
@@ -325,6 +381,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[st], v0, o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[st], v1, o1, 0, 0, 0);
     }
+    if (kt + 1 < t_hi) lstore(cur ^ 1);
+    __syncthreads();  // next tile visible; this tile's buffer free for reuse
   }
   // ---- normalise and store -------------------------------------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -374,6 +432,27 @@ int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
       return -1;
   }
 #undef WN_LN
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+int layernorm2(const float* x, const float* w1, const float* b1, const float* w2,
+               const float* b2, float* y1, float* y2, int M, int D, float eps,
+               hipStream_t s) {
+  WN_CHECK(M > 0, "layernorm2: empty");
+  dim3 g(cdiv(M, 4)), t(256);
+#define WN_LN2(E)                                                               \
+  case E * 64:                                                                  \
+    hipLaunchKernelGGL(layernorm2_kernel<E>, g, t, 0, s, x, w1, b1, w2, b2, y1, \
+                       y2, M, eps);                                             \
+    break;
+  switch (D) {
+    WN_LN2(1) WN_LN2(2) WN_LN2(4) WN_LN2(8) WN_LN2(12) WN_LN2(16) WN_LN2(20)
+    default:
+      set_error("layernorm2: unsupported width " + std::to_string(D));
+      return -1;
+  }
+#undef WN_LN2
   WN_HIP(hipGetLastError());
   return 0;
 }

@@ -17,8 +17,9 @@
 //    hits 16 distinct 16-B slots per 16-lane service group -> conflict-free.
 //    One 16-B LDS read feeds 4 MFMAs (lanes 0-31 carry k..k+3, lanes 32-63
 //    k+4..k+7; any k pairing is legal as long as A and W agree).
-//  * double-buffered LDS, one barrier per K tile; global loads for tile t+1
-//    are issued before the MFMAs of tile t.
+//  * double-buffered LDS, one barrier per K tile; global loads run two tiles
+//    ahead (two named register sets) so that even a 16-MFMA tile hides an
+//    Infinity-Cache / HBM round trip.
 //  * XCD-aware block order: the N tiles of one M panel run on the same XCD so
 //    the A panel is fetched into one L2, not eight.
 //  * epilogue fused: bias, SiLU/ReLU, alpha, residual add, GLU.
@@ -38,18 +39,19 @@ __device__ __forceinline__ float silu_fast(float x) {
   return x * __frcp_rn(1.0f + __expf(-x));
 }
 
-constexpr int BK = 32;
-constexpr int LDS_STRIDE = 36;  // floats
+constexpr int BK = 32;  // K granularity every problem must respect
 
 template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
-          bool CONV>
+          bool CONV, int BK = 32, int PF = 1>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
     GemmArgs p, int tiles_m, int tiles_n, int variant) {
+  constexpr int LDS_STRIDE = BK + 4;  // floats; rows land on distinct 16-B slots
+  constexpr int KC = BK / 4;          // float4 chunks per tile row
   constexpr int NTHR = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
-  constexpr int A_CHUNKS = BM * 8 / NTHR;  // float4 chunks per thread
-  constexpr int B_CHUNKS = BN * 8 / NTHR;
+  constexpr int A_CHUNKS = BM * KC / NTHR;  // float4 chunks per thread
+  constexpr int B_CHUNKS = BN * KC / NTHR;
   static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1 && MT >= 1 && NT >= 1, "tile");
   static_assert(!GLU || NT == 2, "GLU epilogue needs a 64-wide wave tile");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
 #pragma unroll
   for (int i = 0; i < A_CHUNKS; ++i) {
     const int c = tid + NTHR * i;
-    const int row = c >> 3, kc = c & 7;
+    const int row = c / KC, kc = c % KC;
     int grow = m0 + row;
     if (grow > p.M - 1) grow = p.M - 1;
     if (CONV) {
@@ -91,15 +93,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
 #pragma unroll
   for (int i = 0; i < B_CHUNKS; ++i) {
     const int c = tid + NTHR * i;
-    const int row = c >> 3, kc = c & 7;
+    const int row = c / KC, kc = c % KC;
     int grow = n0 + row;
     if (grow > p.N - 1) grow = p.N - 1;
     b_ptr[i] = p.W + (int64_t)grow * p.K + kc * 4;
     b_lds[i] = row * LDS_STRIDE + kc * 4;
   }
 
-  f32x4 ra[A_CHUNKS], rb[B_CHUNKS];
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt, f32x4 (&ra)[A_CHUNKS], f32x4 (&rb)[B_CHUNKS]) {
     const int k0 = kt * BK;
     int64_t aoff = k0;
     if (CONV) {
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
     for (int i = 0; i < B_CHUNKS; ++i)
       rb[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + k0);
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const f32x4 (&ra)[A_CHUNKS],
+                    const f32x4 (&rb)[B_CHUNKS]) {
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i)
       *reinterpret_cast<f32x4*>(smem + buf * TILE + a_lds[i]) = ra[i];
@@ -132,23 +134,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int nk = p.K / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-
   // LDS fragment addresses: row = lane & 31, k sub-block = lane >> 5.
   const int frag_off = (lane & 31) * LDS_STRIDE + (lane >> 5) * 4;
   const int a_frag = (wm * WTM) * LDS_STRIDE + frag_off;
   const int b_frag = (wn_ * WTN) * LDS_STRIDE + frag_off;
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk && !(variant & 8)) gload(kt + 1);
+  auto compute = [&](int cur) {
     const float* cA = smem + cur * TILE + a_frag;
     const float* cB = smem + cur * TILE + BM * LDS_STRIDE + b_frag;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < BK / 8; ++kk) {
       f32x4 fa[MT], fb[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -167,8 +161,42 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                 fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) lstore(cur ^ 1);
+  };
+
+  const int nk = p.K / BK;
+  if constexpr (PF == 2) {
+    // Global prefetch distance 2 (two register sets, statically named): the
+    // loads of tile kt+2 are issued before the MFMAs of tile kt and consumed
+    // one whole iteration later.
+    f32x4 ra0[A_CHUNKS], rb0[B_CHUNKS], ra1[A_CHUNKS], rb1[B_CHUNKS];
+    gload(0, ra0, rb0);
+    if (nk > 1) gload(1, ra1, rb1);
+    lstore(0, ra0, rb0);
     __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      if (kt + 2 < nk) gload(kt + 2, ra0, rb0);
+      compute(0);
+      lstore(1, ra1, rb1);          // tile kt+1, loaded one iteration ago
+      __syncthreads();
+      if (kt + 3 < nk) gload(kt + 3, ra1, rb1);
+      compute(1);
+      if (kt + 2 < nk) lstore(0, ra0, rb0);
+      __syncthreads();
+    }
+    if (kt < nk) compute(0);        // odd tile count: the last tile is in buf 0
+  } else {
+    f32x4 ra[A_CHUNKS], rb[B_CHUNKS];
+    gload(0, ra, rb);
+    lstore(0, ra, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) gload(kt + 1, ra, rb);
+      compute(cur);
+      if (kt + 1 < nk) lstore(cur ^ 1, ra, rb);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ------------------------------------------------------------
@@ -264,11 +292,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
 }
 
 template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
-          bool CONV>
+          bool CONV, int BKT = 32, int PF = 1>
 int launch(const GemmArgs& a, hipStream_t stream) {
   const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
-  const size_t lds = 2 * (BM + BN) * LDS_STRIDE * sizeof(float);
-  auto kern = gemm_f32_kernel<BM, BN, WGM, WGN, ACT, RESID, GLU, CONV>;
+  const size_t lds = 2 * (BM + BN) * (BKT + 4) * sizeof(float);
+  auto kern = gemm_f32_kernel<BM, BN, WGM, WGN, ACT, RESID, GLU, CONV, BKT, PF>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
     WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -285,6 +313,9 @@ int launch(const GemmArgs& a, hipStream_t stream) {
 template <int BM, int BN, int WGM, int WGN, bool CONV>
 int dispatch_epi(const GemmArgs& a, hipStream_t s) {
   const bool resid = a.resid != nullptr;
+  // long K loops stream an operand from HBM / Infinity Cache: prefetch two
+  // tiles ahead there (measured +2..4 %); short ones (K = d) gain nothing
+  const bool pf2 = !CONV && ((a.K >= 1024) != ((g_gemm_variant & 128) != 0));
   if (a.glu) {
     if constexpr (BN / WGN == 64 && !CONV) {
       return launch<BM, BN, WGM, WGN, ACT_NONE, false, true, false>(a, s);
@@ -295,6 +326,9 @@ int dispatch_epi(const GemmArgs& a, hipStream_t s) {
   }
   switch (a.act) {
     case ACT_NONE:
+      if (pf2)
+        return resid ? launch<BM, BN, WGM, WGN, ACT_NONE, true, false, CONV, 32, 2>(a, s)
+                     : launch<BM, BN, WGM, WGN, ACT_NONE, false, false, CONV, 32, 2>(a, s);
       return resid ? launch<BM, BN, WGM, WGN, ACT_NONE, true, false, CONV>(a, s)
                    : launch<BM, BN, WGM, WGN, ACT_NONE, false, false, CONV>(a, s);
     case ACT_SILU:
@@ -303,6 +337,9 @@ int dispatch_epi(const GemmArgs& a, hipStream_t s) {
                      : launch<BM, BN, WGM, WGN, ACT_SILU, false, false, false>(a, s);
       break;
     case ACT_RELU:
+      if (pf2)
+        return resid ? launch<BM, BN, WGM, WGN, ACT_RELU, true, false, CONV, 32, 2>(a, s)
+                     : launch<BM, BN, WGM, WGN, ACT_RELU, false, false, CONV, 32, 2>(a, s);
       return resid ? launch<BM, BN, WGM, WGN, ACT_RELU, true, false, CONV>(a, s)
                    : launch<BM, BN, WGM, WGN, ACT_RELU, false, false, CONV>(a, s);
   }

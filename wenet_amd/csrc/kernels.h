@@ -8,6 +8,12 @@ namespace wn {
 int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
               int ldy, int M, int D, float eps, hipStream_t s);
 
+// y1 = LN(x; w1,b1), y2 = LN(y1; w2,b2) in one pass over contiguous [M][D] rows
+// (y1 may alias x).
+int layernorm2(const float* x, const float* w1, const float* b1, const float* w2,
+               const float* b2, float* y1, float* y2, int M, int D, float eps,
+               hipStream_t s);
+
 // GlobalCMVN + Conv2d(1->C,3,stride 2) + ReLU over the padded (B,T,F) frame
 // tensor, written packed channels-last: out[(t1_off[b]+t1)*F1 + f1][c].
 struct Conv1Args {

@@ -316,7 +316,8 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
   for (int li = 0; li < n_run; ++li) {
     const EncLayer& L = m->layers[li];
     // x += 0.5 * FFN_macaron(LN(x))                 encoder_layer.py:220-228
-    WN_TRY(ln(L.norm_ff_mac, x, t1, M, d, eps, s));
+    // (for li > 0 the previous layer's tail already left LN(x) in t1)
+    if (li == 0) WN_TRY(ln(L.norm_ff_mac, x, t1, M, d, eps, s));
     WN_TRY(ffn_w1(m, L.ffm1, t1, hb, M, s));
     WN_TRY(linear(L.ffm2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 0.5f));
     // x += MHA(LN(x))                               encoder_layer.py:230-238
@@ -351,7 +352,13 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     WN_TRY(ln(L.norm_ff, x, t1, M, d, eps, s));
     WN_TRY(ffn_w1(m, L.ff1, t1, hb, M, s));
     WN_TRY(linear(L.ff2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 0.5f));
-    WN_TRY(ln(L.norm_final, x, x, M, d, eps, s));
+    if (li + 1 < n_run) {
+      const EncLayer& Ln = m->layers[li + 1];
+      WN_TRY(layernorm2(x, L.norm_final.w, L.norm_final.b, Ln.norm_ff_mac.w,
+                        Ln.norm_ff_mac.b, x, t1, M, d, eps, s));
+    } else {
+      WN_TRY(ln(L.norm_final, x, x, M, d, eps, s));
+    }
   }
   WN_TRY(m->enc.ensure((size_t)std::max(M, 1) * d * sizeof(float)));
   if (m->dbg_skip_after_norm) {
