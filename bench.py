@@ -36,11 +36,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
-CONFIG = 'aishell_u2pp'
-BATCH_PER_GPU = 32
 FRAMES = (800, 1200)  # 8..12 s of 10 ms frames, mean ~10 s
 BEAM = 10
+# BASELINE.json `configs`; the default (and the only one the driver runs) is
+# configs[1], the configuration the metric is quoted on.
+WORKLOADS = {
+    'config2': dict(config='aishell_u2pp', batch=32, method='ctc_prefix_beam_search',
+                    kw={}, text='BASELINE.json configs[1]: AIShell u2++ conformer '
+                    '12L/4head/256d fbank80, batch 32 x ~10 s per GPU (8-12 s '
+                    'ragged), ctc_prefix_beam_search beam 10'),
+    'config3': dict(config='librispeech_bidecoder_large', batch=64,
+                    method='attention_rescoring',
+                    kw=dict(ctc_weight=0.5, reverse_weight=0.3),
+                    text='BASELINE.json configs[2]: LibriSpeech conformer '
+                    'bidecoder-large 12L/8head/512d fbank80, batch 64 x ~10 s per GPU, '
+                    'attention_rescoring beam 10, ctc_weight 0.5, reverse_weight 0.3'),
+    'config4': dict(config='wenetspeech_u2pp', batch=32,
+                    method='ctc_prefix_beam_search',
+                    kw=dict(decoding_chunk_size=16, num_decoding_left_chunks=-1),
+                    text='BASELINE.json configs[3]: WenetSpeech u2++ conformer '
+                    '12L/8head/512d, decoding_chunk_size 16 (chunk-mask streaming), '
+                    'batch 32 x ~10 s per GPU, ctc_prefix_beam_search beam 10'),
+}
+CONFIG = 'aishell_u2pp'
+BATCH_PER_GPU = 32
 METHOD = 'ctc_prefix_beam_search'
+DECODE_KW = {}
 
 
 def audio_seconds(n_frames) -> float:
@@ -69,10 +90,10 @@ def cpu_baseline(configs, sd, feats, lens):
         if dt < best_dt:
             best_t, best_dt = nt, dt
     torch.set_num_threads(best_t)
-    O.decode(configs, sd, [METHOD], f[:1], l[:1], beam_size=BEAM)  # warm-up
+    O.decode(configs, sd, [METHOD], f[:1], l[:1], beam_size=BEAM, **DECODE_KW)  # warm-up
     reps, t0 = 0, time.time()
     while True:
-        O.decode(configs, sd, [METHOD], f, l, beam_size=BEAM)
+        O.decode(configs, sd, [METHOD], f, l, beam_size=BEAM, **DECODE_KW)
         reps += 1
         if time.time() - t0 > 12.0 or reps >= 3:
             break
@@ -98,9 +119,16 @@ def main():
     ap.add_argument('--streams', type=int, default=2,
                     help='decodes kept in flight per GPU (wenet_amd/pipeline.py); '
                          '1 = plain back-to-back ASRModel.decode() calls')
+    ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS),
+                    help='config2 = BASELINE.json configs[1] (the metric\'s '
+                         'configuration, default); the others are extra data points')
     ap.add_argument('--tune', default='',
                     help='experiments: comma list of key=value for wn_tune_set')
     args = ap.parse_args()
+    global CONFIG, BATCH_PER_GPU, METHOD, DECODE_KW
+    wl = WORKLOADS[args.workload]
+    CONFIG, BATCH_PER_GPU, METHOD, DECODE_KW = (wl['config'], wl['batch'],
+                                                wl['method'], wl['kw'])
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -108,13 +136,20 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with '
                          f'--nproc-per-node {args.gpus} (WORLD_SIZE={world})')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # WN_BENCH_SHARE_GPU=1: self-test of the N > 1 code path on a 1-GPU box
+    # (every rank on cuda:0, results gathered over gloo); never a measurement.
+    share_gpu = os.environ.get('WN_BENCH_SHARE_GPU') == '1'
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=device)
+        if share_gpu:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=device)
 
     from wenet_amd import _lib, dist as wdist, synthetic as S
     for kv in filter(None, args.tune.split(',')):
@@ -140,14 +175,14 @@ def main():
     def finish(res):
         rec = wdist.pack_results(mine, [r.tokens for r in res],
                                  [r.score for r in res], BATCH_PER_GPU, max_tok,
-                                 device)
+                                 'cpu' if share_gpu else device)
         return wdist.gather_results(rec, world)
 
     def run_steps(n):
         """n decode passes over the batch, `--streams` of them in flight; the
         per-step result gather (one all_gather) stays on the main thread, in
         step order."""
-        futs = [pipe.submit([METHOD], feats_dev, lens, beam_size=BEAM)
+        futs = [pipe.submit([METHOD], feats_dev, lens, beam_size=BEAM, **DECODE_KW)
                 for _ in range(n)]
         out = None
         for f in futs:
@@ -183,7 +218,8 @@ def main():
     pipe.close()
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device='cpu' if share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert len(out) == BATCH_PER_GPU * world, 'result gather lost utterances'
@@ -192,10 +228,11 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total_audio * args.steps / dt
         achieved = (flops.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
+        d_model = configs['encoder_conf']['output_size']
         enc_rows = int(sum(max(0, (int(t) - 7) // 4 + 1) for t in lens.tolist()))
         line = {
             'metric': 'audio-seconds/sec (RTF^-1), 12L Conformer fbank80, '
-                      'ctc_prefix_beam_search',
+                      + METHOD,
             'value': round(value, 1),
             'unit': 'audio_s/s',
             'n_gpus': world,
@@ -208,10 +245,8 @@ def main():
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': 'BASELINE.json configs[1]: AIShell u2++ conformer '
-                            '12L/4head/256d fbank80, batch 32 x ~10 s per GPU '
-                            '(8-12 s ragged), ctc_prefix_beam_search beam 10, '
-                            'features resident in HBM, random-init weights',
+                'workload': wl['text'] + ', features resident in HBM, '
+                            'random-init weights',
                 'global_batch': BATCH_PER_GPU * world,
                 'audio_seconds_per_step': round(total_audio, 1),
                 'encoder_frames_per_gpu': enc_rows,
@@ -221,7 +256,7 @@ def main():
             'roofline': {
                 'bound': 'mfma',
                 'kernel': 'gemm_f32_kernel<128,128,2x4 waves,SiLU> (FFN w_1, '
-                          f'M={enc_rows} N=2048 K=256)',
+                          f'M={enc_rows} N=2048 K={d_model})',
                 'achieved': round(achieved, 2),
                 'peak': FP32_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int row0 = m0 + wm * WTM + i * 32 + row_hi;
-      float* cp = p.C + (int64_t)row0 * p.ldc + col;
+      float* cp = p.C + (int64_t)((variant & 32) ? (row0 & 127) : row0) * p.ldc + col;
       const float* rp = RESID ? p.resid + (int64_t)row0 * p.ldr + col : nullptr;
       float v[16];
 #pragma unroll
@@ -275,7 +275,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
           for (int r = 0; r < 16; ++r) v[r] += rr[r];
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cp[((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
+        for (int r = 0; r < 16; ++r) {
+          if ((variant & 16) && p.alpha != 123456.0f) {  // ablation: compute, no store
+            asm volatile("" ::"v"(v[r]));
+            continue;
+          }
+          cp[((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
