@@ -35,8 +35,9 @@ int g_gemm_tile_glu = 0;
 namespace {
 
 __device__ __forceinline__ float silu_fast(float x) {
-  // x * sigmoid(x) on v_exp_f32 / v_rcp_f32 (each ~1 ulp)
-  return x * __frcp_rn(1.0f + __expf(-x));
+  // x * sigmoid(x) on v_exp_f32 / v_rcp_f32 (each ~1 ulp); __frcp_rn would be
+  // the correctly rounded division sequence (v_div_scale / fmas / fixup)
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
 constexpr int BK = 32;  // K granularity every problem must respect
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
         const float a = acc[i][0][r] + ba;
         const float g = acc[i][1][r] + bg;
         v[r] = (variant & 1) ? a * sigmoid_f(g)
-                             : a * __frcp_rn(1.0f + __expf(-g));
+                             : a * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -237,17 +238,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
   // exp / rcp latencies), then the stores; only the ragged last tiles pay for
   // per-row predicates.
   const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);  // block-uniform
-  if (variant & 4) {  // ablation: no epilogue (accumulators stay live)
-    if (p.alpha == 123456.0f) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) p.C[r + lane] = acc[i][j][r];
-    }
-    return;
-  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn_ * WTN + j * 32 + col_in;
@@ -256,7 +246,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int row0 = m0 + wm * WTM + i * 32 + row_hi;
-      float* cp = p.C + (int64_t)((variant & 32) ? (row0 & 127) : row0) * p.ldc + col;
+      float* cp = p.C + (int64_t)row0 * p.ldc + col;
       const float* rp = RESID ? p.resid + (int64_t)row0 * p.ldr + col : nullptr;
       float v[16];
 #pragma unroll
@@ -275,13 +265,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
           for (int r = 0; r < 16; ++r) v[r] += rr[r];
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if ((variant & 16) && p.alpha != 123456.0f) {  // ablation: compute, no store
-            asm volatile("" ::"v"(v[r]));
-            continue;
-          }
-          cp[((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
-        }
+        for (int r = 0; r < 16; ++r) cp[((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
