@@ -35,6 +35,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_lib_mod = None
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
 FRAMES = (800, 1200)  # 8..12 s of 10 ms frames, mean ~10 s
 BEAM = 10
@@ -110,6 +111,43 @@ def cpu_baseline(configs, sd, feats, lens):
     }
 
 
+def end_to_end_leg(model, lens, device, total_audio, ms_per_step):
+    """PCM -> tokens variant: the same utterance lengths
+    as 16 kHz waveforms resident in HBM go through wn_fbank (Kaldi fbank on the
+    GPU) before the decode.  The fbank pass is timed on its own (it is a separate
+    C-ABI call on the same stream) and added to the measured decode step."""
+    n_samp = [(int(t) - 1) * 160 + 400 for t in lens.tolist()]
+    g = torch.Generator().manual_seed(99)
+    waves = [(torch.rand(n, generator=g) * 0.6 - 0.3).numpy() for n in n_samp]
+    model.compute_fbank(waves)  # warm-up (+ host->device copy of the PCM)
+    offs = np.zeros((len(waves) + 1, ), dtype=np.int64)
+    offs[1:] = np.cumsum(n_samp)
+    pcm = torch.from_numpy(np.concatenate(waves)).to(device)
+    tmax = int(max(lens.tolist()))
+    feats = torch.empty((len(waves), tmax, 80), dtype=torch.float32, device=device)
+    nfr = np.zeros((len(waves), ), dtype=np.int32)
+    L = _lib_mod.lib()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    reps = 10
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib_mod.check(L.wn_fbank(model._h, pcm.data_ptr(), _lib_mod.i64p(offs),
+                                  len(waves), feats.data_ptr(), tmax,
+                                  _lib_mod.i32p(nfr), stream), 'wn_fbank')
+    e1.record()
+    torch.cuda.synchronize()
+    fb_ms = e0.elapsed_time(e1) / reps
+    return {
+        'value': round(total_audio / ((ms_per_step + fb_ms) * 1e-3), 1),
+        'unit': 'audio_s/s',
+        'fbank_ms_per_batch': round(fb_ms, 3),
+        'note': 'PCM resident in HBM -> wn_fbank -> decode; fbank timed separately '
+                f'({reps} reps, HIP events) and added to ms_per_step',
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -152,6 +190,8 @@ def main():
                                     device_id=device)
 
     from wenet_amd import _lib, dist as wdist, synthetic as S
+    global _lib_mod
+    _lib_mod = _lib
     for kv in filter(None, args.tune.split(',')):
         k, v = kv.split('=')
         _lib.check(_lib.lib().wn_tune_set(k.encode(), int(v)), 'tune')
@@ -266,6 +306,9 @@ def main():
                 'traffic': None,
             },
         }
+        if world == 1:
+            line['end_to_end'] = end_to_end_leg(model, lens, device, total_audio,
+                                                ms_per_step)
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(configs, sd, feats, lens)
         print(json.dumps(line), flush=True)

@@ -55,6 +55,14 @@ typedef struct {
   int32_t sos, eos;          /* asr_model.py:59-62 */
   int32_t max_pos;           /* positional table length (5000) */
   float norm_eps;            /* 1e-5 */
+  /* encoder family (wenet/utils/init_model.py:52-97, class_utils.py:37-98) */
+  int32_t encoder_type;      /* 0: conformer (rel_pos, conv2d, swish, macaron)
+                                1: transformer (TransformerEncoderLayer,
+                                   encoder_layer.py:28-127; Whisper encoder) */
+  int32_t input_layer;       /* 0: conv2d (Conv2dSubsampling4)
+                                1: conv1d2 (Conv1dSubsampling2, subsampling.py:117-171) */
+  int32_t activation;        /* FFN activation: 0 swish/SiLU, 1 gelu (exact erf) */
+  int32_t key_bias;          /* attention linear_k has a bias (Whisper: 0) */
 } wn_config;
 
 /* One entry of the reference state_dict (fp32, host memory, C-contiguous). */

@@ -361,6 +361,40 @@ def conformer_layer(x, mask, pos_emb, mask_pad, sd, pfx, h, kernel_size,
     return layer_norm(x, sd, pfx + 'norm_final.')
 
 
+def conv1d_subsampling2(x, x_mask, sd, pfx):
+    """Conv1dSubsampling2.forward, wenet/models/transformer/subsampling.py:145-171
+    + WhisperPositionalEncoding (embedding.py:150-164: xscale = 1, `pe` buffer of
+    1500 rows = [sin | cos])."""
+    time = x.size(1)
+    x = x.transpose(1, 2)
+    x = F.gelu(F.conv1d(x, sd[pfx + 'conv.0.weight'], sd[pfx + 'conv.0.bias'],
+                        padding=1))
+    x = F.gelu(F.conv1d(x, sd[pfx + 'conv.2.weight'], sd[pfx + 'conv.2.bias'],
+                        stride=2, padding=1))
+    x = x.transpose(1, 2)
+    pe = sd[pfx + 'pos_enc.pe']
+    pos_emb = pe[:, 0:x.size(1)]
+    x = x * 1.0 + pos_emb
+    return x, pos_emb, x_mask[:, :, (time + 1) % 2::2]
+
+
+def transformer_layer(x, mask, sd, pfx, h, activation):
+    """TransformerEncoderLayer.forward, encoder_layer.py:94-127
+    (normalize_before=True)."""
+    x = x + mha(*([layer_norm(x, sd, pfx + 'norm1.')] * 3), mask, sd,
+                pfx + 'self_attn.', h)
+    return x + feed_forward(layer_norm(x, sd, pfx + 'norm2.'), sd,
+                            pfx + 'feed_forward.', activation)
+
+
+def whisper_positional_table(d_model: int, max_len: int = 1500):
+    """The `pe` buffer of WhisperPositionalEncoding, embedding.py:154-163."""
+    inc = np.log(10000) / (d_model // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(d_model // 2))
+    st = torch.arange(max_len)[:, np.newaxis] * inv[np.newaxis, :]
+    return torch.cat([torch.sin(st), torch.cos(st)], dim=1).unsqueeze(0)
+
+
 def encoder_forward(configs: dict,
                     sd: Dict[str, torch.Tensor],
                     xs: torch.Tensor,
@@ -381,6 +415,21 @@ def encoder_forward(configs: dict,
     if 'encoder.global_cmvn.mean' in sd:
         xs = global_cmvn(xs, sd['encoder.global_cmvn.mean'],
                          sd['encoder.global_cmvn.istd'])
+    if configs.get('encoder', 'conformer') == 'transformer':
+        # TransformerEncoder as configured by the Whisper recipes
+        # (encoder.py:365-437: conv1d2 + abs_pos_whisper + gelu, full context)
+        assert ec.get('input_layer') == 'conv1d2' and \
+            ec.get('activation_type') == 'gelu'
+        xs, pos_emb, masks = conv1d_subsampling2(xs, masks, sd, 'encoder.embed.')
+        layers = [xs]
+        for i in range(nblocks):
+            xs = transformer_layer(xs, masks, sd, f'encoder.encoders.{i}.', h,
+                                   F.gelu)
+            layers.append(xs)
+        xs = layer_norm(xs, sd, 'encoder.after_norm.')
+        if return_layers:
+            return xs, masks, layers
+        return xs, masks
     xs, pos_emb, masks = conv2d_subsampling4(xs, masks, sd, 'encoder.embed.', d)
     mask_pad = masks
     chunk_masks = add_optional_chunk_mask(

@@ -13,7 +13,7 @@ def case_names(prefix=''):
     return sorted(
         os.path.basename(p)[:-4]
         for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + '*.npz'))
-        if not os.path.basename(p).startswith('fbank'))
+        if not os.path.basename(p).startswith(('fbank', 'whisperenc')))
 
 
 def load_case(name):
@@ -29,5 +29,12 @@ def build_inputs(meta):
     configs = S.make_configs(meta['config'])
     sd = S.make_state_dict(configs, meta['wseed'])
     feats, lens = S.make_features(meta['batch'], tuple(meta['frames']),
-                                  seed=meta['fseed'])
+                                  seed=meta['fseed'],
+                                  feat_dim=configs['input_dim'])
     return configs, sd, feats, lens
+
+
+def whisper_case_names():
+    """Goldens of the Whisper-style TransformerEncoder (+ CTC head)."""
+    return sorted(os.path.basename(p)[:-4]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, 'whisperenc_*.npz')))

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import build_inputs, case_names, load_case
+from golden_util import build_inputs, case_names, load_case, whisper_case_names
 from gpu_util import cached_model, compare_nbest, frame_margins
 
 pytestmark = pytest.mark.gpu
@@ -67,6 +67,67 @@ def test_golden_case(name):
             assert abs(r.score - gr['score']) < tol, (name, b, r.score, gr['score'])
             np.testing.assert_allclose(r.tokens_confidence,
                                        gr['tokens_confidence'], atol=2e-3)
+
+
+@pytest.mark.parametrize('name', whisper_case_names())
+def test_whisper_encoder_golden_case(name):
+    """Whisper-style TransformerEncoder (Conv1dSubsampling2, abs_pos_whisper,
+    gelu, key_bias=False) + CTC head on the GPU against the real reference's
+    committed outputs (BASELINE.json configs[4] family; fp32)."""
+    meta, arrays = load_case(name)
+    configs, sd, model = cached_model(meta['config'], meta['wseed'])
+    _, _, feats, lens = build_inputs(meta)
+    enc, mask = model._forward_encoder(feats.cuda(), lens)
+    enc_lens = mask.squeeze(1).sum(1).cpu().numpy()
+    np.testing.assert_array_equal(enc_lens, arrays['enc_lens'])
+    enc = enc.cpu().numpy()
+    for b, n in enumerate(arrays['enc_lens']):
+        ref = arrays['enc_out'][b, :n]
+        err = np.abs(enc[b, :n] - ref).max()
+        assert err < 2e-3 * max(1.0, np.abs(ref).max()), (name, b, err)
+    res = model.decode(['ctc_greedy_search', 'ctc_prefix_beam_search'],
+                       feats.cuda(), lens, beam_size=meta['beam'])
+    ref_margin = arrays['ctc_topk_val'][..., 0] - arrays['ctc_topk_val'][..., 1]
+    for b in range(meta['batch']):
+        n = arrays['enc_lens'][b]
+        if ref_margin[b, :n].min() > 2e-2:
+            assert res['ctc_greedy_search'][b].tokens == meta['greedy'][b]
+        g = meta['prefix'][b]
+        compare_nbest(res['ctc_prefix_beam_search'][b], g['nbest'],
+                      g['nbest_scores'], g['nbest_times'], what=f'{name}[{b}]')
+    with pytest.raises((RuntimeError, NotImplementedError, AssertionError)):
+        model.decode(['attention_rescoring'], feats.cuda(), lens, beam_size=2)
+
+
+@pytest.mark.parametrize('B,frames', [(5, (3, 140)), (1, (77, 77)), (3, (1, 2))])
+def test_whisper_encoder_layers_vs_oracle(B, frames):
+    """Every TransformerEncoderLayer output against the oracle, ragged batches
+    with odd and even T, down to 1-frame utterances."""
+    from wenet_amd import _lib, synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('whisper_tiny_like', 0)
+    feats, lens = S.make_features(B, frames, seed=55, feat_dim=80)
+    with torch.no_grad():
+        ref, mask, layers = O.encoder_forward(configs, sd, feats, lens,
+                                              return_layers=True)
+    ref_lens = mask.squeeze(1).sum(1).numpy()
+    L = _lib.lib()
+    try:
+        for n in range(len(layers)):
+            _lib.check(L.wn_debug_set(model._h, b'n_layers', n), 'dbg')
+            _lib.check(L.wn_debug_set(model._h, b'skip_after_norm', 1), 'dbg')
+            enc, m = model._forward_encoder(feats.cuda(), lens)
+            np.testing.assert_array_equal(m.squeeze(1).sum(1).cpu().numpy(), ref_lens)
+            enc = enc.cpu()
+            for b in range(B):
+                nb = int(ref_lens[b])
+                if nb:
+                    err = (enc[b, :nb] - layers[n][b, :nb]).abs().max().item()
+                    scale = max(layers[n][b, :nb].abs().max().item(), 1.0)
+                    assert err < 1e-3 * scale, ('layer', n, 'utt', b, err)
+    finally:
+        L.wn_debug_set(model._h, b'n_layers', -1)
+        L.wn_debug_set(model._h, b'skip_after_norm', 0)
 
 
 @pytest.mark.parametrize('config,B,frames,chunk,left', [

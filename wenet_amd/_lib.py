@@ -17,7 +17,9 @@ class WnConfig(Structure):
         'feat_dim', 'd_model', 'n_heads', 'ffn_dim', 'n_layers', 'cnn_kernel',
         'causal', 'use_dynamic_chunk', 'static_chunk_size', 'vocab',
         'has_cmvn', 'dec_heads', 'dec_ffn_dim', 'dec_layers', 'dec_r_layers',
-        'bidirectional', 'sos', 'eos', 'max_pos')] + [('norm_eps', c_float)]
+        'bidirectional', 'sos', 'eos', 'max_pos')] + [('norm_eps', c_float)] + [
+            (n, c_int32) for n in ('encoder_type', 'input_layer', 'activation',
+                                   'key_bias')]
 
 
 class WnTensor(Structure):

@@ -63,7 +63,7 @@ __device__ __forceinline__ float sigmoid_f(float x) {
 // ---- GEMM -----------------------------------------------------------------
 // C[M,N] = epilogue(A[M,K] * W[N,K]^T), fp32 in / fp32 accumulate on
 // v_mfma_f32_32x32x2_f32.  All pointers are device pointers.
-enum GemmAct { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+enum GemmAct { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GELU = 3 };  // GELU: exact (erf)
 
 struct GemmArgs {
   const float* A = nullptr;  // [M, lda] (plain) or gathered (a_row_off)
@@ -78,7 +78,9 @@ struct GemmArgs {
   bool glu = false;  // W rows permuted [32 a | 32 gate] per 64; C has N/2 cols
   // implicit 3x3/stride-2 conv A operand (subsampling conv2): element (row,k)
   // lives at A[a_row_off[row] + (tap/3)*conv_sy + (tap%3)*conv_sx + k%conv_C],
-  // tap = k / conv_C.
+  // tap = k / conv_C.  conv_C == K degenerates to plain gathered rows
+  // A[a_row_off[row] + k] (1-D conv over channels-last frames: the taps of one
+  // output are consecutive input rows).
   const int64_t* a_row_off = nullptr;
   int conv_C = 0;
   int64_t conv_sy = 0, conv_sx = 0;

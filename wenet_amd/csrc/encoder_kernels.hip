@@ -13,34 +13,33 @@ namespace {
 // two-pass mean / variance, wave-shuffle reductions, 16-byte accesses.
 template <int E>
 struct RowRegs {
-  static constexpr int VEC = E >= 4 ? 4 : E;
+  // widest vector that divides the per-lane element count
+  static constexpr int VEC = E % 4 == 0 ? 4 : (E % 2 == 0 ? 2 : 1);
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
   float v[E];
-  __device__ __forceinline__ static int index(int lane, int e) {
-    return (e / VEC) * 64 * VEC + lane * VEC + (e % VEC);
-  }
   __device__ __forceinline__ void load(const float* p, int lane) {
-    if constexpr (VEC == 4) {
 #pragma unroll
-      for (int j = 0; j < E / 4; ++j) {
-        f32x4 t = *reinterpret_cast<const f32x4*>(p + j * 256 + lane * 4);
-        v[j * 4 + 0] = t[0]; v[j * 4 + 1] = t[1];
-        v[j * 4 + 2] = t[2]; v[j * 4 + 3] = t[3];
+    for (int j = 0; j < E / VEC; ++j) {
+      if constexpr (VEC == 1) {
+        v[j] = p[j * 64 + lane];
+      } else {
+        const vec_t t = *reinterpret_cast<const vec_t*>(p + j * 64 * VEC + lane * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[j * VEC + e] = t[e];
       }
-    } else {
-#pragma unroll
-      for (int e = 0; e < E; ++e) v[e] = p[index(lane, e)];
     }
   }
   __device__ __forceinline__ void store(float* p, int lane) const {
-    if constexpr (VEC == 4) {
 #pragma unroll
-      for (int j = 0; j < E / 4; ++j) {
-        f32x4 t = {v[j * 4 + 0], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]};
-        *reinterpret_cast<f32x4*>(p + j * 256 + lane * 4) = t;
+    for (int j = 0; j < E / VEC; ++j) {
+      if constexpr (VEC == 1) {
+        p[j * 64 + lane] = v[j];
+      } else {
+        vec_t t;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) t[e] = v[j * VEC + e];
+        *reinterpret_cast<vec_t*>(p + j * 64 * VEC + lane * VEC) = t;
       }
-    } else {
-#pragma unroll
-      for (int e = 0; e < E; ++e) p[index(lane, e)] = v[e];
     }
   }
 };
@@ -426,7 +425,8 @@ int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
                        M, eps);                                              \
     break;
   switch (D) {
-    WN_LN(1) WN_LN(2) WN_LN(4) WN_LN(8) WN_LN(12) WN_LN(16) WN_LN(20)
+    WN_LN(1) WN_LN(2) WN_LN(3) WN_LN(4) WN_LN(6) WN_LN(8) WN_LN(10) WN_LN(12)
+    WN_LN(16) WN_LN(20)
     default:
       set_error("layernorm: unsupported width " + std::to_string(D));
       return -1;

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
         float x = acc[i][j][r] + b;
         if (ACT == ACT_SILU) x = (variant & 1) ? silu_f(x) : silu_fast(x);
         if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
+        if (ACT == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
         v[r] = x * p.alpha;
       }
       if (full) {
@@ -326,6 +327,9 @@ int dispatch_epi(const GemmArgs& a, hipStream_t s) {
         return resid ? launch<BM, BN, WGM, WGN, ACT_SILU, true, false, false>(a, s)
                      : launch<BM, BN, WGM, WGN, ACT_SILU, false, false, false>(a, s);
       break;
+    case ACT_GELU:
+      return resid ? launch<BM, BN, WGM, WGN, ACT_GELU, true, false, CONV>(a, s)
+                   : launch<BM, BN, WGM, WGN, ACT_GELU, false, false, CONV>(a, s);
     case ACT_RELU:
       if (pf2)
         return resid ? launch<BM, BN, WGM, WGN, ACT_RELU, true, false, CONV, 32, 2>(a, s)
@@ -345,8 +349,8 @@ int gemm_f32(const GemmArgs& a, hipStream_t stream) {
   WN_CHECK(a.A && a.W && a.C, "gemm: null operand");
   const bool conv = a.a_row_off != nullptr;
   if (conv) {
-    WN_CHECK(a.conv_C % BK == 0 && a.K == 9 * a.conv_C,
-             "gemm(conv): K must be 9*C with C % 32 == 0");
+    WN_CHECK(a.conv_C % BK == 0 && (a.K == 9 * a.conv_C || a.K == a.conv_C),
+             "gemm(conv): K must be 9*C (3x3 taps) or C (gathered rows), C % 32 == 0");
   } else {
     WN_CHECK(a.lda % 4 == 0, "gemm: lda must be a multiple of 4 floats");
   }

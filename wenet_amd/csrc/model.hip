@@ -93,6 +93,11 @@ struct EncLayer {
   const float* cpad = nullptr;    // [d]
 };
 
+struct TfLayer {  // TransformerEncoderLayer (encoder_layer.py:28-127)
+  Norm n1, n2;
+  Linear qkv, out, ff1, ff2;
+};
+
 struct DecLayer {
   Norm n1, n2, n3;
   Linear self_qkv, self_out, src_q, src_kv, src_out, ff1, ff2;
@@ -148,6 +153,37 @@ __global__ void scatter_padded_any_kernel(const float* src, int lds,
   }
 }
 
+// Conv1dSubsampling2 front end: utterance b becomes the packed segment
+// [0, x_0 .. x_{len-1}, 0, 0] (len + 3 rows of F floats) so that the k=3, pad=1
+// convolution over time is a plain GEMM over three consecutive rows.
+__global__ void pad_feats_kernel(const float* feats, int T, int F, const int* seg_off,
+                                 const int* len, const float* mean,
+                                 const float* istd, float* xpad) {
+  const int b = blockIdx.y, j = blockIdx.x;
+  const int L = len[b];
+  if (j >= L + 3) return;
+  float* dst = xpad + (int64_t)(seg_off[b] + j) * F;
+  const int t = j - 1;
+  if (t >= 0 && t < L) {
+    const float* src = feats + ((int64_t)b * T + t) * F;
+    for (int i = threadIdx.x; i < F; i += blockDim.x) {
+      float v = src[i];
+      if (mean) v = (v - mean[i]) * istd[i];
+      dst[i] = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < F; i += blockDim.x) dst[i] = 0.f;
+  }
+}
+
+__global__ void zero_rows_kernel(float* base, int D4, const int* rows, int n) {
+  const int r = blockIdx.x;
+  if (r >= n) return;
+  f32x4* d = reinterpret_cast<f32x4*>(base + (int64_t)rows[r] * D4 * 4);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < D4; i += blockDim.x) d[i] = z;
+}
+
 __global__ void embed_kernel(const int* tok, const int* pos, const float* emb,
                              const float* pe, float scale, int D4, float* x) {
   const int r = blockIdx.x;
@@ -199,6 +235,9 @@ struct wn_model {
   Norm after_norm;
   Linear ctc;
   std::vector<EncLayer> layers;
+  std::vector<TfLayer> tf_layers;       // encoder_type 1
+  Linear tconv1, tconv2;                // Conv1dSubsampling2 as gathered-row GEMMs
+  bool fbank_ok = true;
   Decoder left, right;
   std::shared_ptr<DevBuf> pos_tabs = std::make_shared<DevBuf>();
 
@@ -207,6 +246,7 @@ struct wn_model {
   std::vector<int> off, len;            // per utterance (rows layout)
   DevBuf d_off, d_len, d_row_utt, d_off1, d_len1, d_a_row_off;
   DevBuf c1, c2, x, t1, t2, hbuf, qkv, enc;
+  DevBuf xpad, pos_rows, d_row_t, d_zero_rows;
   // ctc
   int ctc_rows = 0, ctc_k = 0;
   bool ctc_valid = false;
@@ -370,6 +410,172 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
   return 0;
 }
 
+// TransformerEncoder (Whisper style): x += MHA(LN(x)); x += FFN(LN(x)); final LN
+// (encoder_layer.py:94-127, encoder.py:176-181).
+int transformer_layers(wn_model* m, hipStream_t s) {
+  const wn_config& c = m->cfg;
+  const int d = c.d_model, M = m->rows;
+  float* x = m->x.as<float>();
+  float* t1 = m->t1.as<float>();
+  float* t2 = m->t2.as<float>();
+  float* hb = m->hbuf.as<float>();
+  float* qkv = m->qkv.as<float>();
+  const float eps = c.norm_eps;
+  int max_len = 0;
+  for (int b = 0; b < m->B; ++b) max_len = std::max(max_len, m->len[b]);
+  const int act = c.activation == 1 ? ACT_GELU : ACT_SILU;
+  const int n_run = m->dbg_layers >= 0 ? std::min(m->dbg_layers, c.n_layers)
+                                      : c.n_layers;
+  for (int li = 0; li < n_run; ++li) {
+    const TfLayer& L = m->tf_layers[li];
+    WN_TRY(ln(L.n1, x, t1, M, d, eps, s));
+    WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s));
+    AttnArgs a;
+    a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d;
+    a.ldq = a.ldk = a.ldv = 3 * d;
+    a.O = t2; a.ldo = d;
+    a.q_off = a.kv_off = m->d_off.as<int>();
+    a.q_len = a.kv_len = m->d_len.as<int>();
+    a.n_seq = m->B; a.n_heads = c.n_heads; a.max_q_len = max_len;
+    a.mask_mode = 0;
+    a.scale = 1.0f / sqrtf(64.0f);
+    WN_TRY(attention(a, s));
+    WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d));
+    WN_TRY(ln(L.n2, x, t1, M, d, eps, s));
+    WN_TRY(linear(L.ff1, t1, d, hb, c.ffn_dim, M, s, act));
+    WN_TRY(linear(L.ff2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d));
+  }
+  WN_TRY(m->enc.ensure((size_t)std::max(M, 1) * d * sizeof(float)));
+  if (m->dbg_skip_after_norm) {
+    WN_HIP(hipMemcpyAsync(m->enc.p, x, (size_t)M * d * sizeof(float),
+                          hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
+  WN_TRY(ln(m->after_norm, x, m->enc.as<float>(), M, d, eps, s));
+  return 0;
+}
+
+// Conv1dSubsampling2 + WhisperPositionalEncoding + the layers above
+// (subsampling.py:117-171, embedding.py:150-164, encoder.py:122-181).
+int encode_transformer(wn_model* m, const float* feats_dev,
+                       const int32_t* feat_lens_host, int B, int T,
+                       float* enc_out_dev, int32_t* enc_lens_host, hipStream_t s) {
+  const wn_config& c = m->cfg;
+  const int d = c.d_model, F = c.feat_dim;
+  // output frames: conv(k3, s2, p1) keeps floor((T-1)/2)+1; the mask keeps
+  // x_mask[:, :, (T+1)%2::2] (subsampling.py:171): frame t' is valid iff
+  // 2t' + (T+1)%2 < len
+  const int Tp = (T - 1) / 2 + 1;
+  const int par = (T + 1) % 2;
+  WN_CHECK(Tp <= c.max_pos, "utterance longer than the positional table");
+  std::vector<int> seg(B), off2(B), len2(B), lens(B);
+  int rows_pad = 0, M = 0;
+  std::vector<int> zero_rows;
+  for (int b = 0; b < B; ++b) {
+    const int L = feat_lens_host[b];
+    WN_CHECK(L >= 0 && L <= T, "wn_encode: feature length out of range");
+    lens[b] = L;
+    seg[b] = rows_pad;
+    rows_pad += L + 3;
+    const int l2 = L > par ? (L - par + 1) / 2 : 0;   // #{t' : 2t' + par < L}
+    off2[b] = M; len2[b] = l2; M += l2;
+    if (enc_lens_host) enc_lens_host[b] = l2;
+    zero_rows.push_back(seg[b]);                       // conv2's left zero pad
+    // conv1 position L exists in the reference only as a padded frame of a
+    // longer batch; when the utterance fills the tensor it is conv2's right
+    // zero pad instead
+    if (L == T) zero_rows.push_back(seg[b] + 1 + L);
+  }
+  m->B = B; m->Tp = Tp; m->off = off2; m->len = len2; m->rows = M;
+  m->ctc_valid = false;
+  if (M == 0) {
+    WN_TRY(m->stage.begin((size_t)B * 16 + 1024));
+    WN_TRY(upload_desc(m, m->d_off, off2, s));
+    WN_TRY(upload_desc(m, m->d_len, len2, s));
+    WN_TRY(m->stage.end(s));
+  } else {
+    std::vector<int64_t> a_off((size_t)M);
+    std::vector<int> row_t((size_t)M);
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < len2[b]; ++t) {
+        // conv2 output t' reads conv1 positions 2t'-1 .. 2t'+1 = c1pad rows
+        // seg + 2t' .. seg + 2t' + 2
+        a_off[off2[b] + t] = (int64_t)(seg[b] + 2 * t) * d;
+        row_t[off2[b] + t] = t;
+      }
+    WN_TRY(m->stage.begin((size_t)M * 16 + (size_t)B * 64 * 5 + zero_rows.size() * 4 +
+                          64 * 12 + 4096));
+    WN_TRY(upload_desc(m, m->d_off, off2, s));
+    WN_TRY(upload_desc(m, m->d_len, len2, s));
+    {
+      std::vector<int> row_utt(M, -1);
+      for (int b = 0; b < B; ++b)
+        for (int t = 0; t < len2[b]; ++t) row_utt[off2[b] + t] = b;
+      WN_TRY(upload_desc(m, m->d_row_utt, row_utt, s));
+    }
+    WN_TRY(upload_desc(m, m->d_off1, seg, s));
+    WN_TRY(upload_desc(m, m->d_len1, lens, s));
+    WN_TRY(upload_desc(m, m->d_row_t, row_t, s));
+    WN_TRY(upload_desc(m, m->d_zero_rows, zero_rows, s));
+    WN_TRY(m->stage.put(m->d_a_row_off, a_off.data(), a_off.size() * sizeof(int64_t), s));
+    WN_TRY(m->stage.end(s));
+    const int K1 = m->tconv1.in;  // 3F rounded up to 32 (zero weights)
+    WN_TRY(m->xpad.ensure(((size_t)rows_pad * F + K1 + 64) * sizeof(float)));
+    WN_TRY(m->c1.ensure(((size_t)rows_pad + 2) * d * sizeof(float)));
+    WN_TRY(m->x.ensure((size_t)M * d * sizeof(float)));
+    WN_TRY(m->t1.ensure((size_t)M * d * sizeof(float)));
+    WN_TRY(m->t2.ensure((size_t)M * d * sizeof(float)));
+    WN_TRY(m->pos_rows.ensure((size_t)M * d * sizeof(float)));
+    WN_TRY(m->hbuf.ensure((size_t)M * c.ffn_dim * sizeof(float)));
+    WN_TRY(m->qkv.ensure((size_t)M * 3 * d * sizeof(float)));
+    int max_len = 0;
+    for (int b = 0; b < B; ++b) max_len = std::max(max_len, lens[b]);
+    // the K padding of the last rows reads a few floats past the data: keep
+    // them finite (they meet zero weights)
+    WN_HIP(hipMemsetAsync(m->xpad.as<float>() + (size_t)rows_pad * F, 0,
+                          (size_t)(K1 + 64) * sizeof(float), s));
+    hipLaunchKernelGGL(pad_feats_kernel, dim3(max_len + 3, B), dim3(64), 0, s,
+                       feats_dev, T, F, m->d_off1.as<int>(), m->d_len1.as<int>(),
+                       m->cmvn_mean, m->cmvn_istd, m->xpad.as<float>());
+    WN_HIP(hipGetLastError());
+    // conv1 (k3, pad 1) + GELU: output row r = taps at xpad rows r, r+1, r+2
+    // -> c1pad row r + 1 (row seg_b is the zero pad in front of utterance b)
+    GemmArgs g1;
+    g1.A = m->xpad.as<float>(); g1.W = m->tconv1.w; g1.bias = m->tconv1.b;
+    g1.C = m->c1.as<float>() + d; g1.M = rows_pad - 2; g1.N = d; g1.K = K1;
+    g1.lda = F; g1.ldc = d; g1.act = ACT_GELU;
+    WN_CHECK(F % 4 == 0, "conv1d2 front end: feature dim must be a multiple of 4");
+    WN_TRY(gemm_f32(g1, s));
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)zero_rows.size()), dim3(64), 0,
+                       s, m->c1.as<float>(), d / 4, m->d_zero_rows.as<int>(),
+                       (int)zero_rows.size());
+    WN_HIP(hipGetLastError());
+    // positional rows pe[t'] (xscale = 1, embedding.py:156)
+    WN_TRY(copy_rows(m->pe, d, m->d_row_t.as<int>(), m->pos_rows.as<float>(), d,
+                     nullptr, M, d, s));
+    // conv2 (k3, stride 2, pad 1) + GELU, + pe: gathered rows of c1pad
+    GemmArgs g2;
+    g2.A = m->c1.as<float>(); g2.W = m->tconv2.w; g2.bias = m->tconv2.b;
+    g2.C = m->x.as<float>(); g2.M = M; g2.N = d; g2.K = 3 * d; g2.ldc = d;
+    g2.act = ACT_GELU; g2.resid = m->pos_rows.as<float>(); g2.ldr = d;
+    g2.a_row_off = m->d_a_row_off.as<int64_t>();
+    g2.conv_C = 3 * d; g2.conv_sy = 0; g2.conv_sx = 0;
+    WN_TRY(gemm_f32(g2, s));
+    WN_TRY(transformer_layers(m, s));
+  }
+  if (enc_out_dev) {
+    if (M > 0) {
+      hipLaunchKernelGGL(scatter_padded_kernel, dim3(Tp, B), dim3(64), 0, s,
+                         m->enc.as<float>(), d, m->d_off.as<int>(),
+                         m->d_len.as<int>(), Tp, d / 4, enc_out_dev);
+      WN_HIP(hipGetLastError());
+    } else if (Tp > 0) {
+      WN_HIP(hipMemsetAsync(enc_out_dev, 0, (size_t)B * Tp * d * sizeof(float), s));
+    }
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // weight ingestion
 struct HostStage {
@@ -481,11 +687,15 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
   const wn_config& c = *cfg;
   WN_CHECK(c.d_model % 64 == 0 && c.n_heads > 0 && c.d_model / c.n_heads == 64,
            "d_model / n_heads must be 64 (all reference Conformer configs)");
-  WN_CHECK(c.dec_heads == 0 || c.d_model / c.dec_heads == 64,
+  WN_CHECK(c.dec_layers == 0 || c.dec_heads == 0 || c.d_model / c.dec_heads == 64,
            "decoder head dim must be 64");
   WN_CHECK(c.ffn_dim % 32 == 0 && c.feat_dim >= 7 && c.feat_dim <= 128,
            "unsupported ffn_dim / feat_dim");
-  WN_CHECK(c.cnn_kernel >= 1 && (c.causal || c.cnn_kernel % 2 == 1),
+  const bool tf = c.encoder_type == 1;
+  WN_CHECK(c.encoder_type == 0 || c.encoder_type == 1, "unknown encoder_type");
+  WN_CHECK(tf ? c.input_layer == 1 : c.input_layer == 0,
+           "supported pairs: conformer + conv2d, transformer + conv1d2");
+  WN_CHECK(tf || (c.cnn_kernel >= 1 && (c.causal || c.cnn_kernel % 2 == 1)),
            "cnn_module_kernel must be odd for a non-causal conv module");
   WN_HIP(hipSetDevice(device));
   std::unique_ptr<wn_model> m(new wn_model());
@@ -504,7 +714,28 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
     hs.add("cmvn.mean", mean, c.feat_dim);
     hs.add("cmvn.istd", istd, c.feat_dim);
   }
-  {  // conv1 (d,1,3,3) -> [tap][c]
+  const int Fin = c.feat_dim;
+  const int K1 = cdiv(3 * Fin, 32) * 32;  // conv1d K, padded with zero weights
+  if (tf) {
+    // Conv1d (n, c, tap) -> [n][tap * C + c] (the taps of one output frame are
+    // three consecutive channels-last input rows)
+    WN_GET(w0, "encoder.embed.conv.0.weight", (int64_t)d * Fin * 3);
+    WN_GET(b0, "encoder.embed.conv.0.bias", d);
+    float* t = hs.alloc("tconv1.w", (size_t)d * K1);
+    for (int n = 0; n < d; ++n)
+      for (int ch = 0; ch < Fin; ++ch)
+        for (int k = 0; k < 3; ++k)
+          t[(size_t)n * K1 + (size_t)k * Fin + ch] = w0[((size_t)n * Fin + ch) * 3 + k];
+    hs.add("tconv1.b", b0, d);
+    WN_GET(w2, "encoder.embed.conv.2.weight", (int64_t)d * d * 3);
+    WN_GET(b2, "encoder.embed.conv.2.bias", d);
+    t = hs.alloc("tconv2.w", (size_t)d * 3 * d);
+    for (int n = 0; n < d; ++n)
+      for (int ch = 0; ch < d; ++ch)
+        for (int k = 0; k < 3; ++k)
+          t[(size_t)n * 3 * d + (size_t)k * d + ch] = w2[((size_t)n * d + ch) * 3 + k];
+    hs.add("tconv2.b", b2, d);
+  } else {  // conv1 (d,1,3,3) -> [tap][c]
     WN_GET(w0, "encoder.embed.conv.0.weight", (int64_t)d * 9);
     WN_GET(b0, "encoder.embed.conv.0.bias", d);
     float* t = hs.alloc("conv1.w", (size_t)9 * d);
@@ -534,6 +765,8 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
   }
   {  // positional table: the `pe` buffer (embedding.py:47-56)
     float* t = hs.alloc("pe", (size_t)c.max_pos * d);
+    WN_CHECK(!tf || src.has("encoder.embed.pos_enc.pe"),
+             "transformer encoder: encoder.embed.pos_enc.pe is required");
     if (src.has("encoder.embed.pos_enc.pe")) {
       WN_GET(pe, "encoder.embed.pos_enc.pe", (int64_t)c.max_pos * d);
       memcpy(t, pe, sizeof(float) * c.max_pos * d);
@@ -577,15 +810,39 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
           last = i;
         }
       }
-      WN_CHECK(first >= 0, "fbank: empty mel filter");
+      if (first < 0) { m->fbank_ok = false; first = last = 0; }  // e.g. 128 bins
       mel_start[b] = first; mel_len[b] = last + 1 - first; mel_off[b] = (int)wts.size();
       for (int i = first; i <= last; ++i) wts.push_back(row[i]);
     }
     hs.add("fbank.mel_w", wts.data(), wts.size());
   }
   WN_TRY(stage_norm(src, hs, "encoder.after_norm", d));
-  WN_TRY(stage_linear(src, hs, "ctc.ctc_lo", V, d));
-  for (int i = 0; i < c.n_layers; ++i) {
+  const bool has_ctc = src.has("ctc.ctc_lo.weight");
+  if (has_ctc) WN_TRY(stage_linear(src, hs, "ctc.ctc_lo", V, d));
+  for (int i = 0; tf && i < c.n_layers; ++i) {
+    const std::string p = "encoder.encoders." + std::to_string(i);
+    WN_TRY(stage_norm(src, hs, p + ".norm1", d));
+    WN_TRY(stage_norm(src, hs, p + ".norm2", d));
+    {  // fused QKV; Whisper's linear_k has no bias (attention.py:29-75)
+      std::vector<float> w((size_t)3 * d * d), b((size_t)3 * d, 0.f);
+      const char* parts[3] = {"linear_q", "linear_k", "linear_v"};
+      for (int j = 0; j < 3; ++j) {
+        const std::string q = p + ".self_attn." + parts[j];
+        WN_GET(pw, q + ".weight", (int64_t)d * d);
+        memcpy(w.data() + (size_t)j * d * d, pw, sizeof(float) * d * d);
+        if (j != 1 || c.key_bias) {
+          WN_GET(pb, q + ".bias", d);
+          memcpy(b.data() + (size_t)j * d, pb, sizeof(float) * d);
+        }
+      }
+      hs.add(p + ".qkv.weight", w.data(), w.size());
+      hs.add(p + ".qkv.bias", b.data(), b.size());
+    }
+    WN_TRY(stage_linear(src, hs, p + ".self_attn.linear_out", d, d));
+    WN_TRY(stage_linear(src, hs, p + ".feed_forward.w_1", F, d));
+    WN_TRY(stage_linear(src, hs, p + ".feed_forward.w_2", d, F));
+  }
+  for (int i = 0; !tf && i < c.n_layers; ++i) {
     const std::string p = "encoder.encoders." + std::to_string(i);
     for (const char* n : {"norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff",
                           "norm_final", "conv_module.norm"})
@@ -659,11 +916,18 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
     Norm n; n.w = W(p + ".weight"); n.b = W(p + ".bias"); return n;
   };
   if (c.has_cmvn) { m->cmvn_mean = W("cmvn.mean"); m->cmvn_istd = W("cmvn.istd"); }
-  m->conv1_w = W("conv1.w"); m->conv1_b = W("conv1.b");
-  m->conv2.w = W("conv2.w"); m->conv2.b = W("conv2.b");
-  m->conv2.out = d; m->conv2.in = 9 * d;
-  m->sub_out.w = W("sub_out.w"); m->sub_out.b = W("sub_out.b");
-  m->sub_out.out = d; m->sub_out.in = d * F2;
+  if (tf) {
+    m->tconv1.w = W("tconv1.w"); m->tconv1.b = W("tconv1.b");
+    m->tconv1.out = d; m->tconv1.in = K1;
+    m->tconv2.w = W("tconv2.w"); m->tconv2.b = W("tconv2.b");
+    m->tconv2.out = d; m->tconv2.in = 3 * d;
+  } else {
+    m->conv1_w = W("conv1.w"); m->conv1_b = W("conv1.b");
+    m->conv2.w = W("conv2.w"); m->conv2.b = W("conv2.b");
+    m->conv2.out = d; m->conv2.in = 9 * d;
+    m->sub_out.w = W("sub_out.w"); m->sub_out.b = W("sub_out.b");
+    m->sub_out.out = d; m->sub_out.in = d * F2;
+  }
   m->pe = W("pe");
   m->fb_window = W("fbank.window"); m->fb_twiddle = W("fbank.twiddle");
   m->fb_mel_w = W("fbank.mel_w");
@@ -677,10 +941,23 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
                      hipMemcpyHostToDevice));
   }
   m->after_norm = NORM("encoder.after_norm");
-  m->ctc = LIN("ctc.ctc_lo", V, d);
-  m->layers.resize(c.n_layers);
-  WN_TRY(m->pos_tabs->ensure((size_t)c.n_layers * c.max_pos * d * sizeof(float)));
-  for (int i = 0; i < c.n_layers; ++i) {
+  if (has_ctc) m->ctc = LIN("ctc.ctc_lo", V, d);
+  if (tf) {
+    m->tf_layers.resize(c.n_layers);
+    for (int i = 0; i < c.n_layers; ++i) {
+      const std::string p = "encoder.encoders." + std::to_string(i);
+      TfLayer& L = m->tf_layers[i];
+      L.n1 = NORM(p + ".norm1"); L.n2 = NORM(p + ".norm2");
+      L.qkv = LIN(p + ".qkv", 3 * d, d);
+      L.out = LIN(p + ".self_attn.linear_out", d, d);
+      L.ff1 = LIN(p + ".feed_forward.w_1", F, d);
+      L.ff2 = LIN(p + ".feed_forward.w_2", d, F);
+    }
+  } else {
+    m->layers.resize(c.n_layers);
+    WN_TRY(m->pos_tabs->ensure((size_t)c.n_layers * c.max_pos * d * sizeof(float)));
+  }
+  for (int i = 0; !tf && i < c.n_layers; ++i) {
     const std::string p = "encoder.encoders." + std::to_string(i);
     EncLayer& L = m->layers[i];
     L.norm_ff_mac = NORM(p + ".norm_ff_macaron");
@@ -761,6 +1038,9 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->after_norm = src->after_norm;
   m->ctc = src->ctc;
   m->layers = src->layers;
+  m->tf_layers = src->tf_layers;
+  m->tconv1 = src->tconv1; m->tconv2 = src->tconv2;
+  m->fbank_ok = src->fbank_ok;
   m->left = src->left; m->right = src->right;
   m->fb_window = src->fb_window; m->fb_twiddle = src->fb_twiddle;
   m->fb_mel_w = src->fb_mel_w;
@@ -829,9 +1109,18 @@ int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host
               int32_t B, int32_t T, int32_t chunk, int32_t left,
               float* enc_out_dev, int32_t* enc_lens_host, void* stream) {
   WN_CHECK(m && feats_dev && feat_lens_host, "wn_encode: null argument");
-  WN_CHECK(!m->layers.empty(), "wn_encode: this handle has no weights");
+  WN_CHECK(!m->layers.empty() || !m->tf_layers.empty(),
+           "wn_encode: this handle has no weights");
   WN_CHECK(B > 0, "wn_encode: empty batch");
   WN_CHECK(chunk != 0, "decoding_chunk_size must not be 0 (asr_model.py:310)");
+  if (m->cfg.encoder_type == 1) {
+    WN_CHECK(chunk < 0 && m->cfg.static_chunk_size <= 0,
+             "chunk decoding is not implemented for the transformer encoder");
+    WN_CHECK(T >= 1, "wn_encode: empty features");
+    WN_HIP(hipSetDevice(m->device));
+    return encode_transformer(m, feats_dev, feat_lens_host, B, T, enc_out_dev,
+                              enc_lens_host, (hipStream_t)stream);
+  }
   WN_CHECK(T >= 7, "wn_encode: at least 7 frames are needed by Conv2dSubsampling4");
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));
@@ -1287,6 +1576,8 @@ int wn_fbank(wn_model* m, const float* pcm_dev, const int64_t* sample_off_host,
              int32_t* n_frames_host, void* stream) {
   WN_CHECK(m && pcm_dev && sample_off_host && feats_dev && n_frames_host && B > 0,
            "wn_fbank: bad argument");
+  WN_CHECK(m->fbank_ok, "wn_fbank: no Kaldi fbank for this feature dimension "
+                        "(Whisper models use log-mel, processor.py:320-369)");
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));
   std::vector<int> nfr(B);

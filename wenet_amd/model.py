@@ -35,18 +35,34 @@ def config_from_yaml(configs: dict) -> _lib.WnConfig:
     """train.yaml dict -> wn_config (keys as init_model.py:100-181 reads them)."""
     ec = configs['encoder_conf']
     dc = configs.get('decoder_conf') or {}
-    if configs.get('encoder', 'conformer') != 'conformer':
-        raise NotImplementedError('only the Conformer encoder is accelerated')
-    checks = dict(input_layer='conv2d', pos_enc_layer_type='rel_pos',
-                  selfattention_layer_type='rel_selfattn',
-                  activation_type='swish', cnn_module_norm='layer_norm',
-                  normalize_before=True, use_cnn_module=True,
-                  macaron_style=True)
-    defaults = dict(input_layer='conv2d', pos_enc_layer_type='rel_pos',
-                    selfattention_layer_type='rel_selfattn',
-                    activation_type='swish', cnn_module_norm='batch_norm',
-                    normalize_before=True, use_cnn_module=True,
-                    macaron_style=True)
+    enc_type = configs.get('encoder', 'conformer')
+    if enc_type == 'conformer':
+        checks = dict(input_layer='conv2d', pos_enc_layer_type='rel_pos',
+                      selfattention_layer_type='rel_selfattn',
+                      activation_type='swish', cnn_module_norm='layer_norm',
+                      normalize_before=True, use_cnn_module=True,
+                      macaron_style=True)
+        defaults = dict(input_layer='conv2d', pos_enc_layer_type='rel_pos',
+                        selfattention_layer_type='rel_selfattn',
+                        activation_type='swish', cnn_module_norm='batch_norm',
+                        normalize_before=True, use_cnn_module=True,
+                        macaron_style=True)
+    elif enc_type == 'transformer':
+        # TransformerEncoder as the Whisper recipes configure it
+        # (examples/aishell/whisper/conf/finetune_whisper_largev3.yaml:1-17)
+        checks = dict(input_layer='conv1d2', pos_enc_layer_type='abs_pos_whisper',
+                      activation_type='gelu', normalize_before=True,
+                      selfattention_layer_type='selfattn',
+                      layer_norm_type='layer_norm',
+                      mlp_type='position_wise_feed_forward')
+        defaults = dict(input_layer='conv2d', pos_enc_layer_type='abs_pos',
+                        activation_type='relu', normalize_before=True,
+                        selfattention_layer_type='selfattn',
+                        layer_norm_type='layer_norm',
+                        mlp_type='position_wise_feed_forward')
+    else:
+        raise NotImplementedError(
+            f'encoder {enc_type!r} is outside the accelerated path')
     for k, v in checks.items():
         got = ec.get(k, defaults[k])
         if got != v:
@@ -79,6 +95,18 @@ def config_from_yaml(configs: dict) -> _lib.WnConfig:
     c.sos, c.eos = sos, eos
     c.max_pos = 5000
     c.norm_eps = ec.get('norm_eps', 1e-5)
+    c.encoder_type = 1 if enc_type == 'transformer' else 0
+    c.input_layer = 1 if ec.get('input_layer') == 'conv1d2' else 0
+    c.activation = 1 if ec.get('activation_type', 'swish') == 'gelu' else 0
+    c.key_bias = int(bool(ec.get('key_bias', True)))
+    if enc_type == 'transformer':
+        c.cnn_kernel, c.causal = 1, 0
+        # the Whisper decoder (learnable positions, tied embedding) is not on
+        # the accelerated path: encoder (+ CTC head) only
+        if dc.get('input_layer', 'embed') != 'embed' or \
+                dc.get('activation_type', 'relu') != 'relu':
+            c.dec_layers = c.dec_r_layers = 0
+            c.bidirectional = 0
     return c
 
 
@@ -143,6 +171,9 @@ class ASRModel:
         if self.device.index is None:
             self.device = torch.device('cuda', torch.cuda.current_device())
         self._cfg = config_from_yaml(configs)
+        pe = state_dict.get('encoder.embed.pos_enc.pe')
+        if pe is not None:  # WhisperPositionalEncoding keeps 1500 rows
+            self._cfg.max_pos = int(pe.shape[-2])
         self.vocab_size = self._cfg.vocab
         self.sos, self.eos = self._cfg.sos, self._cfg.eos
         self.ignore_id = -1
@@ -204,10 +235,11 @@ class ASRModel:
 
     # ---- exported symbols ------------------------------------------------
     def subsampling_rate(self) -> int:  # asr_model.py:360-365
-        return 4
+        return 2 if self._cfg.input_layer == 1 else 4
 
-    def right_context(self) -> int:  # asr_model.py:367-371 (Conv2dSubsampling4)
-        return 6
+    def right_context(self) -> int:  # asr_model.py:367-371
+        # Conv1dSubsampling2: 4 (subsampling.py:143); Conv2dSubsampling4: 6
+        return 4 if self._cfg.input_layer == 1 else 6
 
     def sos_symbol(self) -> int:
         return self.sos
@@ -228,7 +260,10 @@ class ASRModel:
     def _encode(self, speech, lens, chunk, left, want_out: bool):
         B, T, F = speech.shape
         assert F == self._cfg.feat_dim, 'feature dimension mismatch'
-        Tp = ((T - 1) // 2 - 1) // 2
+        if self._cfg.input_layer == 1:  # Conv1dSubsampling2 (k3, s2, p1)
+            Tp = (T - 1) // 2 + 1
+        else:
+            Tp = ((T - 1) // 2 - 1) // 2
         enc_lens = np.zeros((B, ), dtype=np.int32)
         out = None
         if want_out:

@@ -125,6 +125,45 @@ CONFIGS = {
         'model_conf': dict(ctc_weight=0.3, lsm_weight=0.1,
                            length_normalized_loss=False, reverse_weight=0.3),
     },
+    # examples/aishell/whisper/conf/finetune_whisper_largev3.yaml:1-17 (encoder)
+    # at 2 of its 32 blocks: the Whisper-large-v3 widths (1280 / 20 heads /
+    # 5120, 128 mel bins) at a size a CPU reference run can afford.  Encoder +
+    # CTC head only; the Whisper decoder is outside the accelerated path.
+    'whisper_largev3_2blocks': {
+        'input_dim': 128, 'output_dim': 307,
+        'encoder': 'transformer',
+        'encoder_conf': dict(activation_type='gelu', attention_dropout_rate=0.0,
+                             attention_heads=20, dropout_rate=0.0,
+                             input_layer='conv1d2', key_bias=False,
+                             linear_units=5120, normalize_before=True,
+                             num_blocks=2, output_size=1280,
+                             pos_enc_layer_type='abs_pos_whisper',
+                             positional_dropout_rate=0.0, static_chunk_size=-1,
+                             use_dynamic_chunk=False,
+                             use_dynamic_left_chunk=False),
+        'decoder': None, 'decoder_conf': {},
+        'cmvn': None,
+        'model_conf': dict(ctc_weight=0.3, lsm_weight=0.1,
+                           length_normalized_loss=False),
+    },
+    # miniature of the same encoder family (whisper-tiny widths: 384 / 6 heads)
+    'whisper_tiny_like': {
+        'input_dim': 80, 'output_dim': 211,
+        'encoder': 'transformer',
+        'encoder_conf': dict(activation_type='gelu', attention_dropout_rate=0.0,
+                             attention_heads=6, dropout_rate=0.0,
+                             input_layer='conv1d2', key_bias=False,
+                             linear_units=1536, normalize_before=True,
+                             num_blocks=4, output_size=384,
+                             pos_enc_layer_type='abs_pos_whisper',
+                             positional_dropout_rate=0.0, static_chunk_size=-1,
+                             use_dynamic_chunk=False,
+                             use_dynamic_left_chunk=False),
+        'decoder': None, 'decoder_conf': {},
+        'cmvn': None,
+        'model_conf': dict(ctc_weight=0.3, lsm_weight=0.1,
+                           length_normalized_loss=False),
+    },
     # miniature of the offline recipe (symmetric conv, full attention,
     # left-to-right decoder only)
     'tiny_sym': {
@@ -210,7 +249,9 @@ def make_state_dict(configs: dict, seed: int = 0,
     d = ec['output_size']
     h = ec['attention_heads']
     ffn = ec['linear_units']
-    K = ec['cnn_module_kernel']
+    K = ec.get('cnn_module_kernel', 15)
+    if configs.get('encoder', 'conformer') == 'transformer':
+        return _make_transformer_state_dict(configs, seed, sharpen_ctc)
     idim, V = configs['input_dim'], configs['output_dim']
     sd: Dict[str, np.ndarray] = OrderedDict()
 
@@ -318,6 +359,67 @@ def make_state_dict(configs: dict, seed: int = 0,
     for k in list(sd.keys()):
         if k.endswith('output_layer.weight') or k.endswith('output_layer.bias'):
             sd[k] = sd[k] * np.float32(4.0)
+    return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v)))
+                       for k, v in sd.items())
+
+
+def whisper_positional_table(d_model: int, max_len: int = 1500) -> torch.Tensor:
+    """The `pe` buffer of WhisperPositionalEncoding
+    (wenet/models/transformer/embedding.py:154-163)."""
+    inc = np.log(10000) / (d_model // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(d_model // 2))
+    st = torch.arange(max_len)[:, np.newaxis] * inv[np.newaxis, :]
+    return torch.cat([torch.sin(st), torch.cos(st)], dim=1).unsqueeze(0)
+
+
+def _make_transformer_state_dict(configs, seed, sharpen_ctc):
+    """TransformerEncoder (Whisper recipe) + CTC head; names as the reference's
+    state_dict (encoder.embed.conv.{0,2}, encoder.encoders.i.{self_attn,
+    feed_forward,norm1,norm2}, encoder.after_norm, ctc.ctc_lo)."""
+    ec = configs['encoder_conf']
+    d, ffn = ec['output_size'], ec['linear_units']
+    idim, V = configs['input_dim'], configs['output_dim']
+    sd: Dict[str, np.ndarray] = OrderedDict()
+
+    def lin(name, out_f, in_f, bias=True):
+        b = 1.0 / math.sqrt(in_f)
+        sd[name + '.weight'] = _uniform(seed, name + '.weight', (out_f, in_f), b)
+        if bias:
+            sd[name + '.bias'] = _uniform(seed, name + '.bias', (out_f, ), b)
+
+    def norm(name, n):
+        sd[name + '.weight'] = _normal(seed, name + '.weight', (n, ), 0.1, 1.0)
+        sd[name + '.bias'] = _normal(seed, name + '.bias', (n, ), 0.1)
+
+    b = 1.0 / math.sqrt(3 * idim)
+    sd['encoder.embed.conv.0.weight'] = _uniform(seed, 'tconv0.w', (d, idim, 3), b)
+    sd['encoder.embed.conv.0.bias'] = _uniform(seed, 'tconv0.b', (d, ), b)
+    b = 1.0 / math.sqrt(3 * d)
+    sd['encoder.embed.conv.2.weight'] = _uniform(seed, 'tconv2.w', (d, d, 3), b)
+    sd['encoder.embed.conv.2.bias'] = _uniform(seed, 'tconv2.b', (d, ), b)
+    sd['encoder.embed.pos_enc.pe'] = whisper_positional_table(d).numpy().astype(
+        np.float32)
+    norm('encoder.after_norm', d)
+    for i in range(ec['num_blocks']):
+        p = f'encoder.encoders.{i}'
+        lin(p + '.self_attn.linear_q', d, d)
+        lin(p + '.self_attn.linear_k', d, d, bias=bool(ec.get('key_bias', True)))
+        lin(p + '.self_attn.linear_v', d, d)
+        lin(p + '.self_attn.linear_out', d, d)
+        lin(p + '.feed_forward.w_1', ffn, d)
+        lin(p + '.feed_forward.w_2', d, ffn)
+        norm(p + '.norm1', d)
+        norm(p + '.norm2', d)
+    lin('ctc.ctc_lo', V, d)
+    if sharpen_ctc:
+        sd['ctc.ctc_lo.weight'] = sd['ctc.ctc_lo.weight'] * np.float32(12.0)
+        sd['ctc.ctc_lo.bias'] = sd['ctc.ctc_lo.bias'] * np.float32(12.0)
+        n = max(V - 1, 2)
+        a = math.sqrt(2.0 * math.log(n))
+        emax = a - (math.log(math.log(n)) + math.log(4 * math.pi)) / (2 * a) \
+            + 0.5772 / a
+        sd['ctc.ctc_lo.weight'][0, :] = 0.0
+        sd['ctc.ctc_lo.bias'][0] = np.float32(12.0 / math.sqrt(3.0) * emax * 1.10)
     return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v)))
                        for k, v in sd.items())
 
