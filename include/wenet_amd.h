@@ -107,6 +107,17 @@ int wn_fbank(wn_model* m, const float* pcm_dev, const int64_t* sample_off_host,
              int32_t B, float* feats_dev, int32_t max_frames,
              int32_t* n_frames_host, void* stream);
 
+/* compute_log_mel_spectrogram (wenet/dataset/processor.py:320-369, the Whisper
+ * frontend): hann(400) STFT with hop 160 and reflect padding, power of all
+ * frames but the last, slaney mel filters (librosa.filters.mel), log10 with
+ * clamp 1e-10, floor at (utterance max - 8), (x + 4) / 4.  Same buffer
+ * conventions as wn_fbank; n_frames = n_samples / 160; every utterance needs
+ * more than 200 samples.  `padding` / `pad_or_trim` are applied by the caller
+ * to the waveform. */
+int wn_log_mel(wn_model* m, const float* pcm_dev, const int64_t* sample_off_host,
+               int32_t B, int32_t n_mels, float* feats_dev, int32_t max_frames,
+               int32_t* n_frames_host, void* stream);
+
 /* ---- encoder ------------------------------------------------------------ */
 /* ASRModel._forward_encoder / BaseEncoder.forward (asr_model.py:216-239,
  * encoder.py:122-181): GlobalCMVN, Conv2dSubsampling4, rel-pos encoding,

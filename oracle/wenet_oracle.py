@@ -144,6 +144,71 @@ def fbank(waveform: np.ndarray,
     return np.log(mel).astype(np.float32)
 
 
+def slaney_mel_filters(sr: int = 16000, n_fft: int = 400, n_mels: int = 80) -> np.ndarray:
+    """`librosa.filters.mel(sr, n_fft, n_mels)` with its defaults (fmin 0, fmax
+    sr/2, htk=False, norm='slaney') -> (n_mels, 1 + n_fft // 2) fp32.
+
+    librosa is a third-party dependency of the reference (requirements.txt,
+    unpinned) that is absent here; this restates its published algorithm
+    (librosa/filters.py `mel`, librosa/core/convert.py `mel_frequencies`:
+    Slaney's Auditory-Toolbox scale, linear below 1 kHz, log above, area
+    normalisation 2 / (f[i+2] - f[i])).  The reference's in-tree C++ frontend
+    builds the same triangles (runtime/core/frontend/fbank.h:113-134,179-210),
+    but for a 512-point FFT, so it cannot pin this 400-point matrix: the
+    filter matrix itself is parity-UNPINNED (tests check its defining
+    properties only)."""
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= min_log_hz,
+                        min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep,
+                        f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= min_log_mel,
+                        min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(0.0), hz_to_mel(sr / 2.0), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    w = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = np.maximum(0, np.minimum(lower, upper))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def log_mel_spectrogram(waveform: np.ndarray, num_mel_bins: int = 80,
+                        n_fft: int = 400, hop_length: int = 160,
+                        padding: int = 0, pad_or_trim: bool = False,
+                        max_duration: int = 30, sample_rate: int = 16000) -> np.ndarray:
+    """compute_log_mel_spectrogram, wenet/dataset/processor.py:320-369 for ONE
+    utterance (float waveform in [-1, 1]) -> (T, num_mel_bins) fp32.  torch.stft
+    is the reference's own STFT call; the mel matrix is slaney_mel_filters."""
+    w = torch.as_tensor(np.asarray(waveform, dtype=np.float32))
+    if padding > 0:
+        w = F.pad(w, (0, padding))
+    if pad_or_trim:
+        length = max_duration * sample_rate
+        w = w[:length] if w.size(0) >= length else F.pad(w, (0, length - w.size(0)))
+    window = torch.hann_window(n_fft)
+    stft = torch.stft(w, n_fft, hop_length, window=window, return_complex=True)
+    magnitudes = stft[..., :-1].abs()**2
+    filters = torch.from_numpy(slaney_mel_filters(sample_rate, n_fft, num_mel_bins))
+    mel_spec = filters @ magnitudes
+    log_spec = torch.clamp(mel_spec, min=1e-10).log10()
+    log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
+    log_spec = (log_spec + 4.0) / 4.0
+    return log_spec.transpose(0, 1).contiguous().numpy()
+
+
 def padding(feats: List[np.ndarray]) -> Tuple[torch.Tensor, torch.Tensor, List[int]]:
     """wenet/dataset/processor.py:526-577 (feature part): sort by length
     descending, zero-pad to (B, Tmax, F); returns (padded, lengths, order)."""

@@ -376,6 +376,33 @@ def test_fbank_vs_reference_cpp_golden():
                 (metas[i]['case'], np.percentile(err, 99), err.max())
 
 
+@pytest.mark.parametrize('n_mels', [80, 128])
+def test_log_mel_vs_oracle(n_mels):
+    """wn_log_mel (Whisper frontend, processor.py:320-369) against the oracle
+    (torch.stft + restated librosa mel) on ragged waveforms."""
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('tiny_sym', 0)
+    waves = [S.make_audio(n, seed=40 + i) for i, n in enumerate([16000, 7001, 201, 48000])]
+    feats, nfr = model.compute_log_mel_spectrogram(waves, n_mels)
+    feats = feats.cpu().numpy()
+    for i, w in enumerate(waves):
+        ref = O.log_mel_spectrogram(w, n_mels)
+        assert int(nfr[i]) == ref.shape[0] == len(w) // 160
+        got = feats[i, :ref.shape[0]]
+        err = np.abs(got - ref)
+        # fp32 DFT noise only matters in the decade just above the 8-decade floor
+        assert np.percentile(err, 99) < 2e-3 and err.max() < 5e-2, \
+            (i, np.percentile(err, 99), err.max())
+        high = ref > ref.max() - 1.0   # top 4 decades
+        assert err[high].max() < 2e-4, err[high].max()
+        assert np.all(feats[i, ref.shape[0]:] == 0)
+    padded, n2 = model.compute_log_mel_spectrogram(waves[:2], n_mels, pad_or_trim=True)
+    assert padded.shape == (2, 3000, n_mels) and n2.tolist() == [3000, 3000]
+    ref = O.log_mel_spectrogram(waves[1], n_mels, pad_or_trim=True)
+    assert np.percentile(np.abs(padded[1].cpu().numpy() - ref), 99) < 2e-3
+
+
 def test_rejects_cpu_tensors_and_chunk_zero():
     configs, sd, model = cached_model('tiny_sym', 0)
     from wenet_amd import search as S

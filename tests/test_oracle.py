@@ -58,6 +58,39 @@ def test_fbank_matches_live_reference_cpp():
         assert np.abs(got - ref).max() < 5e-4
 
 
+def test_slaney_mel_filter_properties():
+    """The librosa mel matrix is third party and absent (parity unpinned): check
+    its defining properties -- triangles on Slaney's scale, unit area (slaney
+    norm), and the peak value openai-whisper's published 80-bin matrix has."""
+    for n_mels in (80, 128):
+        w = O.slaney_mel_filters(16000, 400, n_mels)
+        assert w.shape == (n_mels, 201) and (w >= 0).all()
+        # each triangle is unimodal with contiguous support
+        for i in range(n_mels):
+            nz = np.flatnonzero(w[i])
+            assert nz.size >= 1 and (np.diff(nz) == 1).all()
+            pk = int(np.argmax(w[i]))
+            assert (np.diff(w[i, nz[0]:pk + 1]) >= 0).all()
+            assert (np.diff(w[i, pk:nz[-1] + 1]) <= 0).all()
+        # peaks move upwards in frequency
+        assert (np.diff([int(np.argmax(r)) for r in w]) >= 0).all()
+        # slaney norm: unit area in Hz where the 40 Hz bin grid resolves a triangle
+        area = w.sum(1) * 40.0
+        assert np.abs(area[n_mels // 2:] - 1.0).max() < 0.12
+    assert abs(O.slaney_mel_filters(16000, 400, 80).max() - 0.025880) < 1e-5
+
+
+def test_log_mel_shape_and_normalisation():
+    from wenet_amd import synthetic as S
+    x = S.make_audio(16000 * 2 + 77, seed=3)
+    f = O.log_mel_spectrogram(x, 80)
+    assert f.shape == ((16000 * 2 + 77) // 160, 80)
+    # (log10 + 4) / 4 with an 8-decade floor: range is exactly 2.0 wide at most
+    assert f.max() - f.min() <= 2.0 + 1e-6
+    g = O.log_mel_spectrogram(x, 128, pad_or_trim=True)
+    assert g.shape == (3000, 128)
+
+
 def test_prefix_beam_known_answer():
     data = torch.tensor([[0.25, 0.40, 0.35], [0.40, 0.35, 0.25],
                          [0.10, 0.50, 0.40]]).log().unsqueeze(0)

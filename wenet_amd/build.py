@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, '..', 'build', 'obj')
 LIB = os.path.join(HERE, 'libwenet_amd.so')
 SOURCES = ['gemm.hip', 'encoder_kernels.hip', 'ctc.hip', 'fbank.hip',
-           'model.hip']
+           'logmel.hip', 'model.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-fno-gpu-rdc', '-Wno-unused-result']
 

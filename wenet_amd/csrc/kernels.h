@@ -119,6 +119,24 @@ struct FbankArgs {
 };
 int fbank_kaldi(const FbankArgs& a, hipStream_t s);
 
+// Whisper log-mel (see logmel.hip): K of the DFT GEMM (400 padded to 416), width
+// of its output (201 cos + 201 sin rows), K of the mel GEMM (201 padded to 224).
+constexpr int LOGMEL_K1 = 416;
+constexpr int LOGMEL_NS = 402;
+constexpr int LOGMEL_K2 = 224;
+struct LogMelArgs {
+  const float* pcm;            // waveforms back to back, float in [-1, 1]
+  const int64_t* sample_off;   // [B + 1] (device)
+  const int* row_utt;          // [rows] utterance of each packed frame
+  const int* frame_off;        // [B] first packed frame of each utterance
+  const float* window;         // [400] periodic hann
+  float* frames;               // [rows][LOGMEL_K1]
+};
+int logmel_frames(const LogMelArgs& a, int rows, hipStream_t s);
+int logmel_power(const float* spec, float* pw, int rows, hipStream_t s);
+int logmel_finish(float* mel, int n_mels, const int* frame_off, const int* n_frames,
+                  float* umax, int B, int max_frames, float* feats, hipStream_t s);
+
 // rows scatter/gather helpers
 int copy_rows(const float* src, int lds, const int* src_rows, float* dst,
               int ldd, const int* dst_rows, int n_rows, int D, hipStream_t s);

@@ -247,6 +247,11 @@ struct wn_model {
   DevBuf d_off, d_len, d_row_utt, d_off1, d_len1, d_a_row_off;
   DevBuf c1, c2, x, t1, t2, hbuf, qkv, enc;
   DevBuf xpad, pos_rows, d_row_t, d_zero_rows;
+  // Whisper log-mel: DFT / window tables (shared), mel matrix per bin count
+  std::shared_ptr<DevBuf> lm_dft = std::make_shared<DevBuf>();
+  std::shared_ptr<std::map<int, std::shared_ptr<DevBuf>>> lm_mel =
+      std::make_shared<std::map<int, std::shared_ptr<DevBuf>>>();
+  DevBuf lm_off, lm_foff, lm_nfr, lm_rowutt, lm_frames, lm_spec, lm_pw, lm_melout, lm_umax;
   // ctc
   int ctc_rows = 0, ctc_k = 0;
   bool ctc_valid = false;
@@ -1041,6 +1046,7 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->tf_layers = src->tf_layers;
   m->tconv1 = src->tconv1; m->tconv2 = src->tconv2;
   m->fbank_ok = src->fbank_ok;
+  m->lm_dft = src->lm_dft; m->lm_mel = src->lm_mel;
   m->left = src->left; m->right = src->right;
   m->fb_window = src->fb_window; m->fb_twiddle = src->fb_twiddle;
   m->fb_mel_w = src->fb_mel_w;
@@ -1603,6 +1609,125 @@ int wn_fbank(wn_model* m, const float* pcm_dev, const int64_t* sample_off_host,
   a.mel_start = tab; a.mel_len = tab + a.n_mel; a.mel_off = tab + 2 * a.n_mel;
   a.mel_w = m->fb_mel_w; a.feats = feats_dev;
   return fbank_kaldi(a, s);
+}
+
+namespace {
+// librosa.filters.mel(sr=16000, n_fft=400, n_mels) (slaney scale + norm), the
+// matrix processor.py:360-361 multiplies with (librosa is third party: its
+// published algorithm is restated; the test oracle restates it independently in
+// numpy).  Row-major [n_mels][LOGMEL_K2].
+std::vector<float> slaney_mel_matrix(int n_mels) {
+  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, logstep = log(6.4) / 27.0;
+  const double min_log_mel = min_log_hz / f_sp;
+  auto hz2mel = [&](double f) {
+    return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+  };
+  auto mel2hz = [&](double mm) {
+    return mm >= min_log_mel ? min_log_hz * exp(logstep * (mm - min_log_mel)) : f_sp * mm;
+  };
+  const int nb = 201;
+  std::vector<double> mel_f(n_mels + 2);
+  const double m_lo = hz2mel(0.0), m_hi = hz2mel(8000.0);
+  for (int i = 0; i < n_mels + 2; ++i)
+    mel_f[i] = mel2hz(m_lo + (m_hi - m_lo) * i / (double)(n_mels + 1));
+  std::vector<float> w((size_t)n_mels * LOGMEL_K2, 0.f);
+  for (int i = 0; i < n_mels; ++i) {
+    const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+    for (int k = 0; k < nb; ++k) {
+      const double f = 8000.0 * k / 200.0;
+      const double lower = (f - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+      const double upper = (mel_f[i + 2] - f) / (mel_f[i + 2] - mel_f[i + 1]);
+      const double v = std::max(0.0, std::min(lower, upper));
+      w[(size_t)i * LOGMEL_K2 + k] = (float)(v * enorm);
+    }
+  }
+  return w;
+}
+}  // namespace
+
+int wn_log_mel(wn_model* m, const float* pcm_dev, const int64_t* sample_off_host,
+               int32_t B, int32_t n_mels, float* feats_dev, int32_t max_frames,
+               int32_t* n_frames_host, void* stream) {
+  WN_CHECK(m && pcm_dev && sample_off_host && feats_dev && n_frames_host && B > 0,
+           "wn_log_mel: bad argument");
+  WN_CHECK(n_mels >= 1 && n_mels <= 256, "wn_log_mel: num_mel_bins");
+  hipStream_t s = (hipStream_t)stream;
+  WN_HIP(hipSetDevice(m->device));
+  std::vector<int> nfr(B), foff(B), row_utt;
+  std::vector<int64_t> off(B + 1);
+  int rows = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t n = sample_off_host[b + 1] - sample_off_host[b];
+    // torch.stft(center=True) reflects n_fft/2 samples: needs n > 200
+    WN_CHECK(n > 200, "wn_log_mel: an utterance needs more than 200 samples");
+    nfr[b] = (int)(n / 160);          // 1 + n // hop frames, the last one dropped
+    WN_CHECK(nfr[b] <= max_frames, "wn_log_mel: max_frames too small");
+    off[b] = sample_off_host[b];
+    foff[b] = rows;
+    rows += nfr[b];
+    n_frames_host[b] = nfr[b];
+    for (int t = 0; t < nfr[b]; ++t) row_utt.push_back(b);
+  }
+  off[B] = sample_off_host[B];
+  if (max_frames == 0) return 0;
+  // ---- tables (once) ---------------------------------------------------------
+  if (!m->lm_dft->p) {
+    // [402][416] cos / -sin rows, then the periodic hann window [400]
+    std::vector<float> t((size_t)LOGMEL_NS * LOGMEL_K1 + 400, 0.f);
+    for (int k = 0; k <= 200; ++k)
+      for (int n = 0; n < 400; ++n) {
+        const double ph = 2.0 * M_PI * (double)((k * n) % 400) / 400.0;
+        t[(size_t)k * LOGMEL_K1 + n] = (float)cos(ph);
+        t[(size_t)(201 + k) * LOGMEL_K1 + n] = (float)-sin(ph);
+      }
+    for (int n = 0; n < 400; ++n)
+      t[(size_t)LOGMEL_NS * LOGMEL_K1 + n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * n / 400.0));
+    WN_TRY(m->lm_dft->ensure(t.size() * sizeof(float)));
+    WN_HIP(hipMemcpy(m->lm_dft->p, t.data(), t.size() * sizeof(float),
+                     hipMemcpyHostToDevice));
+  }
+  std::shared_ptr<DevBuf>& melw = (*m->lm_mel)[n_mels];
+  if (!melw) {
+    melw = std::make_shared<DevBuf>();
+    const std::vector<float> w = slaney_mel_matrix(n_mels);
+    WN_TRY(melw->ensure(w.size() * sizeof(float)));
+    WN_HIP(hipMemcpy(melw->p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (rows == 0) {
+    WN_HIP(hipMemsetAsync(feats_dev, 0, (size_t)B * max_frames * n_mels * sizeof(float), s));
+    return 0;
+  }
+  WN_TRY(m->stage.begin((size_t)B * 32 + (size_t)rows * 4 + 4096));
+  WN_TRY(m->stage.put(m->lm_off, off.data(), off.size() * sizeof(int64_t), s));
+  WN_TRY(m->stage.put(m->lm_foff, foff.data(), foff.size() * sizeof(int), s));
+  WN_TRY(m->stage.put(m->lm_nfr, nfr.data(), nfr.size() * sizeof(int), s));
+  WN_TRY(m->stage.put(m->lm_rowutt, row_utt.data(), row_utt.size() * sizeof(int), s));
+  WN_TRY(m->stage.end(s));
+  WN_TRY(m->lm_frames.ensure((size_t)rows * LOGMEL_K1 * sizeof(float)));
+  WN_TRY(m->lm_spec.ensure((size_t)rows * LOGMEL_NS * sizeof(float)));
+  WN_TRY(m->lm_pw.ensure((size_t)rows * LOGMEL_K2 * sizeof(float)));
+  WN_TRY(m->lm_melout.ensure((size_t)rows * n_mels * sizeof(float)));
+  WN_TRY(m->lm_umax.ensure((size_t)B * sizeof(float)));
+  LogMelArgs a;
+  a.pcm = pcm_dev; a.sample_off = m->lm_off.as<int64_t>();
+  a.row_utt = m->lm_rowutt.as<int>(); a.frame_off = m->lm_foff.as<int>();
+  a.window = m->lm_dft->as<float>() + (size_t)LOGMEL_NS * LOGMEL_K1;
+  a.frames = m->lm_frames.as<float>();
+  WN_TRY(logmel_frames(a, rows, s));
+  GemmArgs g1;  // DFT: [rows, 416] x [402, 416]^T
+  g1.A = m->lm_frames.as<float>(); g1.W = m->lm_dft->as<float>();
+  g1.C = m->lm_spec.as<float>(); g1.M = rows; g1.N = LOGMEL_NS; g1.K = LOGMEL_K1;
+  g1.lda = LOGMEL_K1; g1.ldc = LOGMEL_NS;
+  WN_TRY(gemm_f32(g1, s));
+  WN_TRY(logmel_power(m->lm_spec.as<float>(), m->lm_pw.as<float>(), rows, s));
+  GemmArgs g2;  // mel: [rows, 224] x [n_mels, 224]^T
+  g2.A = m->lm_pw.as<float>(); g2.W = melw->as<float>();
+  g2.C = m->lm_melout.as<float>(); g2.M = rows; g2.N = n_mels; g2.K = LOGMEL_K2;
+  g2.lda = LOGMEL_K2; g2.ldc = n_mels;
+  WN_TRY(gemm_f32(g2, s));
+  return logmel_finish(m->lm_melout.as<float>(), n_mels, m->lm_foff.as<int>(),
+                       m->lm_nfr.as<int>(), m->lm_umax.as<float>(), B, max_frames,
+                       feats_dev, s);
 }
 
 }  // extern "C"

@@ -459,6 +459,39 @@ class ASRModel:
                              _stream_ptr(self.device)), 'wn_fbank')
         return feats, torch.from_numpy(n_frames.copy())
 
+    def compute_log_mel_spectrogram(self, waveforms: List[np.ndarray],
+                                    num_mel_bins: int = 80, padding: int = 0,
+                                    pad_or_trim: bool = False,
+                                    max_duration: int = 30
+                                    ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """processor.compute_log_mel_spectrogram (processor.py:320-369, the
+        Whisper frontend) for a list of float waveforms in [-1, 1] (16 kHz)
+        -> ((B, Tmax, num_mel_bins) features in HBM, lengths)."""
+        ws = []
+        for w in waveforms:
+            w = np.asarray(w, np.float32)
+            if padding > 0:
+                w = np.concatenate([w, np.zeros(padding, np.float32)])
+            if pad_or_trim:
+                n = max_duration * 16000
+                w = w[:n] if len(w) >= n else np.concatenate(
+                    [w, np.zeros(n - len(w), np.float32)])
+            ws.append(w)
+        B = len(ws)
+        offs = np.zeros((B + 1, ), dtype=np.int64)
+        offs[1:] = np.cumsum([len(w) for w in ws])
+        pcm = torch.from_numpy(np.concatenate(ws)).to(self.device)
+        tmax = max(max(len(w) // 160 for w in ws), 1)
+        feats = torch.empty((B, tmax, num_mel_bins), dtype=torch.float32,
+                            device=self.device)
+        n_frames = np.zeros((B, ), dtype=np.int32)
+        _lib.check(
+            self._L.wn_log_mel(self._h, pcm.data_ptr(), _lib.i64p(offs), B,
+                               num_mel_bins, feats.data_ptr(), tmax,
+                               _lib.i32p(n_frames), _stream_ptr(self.device)),
+            'wn_log_mel')
+        return feats, torch.from_numpy(n_frames.copy())
+
     def compute_feature(self, wav_file: str) -> torch.Tensor:
         """cli/model.py:59-66: decode_wav -> (resample) -> compute_fbank."""
         wav = read_wav(wav_file)
