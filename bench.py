@@ -58,6 +58,12 @@ WORKLOADS = {
                     text='BASELINE.json configs[3]: WenetSpeech u2++ conformer '
                     '12L/8head/512d, decoding_chunk_size 16 (chunk-mask streaming), '
                     'batch 32 x ~10 s per GPU, ctc_prefix_beam_search beam 10'),
+    'config5': dict(config='whisper_largev3', batch=16, method='ctc_greedy_search',
+                    kw={}, frames=(3000, 3000), feat_dim=128,
+                    text='BASELINE.json configs[4]: Whisper-large-v3 encoder '
+                    '32L/20head/1280d, 128 mel bins, 30 s windows, batch 16 per GPU, '
+                    'fp32 (not the bf16 / fp8 the config names), + a 307-way CTC head '
+                    'and greedy search'),
 }
 CONFIG = 'aishell_u2pp'
 BATCH_PER_GPU = 32
@@ -201,12 +207,15 @@ def main():
     model = ASRModel(configs, sd, device=device)
 
     # global batch, sharded by length (weak scaling: 32 utterances per GPU)
-    gfeats, glens = S.make_features(BATCH_PER_GPU * world, FRAMES, seed=1234)
+    gfeats, glens = S.make_features(BATCH_PER_GPU * world, wl.get('frames', FRAMES),
+                                    seed=1234, feat_dim=wl.get('feat_dim', 80))
     mine = wdist.shard_indices(glens.tolist(), world, rank)
     lens = glens[mine]
     feats = gfeats[mine, :int(lens.max())].contiguous()
     feats_dev = feats.to(device)
-    total_audio = audio_seconds(glens.tolist())
+    whisper = configs.get('encoder') == 'transformer'
+    total_audio = (float(sum(glens.tolist())) * 0.01 if whisper  # hop 160 @ 16 kHz
+                   else audio_seconds(glens.tolist()))
     max_tok = 256
 
     from wenet_amd.pipeline import DecodePipeline
@@ -269,10 +278,13 @@ def main():
         value = total_audio * args.steps / dt
         achieved = (flops.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
         d_model = configs['encoder_conf']['output_size']
-        enc_rows = int(sum(max(0, (int(t) - 7) // 4 + 1) for t in lens.tolist()))
+        enc_rows = (int(sum((int(t) + 1) // 2 for t in lens.tolist())) if whisper
+                    else int(sum(max(0, (int(t) - 7) // 4 + 1) for t in lens.tolist())))
+        ffn = configs['encoder_conf']['linear_units']
         line = {
-            'metric': 'audio-seconds/sec (RTF^-1), 12L Conformer fbank80, '
-                      + METHOD,
+            'metric': ('audio-seconds/sec (RTF^-1), Whisper-large-v3 encoder, '
+                       if whisper else
+                       'audio-seconds/sec (RTF^-1), 12L Conformer fbank80, ') + METHOD,
             'value': round(value, 1),
             'unit': 'audio_s/s',
             'n_gpus': world,
@@ -296,7 +308,7 @@ def main():
             'roofline': {
                 'bound': 'mfma',
                 'kernel': 'gemm_f32_kernel<128,128,2x4 waves,SiLU> (FFN w_1, '
-                          f'M={enc_rows} N=2048 K={d_model})',
+                          f'M={enc_rows} N={ffn} K={d_model})',
                 'achieved': round(achieved, 2),
                 'peak': FP32_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
@@ -306,10 +318,10 @@ def main():
                 'traffic': None,
             },
         }
-        if world == 1:
+        if world == 1 and not whisper:
             line['end_to_end'] = end_to_end_leg(model, lens, device, total_audio,
                                                 ms_per_step)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not whisper:
             line['cpu_baseline'] = cpu_baseline(configs, sd, feats, lens)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -301,8 +301,8 @@ int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M,
 
 // FFN w_1 GEMM (SiLU epilogue), optionally bracketed by HIP events
 int ffn_w1(wn_model* m, const Linear& l, const float* A, float* C, int M,
-           hipStream_t s) {
-  if (!m->prof_on) return linear(l, A, l.in, C, l.out, M, s, ACT_SILU);
+           hipStream_t s, int act = ACT_SILU) {
+  if (!m->prof_on) return linear(l, A, l.in, C, l.out, M, s, act);
   if (m->prof_used + 2 > m->prof_ev.size()) {
     for (int i = 0; i < 64; ++i) {
       hipEvent_t e;
@@ -311,7 +311,7 @@ int ffn_w1(wn_model* m, const Linear& l, const float* A, float* C, int M,
     }
   }
   WN_HIP(hipEventRecord(m->prof_ev[m->prof_used], s));
-  WN_TRY(linear(l, A, l.in, C, l.out, M, s, ACT_SILU));
+  WN_TRY(linear(l, A, l.in, C, l.out, M, s, act));
   WN_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], s));
   m->prof_used += 2;
   m->prof_flops += 2.0 * M * (double)l.out * l.in;
@@ -447,7 +447,7 @@ int transformer_layers(wn_model* m, hipStream_t s) {
     WN_TRY(attention(a, s));
     WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d));
     WN_TRY(ln(L.n2, x, t1, M, d, eps, s));
-    WN_TRY(linear(L.ff1, t1, d, hb, c.ffn_dim, M, s, act));
+    WN_TRY(ffn_w1(m, L.ff1, t1, hb, M, s, act));
     WN_TRY(linear(L.ff2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d));
   }
   WN_TRY(m->enc.ensure((size_t)std::max(M, 1) * d * sizeof(float)));

@@ -146,6 +146,25 @@ CONFIGS = {
         'model_conf': dict(ctc_weight=0.3, lsm_weight=0.1,
                            length_normalized_loss=False),
     },
+    # the full Whisper-large-v3 encoder (32 blocks; 0.63 G parameters) for
+    # bench.py --workload config5
+    'whisper_largev3': {
+        'input_dim': 128, 'output_dim': 307,
+        'encoder': 'transformer',
+        'encoder_conf': dict(activation_type='gelu', attention_dropout_rate=0.0,
+                             attention_heads=20, dropout_rate=0.0,
+                             input_layer='conv1d2', key_bias=False,
+                             linear_units=5120, normalize_before=True,
+                             num_blocks=32, output_size=1280,
+                             pos_enc_layer_type='abs_pos_whisper',
+                             positional_dropout_rate=0.0, static_chunk_size=-1,
+                             use_dynamic_chunk=False,
+                             use_dynamic_left_chunk=False),
+        'decoder': None, 'decoder_conf': {},
+        'cmvn': None,
+        'model_conf': dict(ctc_weight=0.3, lsm_weight=0.1,
+                           length_normalized_loss=False),
+    },
     # miniature of the same encoder family (whisper-tiny widths: 384 / 6 heads)
     'whisper_tiny_like': {
         'input_dim': 80, 'output_dim': 211,
