@@ -13,7 +13,7 @@ def case_names(prefix=''):
     return sorted(
         os.path.basename(p)[:-4]
         for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + '*.npz'))
-        if not os.path.basename(p).startswith(('fbank', 'whisperenc')))
+        if not os.path.basename(p).startswith(('fbank', 'whisperenc', 'stream_')))
 
 
 def load_case(name):
@@ -38,3 +38,9 @@ def whisper_case_names():
     """Goldens of the Whisper-style TransformerEncoder (+ CTC head)."""
     return sorted(os.path.basename(p)[:-4]
                   for p in glob.glob(os.path.join(GOLDEN_DIR, 'whisperenc_*.npz')))
+
+
+def stream_case_names():
+    """Goldens of the reference's cache-based streaming path (simulate_streaming)."""
+    return sorted(os.path.basename(p)[:-4]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, 'stream_*.npz')))

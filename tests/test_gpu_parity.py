@@ -16,7 +16,8 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import build_inputs, case_names, load_case, whisper_case_names
+from golden_util import (build_inputs, case_names, load_case, stream_case_names,
+                         whisper_case_names)
 from gpu_util import cached_model, compare_nbest, frame_margins
 
 pytestmark = pytest.mark.gpu
@@ -374,6 +375,39 @@ def test_fbank_vs_reference_cpp_golden():
             err = np.abs(feats[i, :ref.shape[0]] - ref)
             assert np.percentile(err, 99) < 2e-3 and err.max() < 5e-2, \
                 (metas[i]['case'], np.percentile(err, 99), err.max())
+
+
+@pytest.mark.parametrize('name', stream_case_names())
+def test_simulate_streaming_vs_reference_cache_path(name):
+    """decode(simulate_streaming=True) against the committed outputs of the
+    reference's cache-based forward_chunk_by_chunk (encoder.py:287-362)."""
+    from wenet_amd import synthetic as S
+    meta, arrays = load_case(name)
+    configs, sd, model = cached_model(meta['config'], meta['wseed'])
+    feats, lens = S.make_features(1, (meta['frames'], meta['frames']),
+                                  seed=meta['fseed'])
+    enc, mask = model._forward_encoder(feats.cuda(), lens, meta['chunk'],
+                                       meta['left'], simulate_streaming=True)
+    assert enc.shape[1] == arrays['enc_out'].shape[0]
+    assert np.abs(enc[0].cpu().numpy() - arrays['enc_out']).max() < 2e-3
+    res = model.decode(METHODS, feats.cuda(), lens, beam_size=meta['beam'],
+                       decoding_chunk_size=meta['chunk'],
+                       num_decoding_left_chunks=meta['left'],
+                       ctc_weight=meta['ctc_weight'],
+                       reverse_weight=meta['reverse_weight'],
+                       simulate_streaming=True)
+    assert res['ctc_greedy_search'][0].tokens == meta['greedy']
+    g = meta['prefix']
+    compare_nbest(res['ctc_prefix_beam_search'][0], g['nbest'], g['nbest_scores'],
+                  g['nbest_times'], what=name)
+    r = res['attention_rescoring'][0]
+    if list(r.tokens) == meta['rescoring']['tokens']:
+        assert abs(r.score - meta['rescoring']['score']) < 1e-3 * (len(r.tokens) + 1)
+    # the reference's preconditions
+    two = torch.cat([feats, feats]).cuda()
+    with pytest.raises(AssertionError):
+        model.decode(METHODS[:1], two, torch.cat([lens, lens]),
+                     decoding_chunk_size=meta['chunk'], simulate_streaming=True)
 
 
 @pytest.mark.parametrize('n_mels', [80, 128])

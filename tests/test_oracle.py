@@ -12,7 +12,8 @@ import pytest
 import torch
 
 from conftest import needs_reference
-from golden_util import build_inputs, case_names, load_case, whisper_case_names
+from golden_util import (build_inputs, case_names, load_case, stream_case_names,
+                         whisper_case_names)
 from oracle import wenet_oracle as O
 
 
@@ -183,6 +184,37 @@ def test_oracle_whisper_encoder_matches_committed_reference_outputs(name):
         assert [list(x) for x in prefix[b].nbest] == g['nbest']
         np.testing.assert_allclose(prefix[b].nbest_scores, g['nbest_scores'],
                                    rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize('name', stream_case_names())
+def test_chunk_mask_path_equals_reference_cache_streaming(name):
+    """The reference's forward_chunk_by_chunk (attention + conv caches,
+    encoder.py:287-362; committed outputs) equals ONE pass under the chunk mask
+    (the oracle's encoder_forward) -- the identity the accelerated
+    `simulate_streaming=True` relies on."""
+    from wenet_amd import synthetic as S
+    meta, arrays = load_case(name)
+    configs = S.make_configs(meta['config'])
+    sd = S.make_state_dict(configs, meta['wseed'])
+    feats, lens = S.make_features(1, (meta['frames'], meta['frames']),
+                                  seed=meta['fseed'])
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        enc, mask = O.encoder_forward(configs, sd, feats, lens, meta['chunk'],
+                                      meta['left'])
+    assert enc.shape[1] == arrays['enc_out'].shape[0]
+    np.testing.assert_allclose(enc[0].numpy(), arrays['enc_out'], rtol=0, atol=5e-5)
+    res = O.decode(configs, sd, ['ctc_greedy_search', 'ctc_prefix_beam_search',
+                                 'attention_rescoring'], feats, lens,
+                   beam_size=meta['beam'], decoding_chunk_size=meta['chunk'],
+                   num_decoding_left_chunks=meta['left'],
+                   ctc_weight=meta['ctc_weight'],
+                   reverse_weight=meta['reverse_weight'])
+    assert res['ctc_greedy_search'][0].tokens == meta['greedy']
+    assert [list(x) for x in res['ctc_prefix_beam_search'][0].nbest] == \
+        meta['prefix']['nbest']
+    assert list(res['attention_rescoring'][0].tokens) == meta['rescoring']['tokens']
+    assert abs(res['attention_rescoring'][0].score - meta['rescoring']['score']) < 1e-3
 
 
 @needs_reference

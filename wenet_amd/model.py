@@ -283,15 +283,32 @@ class ASRModel:
                          simulate_streaming: bool = False):
         """asr_model.py:216-239 -> (encoder_out (B,T',d), encoder_mask (B,1,T'))."""
         if simulate_streaming and decoding_chunk_size > 0:
-            raise NotImplementedError(
-                'forward_chunk_by_chunk (cache-based streaming) is not on the '
-                'accelerated path; use the chunk-mask decode')
+            self._check_simulate_streaming(speech)
         speech, lens = self._prep(speech, speech_lengths)
         out, enc_lens, Tp = self._encode(speech, lens, decoding_chunk_size,
                                          num_decoding_left_chunks, True)
         mask = (torch.arange(Tp, device=self.device).unsqueeze(0) <
                 torch.as_tensor(enc_lens, device=self.device).unsqueeze(1))
         return out, mask.unsqueeze(1)
+
+    def _check_simulate_streaming(self, speech):
+        """`simulate_streaming=True` (asr_model.py:229-233 ->
+        BaseEncoder.forward_chunk_by_chunk, encoder.py:287-362) feeds the
+        utterance chunk by chunk through attention / conv caches.  For a causal
+        chunk-trained Conformer that is the SAME function as one pass under the
+        chunk mask (every chunk sees exactly the cached left context the mask
+        admits; the overlapping subsampling windows reproduce the full-utterance
+        frames), which is what the accelerated encoder runs; the equivalence is
+        pinned against the reference's own cache path
+        (tests/golden/stream_*.npz).  Same preconditions as the reference."""
+        assert speech.shape[0] == 1, 'forward_chunk_by_chunk: batch size must be 1'
+        assert self._cfg.use_dynamic_chunk or self._cfg.static_chunk_size > 0, \
+            'the model was not trained with static or dynamic chunks'
+        if self._cfg.encoder_type != 0 or not self._cfg.causal:
+            raise NotImplementedError(
+                'simulate_streaming is accelerated for causal Conformer encoders '
+                'only (a symmetric conv module sees no right context in '
+                'forward_chunk)')
 
     def _set_encoder_out(self, encoder_out: torch.Tensor, encoder_lens):
         _require_cuda(encoder_out, '_set_encoder_out')
@@ -395,7 +412,7 @@ class ASRModel:
         if context_graph is not None:
             raise NotImplementedError('context biasing is not accelerated')
         if simulate_streaming and decoding_chunk_size > 0:
-            raise NotImplementedError('simulate_streaming is not accelerated')
+            self._check_simulate_streaming(speech)
         speech, lens = self._prep(speech, speech_lengths)
         B = speech.shape[0]
         _, enc_lens, Tp = self._encode(speech, lens, decoding_chunk_size,
