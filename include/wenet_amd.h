@@ -187,6 +187,19 @@ int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host
                            float reverse_weight, float* l2r_logp_host,
                            float* r2l_logp_host, void* stream);
 
+/* One step of attention_beam_search (search.py:252-371): for every running
+ * hypothesis (its utterance index in the current batch, its tokens so far
+ * starting with <sos>), log_softmax(output_layer(after_norm(decoder(...)[:, -1])))
+ * -- TransformerDecoder.forward_one_step, decoder.py:226-281 -- reduced to its
+ * `topk` best (log-prob, token) pairs, sorted.  The cross-attention K/V of the
+ * current batch are projected once and kept for the following steps; the self
+ * attention is recomputed over the prefix (no self-attention cache).
+ * tokens_host is (n_seq, max_len) int32; outputs are (n_seq, topk), host. */
+int wn_decoder_next_topk(wn_model* m, int32_t n_seq, const int32_t* seq_utt_host,
+                         const int32_t* seq_lens_host, const int32_t* tokens_host,
+                         int32_t max_len, int32_t topk, float* logp_host,
+                         int32_t* idx_host, void* stream);
+
 /* ---- raw operators (used by the parity tests and by other hosts) ---------- */
 /* C[M,N] = resid + alpha * act(A[M,K] * W[N,K]^T + bias); act: 0 none,
  * 1 SiLU, 2 ReLU.  fp32 on v_mfma_f32_32x32x2_f32. */

@@ -783,6 +783,77 @@ def attention_rescoring(configs, sd, ctc_prefix_results, encoder_outs,
     return results
 
 
+def mask_finished_scores(score, flag):
+    """wenet/utils/mask.py:258-285."""
+    beam_size = score.size(-1)
+    zero_mask = torch.zeros_like(flag, dtype=torch.bool)
+    if beam_size > 1:
+        unfinished = torch.cat((zero_mask, flag.repeat([1, beam_size - 1])), dim=1)
+        finished = torch.cat((flag, zero_mask.repeat([1, beam_size - 1])), dim=1)
+    else:
+        unfinished, finished = zero_mask, flag
+    score.masked_fill_(unfinished, -float('inf'))
+    score.masked_fill_(finished, 0)
+    return score
+
+
+def attention_beam_search(configs, sd, encoder_out, encoder_mask, beam_size: int = 10,
+                          length_penalty: float = 0.0, sos: int = 2, eos: int = 2):
+    """attention_beam_search, wenet/models/transformer/search.py:252-371 (the
+    non-Whisper branch).  The reference steps the decoder with self/cross
+    attention caches (decoder.py:226-281); a cache only avoids recomputation, so
+    this restatement runs the full decoder on the growing prefixes and takes
+    the last position -- the same numbers."""
+    batch_size, maxlen = encoder_out.shape[0], encoder_out.size(1)
+    running = batch_size * beam_size
+    dc = configs['decoder_conf']
+    if is_bidirectional(configs):
+        lp, nl = 'decoder.left_decoder.', dc.get('num_blocks', 6)
+    else:
+        lp, nl = 'decoder.', dc.get('num_blocks', 6)
+    memory = encoder_out.unsqueeze(1).repeat(1, beam_size, 1, 1).view(
+        running, maxlen, encoder_out.size(2))
+    memory_mask = encoder_mask.unsqueeze(1).repeat(1, beam_size, 1, 1).view(
+        running, 1, maxlen)
+    hyps = torch.ones([running, 1], dtype=torch.long).fill_(sos)
+    scores = torch.tensor([0.0] + [-float('inf')] * (beam_size - 1),
+                          dtype=torch.float).repeat([batch_size]).unsqueeze(1)
+    end_flag = torch.zeros_like(scores, dtype=torch.bool)
+    for i in range(1, maxlen + 1):
+        if end_flag.sum() == running:
+            break
+        lens = torch.full((running, ), i, dtype=torch.long)
+        out = _decoder_forward(configs, sd, lp, nl, memory, memory_mask, hyps, lens)
+        logp = torch.log_softmax(out[:, -1], dim=-1)
+        top_k_logp, top_k_index = logp.topk(beam_size)
+        top_k_logp = mask_finished_scores(top_k_logp, end_flag)
+        top_k_index = top_k_index.masked_fill_(end_flag.repeat([1, beam_size]), eos)
+        scores = scores + top_k_logp
+        scores = scores.view(batch_size, beam_size * beam_size)
+        scores, offset_k_index = scores.topk(k=beam_size)
+        scores = scores.view(-1, 1)
+        base_k_index = torch.arange(batch_size).view(-1, 1).repeat(
+            [1, beam_size]) * beam_size * beam_size
+        best_k_index = base_k_index.view(-1) + offset_k_index.view(-1)
+        best_k_pred = torch.index_select(top_k_index.view(-1), dim=-1,
+                                         index=best_k_index)
+        best_hyps_index = best_k_index // beam_size
+        last_best_k_hyps = torch.index_select(hyps, dim=0, index=best_hyps_index)
+        hyps = torch.cat((last_best_k_hyps, best_k_pred.view(-1, 1)), dim=1)
+        end_flag = torch.eq(hyps[:, -1], eos).view(-1, 1)
+    scores = scores.view(batch_size, beam_size)
+    lengths = hyps.ne(eos).sum(dim=1).view(batch_size, beam_size).float()
+    scores = scores / lengths.pow(length_penalty)
+    best_scores, best_index = scores.max(dim=-1)
+    best_hyps_index = best_index + torch.arange(batch_size, dtype=torch.long) * beam_size
+    best_hyps = torch.index_select(hyps, dim=0, index=best_hyps_index)[:, 1:]
+    results = []
+    for i in range(batch_size):
+        hyp = best_hyps[i]
+        results.append(DecodeResult(hyp[hyp != eos].tolist()))
+    return results
+
+
 def special_symbols(configs):
     """sos/eos as ASRModel.__init__ resolves them (asr_model.py:52-60): from
     tokenizer_conf.special_tokens if present, else vocab_size-1."""
@@ -794,9 +865,10 @@ def special_symbols(configs):
 def decode(configs, sd, methods, speech, speech_lengths, beam_size: int = 1,
            decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1,
            ctc_weight: float = 0.0, reverse_weight: float = 0.0,
-           blank_id: int = 0, blank_penalty: float = 0.0):
-    """ASRModel.decode asr_model.py:267-343 (methods: ctc_greedy_search,
-    ctc_prefix_beam_search, attention_rescoring)."""
+           blank_id: int = 0, blank_penalty: float = 0.0,
+           length_penalty: float = 0.0):
+    """ASRModel.decode asr_model.py:267-343 (methods: attention,
+    ctc_greedy_search, ctc_prefix_beam_search, attention_rescoring)."""
     assert speech.shape[0] == speech_lengths.shape[0]
     assert decoding_chunk_size != 0
     with torch.no_grad():
@@ -808,6 +880,10 @@ def decode(configs, sd, methods, speech, speech_lengths, beam_size: int = 1,
         ctc_probs = ctc_logprobs(sd, encoder_out, blank_penalty, blank_id)
         sos, eos = special_symbols(configs)
         results = {}
+        if 'attention' in methods:
+            results['attention'] = attention_beam_search(
+                configs, sd, encoder_out, encoder_mask, beam_size, length_penalty,
+                sos, eos)
         if 'ctc_greedy_search' in methods:
             results['ctc_greedy_search'] = ctc_greedy_search(
                 ctc_probs, encoder_lens, blank_id)

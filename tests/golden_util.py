@@ -13,7 +13,7 @@ def case_names(prefix=''):
     return sorted(
         os.path.basename(p)[:-4]
         for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + '*.npz'))
-        if not os.path.basename(p).startswith(('fbank', 'whisperenc', 'stream_')))
+        if not os.path.basename(p).startswith(('fbank', 'whisperenc', 'stream_', 'attn_')))
 
 
 def load_case(name):
@@ -44,3 +44,9 @@ def stream_case_names():
     """Goldens of the reference's cache-based streaming path (simulate_streaming)."""
     return sorted(os.path.basename(p)[:-4]
                   for p in glob.glob(os.path.join(GOLDEN_DIR, 'stream_*.npz')))
+
+
+def attention_case_names():
+    """Goldens of the reference's `attention` (autoregressive) decode mode."""
+    return sorted(os.path.basename(p)[:-4]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, 'attn_*.npz')))

@@ -16,7 +16,8 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import (build_inputs, case_names, load_case, stream_case_names,
+from golden_util import (attention_case_names, build_inputs, case_names, load_case,
+                         stream_case_names,
                          whisper_case_names)
 from gpu_util import cached_model, compare_nbest, frame_margins
 
@@ -408,6 +409,23 @@ def test_simulate_streaming_vs_reference_cache_path(name):
     with pytest.raises(AssertionError):
         model.decode(METHODS[:1], two, torch.cat([lens, lens]),
                      decoding_chunk_size=meta['chunk'], simulate_streaming=True)
+
+
+@pytest.mark.parametrize('name', attention_case_names())
+def test_attention_mode_vs_reference(name):
+    """decode(['attention']) (autoregressive beam search through
+    wn_decoder_next_topk) against the committed outputs of the real reference."""
+    meta, _ = load_case(name)
+    configs, sd, model = cached_model(meta['config'], meta['wseed'])
+    _, _, feats, lens = build_inputs(meta)
+    got = model.decode(['attention'], feats.cuda(), lens, beam_size=meta['beam'],
+                       length_penalty=meta['length_penalty'])['attention']
+    assert [list(r.tokens) for r in got] == meta['tokens']
+    # together with the other modes, and after them (batch state is shared)
+    allm = model.decode(['ctc_greedy_search', 'attention', 'attention_rescoring'],
+                        feats.cuda(), lens, beam_size=meta['beam'],
+                        length_penalty=meta['length_penalty'], ctc_weight=0.5)
+    assert [list(r.tokens) for r in allm['attention']] == meta['tokens']
 
 
 @pytest.mark.parametrize('n_mels', [80, 128])

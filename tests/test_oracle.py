@@ -12,7 +12,8 @@ import pytest
 import torch
 
 from conftest import needs_reference
-from golden_util import (build_inputs, case_names, load_case, stream_case_names,
+from golden_util import (attention_case_names, build_inputs, case_names, load_case,
+                         stream_case_names,
                          whisper_case_names)
 from oracle import wenet_oracle as O
 
@@ -215,6 +216,18 @@ def test_chunk_mask_path_equals_reference_cache_streaming(name):
         meta['prefix']['nbest']
     assert list(res['attention_rescoring'][0].tokens) == meta['rescoring']['tokens']
     assert abs(res['attention_rescoring'][0].score - meta['rescoring']['score']) < 1e-3
+
+
+@pytest.mark.parametrize('name', [n for n in attention_case_names() if 'aishell' not in n])
+def test_oracle_attention_mode_matches_committed_reference_outputs(name):
+    """attention_beam_search (search.py:252-371): the oracle's cache-free
+    restatement against the reference's cached decoder steps."""
+    meta, _ = load_case(name)
+    configs, sd, feats, lens = build_inputs(meta)
+    torch.set_num_threads(8)
+    got = O.decode(configs, sd, ['attention'], feats, lens, beam_size=meta['beam'],
+                   length_penalty=meta['length_penalty'])['attention']
+    assert [list(r.tokens) for r in got] == meta['tokens']
 
 
 @needs_reference

@@ -262,6 +262,8 @@ struct wn_model {
   // rescoring
   DevBuf r_tok, r_rtok, r_pos, r_tgt, r_rtgt, r_qoff, r_qlen, r_kvoff, r_kvlen;
   DevBuf r_x, r_t1, r_t2, r_qkv, r_h, r_mem, r_logits, r_out;
+  DevBuf r_mem_all;            // per-layer cross-attention K/V of the current batch
+  bool mem_cache_valid = false;
 
   Stager stage;
   // optional HIP-event bracket around the FFN w_1 GEMM launches (the kernel
@@ -327,6 +329,7 @@ int ln(const Norm& n, const float* x, float* y, int M, int D, float eps,
 int set_layout(wn_model* m, int B, int Tp, const std::vector<int>& off,
                const std::vector<int>& len, int rows, hipStream_t s) {
   m->B = B; m->Tp = Tp; m->off = off; m->len = len; m->rows = rows;
+  m->mem_cache_valid = false;
   std::vector<int> row_utt(std::max(rows, 1), -1);
   for (int b = 0; b < B; ++b)
     for (int t = 0; t < len[b]; ++t) row_utt[off[b] + t] = b;
@@ -493,6 +496,7 @@ int encode_transformer(wn_model* m, const float* feats_dev,
   }
   m->B = B; m->Tp = Tp; m->off = off2; m->len = len2; m->rows = M;
   m->ctc_valid = false;
+  m->mem_cache_valid = false;
   if (M == 0) {
     WN_TRY(m->stage.begin((size_t)B * 16 + 1024));
     WN_TRY(upload_desc(m, m->d_off, off2, s));
@@ -1410,22 +1414,29 @@ int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
 
 // ---------------------------------------------------------------------------
 namespace {
-int run_decoder(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
-                const int* d_tok, const int* d_tgt, float* out_dev,
-                hipStream_t s) {
+// embed + the decoder layers over a ragged batch of R token rows (n_seq
+// sequences); the result stays in m->r_x.  With `mem_cache` the cross-attention
+// K/V projections of the encoder output are computed once per batch and layer
+// and reused by later calls (the autoregressive search calls this per step).
+int decoder_layers(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
+                   const int* d_tok, bool mem_cache, hipStream_t s) {
   const wn_config& c = m->cfg;
-  const int d = c.d_model, V = c.vocab, Menc = m->rows;
+  const int d = c.d_model, Menc = m->rows;
   float* x = m->r_x.as<float>();
   float* t1 = m->r_t1.as<float>();
   float* t2 = m->r_t2.as<float>();
   float* qkv = m->r_qkv.as<float>();
   float* hb = m->r_h.as<float>();
-  float* mem = m->r_mem.as<float>();
   const float eps = c.norm_eps;
+  const size_t mem_layer = (size_t)Menc * 2 * d;
+  const bool fill_cache = mem_cache && !m->mem_cache_valid;
+  if (mem_cache)
+    WN_TRY(m->r_mem_all.ensure(D.layers.size() * mem_layer * sizeof(float)));
   // embed(V,d) * sqrt(d) + pe                          embedding.py:58-76
   hipLaunchKernelGGL(embed_kernel, dim3(R), dim3(64), 0, s, d_tok,
                      m->r_pos.as<int>(), D.embed, D.pe, sqrtf((float)d), d / 4, x);
   WN_HIP(hipGetLastError());
+  int li = 0;
   for (const DecLayer& L : D.layers) {
     // causal self attention                             decoder_layer.py:100-121
     WN_TRY(ln(L.n1, x, t1, R, d, eps, s));
@@ -1443,7 +1454,10 @@ int run_decoder(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
     // (K/V projected once per utterance, not once per hypothesis)
     WN_TRY(ln(L.n2, x, t1, R, d, eps, s));
     WN_TRY(linear(L.src_q, t1, d, t2, d, R, s));
-    WN_TRY(linear(L.src_kv, m->enc.as<float>(), d, mem, 2 * d, Menc, s));
+    float* mem = mem_cache ? m->r_mem_all.as<float>() + (size_t)li * mem_layer
+                           : m->r_mem.as<float>();
+    if (!mem_cache || fill_cache)
+      WN_TRY(linear(L.src_kv, m->enc.as<float>(), d, mem, 2 * d, Menc, s));
     AttnArgs cx;
     cx.Q = t2; cx.ldq = d; cx.K = mem; cx.V = mem + d; cx.ldk = cx.ldv = 2 * d;
     cx.O = t1; cx.ldo = d;
@@ -1457,8 +1471,20 @@ int run_decoder(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
     WN_TRY(ln(L.n3, x, t1, R, d, eps, s));
     WN_TRY(linear(L.ff1, t1, d, hb, c.dec_ffn_dim, R, s, ACT_RELU));
     WN_TRY(linear(L.ff2, hb, c.dec_ffn_dim, x, d, R, s, ACT_NONE, x, d));
+    ++li;
   }
-  WN_TRY(ln(D.after, x, t1, R, d, eps, s));
+  if (fill_cache) m->mem_cache_valid = true;
+  return 0;
+}
+
+int run_decoder(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
+                const int* d_tok, const int* d_tgt, float* out_dev,
+                hipStream_t s) {
+  const wn_config& c = m->cfg;
+  const int d = c.d_model, V = c.vocab;
+  WN_TRY(decoder_layers(m, D, R, n_seq, max_q, d_tok, false, s));
+  float* t1 = m->r_t1.as<float>();
+  WN_TRY(ln(D.after, m->r_x.as<float>(), t1, R, d, c.norm_eps, s));
   WN_TRY(linear(D.out, t1, d, m->r_logits.as<float>(), V, R, s));
   hipLaunchKernelGGL(row_logp_at_kernel, dim3(R), dim3(256), 0, s,
                      m->r_logits.as<float>(), V, V, d_tgt, out_dev);
@@ -1466,6 +1492,77 @@ int run_decoder(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
   return 0;
 }
 }  // namespace
+
+int wn_decoder_next_topk(wn_model* m, int32_t n_seq, const int32_t* seq_utt_host,
+                         const int32_t* seq_lens_host, const int32_t* tokens_host,
+                         int32_t max_len, int32_t topk, float* logp_host,
+                         int32_t* idx_host, void* stream) {
+  WN_CHECK(m && m->B > 0 && m->enc.p, "decoder step: no current batch");
+  WN_CHECK(!m->left.layers.empty(), "decoder step: the model has no attention decoder");
+  WN_CHECK(n_seq > 0 && seq_utt_host && seq_lens_host && tokens_host && logp_host &&
+               idx_host && max_len > 0, "decoder step: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  WN_HIP(hipSetDevice(m->device));
+  const wn_config& c = m->cfg;
+  const int d = c.d_model, V = c.vocab;
+  WN_CHECK(topk >= 1 && topk <= V, "decoder step: top-k");
+  std::vector<int> tok, pos, qoff(n_seq), qlen(n_seq), kvoff(n_seq), kvlen(n_seq),
+      last(n_seq);
+  int max_q = 0;
+  for (int i = 0; i < n_seq; ++i) {
+    const int u = seq_utt_host[i], L = seq_lens_host[i];
+    WN_CHECK(u >= 0 && u < m->B, "decoder step: utterance index");
+    WN_CHECK(L >= 1 && L <= max_len && L <= c.max_pos, "decoder step: sequence length");
+    WN_CHECK(m->len[u] > 0, "decoder step: utterance without encoder frames");
+    qoff[i] = (int)tok.size(); qlen[i] = L;
+    kvoff[i] = m->off[u]; kvlen[i] = m->len[u];
+    max_q = std::max(max_q, L);
+    for (int j = 0; j < L; ++j) {
+      const int t = tokens_host[(int64_t)i * max_len + j];
+      WN_CHECK(t >= 0 && t < V, "decoder step: token id");
+      tok.push_back(t);
+      pos.push_back(j);
+    }
+    last[i] = qoff[i] + L - 1;
+  }
+  const int R = (int)tok.size();
+  WN_TRY(m->stage.begin((size_t)(2 * R + 5 * n_seq + 64) * sizeof(int) + 4096));
+  WN_TRY(upload_desc(m, m->r_tok, tok, s));
+  WN_TRY(upload_desc(m, m->r_pos, pos, s));
+  WN_TRY(upload_desc(m, m->r_qoff, qoff, s));
+  WN_TRY(upload_desc(m, m->r_qlen, qlen, s));
+  WN_TRY(upload_desc(m, m->r_kvoff, kvoff, s));
+  WN_TRY(upload_desc(m, m->r_kvlen, kvlen, s));
+  WN_TRY(upload_desc(m, m->r_tgt, last, s));
+  WN_TRY(m->stage.end(s));
+  WN_TRY(m->r_x.ensure((size_t)R * d * sizeof(float)));
+  WN_TRY(m->r_t1.ensure((size_t)std::max(R, n_seq) * d * sizeof(float)));
+  WN_TRY(m->r_t2.ensure((size_t)std::max(R, n_seq) * d * sizeof(float)));
+  WN_TRY(m->r_qkv.ensure((size_t)R * 3 * d * sizeof(float)));
+  WN_TRY(m->r_h.ensure((size_t)R * c.dec_ffn_dim * sizeof(float)));
+  WN_TRY(m->r_logits.ensure((size_t)n_seq * V * sizeof(float)));
+  WN_TRY(m->r_out.ensure((size_t)2 * n_seq * topk * sizeof(float)));
+  WN_TRY(decoder_layers(m, m->left, R, n_seq, max_q, m->r_tok.as<int>(), true, s));
+  // y = log_softmax(output_layer(after_norm(x[:, -1])))   decoder.py:275-281
+  float* t2 = m->r_t2.as<float>();
+  float* t1 = m->r_t1.as<float>();
+  WN_TRY(copy_rows(m->r_x.as<float>(), d, m->r_tgt.as<int>(), t2, d, nullptr, n_seq, d, s));
+  WN_TRY(ln(m->left.after, t2, t1, n_seq, d, c.norm_eps, s));
+  WN_TRY(linear(m->left.out, t1, d, m->r_logits.as<float>(), V, n_seq, s));
+  float* tv = m->r_out.as<float>();
+  int* ti = reinterpret_cast<int*>(tv + (size_t)n_seq * topk);
+  CtcRowArgs r;
+  r.logits = m->r_logits.as<float>(); r.ld = V; r.M = n_seq; r.V = V; r.k = topk;
+  r.blank = -1; r.blank_penalty = 0.f;
+  r.topk_val = tv; r.topk_idx = ti; r.logp = nullptr; r.ld_out = V;
+  WN_TRY(ctc_logsoftmax_topk(r, s));
+  WN_HIP(hipMemcpyAsync(logp_host, tv, (size_t)n_seq * topk * sizeof(float),
+                        hipMemcpyDeviceToHost, s));
+  WN_HIP(hipMemcpyAsync(idx_host, ti, (size_t)n_seq * topk * sizeof(int),
+                        hipMemcpyDeviceToHost, s));
+  WN_HIP(hipStreamSynchronize(s));
+  return 0;
+}
 
 int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
                            const int32_t* hyp_lens_host,

@@ -394,7 +394,7 @@ class ASRModel:
                                 decoding_chunk_size, num_decoding_left_chunks,
                                 simulate_streaming, context_graph, blank_id,
                                 blank_penalty)
-        return self._decode_end(st, ctc_weight, reverse_weight)
+        return self._decode_end(st, ctc_weight, reverse_weight, length_penalty)
 
     def _decode_begin(self, methods, speech, speech_lengths, beam_size=1,
                       decoding_chunk_size=-1, num_decoding_left_chunks=-1,
@@ -404,11 +404,6 @@ class ASRModel:
         CTC head are queued on the current stream (no host sync)."""
         assert speech.shape[0] == speech_lengths.shape[0]
         assert decoding_chunk_size != 0
-        for mth in methods:
-            if mth == 'attention':
-                raise NotImplementedError(
-                    "'attention' (autoregressive beam search) is not on the "
-                    'accelerated path yet (SURVEY.md section 8f)')
         if context_graph is not None:
             raise NotImplementedError('context biasing is not accelerated')
         if simulate_streaming and decoding_chunk_size > 0:
@@ -425,15 +420,27 @@ class ASRModel:
                                     Tp, _stream_ptr(self.device)),
             'wn_ctc_logprobs')
         return dict(methods=methods, B=B, enc_lens=enc_lens, need_beam=need_beam,
-                    beam_size=beam_size, blank_id=blank_id, speech=speech)
+                    beam_size=beam_size, blank_id=blank_id, speech=speech, Tp=Tp)
 
-    def _decode_end(self, st, ctc_weight=0.0, reverse_weight=0.0):
+    def _decode_end(self, st, ctc_weight=0.0, reverse_weight=0.0,
+                    length_penalty=0.0):
         """Second half of decode(): the searches (+ rescoring) and the result
         records; synchronises the stream."""
         methods, B, enc_lens = st['methods'], st['B'], st['enc_lens']
         beam_size, blank_id = st['beam_size'], st['blank_id']
         results = {}
         max_len = int(enc_lens.max()) if B > 0 else 0
+        if 'attention' in methods:
+            if self._cfg.dec_layers <= 0:
+                raise RuntimeError("'attention' mode: the model has no attention "
+                                   'decoder on the accelerated path')
+            if int(enc_lens.min()) <= 0:
+                raise RuntimeError("'attention' mode: an utterance has no encoder "
+                                   'frames')
+            from wenet_amd.search import attention_beam_search
+            # maxlen = encoder_out.size(1) of the padded reference tensor
+            results['attention'] = attention_beam_search(
+                self, B, st['Tp'], beam_size, length_penalty)
         if 'ctc_greedy_search' in methods:
             results['ctc_greedy_search'] = _greedy(self._h, B, max_len,
                                                    blank_id, self.device)

@@ -56,7 +56,7 @@ class DecodePipeline:
             kw = dict(kw)
             ctc_weight = kw.pop('ctc_weight', 0.0)
             reverse_weight = kw.pop('reverse_weight', 0.0)
-            kw.pop('length_penalty', None)
+            length_penalty = kw.pop('length_penalty', 0.0)
             kw.pop('infos', None)
             with torch.cuda.stream(stream):
                 with self._enc_lock:
@@ -67,7 +67,8 @@ class DecodePipeline:
                     done = torch.cuda.Event()
                     done.record(stream)
                     self._enc_done = done
-                return self.models[i]._decode_end(st, ctc_weight, reverse_weight)
+                return self.models[i]._decode_end(st, ctc_weight, reverse_weight,
+                                                  length_penalty)
         finally:
             self._free.put(i)
 
