@@ -213,9 +213,9 @@ int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,
 int wn_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev,
                     float* y_dev, int32_t M, int32_t D, float eps, void* stream);
 
-/* Measurement hook for bench.py: bracket every launch of the dominant kernel
- * (the FFN w_1 GEMM, positionwise_feed_forward.py:58) with HIP events on the
- * launch stream.  wn_profile_collect waits for them and returns the number of
+/* Measurement hook for bench.py: bracket launches of the dominant kernel (the
+ * FFN w_1 GEMM, positionwise_feed_forward.py:58; every 6th launch, because each
+ * event pair idles the GPU for ~10 us) with HIP events on the launch stream.  wn_profile_collect waits for them and returns the number of
  * launches, their summed duration and their summed algorithmic FLOPs
  * (2*M*N*K each) since the last enable/collect. */
 int wn_profile_enable(wn_model* m, int32_t on);
