@@ -25,7 +25,7 @@ the prefix-beam bookkeeping uses Python floats (fp64) exactly like search.py.
 Citations are path:line under /root/reference/.
 """
 import math
-from collections import defaultdict
+from collections import defaultdict, deque
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -560,18 +560,138 @@ def log_add(*args) -> float:
     return a_max + lsp
 
 
+class ContextGraph:
+    """wenet/utils/context_graph.py:101-265 restated over flat arrays: a trie of
+    the biasing phrases (token-id lists) with Aho-Corasick fail arcs.  Node 0 is
+    the root.  Per node: `edges[n]` {token: child}, `fail[n]`, `node_score[n]`
+    (bonus accumulated from the root), `output_score[n]` (bonus of every phrase
+    that ends at n or at a suffix of n), `is_end[n]`.
+
+    Reference quirks that are kept on purpose (they change scores):
+      * `is_end` is decided when a node is CREATED (context_graph.py:160-171): a
+        phrase that is a proper prefix of an EARLIER phrase never becomes an
+        end node;
+      * the fail search stops at the first root it reaches (:196-202) and the
+        output arc is the nearest `is_end` node on the fail chain (:205-212).
+    """
+
+    def __init__(self, context_list: List[List[int]], context_score: float = 6.0):
+        self.context_score = context_score
+        self.edges = [{}]
+        self.fail = [0]
+        self.node_score = [0.0]
+        self.output_score = [0.0]
+        self.token_score = [0.0]
+        self.is_end = [False]
+        for phrase in context_list:  # context_graph.py:157-172
+            n = 0
+            for i, tok in enumerate(phrase):
+                if tok not in self.edges[n]:
+                    last = i == len(phrase) - 1
+                    score = self.node_score[n] + context_score
+                    self.edges[n][tok] = len(self.edges)
+                    self.edges.append({})
+                    self.fail.append(0)
+                    self.node_score.append(score)
+                    self.output_score.append(score if last else 0)
+                    self.token_score.append(context_score)
+                    self.is_end.append(last)
+                n = self.edges[n][tok]
+        # breadth-first fill of the fail / output arcs, context_graph.py:175-214
+        queue = deque(self.edges[0].values())
+        while queue:
+            cur = queue.popleft()
+            for tok, n in self.edges[cur].items():
+                f = self.fail[cur]
+                if tok in self.edges[f]:
+                    f = self.edges[f][tok]
+                else:
+                    f = self.fail[f]
+                    while tok not in self.edges[f]:
+                        f = self.fail[f]
+                        if f == 0:
+                            break
+                    if tok in self.edges[f]:
+                        f = self.edges[f][tok]
+                self.fail[n] = f
+                out = f
+                while not self.is_end[out]:
+                    out = self.fail[out]
+                    if out == 0:
+                        out = -1
+                        break
+                if out >= 0:
+                    self.output_score[n] += self.output_score[out]
+                queue.append(n)
+
+    @property
+    def num_nodes(self):
+        return len(self.edges) - 1
+
+    def forward_one_step(self, state: int, token: int) -> Tuple[float, int]:
+        """context_graph.py:216-248 -> (bonus, next state)."""
+        if token in self.edges[state]:
+            n = self.edges[state][token]
+            score = self.token_score[n]
+        else:
+            n = self.fail[state]
+            while token not in self.edges[n]:
+                n = self.fail[n]
+                if n == 0:
+                    break
+            if token in self.edges[n]:
+                n = self.edges[n][token]
+            score = self.node_score[n] - self.node_score[state]
+        return score + self.output_score[n], n
+
+    def finalize(self, state: int) -> Tuple[float, int]:
+        """context_graph.py:250-265."""
+        return -self.node_score[state], 0
+
+
+def tokenize_context(lines: List[str], symbol_table: Dict[str, int]) -> List[List[int]]:
+    """context_graph.py:24-58, char units (no BPE model): one phrase per line,
+    ' ' -> U+2581, unknown symbols -> <unk> when the table has one."""
+    out = []
+    for txt in lines:
+        labels = []
+        for ch in txt.strip():
+            ch = '\u2581' if ch == ' ' else ch
+            if ch in symbol_table:
+                labels.append(symbol_table[ch])
+            elif '<unk>' in symbol_table:
+                labels.append(symbol_table['<unk>'])
+        out.append(labels)
+    return out
+
+
 class PrefixScore:
-    """wenet/models/transformer/search.py:64-106 (context graph omitted: it is
-    None on this path)."""
+    """wenet/models/transformer/search.py:64-106."""
     __slots__ = ('s', 'ns', 'v_s', 'v_ns', 'cur_token_prob', 'times_s',
-                 'times_ns')
+                 'times_ns', 'context_state', 'context_score', 'has_context')
 
     def __init__(self, s=float('-inf'), ns=float('-inf'), v_s=float('-inf'),
-                 v_ns=float('-inf')):
+                 v_ns=float('-inf'), context_state=None, context_score=0.0):
         self.s, self.ns, self.v_s, self.v_ns = s, ns, v_s, v_ns
         self.cur_token_prob = float('-inf')
         self.times_s = []
         self.times_ns = []
+        self.context_state = context_state
+        self.context_score = context_score
+        self.has_context = False
+
+    def total_score(self):
+        return self.score() + self.context_score
+
+    def copy_context(self, other):
+        self.context_score = other.context_score
+        self.context_state = other.context_state
+
+    def update_context(self, graph, other, word_id):
+        self.copy_context(other)
+        score, state = graph.forward_one_step(other.context_state, word_id)
+        self.context_score += score
+        self.context_state = state
 
     def score(self):
         return log_add(self.s, self.ns)
@@ -584,8 +704,15 @@ class PrefixScore:
 
 
 def ctc_prefix_beam_search(ctc_probs, ctc_lens, beam_size: int,
-                           blank_id: int = 0) -> List[DecodeResult]:
-    """wenet/models/transformer/search.py:127-249 with context_graph=None.
+                           blank_id: int = 0,
+                           context_graph: Optional[ContextGraph] = None
+                           ) -> List[DecodeResult]:
+    """wenet/models/transformer/search.py:127-249.
+
+    With a context graph every dict entry takes its (state, bonus) from the
+    FIRST contribution that reaches it (`has_context`), the second prune ranks
+    by score + bonus, and after the last frame the bonus is REPLACED by
+    finalize()'s -node_score(state) (search.py:229-234) without re-sorting.
 
     Iteration order is the reference's: top-k tokens in torch.topk order
     (descending log-prob), then `cur_hyps` in beam order; `next_hyps` keeps dict
@@ -595,8 +722,11 @@ def ctc_prefix_beam_search(ctc_probs, ctc_lens, beam_size: int,
     for i in range(ctc_probs.shape[0]):
         ctc_prob = ctc_probs[i]
         num_t = int(ctc_lens[i])
+        cg = context_graph
         cur_hyps = [(tuple(), PrefixScore(s=0.0, ns=-float('inf'), v_s=0.0,
-                                          v_ns=0.0))]
+                                          v_ns=0.0,
+                                          context_state=None if cg is None else 0,
+                                          context_score=0.0))]
         for t in range(0, num_t):
             logp = ctc_prob[t]
             next_hyps = defaultdict(lambda: PrefixScore())
@@ -611,6 +741,9 @@ def ctc_prefix_beam_search(ctc_probs, ctc_lens, beam_size: int,
                         nx.s = log_add(nx.s, ps.score() + prob)
                         nx.v_s = ps.viterbi_score() + prob
                         nx.times_s = ps.times().copy()
+                        if cg is not None and not nx.has_context:
+                            nx.copy_context(ps)
+                            nx.has_context = True
                     elif u == last:
                         n1 = next_hyps[prefix]
                         n1.ns = log_add(n1.ns, ps.ns + prob)
@@ -620,6 +753,9 @@ def ctc_prefix_beam_search(ctc_probs, ctc_lens, beam_size: int,
                                 n1.cur_token_prob = prob
                                 n1.times_ns = ps.times_ns.copy()
                                 n1.times_ns[-1] = t
+                        if cg is not None and not n1.has_context:
+                            n1.copy_context(ps)
+                            n1.has_context = True
                         n2 = next_hyps[prefix + (u, )]
                         n2.ns = log_add(n2.ns, ps.s + prob)
                         if n2.v_ns < ps.v_s + prob:
@@ -627,6 +763,9 @@ def ctc_prefix_beam_search(ctc_probs, ctc_lens, beam_size: int,
                             n2.cur_token_prob = prob
                             n2.times_ns = ps.times_s.copy()
                             n2.times_ns.append(t)
+                        if cg is not None and not n2.has_context:
+                            n2.update_context(cg, ps, u)
+                            n2.has_context = True
                     else:
                         nx = next_hyps[prefix + (u, )]
                         nx.ns = log_add(nx.ns, ps.score() + prob)
@@ -635,11 +774,17 @@ def ctc_prefix_beam_search(ctc_probs, ctc_lens, beam_size: int,
                             nx.cur_token_prob = prob
                             nx.times_ns = ps.times().copy()
                             nx.times_ns.append(t)
-            next_hyps = sorted(next_hyps.items(), key=lambda x: x[1].score(),
+                        if cg is not None and not nx.has_context:
+                            nx.update_context(cg, ps, u)
+                            nx.has_context = True
+            next_hyps = sorted(next_hyps.items(), key=lambda x: x[1].total_score(),
                                reverse=True)
             cur_hyps = next_hyps[:beam_size]
+        if cg is not None:
+            for _, ps in cur_hyps:
+                ps.context_score, ps.context_state = cg.finalize(ps.context_state)
         nbest = [y[0] for y in cur_hyps]
-        nbest_scores = [y[1].score() for y in cur_hyps]
+        nbest_scores = [y[1].total_score() for y in cur_hyps]
         nbest_times = [y[1].times() for y in cur_hyps]
         results.append(
             DecodeResult(tokens=nbest[0], score=nbest_scores[0],
@@ -866,7 +1011,7 @@ def decode(configs, sd, methods, speech, speech_lengths, beam_size: int = 1,
            decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1,
            ctc_weight: float = 0.0, reverse_weight: float = 0.0,
            blank_id: int = 0, blank_penalty: float = 0.0,
-           length_penalty: float = 0.0):
+           length_penalty: float = 0.0, context_graph=None):
     """ASRModel.decode asr_model.py:267-343 (methods: attention,
     ctc_greedy_search, ctc_prefix_beam_search, attention_rescoring)."""
     assert speech.shape[0] == speech_lengths.shape[0]
@@ -889,12 +1034,12 @@ def decode(configs, sd, methods, speech, speech_lengths, beam_size: int = 1,
                 ctc_probs, encoder_lens, blank_id)
         if 'ctc_prefix_beam_search' in methods:
             results['ctc_prefix_beam_search'] = ctc_prefix_beam_search(
-                ctc_probs, encoder_lens, beam_size, blank_id)
+                ctc_probs, encoder_lens, beam_size, blank_id, context_graph)
         if 'attention_rescoring' in methods:
             pre = results.get('ctc_prefix_beam_search')
             if pre is None:
                 pre = ctc_prefix_beam_search(ctc_probs, encoder_lens, beam_size,
-                                             blank_id)
+                                             blank_id, context_graph)
             results['attention_rescoring'] = attention_rescoring(
                 configs, sd, pre, encoder_out, encoder_lens, ctc_weight,
                 reverse_weight, sos, eos)

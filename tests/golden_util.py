@@ -13,7 +13,7 @@ def case_names(prefix=''):
     return sorted(
         os.path.basename(p)[:-4]
         for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + '*.npz'))
-        if not os.path.basename(p).startswith(('fbank', 'whisperenc', 'stream_', 'attn_')))
+        if not os.path.basename(p).startswith(('fbank', 'whisperenc', 'stream_', 'attn_', 'ctx')))
 
 
 def load_case(name):
@@ -50,3 +50,15 @@ def attention_case_names():
     """Goldens of the reference's `attention` (autoregressive) decode mode."""
     return sorted(os.path.basename(p)[:-4]
                   for p in glob.glob(os.path.join(GOLDEN_DIR, 'attn_*.npz')))
+
+
+def context_case_names():
+    """Goldens of context-biased decoding through a model (ContextGraph)."""
+    return sorted(os.path.basename(p)[:-4]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, 'ctx_*.npz')))
+
+
+def context_search_case_names():
+    """Goldens of the context-biased ctc_prefix_beam_search on seeded log-probs."""
+    return sorted(os.path.basename(p)[:-4]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, 'ctxsearch_*.npz')))

@@ -12,7 +12,8 @@ import pytest
 import torch
 
 from conftest import needs_reference
-from golden_util import (attention_case_names, build_inputs, case_names, load_case,
+from golden_util import (attention_case_names, build_inputs, case_names,
+                         context_case_names, context_search_case_names, load_case,
                          stream_case_names,
                          whisper_case_names)
 from oracle import wenet_oracle as O
@@ -306,3 +307,131 @@ def test_oracle_matches_live_reference(config, chunk, left, beam):
         assert list(rr.tokens) == list(gr.tokens)
         assert abs(rr.score - gr.score) < 1e-5
         assert abs(rr.confidence - gr.confidence) < 1e-6
+
+
+# --------------------------------------------------------------------------
+# context biasing (ContextGraph + ctc_prefix_beam_search, search.py:127-249)
+
+
+def _check_prefix_results(got, want):
+    for b, r in enumerate(got):
+        assert [list(h) for h in r.nbest] == want['nbest'][b], b
+        assert [list(t) for t in r.nbest_times] == want['nbest_times'][b], b
+        np.testing.assert_allclose(r.nbest_scores, want['nbest_scores'][b],
+                                   rtol=0, atol=1e-9)
+
+
+def test_context_graph_known_answer():
+    """Hand-checked Aho-Corasick bonuses: phrases [1,2,3] and [2,3] at 2.0."""
+    g = O.ContextGraph([[1, 2, 3], [2, 3]], 2.0)
+    assert g.num_nodes == 5
+    s1, n1 = g.forward_one_step(0, 1)
+    s2, n2 = g.forward_one_step(n1, 2)
+    s3, n3 = g.forward_one_step(n2, 3)
+    # the third token completes [1,2,3] (6.0) AND the suffix phrase [2,3] (4.0)
+    assert (s1, s2, s3) == (2.0, 2.0, 2.0 + 6.0 + 4.0)
+    # a mismatch after [1,2] falls back to the root and takes the bonus back
+    s, n = g.forward_one_step(n2, 7)
+    assert (s, n) == (-4.0, 0)
+    # ... unless a suffix still matches: [1,2] + 2 -> root -> [2]
+    s, n = g.forward_one_step(n2, 2)
+    assert s == 2.0 - 4.0 and g.node_score[n] == 2.0
+    assert g.finalize(n2) == (-4.0, 0)
+
+
+def test_context_graph_is_end_only_at_creation():
+    """context_graph.py:160-171: [1,2] added after [1,2,3] never ends a phrase."""
+    g = O.ContextGraph([[1, 2, 3], [1, 2]], 1.0)
+    n = g.edges[g.edges[0][1]][2]
+    assert not g.is_end[n] and g.output_score[n] == 0
+    g2 = O.ContextGraph([[1, 2], [1, 2, 3]], 1.0)
+    n = g2.edges[g2.edges[0][1]][2]
+    assert g2.is_end[n] and g2.output_score[n] == 2.0
+
+
+@pytest.mark.parametrize('name', context_search_case_names())
+def test_oracle_context_search_matches_committed_reference_outputs(name):
+    from wenet_amd import synthetic as S
+    meta, _ = load_case(name)
+    logp, lens = S.peaky_logprobs(meta['batch'], meta['frames'], meta['vocab'],
+                                  meta['peak'], meta['seed'])
+    g = O.ContextGraph(meta['phrases'], meta['context_score'])
+    got = O.ctc_prefix_beam_search(logp, lens, meta['beam'], 0, g)
+    _check_prefix_results(got, meta['prefix'])
+
+
+@pytest.mark.parametrize('name', context_case_names())
+def test_oracle_context_decode_matches_committed_reference_outputs(name):
+    meta, _ = load_case(name)
+    configs, sd, feats, lens = build_inputs(meta)
+    torch.set_num_threads(8)
+    g = O.ContextGraph(meta['phrases'], meta['context_score'])
+    res = O.decode(configs, sd, ['ctc_prefix_beam_search', 'attention_rescoring'],
+                   feats, lens, beam_size=meta['beam'], ctc_weight=meta['ctc_weight'],
+                   reverse_weight=meta['reverse_weight'],
+                   blank_penalty=meta['blank_penalty'], context_graph=g)
+    for b, r in enumerate(res['ctc_prefix_beam_search']):
+        assert [list(h) for h in r.nbest] == meta['prefix']['nbest'][b], b
+        np.testing.assert_allclose(r.nbest_scores, meta['prefix']['nbest_scores'][b],
+                                   rtol=0, atol=2e-3)
+    assert [list(r.tokens) for r in res['attention_rescoring']] == meta['rescoring_tokens']
+    np.testing.assert_allclose([r.score for r in res['attention_rescoring']],
+                               meta['rescoring_scores'], rtol=0, atol=2e-3)
+
+
+@needs_reference
+def test_context_graph_matches_live_reference(tmp_path):
+    """Graph arrays, every transition and the char tokenizer against
+    wenet/utils/context_graph.py on random phrase lists."""
+    from oracle import _ref_harness, gen_golden_context
+    _ref_harness.install()
+    from wenet.utils.context_graph import ContextGraph as RefGraph
+    rng = np.random.RandomState(0)
+    for trial in range(20):
+        vocab = int(rng.randint(3, 9))
+        phrases = [[int(t) for t in rng.randint(1, vocab, rng.randint(1, 6))]
+                   for _ in range(rng.randint(1, 12))]
+        ref = gen_golden_context.reference_graph(phrases, 1.5)
+        g = O.ContextGraph(phrases, 1.5)
+        assert g.num_nodes == ref.num_nodes
+        # walk both automata in lock step over random token streams
+        for _ in range(30):
+            rs, s = ref.root, 0
+            for tok in rng.randint(0, vocab + 1, 25):
+                r_score, rs = ref.forward_one_step(rs, int(tok))
+                o_score, s = g.forward_one_step(s, int(tok))
+                assert r_score == o_score and rs.id == s
+                assert ref.finalize(rs)[0] == g.finalize(s)[0]
+    # tokenizer (char units): spaces, unknown symbols, <unk>
+    table = {'<blank>': 0, '<unk>': 1, 'a': 2, 'b': 3, '\u2581': 4, '\u4f60': 5}
+    lines = ['ab a\n', ' b\u4f60z \n', '\n', 'zzz\n']
+    path = tmp_path / 'ctx.txt'
+    path.write_text(''.join(lines), encoding='utf8')
+    ref = RefGraph(str(path), table, None, 2.0)
+    assert O.tokenize_context(lines, table) == ref.context_list
+    table.pop('<unk>')
+    ref = RefGraph(str(path), table, None, 2.0)
+    assert O.tokenize_context(lines, table) == ref.context_list
+
+
+@needs_reference
+def test_oracle_context_search_matches_live_reference():
+    from oracle import _ref_harness, gen_golden_context
+    from wenet_amd import synthetic as S
+    _ref_harness.install()
+    from wenet.models.transformer.search import ctc_prefix_beam_search as ref_search
+    rng = np.random.RandomState(7)
+    for trial in range(6):
+        vocab = int(rng.randint(5, 30))
+        beam = int(rng.randint(1, min(vocab, 12)))
+        logp, lens = S.peaky_logprobs(3, (10, 60), vocab, float(rng.uniform(1, 5)),
+                                      100 + trial)
+        phrases = [[int(t) for t in rng.randint(1, vocab, rng.randint(1, 5))]
+                   for _ in range(rng.randint(1, 15))]
+        cs = float(rng.choice([0.5, 2.0, 6.0]))
+        ref = ref_search(logp, lens, beam, gen_golden_context.reference_graph(phrases, cs), 0)
+        got = O.ctc_prefix_beam_search(logp, lens, beam, 0, O.ContextGraph(phrases, cs))
+        for r, o in zip(ref, got):
+            assert [tuple(h) for h in r.nbest] == [tuple(h) for h in o.nbest]
+            assert r.nbest_scores == o.nbest_scores
+            assert r.nbest_times == o.nbest_times

@@ -513,3 +513,18 @@ def write_model_dir(path: str, name: str, seed: int = 0) -> str:
         yaml.safe_dump(configs, f)
     torch.save(sd, os.path.join(path, 'final.pt'))
     return path
+
+
+def peaky_logprobs(batch: int, frames, vocab: int, peak: float, seed: int):
+    """Seeded (B, T, V) float32 log-softmax rows with two boosted tokens per frame
+    and frequent blanks (token 0), plus int32 lengths in `frames`: inputs for the
+    search-only fixtures (prefixes re-merge, biasing phrases match often)."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(frames[0], frames[1] + 1, (batch, ), generator=g)
+    lens[0] = frames[1]
+    T = int(lens.max())
+    x = torch.randn(batch, T, vocab, generator=g)
+    hot = torch.randint(0, vocab, (batch, T, 2), generator=g)
+    x.scatter_add_(2, hot, torch.full(hot.shape, float(peak)))
+    x[..., 0] += 1.0
+    return torch.log_softmax(x, dim=-1), lens.to(torch.int32)
