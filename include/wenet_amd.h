@@ -161,7 +161,24 @@ int wn_set_ctc_probs(wn_model* m, const float* logp_dev,
 int wn_ctc_greedy_search(wn_model* m, int32_t blank_id, int32_t* tokens_host,
                          int32_t* tok_lens_host, int32_t max_len, void* stream);
 
-/* ctc_prefix_beam_search (search.py:127-249, context_graph=None).  Outputs,
+/* Context biasing: install (n_nodes > 0) or clear (n_nodes == 0) a flattened
+ * ContextGraph (wenet/utils/context_graph.py:101-265) on this handle; later
+ * wn_ctc_prefix_beam_search calls are biased by it exactly like
+ * ctc_prefix_beam_search(..., context_graph) (search.py:127-249): per-entry trie
+ * state and bonus taken from the first contribution, second prune on
+ * score + bonus, finalize() at the end.  All arrays are HOST arrays, copied.
+ * Node 0 is the root (fail[0] = 0); `fail`, `node_score`, `output_score`,
+ * `token_score` have n_nodes entries (ContextState.fail.id / node_score /
+ * output_score / token_score); the trie arcs (ContextState.next) are the n_edges
+ * triples edge_from[i] --edge_token[i]--> edge_to[i]. */
+int wn_set_context_graph(wn_model* m, int32_t n_nodes, const int32_t* fail,
+                         const double* node_score, const double* output_score,
+                         const double* token_score, int32_t n_edges,
+                         const int32_t* edge_from, const int32_t* edge_token,
+                         const int32_t* edge_to, void* stream);
+
+/* ctc_prefix_beam_search (search.py:127-249; context_graph = the graph set with
+ * wn_set_context_graph, None by default).  Outputs,
  * all host: n_hyps (B); hyp_lens, hyp_tlens (B, beam); hyp_tokens, hyp_times
  * (B, beam, max_len); hyp_scores (B, beam) fp64.  The n-best list also stays
  * on the device for wn_attention_rescoring. */

@@ -12,10 +12,11 @@ def log_add2(a,b):
     if a==NEG and b==NEG: return NEG
     m=max(a,b); return m+math.log(math.exp(a-m)+math.exp(b-m))
 class H: pass
-def emul(logp, T, beam, blank=0, canonical=True):
+def emul(logp, T, beam, blank=0, canonical=True, graph=None):
     root=H(); root.key=(); root.node=0; root.last=-1; root.par=None; root.s=0.0; root.ns=NEG; root.vs=0.0; root.vns=0.0
     root.ts=[]; root.tns=[]; root.score=0.0; root.vit=0.0; root.tim=[]
     root.parkey=None
+    root.cs=0; root.cx=0.0   # context state / bonus (graph is not None)
     beamh=[root]; nodec=[1]
     for t in range(T):
         lp=logp[t]; tv,ti=lp.topk(beam); tok=ti.tolist(); l=[float(x) for x in tv.tolist()]
@@ -58,6 +59,17 @@ def emul(logp, T, beam, blank=0, canonical=True):
                             v=va
                             if ctp<p: ctp=p; tl=rep(K.tns)
                 E.vns=v; E.tns=tl
+            if graph is not None:
+                # first visitor of key K in the reference's loop order decides
+                first=1<<30; from_parent=False
+                if qb>=0: first=qb*nb+r
+                if ql>=0:
+                    first=min(first,ql*nb+r)
+                    if rp>=0 and ql*nb+rp<first: from_parent=True
+                if from_parent:
+                    sc,st=graph.forward_one_step(beamh[rp].cs,K.last); E.cx=beamh[rp].cx+sc; E.cs=st
+                else:
+                    E.cx=K.cx; E.cs=K.cs
             E.seq=seq; ents.append(E)
         for r,P in enumerate(beamh):
             for q in range(beam):
@@ -72,9 +84,13 @@ def emul(logp, T, beam, blank=0, canonical=True):
                 E=H(); E.s=NEG;E.ns=x;E.vs=NEG;E.vns=NEG;E.ts=[];E.tns=[]
                 if v>NEG: E.vns=v; E.tns=list(tb)+[t]
                 E.key=ck; E.node=None; E.par=P.node; E.last=u; E.parkey=P.key; E.seq=(q*nb+r)*2+sub
+                if graph is not None:
+                    sc,st=graph.forward_one_step(P.cs,u); E.cx=P.cx+sc; E.cs=st
                 ents.append(E)
-        for E in ents: E.score=log_add2(E.s,E.ns)
-        ents.sort(key=lambda E:(-E.score if E.score>NEG else float('inf'),E.seq))
+        for E in ents:
+            E.score=log_add2(E.s,E.ns)
+            E.total=E.score+E.cx if graph is not None else E.score
+        ents.sort(key=lambda E:(-E.total if E.total>NEG else float('inf'),E.seq))
         newb=[]
         for E in ents[:beam]:
             if E.node is None: E.node=nodec[0]; nodec[0]+=1
@@ -82,4 +98,6 @@ def emul(logp, T, beam, blank=0, canonical=True):
             E.tim=E.ts if E.vs>E.vns else E.tns
             newb.append(E)
         beamh=newb
+    if graph is not None:
+        return [(h.key,h.score+graph.finalize(h.cs)[0],h.tim) for h in beamh]
     return [(h.key,h.score,h.tim) for h in beamh]

@@ -16,7 +16,8 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import (attention_case_names, build_inputs, case_names, load_case,
+from golden_util import (attention_case_names, build_inputs, case_names,
+                         context_case_names, context_search_case_names, load_case,
                          stream_case_names,
                          whisper_case_names)
 from gpu_util import cached_model, compare_nbest, frame_margins
@@ -491,3 +492,143 @@ def test_pipeline_two_streams_matches_sequential_decode():
                     if a.nbest is not None:
                         assert [list(x) for x in a.nbest] == [list(x) for x in b.nbest]
                         assert list(a.nbest_scores) == list(b.nbest_scores)
+
+
+# --------------------------------------------------------------------------
+# context biasing (ContextGraph, search.py:127-249 with context_graph)
+
+
+def _same_nbest(got, want_nbest, want_scores, want_times, what=''):
+    assert [list(x) for x in got.nbest] == [list(x) for x in want_nbest], what
+    assert [list(x) for x in got.nbest_times] == [list(x) for x in want_times], what
+    np.testing.assert_allclose(got.nbest_scores, want_scores, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', context_search_case_names())
+def test_context_search_vs_reference_golden(name):
+    """The reference's biased ctc_prefix_beam_search on seeded log-probs (the
+    same fp32 tensor goes to the GPU): n-best lists, order, time stamps
+    identical, fp64 scores to 1e-9."""
+    from wenet_amd import search as S
+    from wenet_amd import synthetic
+    from wenet_amd.context_graph import ContextGraph
+    meta, _ = load_case(name)
+    logp, lens = synthetic.peaky_logprobs(meta['batch'], meta['frames'], meta['vocab'],
+                                          meta['peak'], meta['seed'])
+    g = ContextGraph(context_list=meta['phrases'], context_score=meta['context_score'])
+    got = S.ctc_prefix_beam_search(logp.cuda(), lens, meta['beam'], g, 0)
+    w = meta['prefix']
+    for b in range(meta['batch']):
+        _same_nbest(got[b], w['nbest'][b], w['nbest_scores'][b], w['nbest_times'][b],
+                    f'{name}[{b}]')
+    # the handle's graph is cleared afterwards: an unbiased search is unbiased
+    O = _oracle()
+    plain = S.ctc_prefix_beam_search(logp.cuda(), lens, meta['beam'], None, 0)
+    ref = O.ctc_prefix_beam_search(logp, lens, meta['beam'])
+    for b in range(meta['batch']):
+        _same_nbest(plain[b], ref[b].nbest, ref[b].nbest_scores, ref[b].nbest_times)
+
+
+@pytest.mark.parametrize('V,T,beam,n_phr,score', [
+    (4, 60, 3, 5, 1.0), (6, 90, 5, 12, 2.5), (9, 50, 8, 30, 0.7), (30, 70, 10, 40, 6.0),
+    (5, 40, 16, 10, 3.0), (12, 100, 1, 8, 2.0)])
+def test_context_search_stress_vs_oracle(V, T, beam, n_phr, score):
+    """Random graphs over tiny vocabularies: phrases match, overlap, fail and
+    re-merge in almost every frame; 32 utterances per case."""
+    from wenet_amd import search as S
+    from wenet_amd import synthetic
+    from wenet_amd.context_graph import ContextGraph
+    O = _oracle()
+    beam = min(beam, V)
+    rng = np.random.RandomState(V * 100 + T)
+    phrases = [[int(t) for t in rng.randint(1, V, rng.randint(1, 6))]
+               for _ in range(n_phr)]
+    logp, lens = synthetic.peaky_logprobs(32, (1, T), V, 2.5, V * 7 + beam)
+    ref = O.ctc_prefix_beam_search(logp, lens, beam, 0, O.ContextGraph(phrases, score))
+    got = S.ctc_prefix_beam_search(logp.cuda(), lens, beam,
+                                   ContextGraph(context_list=phrases,
+                                                context_score=score), 0)
+    for b in range(32):
+        _same_nbest(got[b], ref[b].nbest, ref[b].nbest_scores, ref[b].nbest_times,
+                    f'utt {b}')
+
+
+@pytest.mark.parametrize('name', context_case_names())
+def test_context_decode_vs_reference_golden(name):
+    """decode(..., context_graph=g) through the model: (1) the biased search on
+    the GPU's own CTC log-probs equals the oracle's on the same tensor, bit for
+    bit; (2) the reference's committed result: best hypothesis, scores of the
+    shared hypotheses, rescoring result."""
+    from wenet_amd.context_graph import ContextGraph
+    O = _oracle()
+    meta, _ = load_case(name)
+    configs, sd, model = cached_model(meta['config'], meta['wseed'])
+    _, _, feats, lens = build_inputs(meta)
+    g = ContextGraph(context_list=meta['phrases'], context_score=meta['context_score'])
+    kw = dict(beam_size=meta['beam'], ctc_weight=meta['ctc_weight'],
+              reverse_weight=meta['reverse_weight'],
+              blank_penalty=meta['blank_penalty'])
+    res = model.decode(['ctc_prefix_beam_search', 'attention_rescoring'], feats.cuda(),
+                       lens, context_graph=g, **kw)
+    enc, mask = model._forward_encoder(feats.cuda(), lens)
+    enc_lens = mask.squeeze(1).sum(1).cpu()
+    logp = model.ctc_logprobs(enc, meta['blank_penalty'], 0, encoder_lens=enc_lens).cpu()
+    ref = O.ctc_prefix_beam_search(logp, enc_lens, meta['beam'], 0,
+                                   O.ContextGraph(meta['phrases'], meta['context_score']))
+    w = meta['prefix']
+    for b in range(meta['batch']):
+        got = res['ctc_prefix_beam_search'][b]
+        _same_nbest(got, ref[b].nbest, ref[b].nbest_scores, ref[b].nbest_times,
+                    f'{name}[{b}]')
+        assert list(got.tokens) == w['nbest'][b][0], (name, b)
+        shared = 0
+        for i, h in enumerate(w['nbest'][b]):
+            if h in [list(x) for x in got.nbest]:
+                j = [list(x) for x in got.nbest].index(h)
+                assert abs(got.nbest_scores[j] - w['nbest_scores'][b][i]) < 2e-3
+                shared += 1
+        assert shared >= len(w['nbest'][b]) - 1, (name, b, shared)
+        r = res['attention_rescoring'][b]
+        assert list(r.tokens) == meta['rescoring_tokens'][b], (name, b)
+        assert abs(r.score - meta['rescoring_scores'][b]) < 1e-3 * (len(r.tokens) + 1)
+    # the same model without a graph is unbiased again (the handle is cleared)
+    plain = model.decode(['ctc_prefix_beam_search'], feats.cuda(), lens, **kw)
+    ref0 = O.ctc_prefix_beam_search(logp, enc_lens, meta['beam'], 0)
+    for b in range(meta['batch']):
+        _same_nbest(plain['ctc_prefix_beam_search'][b], ref0[b].nbest,
+                    ref0[b].nbest_scores, ref0[b].nbest_times)
+
+
+def test_context_graph_object_of_the_reference_is_accepted():
+    """A duck-typed reference ContextGraph (root ContextState with next / fail /
+    node_score / output_score / token_score) is flattened and gives the same
+    result as the native class."""
+    from wenet_amd import search as S
+    from wenet_amd import synthetic
+    from wenet_amd.context_graph import ContextGraph
+
+    class St:
+        def __init__(self, token, token_score, node_score, output_score):
+            self.token, self.token_score = token, token_score
+            self.node_score, self.output_score = node_score, output_score
+            self.next, self.fail = {}, None
+
+    phrases = [[1, 2, 3], [2, 3], [3, 1]]
+    g = ContextGraph(context_list=phrases, context_score=2.0)
+    f = g.flat()
+    nodes = [St(-1 if i == 0 else 0, f.token_score[i], f.node_score[i],
+                f.output_score[i]) for i in range(f.n_nodes)]
+    for a, t, b in zip(f.edge_from, f.edge_token, f.edge_to):
+        nodes[a].next[int(t)] = nodes[b]
+        nodes[b].token = int(t)
+    for i, n in enumerate(nodes):
+        n.fail = nodes[f.fail[i]]
+
+    class RefLike:
+        root = nodes[0]
+
+    logp, lens = synthetic.peaky_logprobs(6, (20, 50), 5, 2.0, 3)
+    a = S.ctc_prefix_beam_search(logp.cuda(), lens, 4, g, 0)
+    b = S.ctc_prefix_beam_search(logp.cuda(), lens, 4, RefLike(), 0)
+    for x, y in zip(a, b):
+        _same_nbest(x, y.nbest, y.nbest_scores, y.nbest_times)

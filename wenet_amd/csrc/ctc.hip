@@ -186,7 +186,42 @@ struct HypSoA {  // the beam, structure of arrays
   int ts[MAXB], tns[MAXB], tnsp[MAXB];  // times_s / times_ns heads (0 = empty
                                         // list), predecessor of the tns head
   int tim[MAXB];                        // times() head
+  // context biasing (search.py:81-82): trie state and accumulated bonus
+  double cscore[MAXB];
+  int cstate[MAXB];
 };
+
+// ContextGraph.forward_one_step (context_graph.py:216-248): child of `state`
+// by `token`, or along the fail arcs; returns the bonus, *next = new state.
+__device__ __forceinline__ int ctx_child(const CtxGraph& g, int state, int token) {
+  const u64 key = ((u64)(unsigned)state << 32) | (unsigned)token;
+  unsigned h = ctx_slot(key, g.mask);
+  while (true) {
+    const u64 k = g.keys[h];
+    if (k == key) return g.vals[h];
+    if (k == CTX_EMPTY) return -1;
+    h = (h + 1) & g.mask;
+  }
+}
+__device__ __noinline__ double ctx_step(const CtxGraph& g, int state, int token, int* next) {
+  int n = ctx_child(g, state, token);
+  double score;
+  if (n >= 0) {
+    score = g.token_score[n];
+  } else {
+    n = g.fail[state];
+    int c = ctx_child(g, n, token);
+    while (c < 0) {
+      n = g.fail[n];
+      c = ctx_child(g, n, token);
+      if (n == 0) break;
+    }
+    if (c >= 0) n = c;
+    score = g.node_score[n] - g.node_score[state];
+  }
+  *next = n;
+  return score + g.output_score[n];
+}
 
 // exp(d) for d in [-37, 0]: k = rint(d log2 e), r = d - k ln2 (two-part),
 // degree-13 Taylor on |r| <= 0.347 (truncation 4e-18), scaled by 2^k.
@@ -269,7 +304,9 @@ constexpr int PB_CHUNKS = (MAXE + 63) / 64;  // 5: beam up to 16
 
 // NCH = 64-entry chunks the rank pass scans: compile-time so that the pass has
 // no per-chunk branches (2 covers beam <= 10, the default of every recipe).
-template <int NCH>
+// CTX: context biasing compiled in (a.cg set); the plain search keeps its own
+// instantiation so that its frame loop carries none of this.
+template <int NCH, bool CTX>
 __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63;
@@ -304,6 +341,7 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
     h.ts[0] = 0; h.tns[0] = 0; h.tnsp[0] = 0; h.tim[0] = 0;
     h.s[0] = 0.0; h.ns[0] = NEG_INF; h.vs[0] = 0.0; h.vns[0] = 0.0;  // search.py:144-147
     h.score[0] = 0.0; h.vit[0] = 0.0;
+    h.cstate[0] = 0; h.cscore[0] = 0.0;   // search.py:148-150: root, no bonus
     s_nvalid[0] = 0; s_nvalid[1] = 0;
     s_tie[0] = 0; s_tie[1] = 0;
   }
@@ -352,6 +390,8 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
     int Ets = 0, Etns_src = 0, Etns_op = 0, Etnsp = 0;  // op: 0 empty, 1 append t, 2 replace last
     int Ekey = -1, Epar = -1, Etoken = -1, Edepth = 0, seq = 0x7fffffff;
     u64 Ehash = 0, Eparh = 0;
+    double Ecx = 0.0;  // context bonus / state of the entry: set by the FIRST
+    int Ecs = 0;       // contribution in the reference's loop order (has_context)
     if (tid < nb) {
       // ---- unchanged prefix K = H[r] ------------------------------------------
       const int r = tid;
@@ -417,6 +457,23 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
           }
           Evns = v; Etns_src = tsrc; Etns_op = top;
         }
+        if (CTX) {
+          // visits of key K in loop order (token rank outer, hyp inner): K's own
+          // blank (qb, r) and repeat (ql, r) copy K's context, the parent's
+          // extension (ql, rp) walks the graph from the parent's state
+          int first = 0x7fffffff;
+          bool from_parent = false;
+          if (qb >= 0) first = qb * nb + r;
+          if (ql >= 0) {
+            first = min(first, ql * nb + r);
+            if (rp >= 0 && ql * nb + rp < first) from_parent = true;
+          }
+          if (from_parent) {
+            Ecx = H.cscore[rp] + ctx_step(a.cg, H.cstate[rp], Klast, &Ecs);
+          } else {
+            Ecx = H.cscore[r]; Ecs = H.cstate[r];
+          }
+        }
       }
     } else if (tid >= 64 && x_r < nb) {
       // ---- extension P + u ----------------------------------------------------
@@ -441,11 +498,14 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
         Ekey = -1; Epar = H.node[r]; Etoken = u; Edepth = H.depth[r] + 1;
         Ehash = ch; Eparh = Ph;
         seq = (q * nb + r) * 2 + sub;
+        if (CTX) Ecx = H.cscore[r] + ctx_step(a.cg, H.cstate[r], u, &Ecs);
       }
     }
     const double Escore = log_add2_fast(Es, Ens);
+    // second prune key: total_score() = score() + context_score (search.py:93-94)
+    const double Etotal = CTX ? Escore + Ecx : Escore;
     if (my_slot < n_ent) {
-      e_score[my_slot] = valid ? Escore : NEG_INF;
+      e_score[my_slot] = valid ? Etotal : NEG_INF;
       e_seq[my_slot] = valid ? seq : 0x7fffffff;
     }
     {
@@ -540,6 +600,7 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
         Hn.score[rank] = Escore;
         Hn.vit[rank] = Evs > Evns ? Evs : Evns;   // search.py:87-88
         Hn.tim[rank] = Evs > Evns ? Ets : tns;    // search.py:90-91
+        if (CTX) { Hn.cscore[rank] = Ecx; Hn.cstate[rank] = Ecs; }
       }
     }
     if (nx_on) {
@@ -565,7 +626,9 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
       const HypSoA& h = hyp[cur];
       const int L = h.depth[tid];
       a.hyp_lens[o] = L;
-      a.hyp_scores[o] = h.score[tid];
+      // search.py:229-237: finalize() REPLACES the bonus by -node_score(state)
+      a.hyp_scores[o] = CTX ? h.score[tid] + (-a.cg.node_score[h.cstate[tid]])
+                            : h.score[tid];
       // The token list and the time list are walked in ONE loop (two
       // independent chains of dependent loads overlap).  times() is either
       // never set (head 0) or has one entry per token; anything else falls
@@ -650,10 +713,18 @@ int ctc_prefix_beam(const PrefixBeamArgs& a, hipStream_t s) {
   WN_CHECK(a.k == a.beam, "prefix beam: top-k width must equal the beam");
   static_assert(64 + MAXB * MAXB <= PB_THREADS, "one thread per entry");
   static_assert(PB_CHUNK * MAXB <= PB_THREADS, "one thread per staged top-k pair");
-  if (MAXB + a.beam * a.beam <= 128)
-    hipLaunchKernelGGL(prefix_beam_kernel<2>, dim3(a.B), dim3(PB_THREADS), 0, s, a);
-  else
-    hipLaunchKernelGGL(prefix_beam_kernel<PB_CHUNKS>, dim3(a.B), dim3(PB_THREADS), 0, s, a);
+  const bool small = MAXB + a.beam * a.beam <= 128;
+  if (a.cg.keys == nullptr) {
+    if (small)
+      hipLaunchKernelGGL((prefix_beam_kernel<2, false>), dim3(a.B), dim3(PB_THREADS), 0, s, a);
+    else
+      hipLaunchKernelGGL((prefix_beam_kernel<PB_CHUNKS, false>), dim3(a.B), dim3(PB_THREADS), 0, s, a);
+  } else {
+    if (small)
+      hipLaunchKernelGGL((prefix_beam_kernel<2, true>), dim3(a.B), dim3(PB_THREADS), 0, s, a);
+    else
+      hipLaunchKernelGGL((prefix_beam_kernel<PB_CHUNKS, true>), dim3(a.B), dim3(PB_THREADS), 0, s, a);
+  }
   WN_HIP(hipGetLastError());
   return 0;
 }

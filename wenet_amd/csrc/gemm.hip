@@ -360,7 +360,7 @@ int gemm_f32(const GemmArgs& a, hipStream_t stream) {
   // shrinks with the problem so that the grid still covers the 256 CUs.
   //   1: 128x128, 2x4 waves   2: 128x128, 4x2 waves (64-wide wave tile: GLU)
   //   3: 64x128, 2x4 waves    4: 64x128, 2x2 waves (GLU)   5: 64x64, 2x2 waves
-  //   6: 128x128, 2x2 waves
+  //   6: 128x128, 2x2 waves   7: 256x256, 4x2 waves (144 KB LDS, 1 block per CU)
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
   const int64_t t64x128 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 128);
   int cfg;

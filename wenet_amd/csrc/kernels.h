@@ -82,6 +82,25 @@ int ctc_greedy_collapse(const int* top1, int top1_stride, const int* off,
                         int out_stride, int* out_lens, hipStream_t s);
 
 // CTC prefix beam search, one workgroup per utterance.
+// Flattened ContextGraph (wenet/utils/context_graph.py): node 0 is the root;
+// the trie edges live in an open-addressing hash table keyed by
+// (state << 32 | token), linear probing, `mask` + 1 slots, empty = ~0.
+struct CtxGraph {
+  const int* fail = nullptr;              // [n_nodes]
+  const double* node_score = nullptr;     // [n_nodes]
+  const double* output_score = nullptr;   // [n_nodes]
+  const double* token_score = nullptr;    // [n_nodes]
+  const unsigned long long* keys = nullptr;
+  const int* vals = nullptr;
+  unsigned mask = 0;
+};
+constexpr unsigned long long CTX_EMPTY = ~0ull;
+__host__ __device__ inline unsigned ctx_slot(unsigned long long key, unsigned mask) {
+  unsigned long long z = key * 0x9E3779B97F4A7C15ull;
+  z ^= z >> 29;
+  return (unsigned)z & mask;
+}
+
 struct PrefixBeamArgs {
   const float* topk_val; const int* topk_idx; int k;  // [rows][k]
   const int* off; const int* len; int B;
@@ -98,6 +117,7 @@ struct PrefixBeamArgs {
   // optional phase timing of workgroup 0 (s_memtime cycles, summed over
   // frames): [0] eval, [1] rank, [2] select/write, [3] frames, [4] emit
   long long* dbg_cycles = nullptr;
+  CtxGraph cg;  // keys == nullptr: no context biasing
 };
 int64_t prefix_beam_pool_ints(int max_len, int beam);
 // out[i] = log_add(a[i], b[i]) with the search's own fp64 routine (parity test)

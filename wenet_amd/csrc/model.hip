@@ -279,6 +279,9 @@ struct wn_model {
   const float* fb_window = nullptr; const float* fb_twiddle = nullptr;
   const float* fb_mel_w = nullptr;
   std::shared_ptr<DevBuf> fb_tab_i = std::make_shared<DevBuf>();
+  // context biasing tables (wn_set_context_graph); ctx.keys == nullptr: none
+  std::shared_ptr<DevBuf> ctx_buf;
+  CtxGraph ctx;
   DevBuf fb_off, fb_nfr;
 
   int F1() const { return (cfg.feat_dim - 1) / 2; }
@@ -1059,6 +1062,7 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->left = src->left; m->right = src->right;
   m->fb_window = src->fb_window; m->fb_twiddle = src->fb_twiddle;
   m->fb_mel_w = src->fb_mel_w;
+  m->ctx_buf = src->ctx_buf; m->ctx = src->ctx;
   *out = m.release();
   return 0;
 }
@@ -1361,6 +1365,78 @@ int wn_ctc_greedy_search(wn_model* m, int32_t blank_id, int32_t* tokens_host,
   return 0;
 }
 
+int wn_set_context_graph(wn_model* m, int32_t n_nodes, const int32_t* fail,
+                         const double* node_score, const double* output_score,
+                         const double* token_score, int32_t n_edges,
+                         const int32_t* edge_from, const int32_t* edge_token,
+                         const int32_t* edge_to, void* stream) {
+  WN_CHECK(m, "context graph: null model");
+  if (n_nodes <= 0) {
+    m->ctx = CtxGraph();
+    m->ctx_buf.reset();
+    return 0;
+  }
+  WN_CHECK(fail && node_score && output_score && token_score,
+           "context graph: null node array");
+  WN_CHECK(n_edges >= 0 && (n_edges == 0 || (edge_from && edge_token && edge_to)),
+           "context graph: null edge array");
+  WN_CHECK(fail[0] == 0, "context graph: node 0 must be the root (fail[0] == 0)");
+  for (int i = 0; i < n_nodes; ++i)
+    WN_CHECK(fail[i] >= 0 && fail[i] < n_nodes, "context graph: fail arc out of range");
+  hipStream_t s = (hipStream_t)stream;
+  WN_HIP(hipSetDevice(m->device));
+  unsigned slots = 16;
+  while (slots < 2u * (unsigned)n_edges) slots *= 2;
+  std::vector<unsigned long long> keys(slots, CTX_EMPTY);
+  std::vector<int> vals(slots, -1);
+  for (int i = 0; i < n_edges; ++i) {
+    WN_CHECK(edge_from[i] >= 0 && edge_from[i] < n_nodes && edge_to[i] > 0 &&
+                 edge_to[i] < n_nodes && edge_token[i] >= 0,
+             "context graph: edge out of range");
+    const unsigned long long key =
+        ((unsigned long long)(unsigned)edge_from[i] << 32) | (unsigned)edge_token[i];
+    unsigned h = ctx_slot(key, slots - 1);
+    while (keys[h] != CTX_EMPTY) {
+      WN_CHECK(keys[h] != key, "context graph: duplicate edge");
+      h = (h + 1) & (slots - 1);
+    }
+    keys[h] = key;
+    vals[h] = edge_to[i];
+  }
+  // one slab: keys | 3 x double[n] | fail[n] | vals[slots]
+  const size_t o_keys = 0;
+  const size_t o_ns = o_keys + slots * sizeof(unsigned long long);
+  const size_t o_os = o_ns + (size_t)n_nodes * sizeof(double);
+  const size_t o_ts = o_os + (size_t)n_nodes * sizeof(double);
+  const size_t o_fail = o_ts + (size_t)n_nodes * sizeof(double);
+  const size_t o_vals = o_fail + (size_t)n_nodes * sizeof(int);
+  const size_t total = o_vals + slots * sizeof(int);
+  std::vector<char> host(total);
+  memcpy(host.data() + o_keys, keys.data(), slots * sizeof(unsigned long long));
+  memcpy(host.data() + o_ns, node_score, (size_t)n_nodes * sizeof(double));
+  memcpy(host.data() + o_os, output_score, (size_t)n_nodes * sizeof(double));
+  memcpy(host.data() + o_ts, token_score, (size_t)n_nodes * sizeof(double));
+  memcpy(host.data() + o_fail, fail, (size_t)n_nodes * sizeof(int));
+  memcpy(host.data() + o_vals, vals.data(), slots * sizeof(int));
+  // a fresh buffer: clones of this handle may still search with the old one
+  auto buf = std::make_shared<DevBuf>();
+  WN_TRY(buf->ensure(total));
+  WN_HIP(hipMemcpyAsync(buf->p, host.data(), total, hipMemcpyHostToDevice, s));
+  WN_HIP(hipStreamSynchronize(s));
+  char* base = buf->as<char>();
+  CtxGraph g;
+  g.keys = reinterpret_cast<const unsigned long long*>(base + o_keys);
+  g.node_score = reinterpret_cast<const double*>(base + o_ns);
+  g.output_score = reinterpret_cast<const double*>(base + o_os);
+  g.token_score = reinterpret_cast<const double*>(base + o_ts);
+  g.fail = reinterpret_cast<const int*>(base + o_fail);
+  g.vals = reinterpret_cast<const int*>(base + o_vals);
+  g.mask = slots - 1;
+  m->ctx_buf = buf;
+  m->ctx = g;
+  return 0;
+}
+
 int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
                               int32_t* n_hyps_host, int32_t* hyp_lens_host,
                               int32_t* hyp_tlens_host, int32_t* hyp_tokens_host,
@@ -1393,6 +1469,7 @@ int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
   a.n_hyps = m->pb_nh.as<int>(); a.hyp_lens = m->pb_len.as<int>();
   a.hyp_tlens = m->pb_tlen.as<int>(); a.hyp_tokens = m->pb_tok.as<int>();
   a.hyp_times = m->pb_tim.as<int>(); a.hyp_scores = m->pb_score.as<double>();
+  a.cg = m->ctx;
   static const bool pb_dbg = getenv("WN_PB_CYCLES") != nullptr;  // debugging aid
   if (pb_dbg) {
     WN_TRY(m->pb_dbg.ensure(8 * sizeof(long long)));

@@ -404,8 +404,7 @@ class ASRModel:
         CTC head are queued on the current stream (no host sync)."""
         assert speech.shape[0] == speech_lengths.shape[0]
         assert decoding_chunk_size != 0
-        if context_graph is not None:
-            raise NotImplementedError('context biasing is not accelerated')
+        self._use_context_graph(context_graph)
         if simulate_streaming and decoding_chunk_size > 0:
             self._check_simulate_streaming(speech)
         speech, lens = self._prep(speech, speech_lengths)
@@ -421,6 +420,16 @@ class ASRModel:
             'wn_ctc_logprobs')
         return dict(methods=methods, B=B, enc_lens=enc_lens, need_beam=need_beam,
                     beam_size=beam_size, blank_id=blank_id, speech=speech, Tp=Tp)
+
+    def _use_context_graph(self, graph):
+        """Install / clear the biasing graph of the next prefix beam search
+        (search.py:127-131 takes it as an argument; the C ABI keeps it on the
+        handle).  The upload is skipped while the same graph object stays."""
+        if graph is getattr(self, '_ctx_graph', None):
+            return
+        from wenet_amd import context_graph as cg
+        cg.install(self._L, self._h, graph, _stream_ptr(self.device))
+        self._ctx_graph = graph
 
     def _decode_end(self, st, ctc_weight=0.0, reverse_weight=0.0,
                     length_penalty=0.0):

@@ -144,11 +144,16 @@ def ctc_prefix_beam_search(ctc_probs: torch.Tensor,
                            context_graph=None,
                            blank_id: int = 0) -> List[DecodeResult]:
     """search.py:127-249 on a (B, T, V) log-prob tensor in HBM."""
-    if context_graph is not None:
-        raise NotImplementedError(
-            'context biasing (ContextGraph) is outside the accelerated path')
     h, B, T, _keep = _set_probs(ctc_probs, ctc_lens, beam_size)
-    return _prefix_beam(h, B, T, beam_size, blank_id, ctc_probs.device)[0]
+    if context_graph is None:
+        return _prefix_beam(h, B, T, beam_size, blank_id, ctc_probs.device)[0]
+    from wenet_amd import context_graph as cg
+    sp = _stream_ptr(ctc_probs.device)
+    cg.install(_lib.lib(), h, context_graph, sp)
+    try:
+        return _prefix_beam(h, B, T, beam_size, blank_id, ctc_probs.device)[0]
+    finally:
+        cg.install(_lib.lib(), h, None, sp)
 
 
 def rescore_from_logps(hyps_per_utt, ctc_scores_per_utt, times_per_utt,
