@@ -512,6 +512,141 @@ def encoder_forward(configs: dict,
 
 
 # --------------------------------------------------------------------------
+# streaming: one chunk at a time with attention / convolution caches
+
+
+def rel_pos_mha_cached(x, pos_emb, sd, pfx, h, k_cache, v_cache):
+    """RelPositionMultiHeadedAttention.forward with a key/value cache and the
+    all-ones mask of forward_chunk (attention.py:180-245,364-438): the new keys
+    and values are appended to the cached ones; every key is visible."""
+    d_k = x.size(-1) // h
+    q, k, v = _qkv(x, x, x, sd, pfx, h)
+    if k_cache is not None and k_cache.size(0) > 0:
+        k = torch.cat([k_cache, k], dim=2)
+        v = torch.cat([v_cache, v], dim=2)
+    q = q.transpose(1, 2)
+    p = F.linear(pos_emb, sd[pfx + 'linear_pos.weight'])
+    p = p.view(pos_emb.size(0), -1, h, d_k).transpose(1, 2)
+    q_u = (q + sd[pfx + 'pos_bias_u']).transpose(1, 2)
+    q_v = (q + sd[pfx + 'pos_bias_v']).transpose(1, 2)
+    scores = (torch.matmul(q_u, k.transpose(-2, -1)) +
+              torch.matmul(q_v, p.transpose(-2, -1))) / math.sqrt(d_k)
+    out = _forward_attention(v, scores, torch.ones((0, 0, 0), dtype=torch.bool),
+                             sd, pfx, h, d_k)
+    return out, (k, v)
+
+
+def conv_module_cached(x, sd, pfx, kernel_size, causal, activation, cache):
+    """ConvolutionModule.forward with its left-context cache and no pad mask
+    (convolution.py:98-153): for a causal module the cached `lorder` input
+    frames (zeros for the first chunk) are put in front BEFORE pointwise_conv1,
+    and the last `lorder` frames of that extended input are the new cache."""
+    x = x.transpose(1, 2)
+    lorder = kernel_size - 1 if causal else 0
+    if lorder > 0:
+        if cache is None or cache.size(2) == 0:
+            x = F.pad(x, (lorder, 0), 'constant', 0.0)
+        else:
+            x = torch.cat((cache, x), dim=2)
+        new_cache = x[:, :, -lorder:]
+    else:
+        new_cache = torch.zeros((0, 0, 0), dtype=x.dtype)
+    x = F.glu(F.conv1d(x, sd[pfx + 'pointwise_conv1.weight'],
+                       sd[pfx + 'pointwise_conv1.bias']), dim=1)
+    c = x.size(1)
+    x = F.conv1d(x, sd[pfx + 'depthwise_conv.weight'],
+                 sd[pfx + 'depthwise_conv.bias'],
+                 padding=0 if causal else (kernel_size - 1) // 2, groups=c)
+    x = activation(F.layer_norm(x.transpose(1, 2), (c, ), sd[pfx + 'norm.weight'],
+                                sd[pfx + 'norm.bias'], 1e-5)).transpose(1, 2)
+    x = F.conv1d(x, sd[pfx + 'pointwise_conv2.weight'],
+                 sd[pfx + 'pointwise_conv2.bias'])
+    return x.transpose(1, 2), new_cache
+
+
+def forward_chunk(configs, sd, xs, offset: int, required_cache_size: int,
+                  att_cache=None, cnn_cache=None):
+    """BaseEncoder.forward_chunk for a ConformerEncoder, encoder.py:204-285
+    (== ASRModel.forward_encoder_chunk, asr_model.py:385-427).  xs (1, time, F);
+    att_cache (L, heads, cache_t1, 2 d_k) or None/empty; cnn_cache
+    (L, 1, d, lorder) or None/empty -> (ys (1, chunk, d), new_att_cache,
+    new_cnn_cache)."""
+    ec = configs['encoder_conf']
+    d = ec.get('output_size', 256)
+    h = ec.get('attention_heads', 4)
+    nblocks = ec.get('num_blocks', 6)
+    ksize = ec.get('cnn_module_kernel', 15)
+    causal = ec.get('causal', False)
+    assert xs.size(0) == 1
+    if att_cache is None:
+        att_cache = torch.zeros(0, 0, 0, 0)
+    if cnn_cache is None:
+        cnn_cache = torch.zeros(0, 0, 0, 0)
+    masks = torch.ones(1, 1, xs.size(1), dtype=torch.bool)
+    xs = global_cmvn(xs, sd['encoder.global_cmvn.mean'], sd['encoder.global_cmvn.istd'])
+    xs, _, _ = conv2d_subsampling4(xs, masks, sd, 'encoder.embed.', d)
+    cache_t1 = att_cache.size(2)
+    chunk = xs.size(1)
+    key_size = cache_t1 + chunk
+    pe = sd.get('encoder.embed.pos_enc.pe')
+    if pe is None:
+        pe = positional_encoding_table(d)
+    pos_emb = pe[:, offset - cache_t1:offset - cache_t1 + key_size]  # embedding.py:112-132
+    if required_cache_size < 0:
+        next_start = 0
+    elif required_cache_size == 0:
+        next_start = key_size
+    else:
+        next_start = max(key_size - required_cache_size, 0)
+    r_att, r_cnn = [], []
+    dk = d // h
+    for i in range(nblocks):
+        pfx = f'encoder.encoders.{i}.'
+        if att_cache.size(0) > 0:
+            kc, vc = att_cache[i:i + 1, :, :, :dk], att_cache[i:i + 1, :, :, dk:]
+        else:
+            kc = vc = None
+        cc = cnn_cache[i] if cnn_cache.size(0) > 0 else None
+        # ConformerEncoderLayer.forward with caches, encoder_layer.py:188-265
+        x = xs + 0.5 * feed_forward(layer_norm(xs, sd, pfx + 'norm_ff_macaron.'), sd,
+                                    pfx + 'feed_forward_macaron.', F.silu)
+        att, (k, v) = rel_pos_mha_cached(layer_norm(x, sd, pfx + 'norm_mha.'), pos_emb,
+                                         sd, pfx + 'self_attn.', h, kc, vc)
+        x = x + att
+        cv, new_cnn = conv_module_cached(layer_norm(x, sd, pfx + 'norm_conv.'), sd,
+                                         pfx + 'conv_module.', ksize, causal, F.silu, cc)
+        x = x + cv
+        x = x + 0.5 * feed_forward(layer_norm(x, sd, pfx + 'norm_ff.'), sd,
+                                   pfx + 'feed_forward.', F.silu)
+        xs = layer_norm(x, sd, pfx + 'norm_final.')
+        r_att.append(torch.cat((k, v), dim=-1)[:, :, next_start:, :])
+        r_cnn.append(new_cnn.unsqueeze(0))
+    xs = layer_norm(xs, sd, 'encoder.after_norm.')
+    return xs, torch.cat(r_att, dim=0), torch.cat(r_cnn, dim=0)
+
+
+def forward_chunk_by_chunk(configs, sd, xs, decoding_chunk_size: int,
+                           num_decoding_left_chunks: int = -1):
+    """BaseEncoder.forward_chunk_by_chunk, encoder.py:287-362: overlapping
+    feature windows, one forward_chunk each."""
+    assert decoding_chunk_size > 0
+    subsampling, context = 4, 7  # Conv2dSubsampling4: rate 4, right_context 6 (+1)
+    stride = subsampling * decoding_chunk_size
+    window = (decoding_chunk_size - 1) * subsampling + context
+    n = xs.size(1)
+    att_cache = cnn_cache = None
+    outs, offset = [], 0
+    required = decoding_chunk_size * num_decoding_left_chunks
+    for cur in range(0, n - context + 1, stride):
+        y, att_cache, cnn_cache = forward_chunk(configs, sd, xs[:, cur:min(cur + window, n)],
+                                                offset, required, att_cache, cnn_cache)
+        outs.append(y)
+        offset += y.size(1)
+    ys = torch.cat(outs, 1)
+    return ys, torch.ones((1, 1, ys.size(1)), dtype=torch.bool)
+
+
+# --------------------------------------------------------------------------
 # CTC head and searches
 
 

@@ -13,7 +13,7 @@ def case_names(prefix=''):
     return sorted(
         os.path.basename(p)[:-4]
         for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + '*.npz'))
-        if not os.path.basename(p).startswith(('fbank', 'whisperenc', 'stream_', 'attn_', 'ctx')))
+        if not os.path.basename(p).startswith(('fbank', 'whisperenc', 'stream_', 'attn_', 'ctx', 'chunk_')))
 
 
 def load_case(name):
@@ -62,3 +62,18 @@ def context_search_case_names():
     """Goldens of the context-biased ctc_prefix_beam_search on seeded log-probs."""
     return sorted(os.path.basename(p)[:-4]
                   for p in glob.glob(os.path.join(GOLDEN_DIR, 'ctxsearch_*.npz')))
+
+
+def chunk_case_names():
+    """Goldens of the reference's forward_chunk API (outputs + caches)."""
+    return sorted(os.path.basename(p)[:-4]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, 'chunk_*.npz')))
+
+
+def chunk_windows(n_frames, chunk):
+    """Feature windows (start, end) of forward_chunk_by_chunk (encoder.py:337-352)
+    for Conv2dSubsampling4: rate 4, right context 6."""
+    context, stride = 7, 4 * chunk
+    window = (chunk - 1) * 4 + context
+    return [(cur, min(cur + window, n_frames))
+            for cur in range(0, n_frames - context + 1, stride)]

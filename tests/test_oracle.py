@@ -13,6 +13,7 @@ import torch
 
 from conftest import needs_reference
 from golden_util import (attention_case_names, build_inputs, case_names,
+                         chunk_case_names, chunk_windows,
                          context_case_names, context_search_case_names, load_case,
                          stream_case_names,
                          whisper_case_names)
@@ -435,3 +436,44 @@ def test_oracle_context_search_matches_live_reference():
             assert [tuple(h) for h in r.nbest] == [tuple(h) for h in o.nbest]
             assert r.nbest_scores == o.nbest_scores
             assert r.nbest_times == o.nbest_times
+
+
+# --------------------------------------------------------------------------
+# forward_chunk (attention / convolution caches), encoder.py:204-285
+
+
+@pytest.mark.parametrize('name', chunk_case_names())
+def test_oracle_forward_chunk_matches_committed_reference_outputs(name):
+    from wenet_amd import synthetic as S
+    meta, arrays = load_case(name)
+    configs = S.make_configs(meta['config'])
+    sd = S.make_state_dict(configs, meta['wseed'])
+    feats, _ = S.make_features(1, (meta['frames'], meta['frames']), seed=meta['fseed'])
+    torch.set_num_threads(8)
+    att = cnn = None
+    outs, offset = [], 0
+    required = meta['chunk'] * meta['left']
+    for i, (a, b) in enumerate(chunk_windows(meta['frames'], meta['chunk'])):
+        y, att, cnn = O.forward_chunk(configs, sd, feats[:, a:b], offset, required,
+                                      att, cnn)
+        outs.append(y)
+        offset += y.size(1)
+        if i == meta['probe']:
+            assert tuple(att.shape) == arrays['att_probe'].shape
+            assert tuple(cnn.shape) == arrays['cnn_probe'].shape
+            if att.numel():
+                assert np.abs(att.numpy() - arrays['att_probe']).max() < 1e-4
+            if cnn.numel():
+                assert np.abs(cnn.numpy() - arrays['cnn_probe']).max() < 1e-4
+    assert [int(y.size(1)) for y in outs] == meta['chunk_sizes']
+    ys = torch.cat(outs, 1)[0].numpy()
+    assert np.abs(ys - arrays['enc_out']).max() < 1e-4
+    assert tuple(att.shape) == arrays['att_last'].shape
+    if att.numel():
+        assert np.abs(att.numpy() - arrays['att_last']).max() < 1e-4
+    assert tuple(cnn.shape) == arrays['cnn_last'].shape
+    if cnn.numel():
+        assert np.abs(cnn.numpy() - arrays['cnn_last']).max() < 1e-4
+    if meta['config'] != 'tiny_sym':
+        by, _ = O.forward_chunk_by_chunk(configs, sd, feats, meta['chunk'], meta['left'])
+        assert torch.equal(by[0], torch.cat(outs, 1)[0])
