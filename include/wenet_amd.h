@@ -134,6 +134,29 @@ int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host
               int32_t num_left_chunks, float* enc_out_dev,
               int32_t* enc_lens_host, void* stream);
 
+/* Streaming: BaseEncoder.forward_chunk (encoder.py:204-285) ==
+ * ASRModel.forward_encoder_chunk (asr_model.py:385-427), batch 1, Conformer.
+ *   feats_dev         (time, feat_dim) feature window of this chunk,
+ *                     time = (chunk - 1) * 4 + 7 (shorter for the last chunk)
+ *   offset            encoder frames emitted so far
+ *   required_cache_size  < 0: keep all history; 0: none; > 0: that many frames
+ *   att_cache_dev     (n_layers, heads, cache_t1, 128) K|V cache, NULL iff
+ *                     cache_t1 == 0 (the reference's (0,0,0,0) tensor)
+ *   cnn_cache_dev     (n_layers, 1, d_model, lorder) causal-conv left context,
+ *                     NULL for the first chunk (zeros); lorder = cnn_kernel - 1
+ *                     for causal models, 0 otherwise (no cnn cache at all)
+ * Outputs: out_dev (chunk, d_model), chunk = ((time-1)/2-1)/2;
+ * new_att_cache_dev (n_layers, heads, new_t1, 128) with
+ *   new_t1 = cache_t1 + chunk - next_cache_start (encoder.py:258-263);
+ * new_cnn_cache_dev like cnn_cache_dev.  The new caches must not alias the
+ * inputs.  *chunk_out / *new_cache_t1_out (host, optional) return the two
+ * sizes.  Nothing is synchronised; the handle's "current batch" is cleared. */
+int wn_encode_chunk(wn_model* m, const float* feats_dev, int32_t time, int32_t offset,
+                    int32_t required_cache_size, const float* att_cache_dev,
+                    int32_t cache_t1, const float* cnn_cache_dev, float* out_dev,
+                    float* new_att_cache_dev, float* new_cnn_cache_dev,
+                    int32_t* chunk_out, int32_t* new_cache_t1_out, void* stream);
+
 /* Use caller-provided padded encoder output (B, Tp, d_model) + lengths as the
  * current batch (for the reference's free functions that take encoder_out). */
 int wn_set_encoder_out(wn_model* m, const float* enc_out_dev,

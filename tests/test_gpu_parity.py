@@ -17,6 +17,7 @@ import pytest
 import torch
 
 from golden_util import (attention_case_names, build_inputs, case_names,
+                         chunk_case_names, chunk_windows,
                          context_case_names, context_search_case_names, load_case,
                          stream_case_names,
                          whisper_case_names)
@@ -632,3 +633,79 @@ def test_context_graph_object_of_the_reference_is_accepted():
     b = S.ctc_prefix_beam_search(logp.cuda(), lens, 4, RefLike(), 0)
     for x, y in zip(a, b):
         _same_nbest(x, y.nbest, y.nbest_scores, y.nbest_times)
+
+
+# --------------------------------------------------------------------------
+# streaming API: forward_encoder_chunk with caches (encoder.py:204-362)
+
+
+@pytest.mark.parametrize('name', chunk_case_names())
+def test_forward_encoder_chunk_vs_reference_golden(name):
+    """Chunk outputs and the attention / convolution caches (the reference's
+    tensor layouts) against the real reference's forward_encoder_chunk."""
+    from wenet_amd import synthetic as S
+    meta, arrays = load_case(name)
+    configs, sd, model = cached_model(meta['config'], meta['wseed'])
+    feats, _ = S.make_features(1, (meta['frames'], meta['frames']), seed=meta['fseed'])
+    feats = feats.cuda()
+    att = cnn = None
+    outs, offset = [], 0
+    required = meta['chunk'] * meta['left']
+
+    def close(t, want, what):
+        assert tuple(t.shape) == want.shape, (what, tuple(t.shape), want.shape)
+        if want.size:
+            err = np.abs(t.cpu().numpy() - want).max()
+            assert err < 2e-3, (name, what, err)
+
+    for i, (a, b) in enumerate(chunk_windows(meta['frames'], meta['chunk'])):
+        y, att, cnn = model.forward_encoder_chunk(feats[:, a:b], offset, required, att, cnn)
+        outs.append(y)
+        offset += y.size(1)
+        if i == meta['probe']:
+            close(att, arrays['att_probe'], 'att_probe')
+            close(cnn, arrays['cnn_probe'], 'cnn_probe')
+    assert [int(y.size(1)) for y in outs] == meta['chunk_sizes']
+    close(torch.cat(outs, 1)[0], arrays['enc_out'], 'enc_out')
+    close(att, arrays['att_last'], 'att_last')
+    close(cnn, arrays['cnn_last'], 'cnn_last')
+    if meta['config'] != 'tiny_sym':
+        ys, mask = model.forward_encoder_chunk_by_chunk(feats, meta['chunk'], meta['left'])
+        assert torch.equal(ys, torch.cat(outs, 1)) and mask.shape == (1, 1, ys.size(1))
+        # causal chunk-trained model: the cache path equals the chunk-mask path
+        full, _ = model._forward_encoder(feats, torch.tensor([meta['frames']]),
+                                         meta['chunk'], meta['left'])
+        assert (full[0] - ys[0]).abs().max() < 2e-3
+        logp = model.ctc_activation(ys)
+        assert logp.shape == (1, ys.size(1), model.vocab_size)
+        assert torch.allclose(logp.exp().sum(-1), torch.ones_like(logp[..., 0]), atol=1e-4)
+
+
+def test_forward_encoder_chunk_vs_oracle_random_sessions():
+    """Sessions with varying window lengths and cache policies against the
+    oracle's forward_chunk on the same inputs and caches."""
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('tiny_causal', 1)
+    rng = np.random.RandomState(3)
+    for session in range(4):
+        feats, _ = S.make_features(1, (260, 260), seed=200 + session)
+        required = int(rng.choice([-1, 0, 5, 9]))
+        att = cnn = o_att = o_cnn = None
+        offset, cur = 0, 0
+        while cur + 7 <= 260:
+            time = int(rng.choice([7, 11, 19, 23, 35]))
+            win = feats[:, cur:min(cur + time, 260)]
+            y, att, cnn = model.forward_encoder_chunk(win.cuda(), offset, required, att, cnn)
+            oy, o_att, o_cnn = O.forward_chunk(configs, sd, win, offset, required,
+                                               o_att, o_cnn)
+            assert tuple(y.shape) == tuple(oy.shape)
+            assert (y.cpu() - oy).abs().max() < 2e-3
+            assert tuple(att.shape) == tuple(o_att.shape)
+            if o_att.numel():
+                assert (att.cpu() - o_att).abs().max() < 2e-3
+            assert (cnn.cpu() - o_cnn).abs().max() < 2e-3
+            # continue from the ORACLE's caches: errors must not compound in the test
+            att, cnn = o_att.cuda(), o_cnn.cuda()
+            offset += y.size(1)
+            cur += 4 * y.size(1)

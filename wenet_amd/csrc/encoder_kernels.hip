@@ -508,6 +508,70 @@ int copy_rows(const float* src, int lds, const int* src_rows, float* dst,
   return 0;
 }
 
+// ---- streaming (forward_chunk) cache plumbing -------------------------------
+namespace {
+// One float4 per thread: frame j of [cache | chunk], head h, 4 of the 128
+// (K | V) floats.  Writes the contiguous [Tk][2d] K|V rows the attention
+// kernel reads and, for frames >= next_start, the new cache slice
+// (heads, new_t1, 128) of this layer (attention.py:207-215, encoder.py:271-279).
+__global__ void chunk_kv_kernel(const float* cache, int t1, const float* qkv, int R,
+                                int H, float* kv, float* new_cache, int next_start) {
+  const int d = H * 64, Tk = t1 + R;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Tk * H * 32) return;
+  const int e = i & 31, h = (i >> 5) % H, j = i / (32 * H);
+  const bool is_v = e >= 16;
+  const int c = h * 64 + (e & 15) * 4;
+  f32x4 v;
+  if (j < t1)
+    v = *reinterpret_cast<const f32x4*>(cache + ((int64_t)h * t1 + j) * 128 + e * 4);
+  else
+    v = *reinterpret_cast<const f32x4*>(qkv + (int64_t)(j - t1) * 3 * d +
+                                        (is_v ? 2 * d : d) + c);
+  *reinterpret_cast<f32x4*>(kv + (int64_t)j * 2 * d + (is_v ? d : 0) + c) = v;
+  if (j >= next_start) {
+    const int nt = Tk - next_start;
+    *reinterpret_cast<f32x4*>(new_cache + ((int64_t)h * nt + (j - next_start)) * 128 +
+                              e * 4) = v;
+  }
+}
+
+// Causal convolution input with its left context (convolution.py:121-130):
+// rows [0, lorder) come from the cache ((d, lorder) channel-major; zeros for
+// the first chunk), rows lorder.. are the chunk; the last lorder rows are the
+// new cache.
+__global__ void chunk_conv_in_kernel(const float* cache, const float* x, int R, int d,
+                                     int lorder, float* xext, float* new_cache) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (lorder + R) * d) return;
+  const int row = i / d, c = i - row * d;
+  const float v = row < lorder ? (cache ? cache[(int64_t)c * lorder + row] : 0.f)
+                               : x[(int64_t)(row - lorder) * d + c];
+  xext[i] = v;
+  if (row >= R) new_cache[(int64_t)c * lorder + (row - R)] = v;
+}
+}  // namespace
+
+int chunk_kv_assemble(const float* cache, int t1, const float* qkv, int R, int H,
+                      float* kv, float* new_cache, int next_start, hipStream_t s) {
+  const int n = (t1 + R) * H * 32;
+  WN_CHECK(R > 0 && H > 0 && t1 >= 0 && (t1 == 0 || cache), "chunk kv: bad argument");
+  hipLaunchKernelGGL(chunk_kv_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, cache, t1,
+                     qkv, R, H, kv, new_cache, next_start);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+int chunk_conv_input(const float* cache, const float* x, int R, int d, int lorder,
+                     float* xext, float* new_cache, hipStream_t s) {
+  WN_CHECK(R > 0 && lorder > 0, "chunk conv: bad argument");
+  const int n = (lorder + R) * d;
+  hipLaunchKernelGGL(chunk_conv_in_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, cache,
+                     x, R, d, lorder, xext, new_cache);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
 int fill_zero(void* p, size_t bytes, hipStream_t s) {
   WN_HIP(hipMemsetAsync(p, 0, bytes, s));
   return 0;

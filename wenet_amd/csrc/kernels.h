@@ -158,6 +158,11 @@ int logmel_finish(float* mel, int n_mels, const int* frame_off, const int* n_fra
                   float* umax, int B, int max_frames, float* feats, hipStream_t s);
 
 // rows scatter/gather helpers
+// forward_chunk cache plumbing (see encoder_kernels.hip)
+int chunk_kv_assemble(const float* cache, int t1, const float* qkv, int R, int H,
+                      float* kv, float* new_cache, int next_start, hipStream_t s);
+int chunk_conv_input(const float* cache, const float* x, int R, int d, int lorder,
+                     float* xext, float* new_cache, hipStream_t s);
 int copy_rows(const float* src, int lds, const int* src_rows, float* dst,
               int ldd, const int* dst_rows, int n_rows, int D, hipStream_t s);
 int fill_zero(void* p, size_t bytes, hipStream_t s);

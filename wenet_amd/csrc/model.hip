@@ -247,6 +247,7 @@ struct wn_model {
   DevBuf d_off, d_len, d_row_utt, d_off1, d_len1, d_a_row_off;
   DevBuf c1, c2, x, t1, t2, hbuf, qkv, enc;
   DevBuf xpad, pos_rows, d_row_t, d_zero_rows;
+  DevBuf ck_kv, ck_xext, ck_glu, ck_desc, ck_rowutt;  // forward_chunk scratch
   // Whisper log-mel: DFT / window tables (shared), mel matrix per bin count
   std::shared_ptr<DevBuf> lm_dft = std::make_shared<DevBuf>();
   std::shared_ptr<std::map<int, std::shared_ptr<DevBuf>>> lm_mel =
@@ -349,6 +350,70 @@ int set_layout(wn_model* m, int B, int Tp, const std::vector<int>& off,
   return 0;
 }
 
+// GlobalCMVN + Conv2dSubsampling4 + RelPositionalEncoding scale for a padded
+// (B, T, F) feature batch: sets the row layout and leaves x = embed(xs) in m->x
+// (encoder.py:155-157, subsampling.py:203-228, embedding.py:134-147).  `pos0` is
+// the position of the first output frame (streaming offset).
+int subsample_conv2d4(wn_model* m, const float* feats_dev,
+                      const int32_t* feat_lens_host, int B, int T,
+                      int32_t* enc_lens_host, int pos0, hipStream_t s) {
+  const wn_config& c = m->cfg;
+  const int d = c.d_model, F1 = m->F1(), F2 = m->F2();
+  const int Tp = ((T - 1) / 2 - 1) / 2;
+  WN_CHECK(pos0 + Tp <= c.max_pos, "utterance longer than the positional table");
+  std::vector<int> off2(B), len2(B), off1(B), len1(B);
+  int M = 0, M1 = 0, max_t1 = 0;
+  for (int b = 0; b < B; ++b) {
+    const int L = feat_lens_host[b];
+    WN_CHECK(L >= 0 && L <= T, "wn_encode: feature length out of range");
+    // mask[:, :, 2::2][:, :, 2::2] (subsampling.py:228): frames 6 + 4k < L
+    const int l2 = L > 6 ? (L - 7) / 4 + 1 : 0;
+    off2[b] = M; len2[b] = l2; M += l2;
+    const int l1 = l2 > 0 ? 2 * l2 + 1 : 0;
+    off1[b] = M1; len1[b] = l1; M1 += l1;
+    max_t1 = std::max(max_t1, l1);
+    if (enc_lens_host) enc_lens_host[b] = l2;
+  }
+  WN_TRY(set_layout(m, B, Tp, off2, len2, M, s));
+  if (M == 0) WN_TRY(m->stage.end(s));
+  if (M > 0) {
+    WN_TRY(upload_desc(m, m->d_off1, off1, s));
+    WN_TRY(upload_desc(m, m->d_len1, len1, s));
+    WN_TRY(m->stage.end(s));
+    WN_TRY(m->c1.ensure((size_t)M1 * F1 * d * sizeof(float)));
+    WN_TRY(m->c2.ensure((size_t)M * F2 * d * sizeof(float)));
+    WN_TRY(m->x.ensure((size_t)M * d * sizeof(float)));
+    WN_TRY(m->t1.ensure((size_t)M * d * sizeof(float)));
+    WN_TRY(m->t2.ensure((size_t)M * d * sizeof(float)));
+    WN_TRY(m->hbuf.ensure((size_t)M * c.ffn_dim * sizeof(float)));
+    WN_TRY(m->qkv.ensure((size_t)M * 3 * d * sizeof(float)));
+    WN_TRY(m->d_a_row_off.ensure((size_t)M * F2 * sizeof(int64_t)));
+    // GlobalCMVN + conv1 + ReLU                        encoder.py:155, subsampling.py:188
+    Conv1Args c1;
+    c1.feats = feats_dev; c1.mean = m->cmvn_mean; c1.istd = m->cmvn_istd;
+    c1.w = m->conv1_w; c1.bias = m->conv1_b; c1.out = m->c1.as<float>();
+    c1.t1_off = m->d_off1.as<int>(); c1.t1_len = m->d_len1.as<int>();
+    c1.B = B; c1.T = T; c1.F = c.feat_dim; c1.F1 = F1; c1.C = d; c1.max_t1 = max_t1;
+    WN_TRY(cmvn_conv1_relu(c1, s));
+    // conv2 + ReLU as an implicit GEMM                 subsampling.py:191-192
+    hipLaunchKernelGGL(build_conv2_rows_kernel, dim3(cdiv(M * F2, 256)),
+                       dim3(256), 0, s, m->d_row_utt.as<int>(),
+                       m->d_off.as<int>(), m->d_off1.as<int>(), M, F1, F2, d,
+                       m->d_a_row_off.as<int64_t>());
+    WN_HIP(hipGetLastError());
+    GemmArgs g;
+    g.A = m->c1.as<float>(); g.W = m->conv2.w; g.bias = m->conv2.b;
+    g.C = m->c2.as<float>(); g.M = M * F2; g.N = d; g.K = 9 * d; g.ldc = d;
+    g.act = ACT_RELU; g.a_row_off = m->d_a_row_off.as<int64_t>();
+    g.conv_C = d; g.conv_sy = (int64_t)F1 * d; g.conv_sx = d;
+    WN_TRY(gemm_f32(g, s));
+    // Linear(d*F2 -> d) * sqrt(d)                      subsampling.py:225-226, embedding.py:144
+    WN_TRY(linear(m->sub_out, m->c2.as<float>(), F2 * d, m->x.as<float>(), d, M,
+                  s, ACT_NONE, nullptr, 0, sqrtf((float)d)));
+  }
+  return 0;
+}
+
 int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
   const wn_config& c = m->cfg;
   const int d = c.d_model, M = m->rows;
@@ -423,6 +488,90 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     return 0;
   }
   WN_TRY(ln(m->after_norm, x, m->enc.as<float>(), M, d, eps, s));
+  return 0;
+}
+
+// The Conformer layers over ONE chunk of R frames with the streaming caches
+// (ConformerEncoderLayer.forward with att_cache / cnn_cache, encoder_layer.py:
+// 188-265, driven by BaseEncoder.forward_chunk, encoder.py:246-285).  Same
+// kernels as encoder_layers; attention sees [cache | chunk] keys with the
+// position rows offset - t1 ..., the causal convolution sees its cached left
+// context.  All masks are the all-ones fakes of forward_chunk.
+int encoder_layers_chunk(wn_model* m, int R, int offset, int t1c, int next_start,
+                         const float* att_cache, const float* cnn_cache,
+                         float* new_att, float* new_cnn, float* out, hipStream_t s) {
+  const wn_config& c = m->cfg;
+  const int d = c.d_model, H = c.n_heads, M = R;
+  const int lorder = c.causal ? c.cnn_kernel - 1 : 0;
+  const int Tk = t1c + R, nt = Tk - next_start, LR = lorder + R;
+  float* x = m->x.as<float>();
+  float* t1 = m->t1.as<float>();
+  float* t2 = m->t2.as<float>();
+  float* hb = m->hbuf.as<float>();
+  float* qkv = m->qkv.as<float>();
+  const float eps = c.norm_eps;
+  WN_TRY(m->ck_kv.ensure((size_t)Tk * 2 * d * sizeof(float)));
+  WN_TRY(m->ck_xext.ensure((size_t)LR * d * sizeof(float)));
+  WN_TRY(m->ck_glu.ensure((size_t)LR * d * sizeof(float)));
+  // descriptors: [0] = 0 (row offset), [1] = R, [2] = Tk, [3] = LR; row->utt = 0
+  const std::vector<int> desc = {0, R, Tk, LR};
+  const std::vector<int> rowutt(LR, 0);
+  WN_TRY(m->stage.begin((size_t)(LR + 64) * sizeof(int) + 1024));
+  WN_TRY(upload_desc(m, m->ck_desc, desc, s));
+  WN_TRY(upload_desc(m, m->ck_rowutt, rowutt, s));
+  WN_TRY(m->stage.end(s));
+  const int* dd = m->ck_desc.as<int>();
+  float* kv = m->ck_kv.as<float>();
+  float* xext = m->ck_xext.as<float>();
+  float* glu = m->ck_glu.as<float>();
+  for (int li = 0; li < c.n_layers; ++li) {
+    const EncLayer& L = m->layers[li];
+    WN_TRY(ln(L.norm_ff_mac, x, t1, M, d, eps, s));
+    WN_TRY(linear(L.ffm1, t1, d, hb, c.ffn_dim, M, s, ACT_SILU));
+    WN_TRY(linear(L.ffm2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 0.5f));
+    // attention over [cached | new] keys             attention.py:180-245,364-438
+    WN_TRY(ln(L.norm_mha, x, t1, M, d, eps, s));
+    WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s));
+    WN_TRY(chunk_kv_assemble(att_cache ? att_cache + (size_t)li * H * t1c * 128 : nullptr,
+                             t1c, qkv, R, H, kv, new_att + (size_t)li * H * nt * 128,
+                             next_start, s));
+    AttnArgs a;
+    a.Q = qkv; a.ldq = 3 * d;
+    a.K = kv; a.V = kv + d; a.ldk = a.ldv = 2 * d;
+    // key j of this call sits at position offset - t1 + j   encoder.py:256-257
+    a.P = L.pos_tab + (size_t)(offset - t1c) * d; a.ldp = d;
+    a.bias_u = L.bias_u; a.bias_v = L.bias_v;
+    a.O = t2; a.ldo = d;
+    a.q_off = dd; a.q_len = dd + 1; a.kv_off = dd; a.kv_len = dd + 2;
+    a.n_seq = 1; a.n_heads = H; a.max_q_len = R;
+    a.mask_mode = 0;
+    a.scale = 1.0f / sqrtf(64.0f);
+    WN_TRY(attention(a, s));
+    WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d));
+    // convolution module with its left-context cache  convolution.py:98-153
+    WN_TRY(ln(L.norm_conv, x, t1, M, d, eps, s));
+    const float* conv_in = t1;
+    if (lorder > 0) {
+      WN_TRY(chunk_conv_input(cnn_cache ? cnn_cache + (size_t)li * d * lorder : nullptr,
+                              t1, R, d, lorder, xext, new_cnn + (size_t)li * d * lorder, s));
+      conv_in = xext;
+    }
+    WN_TRY(linear(L.pw1, conv_in, d, glu, d, LR, s, ACT_NONE, nullptr, 0, 1.0f, true));
+    DwConvArgs dw;
+    dw.x = glu; dw.ldx = d; dw.wt = L.dw_wt; dw.bias = L.dw_b; dw.cpad = L.cpad;
+    dw.ln_w = L.conv_norm.w; dw.ln_b = L.conv_norm.b;
+    dw.y = xext; dw.ldy = d;
+    dw.row_utt = m->ck_rowutt.as<int>(); dw.off = dd; dw.len = dd + 3;
+    dw.M = LR; dw.D = d; dw.K = c.cnn_kernel; dw.causal = c.causal;
+    dw.t_max = LR; dw.eps = 1e-5f;
+    WN_TRY(dwconv_ln_silu(dw, s));
+    WN_TRY(linear(L.pw2, xext + (size_t)lorder * d, d, x, d, M, s, ACT_NONE, x, d));
+    WN_TRY(ln(L.norm_ff, x, t1, M, d, eps, s));
+    WN_TRY(linear(L.ff1, t1, d, hb, c.ffn_dim, M, s, ACT_SILU));
+    WN_TRY(linear(L.ff2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 0.5f));
+    WN_TRY(ln(L.norm_final, x, x, M, d, eps, s));
+  }
+  WN_TRY(ln(m->after_norm, x, out, M, d, eps, s));
   return 0;
 }
 
@@ -1144,58 +1293,11 @@ int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));
   const wn_config& c = m->cfg;
-  const int d = c.d_model, F1 = m->F1(), F2 = m->F2();
+  const int d = c.d_model;
   const int Tp = ((T - 1) / 2 - 1) / 2;
-  WN_CHECK(Tp <= c.max_pos, "utterance longer than the positional table");
-  std::vector<int> off2(B), len2(B), off1(B), len1(B);
-  int M = 0, M1 = 0, max_t1 = 0;
-  for (int b = 0; b < B; ++b) {
-    const int L = feat_lens_host[b];
-    WN_CHECK(L >= 0 && L <= T, "wn_encode: feature length out of range");
-    // mask[:, :, 2::2][:, :, 2::2] (subsampling.py:228): frames 6 + 4k < L
-    const int l2 = L > 6 ? (L - 7) / 4 + 1 : 0;
-    off2[b] = M; len2[b] = l2; M += l2;
-    const int l1 = l2 > 0 ? 2 * l2 + 1 : 0;
-    off1[b] = M1; len1[b] = l1; M1 += l1;
-    max_t1 = std::max(max_t1, l1);
-    if (enc_lens_host) enc_lens_host[b] = l2;
-  }
-  WN_TRY(set_layout(m, B, Tp, off2, len2, M, s));
-  if (M == 0) WN_TRY(m->stage.end(s));
+  WN_TRY(subsample_conv2d4(m, feats_dev, feat_lens_host, B, T, enc_lens_host, 0, s));
+  const int M = m->rows;
   if (M > 0) {
-    WN_TRY(upload_desc(m, m->d_off1, off1, s));
-    WN_TRY(upload_desc(m, m->d_len1, len1, s));
-    WN_TRY(m->stage.end(s));
-    WN_TRY(m->c1.ensure((size_t)M1 * F1 * d * sizeof(float)));
-    WN_TRY(m->c2.ensure((size_t)M * F2 * d * sizeof(float)));
-    WN_TRY(m->x.ensure((size_t)M * d * sizeof(float)));
-    WN_TRY(m->t1.ensure((size_t)M * d * sizeof(float)));
-    WN_TRY(m->t2.ensure((size_t)M * d * sizeof(float)));
-    WN_TRY(m->hbuf.ensure((size_t)M * c.ffn_dim * sizeof(float)));
-    WN_TRY(m->qkv.ensure((size_t)M * 3 * d * sizeof(float)));
-    WN_TRY(m->d_a_row_off.ensure((size_t)M * F2 * sizeof(int64_t)));
-    // GlobalCMVN + conv1 + ReLU                        encoder.py:155, subsampling.py:188
-    Conv1Args c1;
-    c1.feats = feats_dev; c1.mean = m->cmvn_mean; c1.istd = m->cmvn_istd;
-    c1.w = m->conv1_w; c1.bias = m->conv1_b; c1.out = m->c1.as<float>();
-    c1.t1_off = m->d_off1.as<int>(); c1.t1_len = m->d_len1.as<int>();
-    c1.B = B; c1.T = T; c1.F = c.feat_dim; c1.F1 = F1; c1.C = d; c1.max_t1 = max_t1;
-    WN_TRY(cmvn_conv1_relu(c1, s));
-    // conv2 + ReLU as an implicit GEMM                 subsampling.py:191-192
-    hipLaunchKernelGGL(build_conv2_rows_kernel, dim3(cdiv(M * F2, 256)),
-                       dim3(256), 0, s, m->d_row_utt.as<int>(),
-                       m->d_off.as<int>(), m->d_off1.as<int>(), M, F1, F2, d,
-                       m->d_a_row_off.as<int64_t>());
-    WN_HIP(hipGetLastError());
-    GemmArgs g;
-    g.A = m->c1.as<float>(); g.W = m->conv2.w; g.bias = m->conv2.b;
-    g.C = m->c2.as<float>(); g.M = M * F2; g.N = d; g.K = 9 * d; g.ldc = d;
-    g.act = ACT_RELU; g.a_row_off = m->d_a_row_off.as<int64_t>();
-    g.conv_C = d; g.conv_sy = (int64_t)F1 * d; g.conv_sx = d;
-    WN_TRY(gemm_f32(g, s));
-    // Linear(d*F2 -> d) * sqrt(d)                      subsampling.py:225-226, embedding.py:144
-    WN_TRY(linear(m->sub_out, m->c2.as<float>(), F2 * d, m->x.as<float>(), d, M,
-                  s, ACT_NONE, nullptr, 0, sqrtf((float)d)));
     WN_TRY(encoder_layers(m, chunk, left, s));
   }
   if (enc_out_dev) {
@@ -1208,6 +1310,45 @@ int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host
       WN_HIP(hipMemsetAsync(enc_out_dev, 0, (size_t)B * Tp * d * sizeof(float), s));
     }
   }
+  return 0;
+}
+
+int wn_encode_chunk(wn_model* m, const float* feats_dev, int32_t time, int32_t offset,
+                    int32_t required_cache_size, const float* att_cache_dev,
+                    int32_t cache_t1, const float* cnn_cache_dev, float* out_dev,
+                    float* new_att_cache_dev, float* new_cnn_cache_dev,
+                    int32_t* chunk_out, int32_t* new_cache_t1_out, void* stream) {
+  WN_CHECK(m && feats_dev && out_dev, "wn_encode_chunk: null argument");
+  WN_CHECK(!m->layers.empty() && m->cfg.encoder_type == 0,
+           "wn_encode_chunk: needs a Conformer encoder");
+  WN_CHECK(time >= 7, "wn_encode_chunk: at least 7 frames are needed by Conv2dSubsampling4");
+  WN_CHECK(offset >= 0 && cache_t1 >= 0 && cache_t1 <= offset,
+           "wn_encode_chunk: need 0 <= cache_t1 <= offset");
+  WN_CHECK(cache_t1 == 0 || att_cache_dev, "wn_encode_chunk: att_cache is null");
+  hipStream_t s = (hipStream_t)stream;
+  WN_HIP(hipSetDevice(m->device));
+  const wn_config& c = m->cfg;
+  const int R = ((time - 1) / 2 - 1) / 2;
+  const int key = cache_t1 + R;
+  // encoder.py:258-263
+  const int next_start = required_cache_size < 0 ? 0
+                         : required_cache_size == 0 ? key
+                         : std::max(key - required_cache_size, 0);
+  const int nt = key - next_start;
+  const int lorder = c.causal ? c.cnn_kernel - 1 : 0;
+  WN_CHECK(nt == 0 || new_att_cache_dev, "wn_encode_chunk: new_att_cache is null");
+  WN_CHECK(lorder == 0 || new_cnn_cache_dev, "wn_encode_chunk: new_cnn_cache is null");
+  WN_CHECK(offset + R <= c.max_pos, "wn_encode_chunk: offset beyond the positional table");
+  const int32_t len = time;
+  WN_TRY(subsample_conv2d4(m, feats_dev, &len, 1, time, nullptr, offset, s));
+  WN_CHECK(m->rows == R, "wn_encode_chunk: internal row count");
+  // nt == 0: the kernel writes no cache rows, any non-null pointer will do
+  float* natt = new_att_cache_dev ? new_att_cache_dev : out_dev;
+  WN_TRY(encoder_layers_chunk(m, R, offset, cache_t1, next_start, att_cache_dev,
+                              cnn_cache_dev, natt, new_cnn_cache_dev, out_dev, s));
+  m->rows = 0; m->B = 0;  // the handle holds no decodable batch after a chunk call
+  if (chunk_out) *chunk_out = R;
+  if (new_cache_t1_out) *new_cache_t1_out = nt;
   return 0;
 }
 

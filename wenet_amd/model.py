@@ -291,6 +291,94 @@ class ASRModel:
                 torch.as_tensor(enc_lens, device=self.device).unsqueeze(1))
         return out, mask.unsqueeze(1)
 
+    # ---- streaming API: one chunk at a time with caches ----------------------
+    def forward_encoder_chunk(self, xs: torch.Tensor, offset: int,
+                              required_cache_size: int,
+                              att_cache: Optional[torch.Tensor] = None,
+                              cnn_cache: Optional[torch.Tensor] = None
+                              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """asr_model.py:385-427 / BaseEncoder.forward_chunk (encoder.py:204-285):
+        xs (1, time, mel) on the device; att_cache (elayers, head, cache_t1,
+        d_k * 2) and cnn_cache (elayers, 1, hidden, lorder), or empty / None for
+        the first chunk -> (ys (1, chunk, hidden), new_att_cache, new_cnn_cache)
+        in the reference's cache layouts (device tensors)."""
+        cfg = self._cfg
+        if cfg.encoder_type != 0:
+            raise NotImplementedError('forward_encoder_chunk: Conformer encoders only')
+        _require_cuda(xs, 'forward_encoder_chunk')
+        assert xs.dim() == 3 and xs.size(0) == 1
+        xs = xs.detach().to(torch.float32).contiguous()
+        time = xs.size(1)
+        chunk = ((time - 1) // 2 - 1) // 2
+        L, H, d = cfg.n_layers, cfg.n_heads, cfg.d_model
+        lorder = cfg.cnn_kernel - 1 if cfg.causal else 0
+        t1 = 0
+        att_ptr = None
+        if att_cache is not None and att_cache.numel() > 0:
+            _require_cuda(att_cache, 'forward_encoder_chunk(att_cache)')
+            assert tuple(att_cache.shape[:2]) == (L, H) and att_cache.size(3) == 128
+            att_cache = att_cache.detach().to(torch.float32).contiguous()
+            t1 = att_cache.size(2)
+            att_ptr = att_cache.data_ptr()
+        cnn_ptr = None
+        if cnn_cache is not None and cnn_cache.numel() > 0:
+            _require_cuda(cnn_cache, 'forward_encoder_chunk(cnn_cache)')
+            assert tuple(cnn_cache.shape) == (L, 1, d, lorder)
+            cnn_cache = cnn_cache.detach().to(torch.float32).contiguous()
+            cnn_ptr = cnn_cache.data_ptr()
+        key = t1 + chunk
+        if required_cache_size < 0:
+            start = 0
+        elif required_cache_size == 0:
+            start = key
+        else:
+            start = max(key - required_cache_size, 0)
+        ys = torch.empty((1, chunk, d), dtype=torch.float32, device=self.device)
+        new_att = torch.empty((L, H, key - start, 128), dtype=torch.float32,
+                              device=self.device)
+        if lorder > 0:
+            new_cnn = torch.empty((L, 1, d, lorder), dtype=torch.float32,
+                                  device=self.device)
+        else:
+            new_cnn = torch.zeros((L, 0, 0, 0), dtype=torch.float32, device=self.device)
+        _lib.check(
+            self._L.wn_encode_chunk(self._h, xs.data_ptr(), time, int(offset),
+                                    int(required_cache_size), att_ptr, t1, cnn_ptr,
+                                    ys.data_ptr(),
+                                    new_att.data_ptr() if new_att.numel() else None,
+                                    new_cnn.data_ptr() if lorder > 0 else None,
+                                    None, None, _stream_ptr(self.device)),
+            'wn_encode_chunk')
+        return ys, new_att, new_cnn
+
+    def forward_encoder_chunk_by_chunk(self, xs: torch.Tensor, decoding_chunk_size: int,
+                                       num_decoding_left_chunks: int = -1
+                                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """BaseEncoder.forward_chunk_by_chunk (encoder.py:287-362) on the
+        streaming API above: overlapping feature windows, caches carried from
+        chunk to chunk -> (ys (1, T', hidden), masks (1, 1, T'))."""
+        assert decoding_chunk_size > 0
+        assert self._cfg.static_chunk_size > 0 or self._cfg.use_dynamic_chunk
+        subsampling = self.subsampling_rate()
+        context = self.right_context() + 1
+        stride = subsampling * decoding_chunk_size
+        window = (decoding_chunk_size - 1) * subsampling + context
+        n = xs.size(1)
+        att_cache = cnn_cache = None
+        outs, offset = [], 0
+        required = decoding_chunk_size * num_decoding_left_chunks
+        for cur in range(0, n - context + 1, stride):
+            y, att_cache, cnn_cache = self.forward_encoder_chunk(
+                xs[:, cur:min(cur + window, n)], offset, required, att_cache, cnn_cache)
+            outs.append(y)
+            offset += y.size(1)
+        ys = torch.cat(outs, 1)
+        return ys, torch.ones((1, 1, ys.size(1)), dtype=torch.bool, device=ys.device)
+
+    def ctc_activation(self, xs: torch.Tensor) -> torch.Tensor:
+        """asr_model.py:429-440: CTC log-softmax of an encoder output."""
+        return self.ctc_logprobs(xs)
+
     def _check_simulate_streaming(self, speech):
         """`simulate_streaming=True` (asr_model.py:229-233 ->
         BaseEncoder.forward_chunk_by_chunk, encoder.py:287-362) feeds the
