@@ -709,3 +709,95 @@ def test_forward_encoder_chunk_vs_oracle_random_sessions():
             att, cnn = o_att.cuda(), o_cnn.cuda()
             offset += y.size(1)
             cur += 4 * y.size(1)
+
+
+# --------------------------------------------------------------------------
+# the recognize CLI end to end (wav list -> result files)
+
+
+def test_recognize_cli_end_to_end(tmp_path):
+    """wenet_amd.bin.recognize on a list of wav files: lines in the reference's
+    order (batches in list order, longest first inside a batch); tokens equal to
+    a direct decode() of the same features and, for greedy search, to the oracle
+    on oracle-computed fbank features."""
+    import json
+    import wave
+    import yaml
+    from wenet_amd import synthetic as S
+    from wenet_amd.bin import recognize as R
+    O = _oracle()
+    configs, sd, model = cached_model('tiny_causal', 0)
+    V = configs['output_dim']
+    units = tmp_path / 'units.txt'
+    syms = ['<blank>', '<unk>'] + [f't{i}' for i in range(2, V - 1)] + ['<sos/eos>']
+    units.write_text(''.join(f'{s} {i}\n' for i, s in enumerate(syms)))
+    cfg = dict(configs)
+    cfg['tokenizer'] = 'char'
+    cfg['tokenizer_conf'] = dict(symbol_table_path=str(units), non_lang_syms_path=None,
+                                 connect_symbol=' ')
+    cfg['dataset_conf'] = dict(fbank_conf=dict(num_mel_bins=80, frame_length=25,
+                                               frame_shift=10, dither=0.1))
+    (tmp_path / 'train.yaml').write_text(yaml.safe_dump(cfg))
+    torch.save(sd, tmp_path / 'final.pt')
+    rng = np.random.RandomState(11)
+    entries, pcm = [], {}
+    for i in range(7):
+        n = int(rng.randint(16000, 40000))
+        t = np.arange(n) / 16000.0
+        x = 0.3 * np.sin(2 * np.pi * (200 + 90 * i) * t) + 0.05 * rng.randn(n)
+        x16 = np.clip(x * 32768, -32768, 32767).astype(np.int16)
+        path = tmp_path / f'u{i}.wav'
+        with wave.open(str(path), 'wb') as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(x16.tobytes())
+        entries.append((f'utt{i}', str(path)))
+        pcm[f'utt{i}'] = x16.astype(np.float32) / 32768.0
+    lst = tmp_path / 'data.list'
+    lst.write_text(''.join(json.dumps(dict(key=k, wav=w, txt='')) + '\n'
+                           for k, w in entries))
+    modes = ['ctc_greedy_search', 'ctc_prefix_beam_search', 'attention_rescoring']
+    out = tmp_path / 'out'
+    rc = R.main(['--config', str(tmp_path / 'train.yaml'), '--checkpoint',
+                 str(tmp_path / 'final.pt'), '--test_data', str(lst), '--result_dir',
+                 str(out), '--batch_size', '3', '--beam_size', '4', '--ctc_weight', '0.5',
+                 '--reverse_weight', '0.3', '--blank_penalty', '3.0', '--modes'] + modes)
+    assert rc == 0
+    got = {m: (out / m / 'text').read_text().splitlines() for m in modes}
+    # expected: batch by batch, direct decode of device fbank features
+    want = {m: [] for m in modes}
+    greedy_ref = {}
+    for batch in R.static_batches(entries, 3):
+        waves = [pcm[k] for k, _ in batch]
+        feats, nfr = model.compute_fbank(waves)
+        perm = R.padding_order(nfr.tolist())
+        idx = torch.as_tensor(perm)
+        f = feats.index_select(0, idx.cuda())[:, :int(nfr.max())].contiguous()
+        res = model.decode(modes, f, nfr.index_select(0, idx), beam_size=4, ctc_weight=0.5,
+                           reverse_weight=0.3, blank_penalty=3.0)
+        for j, i in enumerate(perm):
+            for m in modes:
+                toks = res[m][j].tokens
+                want[m].append(batch[i][0] + ' ' + ' '.join(syms[t] for t in toks))
+        # oracle: fbank + encoder + greedy on the CPU for the same waveforms
+        ofe = [torch.as_tensor(O.fbank(pcm[batch[i][0]])) for i in perm]
+        of = torch.nn.utils.rnn.pad_sequence(ofe, batch_first=True)
+        ol = torch.tensor([x.shape[0] for x in ofe], dtype=torch.int32)
+        ores = O.decode(configs, sd, ['ctc_greedy_search'], of, ol, blank_penalty=3.0)
+        enc, mask = O.encoder_forward(configs, sd, of, ol)
+        margins = frame_margins(O.ctc_logprobs(sd, enc, 3.0))
+        for j, i in enumerate(perm):
+            n = int(mask[j].sum())
+            if margins[j, :n].min() > 2e-2:
+                greedy_ref[batch[i][0]] = ' '.join(syms[t] for t in
+                                                   ores['ctc_greedy_search'][j].tokens)
+    for m in modes:
+        assert got[m] == want[m], m
+    checked = 0
+    for ln in got['ctc_greedy_search']:
+        key, _, text = ln.partition(' ')
+        if key in greedy_ref:
+            assert text == greedy_ref[key], key
+            checked += 1
+    assert checked >= 3

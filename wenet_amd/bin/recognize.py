@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""Batch recognition on MI355X: the data side of `wenet/bin/recognize.py`.
+
+Same command line (the subset that applies to the accelerated path), same
+result files: for every mode a `<result_dir>/<mode>/text` with one
+`<key> <text>` line per utterance, batches in list order and -- inside a batch
+-- longest utterance first, exactly the order the reference's `padding`
+produces (recognize.py:193-311, processor.py:526-577).
+
+What differs is where the work runs:
+  * wav files are read by host threads ahead of the GPU (16 kHz PCM16; no
+    resampler), fbank is computed on the device (`wn_fbank`) straight into the
+    padded batch tensor;
+  * two batches are in flight on the GPU (`wenet_amd.pipeline.DecodePipeline`):
+    the CTC search of batch i runs under the encoder of batch i+1;
+  * under `torchrun` every rank takes every world_size-th batch (the
+    reference's `tools/decode.sh` split, without separate processes per list
+    file) and rank 0 merges the per-rank parts into the final files.
+
+    python -m wenet_amd.bin.recognize --config train.yaml --checkpoint final.pt \\
+        --test_data data.list --result_dir out --modes ctc_prefix_beam_search \\
+        attention_rescoring --batch_size 32 --beam_size 10 --ctc_weight 0.5
+"""
+import argparse
+import concurrent.futures
+import json
+import logging
+import os
+import sys
+from typing import Dict, Iterable, List, Sequence, Tuple
+
+import numpy as np
+
+MODES = ('attention', 'ctc_greedy_search', 'ctc_prefix_beam_search',
+         'attention_rescoring')
+
+
+def get_args(argv=None):
+    p = argparse.ArgumentParser(description='recognize with a wenet_amd model')
+    p.add_argument('--config', required=True, help='config file (train.yaml)')
+    p.add_argument('--test_data', required=True, help='test data list (jsonl)')
+    p.add_argument('--data_type', default='raw', choices=['raw', 'shard'])
+    p.add_argument('--gpu', type=int, default=-1,
+                   help='device index (default: LOCAL_RANK, else 0)')
+    p.add_argument('--device', default='cuda', choices=['cuda'],
+                   help='only the MI355X path exists; there is no CPU fallback')
+    p.add_argument('--dtype', default='fp32', choices=['fp32'])
+    p.add_argument('--num_workers', type=int, default=4,
+                   help='host threads reading wav files ahead of the GPU')
+    p.add_argument('--checkpoint', required=True, help='checkpoint model (.pt)')
+    p.add_argument('--beam_size', type=int, default=10)
+    p.add_argument('--length_penalty', type=float, default=0.0)
+    p.add_argument('--blank_penalty', type=float, default=0.0)
+    p.add_argument('--result_dir', required=True)
+    p.add_argument('--batch_size', type=int, default=16)
+    p.add_argument('--modes', nargs='+', required=True,
+                   help='decoding modes: ' + ' '.join(MODES))
+    p.add_argument('--ctc_weight', type=float, default=0.0)
+    p.add_argument('--decoding_chunk_size', type=int, default=-1)
+    p.add_argument('--num_decoding_left_chunks', type=int, default=-1)
+    p.add_argument('--simulate_streaming', action='store_true')
+    p.add_argument('--reverse_weight', type=float, default=0.0)
+    p.add_argument('--override_config', action='append', default=[])
+    p.add_argument('--context_bias_mode', type=str, default='',
+                   help="'decoding-graph' enables context biasing")
+    p.add_argument('--context_list_path', type=str, default='')
+    p.add_argument('--context_graph_score', type=float, default=0.0)
+    p.add_argument('--streams', type=int, default=2,
+                   help='decode() calls in flight on the GPU')
+    args = p.parse_args(argv)
+    for m in args.modes:
+        if m not in MODES:
+            p.error(f'mode {m!r} is not on the accelerated path (have: {MODES})')
+    if args.data_type != 'raw':
+        p.error("only --data_type raw (a list of wav files) is supported")
+    return args
+
+
+def override_config(configs: dict, items: Sequence[str]) -> dict:
+    """wenet/utils/config.py override_config: `a.b.c value` strings."""
+    import yaml
+    for item in items:
+        arr = item.split()
+        if len(arr) != 2:
+            raise ValueError(f"the format of override_config is 'key value': {item!r}")
+        keys, d = arr[0].split('.'), configs
+        for i, k in enumerate(keys):
+            if k not in d:
+                raise KeyError(f'override_config: unknown key {arr[0]}')
+            if i == len(keys) - 1:
+                d[k] = yaml.load(arr[1], Loader=yaml.FullLoader)
+            else:
+                d = d[k]
+    return configs
+
+
+def read_data_list(path: str) -> List[Tuple[str, str]]:
+    """`raw` lists (processor.parse_raw, processor.py:104-122): one JSON object
+    per line with `key`, `wav` (and `txt`, unused here)."""
+    out = []
+    with open(path, 'r', encoding='utf8') as f:
+        for ln, line in enumerate(f, 1):
+            line = line.strip()
+            if not line:
+                continue
+            obj = json.loads(line)
+            if 'key' not in obj or 'wav' not in obj:
+                raise ValueError(f'{path}:{ln}: need "key" and "wav"')
+            out.append((obj['key'], obj['wav']))
+    return out
+
+
+def static_batches(entries: Sequence, batch_size: int) -> List[List]:
+    """processor.static_batch (processor.py:470-486): consecutive groups."""
+    assert batch_size > 0
+    return [list(entries[i:i + batch_size]) for i in range(0, len(entries), batch_size)]
+
+
+def padding_order(n_frames: Sequence[int]) -> List[int]:
+    """Order of the utterances inside a batch: feature length descending
+    (processor.padding, processor.py:539-541), ties in list order."""
+    return sorted(range(len(n_frames)), key=lambda i: (-int(n_frames[i]), i))
+
+
+def check_feature_conf(configs: dict):
+    dc = configs.get('dataset_conf', {})
+    if dc.get('feats_type', 'fbank') != 'fbank':
+        raise NotImplementedError('recognize: fbank features only')
+    fc = dc.get('fbank_conf', {})
+    if (fc.get('num_mel_bins', 80) != configs.get('input_dim', 80)
+            or fc.get('frame_length', 25) != 25 or fc.get('frame_shift', 10) != 10):
+        raise NotImplementedError('recognize: fbank must be 25 ms / 10 ms frames with '
+                                  'input_dim mel bins')
+    if dc.get('resample_conf', {}).get('resample_rate', 16000) != 16000:
+        raise NotImplementedError('recognize: 16 kHz models only')
+
+
+def format_line(key: str, text: str) -> str:
+    return '{} {}'.format(key, text)  # recognize.py:304-306
+
+
+def merge_parts(result_dir: str, modes: Iterable[str], world_size: int, n_batches: int):
+    """Rank files `<mode>/text.part<r>` hold `<batch index>\\t<line>` records;
+    write `<mode>/text` in batch order."""
+    for mode in modes:
+        d = os.path.join(result_dir, mode)
+        per_batch: Dict[int, List[str]] = {}
+        for r in range(world_size):
+            part = os.path.join(d, f'text.part{r}')
+            with open(part, 'r', encoding='utf8') as f:
+                for rec in f:
+                    bi, line = rec.rstrip('\n').split('\t', 1)
+                    per_batch.setdefault(int(bi), []).append(line)
+            os.remove(part)
+        with open(os.path.join(d, 'text'), 'w', encoding='utf8') as f:
+            for bi in range(n_batches):
+                for line in per_batch.get(bi, []):
+                    f.write(line + '\n')
+
+
+def load_state(configs: dict, checkpoint: str):
+    """Checkpoint tensors (+ the global CMVN the reference builds from
+    cmvn_conf, init_model.py:100-111)."""
+    import torch
+    from wenet_amd.model import load_cmvn
+    sd = dict(torch.load(checkpoint, map_location='cpu', mmap=True))
+    if configs.get('cmvn') == 'global_cmvn' and 'encoder.global_cmvn.mean' not in sd:
+        cc = configs['cmvn_conf']
+        mean, istd = load_cmvn(cc['cmvn_file'], cc['is_json_cmvn'])
+        sd['encoder.global_cmvn.mean'] = torch.from_numpy(mean).float()
+        sd['encoder.global_cmvn.istd'] = torch.from_numpy(istd).float()
+    return sd
+
+
+def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches,
+              args, blank_id: int, context_graph, emit):
+    """Decode `my_batches` (indices into `batches`); `emit(batch_index, mode,
+    line)` receives the result lines in order."""
+    import torch
+    from wenet_amd.model import read_wav
+    from wenet_amd.pipeline import DecodePipeline
+    kw = dict(beam_size=args.beam_size,
+              decoding_chunk_size=args.decoding_chunk_size,
+              num_decoding_left_chunks=args.num_decoding_left_chunks,
+              ctc_weight=args.ctc_weight,
+              simulate_streaming=args.simulate_streaming,
+              reverse_weight=args.reverse_weight, context_graph=context_graph,
+              blank_id=blank_id, blank_penalty=args.blank_penalty,
+              length_penalty=args.length_penalty)
+    max_fmt = max(len(m) for m in args.modes)
+    depth = max(2, 2 * args.streams)  # batches of wav data read ahead
+    readers = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, args.num_workers))
+
+    def load(bi):
+        return [readers.submit(read_wav, wav) for _, wav in batches[bi]]
+
+    pending_wavs = {}
+    order = list(my_batches)
+    for bi in order[:depth]:
+        pending_wavs[bi] = load(bi)
+    inflight = []  # (batch index, keys in output order, future)
+
+    def drain(n_keep):
+        while len(inflight) > n_keep:
+            bi, keys, fut = inflight.pop(0)
+            results = fut.result()
+            for i, key in enumerate(keys):
+                for mode in args.modes:
+                    text = tokenizer.detokenize(results[mode][i].tokens)[0]
+                    line = format_line(key, text)
+                    logging.info('%s %s', mode.ljust(max_fmt), line)
+                    emit(bi, mode, line)
+
+    with DecodePipeline(model, n_streams=args.streams) as pipe:
+        for pos, bi in enumerate(order):
+            waves = [f.result() for f in pending_wavs.pop(bi)]
+            if pos + depth < len(order):
+                nxt = order[pos + depth]
+                pending_wavs[nxt] = load(nxt)
+            feats, n_frames = model.compute_fbank(waves)
+            perm = padding_order(n_frames.tolist())
+            idx = torch.as_tensor(perm, dtype=torch.long)
+            feats = feats.index_select(0, idx.to(feats.device))
+            lens = n_frames.index_select(0, idx)
+            tmax = int(lens.max()) if len(perm) else 0
+            feats = feats[:, :tmax].contiguous()
+            keys = [batches[bi][i][0] for i in perm]
+            inflight.append((bi, keys, pipe.submit(args.modes, feats, lens, **kw)))
+            drain(args.streams)
+        drain(0)
+    readers.shutdown(wait=True)
+
+
+def main(argv=None):
+    args = get_args(argv)
+    logging.basicConfig(level=logging.INFO,
+                        format='%(asctime)s %(levelname)s %(message)s')
+    import torch
+    import yaml
+    from wenet_amd.model import ASRModel
+    from wenet_amd.tokenizer import get_blank_id, init_tokenizer
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dev_index = args.gpu if args.gpu >= 0 else local
+    device = torch.device('cuda', dev_index)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+
+    with open(args.config, 'r') as fin:
+        configs = yaml.load(fin, Loader=yaml.FullLoader)
+    if args.override_config:
+        configs = override_config(configs, args.override_config)
+    check_feature_conf(configs)
+    tokenizer = init_tokenizer(configs)
+    blank_id = get_blank_id(configs, tokenizer.symbol_table)
+    logging.info('blank_id is %d', blank_id)
+    model = ASRModel(configs, load_state(configs, args.checkpoint), device)
+
+    context_graph = None
+    if 'decoding-graph' in args.context_bias_mode:
+        from wenet_amd.context_graph import ContextGraph
+        context_graph = ContextGraph(args.context_list_path, tokenizer.symbol_table,
+                                     configs['tokenizer_conf'].get('bpe_path'),
+                                     args.context_graph_score)
+
+    batches = static_batches(read_data_list(args.test_data), args.batch_size)
+    mine = list(range(rank, len(batches), world))
+    files = {}
+    for mode in args.modes:
+        d = os.path.join(args.result_dir, mode)
+        os.makedirs(d, exist_ok=True)
+        files[mode] = open(os.path.join(d, f'text.part{rank}'), 'w', encoding='utf8')
+
+    def emit(bi, mode, line):
+        files[mode].write(f'{bi}\t{line}\n')
+
+    recognize(model, tokenizer, batches, mine, args, blank_id, context_graph, emit)
+    for f in files.values():
+        f.close()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        merge_parts(args.result_dir, args.modes, world, len(batches))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -668,5 +668,12 @@ def load_model(model_name_or_path: str, device='cuda') -> ASRModel:
         sd['encoder.global_cmvn.mean'] = torch.from_numpy(mean).float()
         sd['encoder.global_cmvn.istd'] = torch.from_numpy(istd).float()
     model = ASRModel(configs, sd, device)
-    model.tokenizer = _Tokenizer(os.path.join(model_dir, 'units.txt'))
+    # cli/model.py:35-46: the config's tokenizer with its files looked up in the
+    # model directory; older packages without tokenizer_conf fall back to units.txt
+    if 'tokenizer_conf' in configs and \
+            configs['tokenizer_conf'].get('symbol_table_path') is not None:
+        from wenet_amd.tokenizer import init_tokenizer
+        model.tokenizer = init_tokenizer(configs, model_dir)
+    else:
+        model.tokenizer = _Tokenizer(os.path.join(model_dir, 'units.txt'))
     return model
