@@ -96,6 +96,15 @@ int wn_model_clone(const wn_model* src, wn_model** out);
 int wn_workspace_create(int32_t device, wn_model** out);
 
 /* ---- features ---------------------------------------------------------- */
+/* processor.resample (dataset/processor.py:177-196): torchaudio's
+ * Resample(orig_freq, new_freq) with its defaults -- polyphase windowed sinc
+ * (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99), output length
+ * ceil(new * n_in / orig) = wn_resample_length().  pcm_dev (n_in) -> out_dev
+ * (n_out) float, both on the device; equal rates copy. */
+int64_t wn_resample_length(int64_t n_in, int32_t orig_freq, int32_t new_freq);
+int wn_resample(wn_model* m, const float* pcm_dev, int64_t n_in, int32_t orig_freq,
+                int32_t new_freq, float* out_dev, int64_t n_out, void* stream);
+
 /* compute_fbank (wenet/dataset/processor.py:226-256 -> kaldi.fbank with
  * num_mel_bins, 25 ms / 10 ms, dither 0, povey window; arithmetic restated
  * from runtime/core/frontend/fbank.h:250-327) + padding

@@ -18,7 +18,12 @@ Pinning (see tests/test_oracle.py and tests/golden/):
     compiled from where it lies into oracle/_ref/ (oracle/Makefile), golden rows
     committed in tests/golden/fbank_*.npz.  torchaudio.compliance.kaldi (the
     Python path's third-party fbank, unpinned `torchaudio>=2.1.2`) is absent, so
-    the Python-side fbank parity is anchored on that C++ restatement.
+    the Python-side fbank parity is anchored on that C++ restatement;
+  * context biasing, forward_chunk caches, attention mode, Whisper encoder:
+    goldens generated from the unmodified reference (oracle/gen_golden_*.py);
+  * `resample` ONLY: PARITY UNPINNED -- torchaudio's Resample is third party,
+    absent and un-vendored, and the reference holds no test for it; restated
+    from the published algorithm and checked through properties.
 
 All arithmetic is fp32 like the reference default (wenet/bin/recognize.py:250);
 the prefix-beam bookkeeping uses Python floats (fp64) exactly like search.py.
@@ -207,6 +212,51 @@ def log_mel_spectrogram(waveform: np.ndarray, num_mel_bins: int = 80,
     log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
     log_spec = (log_spec + 4.0) / 4.0
     return log_spec.transpose(0, 1).contiguous().numpy()
+
+
+def resample(waveform: np.ndarray, orig_freq: int, new_freq: int = 16000) -> np.ndarray:
+    """processor.resample (wenet/dataset/processor.py:177-196) =
+    torchaudio.transforms.Resample(orig_freq, new_freq)(waveform) with its
+    defaults (resampling_method 'sinc_interp_hann', lowpass_filter_width 6,
+    rolloff 0.99).
+
+    PARITY UNPINNED for this one function: torchaudio is a third-party
+    dependency that is neither vendored in /root/reference nor installed here
+    (requirements.txt: torchaudio>=2.1.2, unpinned), and the reference has no
+    test or golden vector at this call site.  The algorithm is restated from
+    torchaudio 2.1's published `_get_sinc_resample_kernel` /
+    `_apply_sinc_resample_kernel`: reduce the rates by their gcd; per output
+    phase i in [0, new) a windowed-sinc filter of 2*width + orig taps,
+    width = ceil(6 * orig / (0.99 * min(orig, new))), evaluated in fp64 and
+    stored fp32; zero-pad (width, width + orig); strided correlation (stride
+    orig); keep ceil(new * len / orig) samples.  tests/ check it through
+    properties (identity, length, DC gain, tone preservation) and against
+    scipy.signal.resample_poly on band-limited input."""
+    x = np.asarray(waveform, dtype=np.float32)
+    if orig_freq == new_freq:
+        return x
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    lpw, rolloff = 6, 0.99
+    base = min(orig, new) * rolloff
+    width = math.ceil(lpw * orig / base)
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx
+    t = np.clip(t * base, -lpw, lpw)
+    window = np.cos(t * math.pi / lpw / 2) ** 2
+    t = t * math.pi
+    with np.errstate(invalid='ignore', divide='ignore'):
+        kernels = np.where(t == 0, 1.0, np.sin(t) / t)
+    kernels = (kernels * window * (base / orig)).astype(np.float32)  # (new, K)
+    n = x.shape[-1]
+    padded = np.concatenate([np.zeros(width, np.float32), x,
+                             np.zeros(width + orig, np.float32)])
+    K = kernels.shape[1]
+    n_win = (padded.shape[0] - K) // orig + 1
+    win = np.lib.stride_tricks.sliding_window_view(padded, K)[::orig][:n_win]
+    out = (win.astype(np.float32) @ kernels.T).reshape(-1)  # (n_win, new) row-major
+    target = -(-new * n // orig)
+    return out[:target].astype(np.float32)
 
 
 def padding(feats: List[np.ndarray]) -> Tuple[torch.Tensor, torch.Tensor, List[int]]:

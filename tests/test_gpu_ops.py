@@ -150,3 +150,24 @@ def test_log_add_matches_reference_formula():
     scale = np.maximum(np.abs(want[fin]), np.abs(np.maximum(a, b)[fin]))
     ulp = np.spacing(np.maximum(scale, 1e-300))
     assert (err <= 4 * ulp).all(), (err / ulp).max()
+
+
+@pytest.mark.parametrize('orig,new,n', [(8000, 16000, 12345), (44100, 16000, 50001),
+                                        (48000, 16000, 30000), (22050, 16000, 7),
+                                        (16000, 8000, 16001), (11025, 16000, 9999),
+                                        (16000, 16000, 500)])
+def test_resample_vs_oracle(orig, new, n):
+    """wn_resample (processor.resample; torchaudio Resample defaults) against the
+    oracle's restatement: same taps (fp64 -> fp32), fp32 accumulation."""
+    import ctypes
+    from oracle import wenet_oracle as O
+    from gpu_util import cached_model
+    _, _, model = cached_model('tiny_sym', 0)
+    rng = np.random.RandomState(orig % 97 + n)
+    x = (rng.rand(n).astype(np.float32) * 2 - 1) * 0.7
+    got = model.resample(x, orig, new)
+    want = O.resample(x, orig, new)
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.abs(got - want).max() < 2e-5, np.abs(got - want).max()
+    L = model._L
+    assert L.wn_resample_length(n, orig, new) == want.shape[0]

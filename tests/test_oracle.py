@@ -477,3 +477,39 @@ def test_oracle_forward_chunk_matches_committed_reference_outputs(name):
     if meta['config'] != 'tiny_sym':
         by, _ = O.forward_chunk_by_chunk(configs, sd, feats, meta['chunk'], meta['left'])
         assert torch.equal(by[0], torch.cat(outs, 1)[0])
+
+
+# --------------------------------------------------------------------------
+# resample (processor.py:177-196; torchaudio absent -> properties only)
+
+
+def test_resample_properties():
+    """PARITY UNPINNED (see O.resample): the restated torchaudio algorithm is
+    checked through what any correct band-limited resampler must satisfy."""
+    from scipy.signal import resample_poly
+    x = np.random.RandomState(0).randn(5000).astype(np.float32)
+    assert O.resample(x, 16000, 16000) is not None
+    np.testing.assert_array_equal(O.resample(x, 16000, 16000), x)
+    for orig, new in [(8000, 16000), (44100, 16000), (48000, 16000), (22050, 16000),
+                      (16000, 8000), (11025, 16000)]:
+        n = 3 * orig // 4 + 13
+        t = np.arange(n) / orig
+        f0 = 0.1 * min(orig, new)          # well inside both pass bands
+        tone = (0.5 * np.sin(2 * np.pi * f0 * t)).astype(np.float32)
+        y = O.resample(tone, orig, new)
+        assert y.dtype == np.float32
+        assert y.shape[0] == -(-new * n // orig)          # ceil(new * n / orig)
+        want = 0.5 * np.sin(2 * np.pi * f0 * np.arange(y.shape[0]) / new)
+        edge = 200
+        assert np.abs(y[edge:-edge] - want[edge:-edge]).max() < 2e-3, (orig, new)
+        dc = O.resample(np.ones(n, np.float32), orig, new)
+        assert np.abs(dc[edge:-edge] - 1.0).max() < 2e-3
+        g = np.gcd(orig, new)
+        poly = resample_poly(tone.astype(np.float64), new // g, orig // g)
+        m = min(len(poly), len(y))
+        assert np.abs(y[edge:m - edge] - poly[edge:m - edge]).max() < 5e-3
+    # linear: resample(a x + b z) == a resample(x) + b resample(z)
+    z = np.random.RandomState(1).randn(5000).astype(np.float32)
+    lhs = O.resample(2 * x - 3 * z, 44100, 16000)
+    rhs = 2 * O.resample(x, 44100, 16000) - 3 * O.resample(z, 44100, 16000)
+    assert np.abs(lhs - rhs).max() < 1e-4

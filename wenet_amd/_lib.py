@@ -30,7 +30,7 @@ class WnTensor(Structure):
 # every symbol include/wenet_amd.h declares
 EXPORTS = [
     'wn_last_error', 'wn_version', 'wn_model_create', 'wn_model_destroy', 'wn_model_clone',
-    'wn_workspace_create', 'wn_fbank', 'wn_log_mel', 'wn_encode', 'wn_encode_chunk', 'wn_set_encoder_out',
+    'wn_workspace_create', 'wn_resample_length', 'wn_resample', 'wn_fbank', 'wn_log_mel', 'wn_encode', 'wn_encode_chunk', 'wn_set_encoder_out',
     'wn_ctc_logprobs', 'wn_set_ctc_probs', 'wn_ctc_greedy_search',
     'wn_set_context_graph', 'wn_ctc_prefix_beam_search', 'wn_attention_rescoring', 'wn_decoder_next_topk', 'wn_op_gemm',
     'wn_op_layernorm', 'wn_op_log_add', 'wn_debug_set', 'wn_profile_enable',
@@ -70,6 +70,9 @@ def lib():
     L.wn_ctc_logprobs.argtypes = [vp, i32, i32, f32, vp, i32, vp]
     L.wn_encode_chunk.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, pi32,
                                   pi32, vp]
+    L.wn_resample_length.argtypes = [ctypes.c_int64, i32, i32]
+    L.wn_resample_length.restype = ctypes.c_int64
+    L.wn_resample.argtypes = [vp, vp, ctypes.c_int64, i32, i32, vp, ctypes.c_int64, vp]
     L.wn_set_ctc_probs.argtypes = [vp, vp, pi32, i32, i32, i32, i32, vp]
     L.wn_ctc_greedy_search.argtypes = [vp, i32, pi32, pi32, i32, vp]
     L.wn_set_context_graph.argtypes = [vp, i32, pi32, pf64, pf64, pf64, i32, pi32, pi32,

@@ -8,9 +8,9 @@ result files: for every mode a `<result_dir>/<mode>/text` with one
 produces (recognize.py:193-311, processor.py:526-577).
 
 What differs is where the work runs:
-  * wav files are read by host threads ahead of the GPU (16 kHz PCM16; no
-    resampler), fbank is computed on the device (`wn_fbank`) straight into the
-    padded batch tensor;
+  * wav files (PCM16) are read by host threads ahead of the GPU, rates other
+    than 16 kHz are resampled on the device (`wn_resample`), fbank is computed
+    on the device (`wn_fbank`) straight into the padded batch tensor;
   * two batches are in flight on the GPU (`wenet_amd.pipeline.DecodePipeline`):
     the CTC search of batch i runs under the encoder of batch i+1;
   * under `torchrun` every rank takes every world_size-th batch (the
@@ -178,6 +178,9 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
     line)` receives the result lines in order."""
     import torch
     from wenet_amd.model import read_wav
+
+    def read16k(path):  # host threads read; rates other than 16 kHz go through
+        return read_wav(path, return_rate=True)  # the device resampler below
     from wenet_amd.pipeline import DecodePipeline
     kw = dict(beam_size=args.beam_size,
               decoding_chunk_size=args.decoding_chunk_size,
@@ -192,7 +195,7 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
     readers = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, args.num_workers))
 
     def load(bi):
-        return [readers.submit(read_wav, wav) for _, wav in batches[bi]]
+        return [readers.submit(read16k, wav) for _, wav in batches[bi]]
 
     pending_wavs = {}
     order = list(my_batches)
@@ -213,7 +216,8 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
 
     with DecodePipeline(model, n_streams=args.streams) as pipe:
         for pos, bi in enumerate(order):
-            waves = [f.result() for f in pending_wavs.pop(bi)]
+            waves = [w if sr == 16000 else model.resample(w, sr, 16000)
+                     for w, sr in (f.result() for f in pending_wavs.pop(bi))]
             if pos + depth < len(order):
                 nxt = order[pos + depth]
                 pending_wavs[nxt] = load(nxt)

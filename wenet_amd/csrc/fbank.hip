@@ -88,7 +88,40 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a) {
   }
 }
 
+// Polyphase sinc resampler (torchaudio.functional.resample as called by
+// processor.resample, processor.py:177-196): output sample t = j * new + i is the
+// dot product of phase i's K taps with the input window starting at
+// j * orig - width (zero outside the signal).  One thread per output sample;
+// the taps of a phase are read by consecutive lanes of other phases -> the table
+// stays in L1/L2, the signal is read ~K/orig times from cache.  HBM-bound.
+__global__ __launch_bounds__(256) void resample_kernel(
+    const float* __restrict__ x, int64_t n_in, const float* __restrict__ taps, int K,
+    int width, int orig, int nnew, float* __restrict__ out, int64_t n_out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out) return;
+  const int64_t j = t / nnew;
+  const int i = (int)(t - j * nnew);
+  const float* w = taps + (int64_t)i * K;
+  const int64_t base = j * orig - width;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int64_t src = base + k;
+    const float v = (src >= 0 && src < n_in) ? x[src] : 0.f;
+    acc = fmaf(w[k], v, acc);
+  }
+  out[t] = acc;
+}
+
 }  // namespace
+
+int resample_sinc(const float* x, int64_t n_in, const float* taps, int K, int width,
+                  int orig, int nnew, float* out, int64_t n_out, hipStream_t s) {
+  WN_CHECK(n_out > 0 && K > 0, "resample: empty");
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)cdiv(n_out, (int64_t)256)),
+                     dim3(256), 0, s, x, n_in, taps, K, width, orig, nnew, out, n_out);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
 
 int fbank_kaldi(const FbankArgs& a, hipStream_t s) {
   WN_CHECK(a.B > 0 && a.max_frames > 0, "fbank: empty");

@@ -138,6 +138,9 @@ struct FbankArgs {
   float* feats;              // (B, max_frames, n_mel)
 };
 int fbank_kaldi(const FbankArgs& a, hipStream_t s);
+// polyphase sinc resampler (see fbank.hip); taps [nnew][K]
+int resample_sinc(const float* x, int64_t n_in, const float* taps, int K, int width,
+                  int orig, int nnew, float* out, int64_t n_out, hipStream_t s);
 
 // Whisper log-mel (see logmel.hip): K of the DFT GEMM (400 padded to 416), width
 // of its output (201 cos + 201 sin rows), K of the mel GEMM (201 padded to 224).

@@ -250,6 +250,9 @@ struct wn_model {
   DevBuf ck_kv, ck_xext, ck_glu, ck_desc, ck_rowutt;  // forward_chunk scratch
   // Whisper log-mel: DFT / window tables (shared), mel matrix per bin count
   std::shared_ptr<DevBuf> lm_dft = std::make_shared<DevBuf>();
+  // resampler taps per (orig, new) rate pair (wn_resample)
+  std::shared_ptr<std::map<std::pair<int, int>, std::shared_ptr<DevBuf>>> rs_taps =
+      std::make_shared<std::map<std::pair<int, int>, std::shared_ptr<DevBuf>>>();
   std::shared_ptr<std::map<int, std::shared_ptr<DevBuf>>> lm_mel =
       std::make_shared<std::map<int, std::shared_ptr<DevBuf>>>();
   DevBuf lm_off, lm_foff, lm_nfr, lm_rowutt, lm_frames, lm_spec, lm_pw, lm_melout, lm_umax;
@@ -1208,6 +1211,7 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->tconv1 = src->tconv1; m->tconv2 = src->tconv2;
   m->fbank_ok = src->fbank_ok;
   m->lm_dft = src->lm_dft; m->lm_mel = src->lm_mel;
+  m->rs_taps = src->rs_taps;
   m->left = src->left; m->right = src->right;
   m->fb_window = src->fb_window; m->fb_twiddle = src->fb_twiddle;
   m->fb_mel_w = src->fb_mel_w;
@@ -1895,6 +1899,63 @@ int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,
 int wn_op_layernorm(const float* x, const float* w, const float* b, float* y,
                     int32_t M, int32_t D, float eps, void* stream) {
   return layernorm(x, D, w, b, y, D, M, D, eps, (hipStream_t)stream);
+}
+
+namespace {
+int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+}  // namespace
+
+int64_t wn_resample_length(int64_t n_in, int32_t orig_freq, int32_t new_freq) {
+  if (n_in <= 0 || orig_freq <= 0 || new_freq <= 0) return 0;
+  const int g = gcd_int(orig_freq, new_freq);
+  const int64_t o = orig_freq / g, n = new_freq / g;
+  return (n * n_in + o - 1) / o;  // ceil(new * length / orig)
+}
+
+int wn_resample(wn_model* m, const float* pcm_dev, int64_t n_in, int32_t orig_freq,
+                int32_t new_freq, float* out_dev, int64_t n_out, void* stream) {
+  WN_CHECK(m && pcm_dev && out_dev, "wn_resample: null argument");
+  WN_CHECK(orig_freq > 0 && new_freq > 0 && n_in > 0, "wn_resample: bad rate or length");
+  WN_CHECK(n_out == wn_resample_length(n_in, orig_freq, new_freq),
+           "wn_resample: n_out must be wn_resample_length(n_in, orig, new)");
+  hipStream_t s = (hipStream_t)stream;
+  WN_HIP(hipSetDevice(m->device));
+  if (orig_freq == new_freq) {  // Resample.forward returns the input unchanged
+    WN_HIP(hipMemcpyAsync(out_dev, pcm_dev, (size_t)n_in * sizeof(float),
+                          hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
+  const int g = gcd_int(orig_freq, new_freq);
+  const int orig = orig_freq / g, nnew = new_freq / g;
+  // sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99 (the defaults of
+  // torchaudio.transforms.Resample); taps in fp64, stored fp32
+  const double lpw = 6.0, rolloff = 0.99;
+  const double base = std::min(orig, nnew) * rolloff;
+  const int width = (int)std::ceil(lpw * orig / base);
+  const int K = 2 * width + orig;
+  std::shared_ptr<DevBuf>& buf = (*m->rs_taps)[{orig, nnew}];
+  if (!buf) {
+    std::vector<float> taps((size_t)nnew * K);
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < nnew; ++i) {
+      for (int k = 0; k < K; ++k) {
+        double t = (-(double)i / nnew + (double)(k - width) / orig) * base;
+        t = std::min(std::max(t, -lpw), lpw);
+        const double c = std::cos(t * pi / lpw / 2.0);
+        const double win = c * c;
+        const double tp = t * pi;
+        const double sinc = tp == 0.0 ? 1.0 : std::sin(tp) / tp;
+        taps[(size_t)i * K + k] = (float)(sinc * win * (base / orig));
+      }
+    }
+    auto nb = std::make_shared<DevBuf>();
+    WN_TRY(nb->ensure(taps.size() * sizeof(float)));
+    WN_HIP(hipMemcpy(nb->p, taps.data(), taps.size() * sizeof(float),
+                     hipMemcpyHostToDevice));
+    buf = nb;
+  }
+  return resample_sinc(pcm_dev, n_in, buf->as<float>(), K, width, orig, nnew, out_dev,
+                       n_out, s);
 }
 
 int wn_fbank(wn_model* m, const float* pcm_dev, const int64_t* sample_off_host,

@@ -613,10 +613,28 @@ class ASRModel:
             'wn_log_mel')
         return feats, torch.from_numpy(n_frames.copy())
 
+    def resample(self, waveform, orig_freq: int, new_freq: int = 16000) -> np.ndarray:
+        """processor.resample (processor.py:177-196; torchaudio Resample
+        defaults) of one float waveform on the device -> host float32 array."""
+        x = torch.as_tensor(np.asarray(waveform, dtype=np.float32)).to(self.device)
+        n_in = int(x.numel())
+        n_out = int(self._L.wn_resample_length(n_in, int(orig_freq), int(new_freq)))
+        out = torch.empty((n_out, ), dtype=torch.float32, device=self.device)
+        if n_out > 0:
+            _lib.check(
+                self._L.wn_resample(self._h, x.data_ptr(), n_in, int(orig_freq),
+                                    int(new_freq), out.data_ptr(), n_out,
+                                    _stream_ptr(self.device)), 'wn_resample')
+        return out.cpu().numpy()
+
+    def load_wav(self, wav_file: str) -> np.ndarray:
+        """decode_wav + resample to 16 kHz (processor.py:125-153,177-196)."""
+        wav, rate = read_wav(wav_file, return_rate=True)
+        return wav if rate == 16000 else self.resample(wav, rate, 16000)
+
     def compute_feature(self, wav_file: str) -> torch.Tensor:
-        """cli/model.py:59-66: decode_wav -> (resample) -> compute_fbank."""
-        wav = read_wav(wav_file)
-        feats, lens = self.compute_fbank([wav])
+        """cli/model.py:59-66: decode_wav -> resample -> compute_fbank."""
+        feats, lens = self.compute_fbank([self.load_wav(wav_file)])
         return feats[0, :int(lens[0])]
 
     def transcribe(self, wav: str) -> DecodeResult:
@@ -631,18 +649,22 @@ class ASRModel:
         return result
 
 
-def read_wav(path: str) -> np.ndarray:
-    """16-bit PCM wav -> mono float32 in [-1, 1) like torchaudio.load
-    (processor.py:141-148); 16 kHz only (resampling is not accelerated)."""
+def read_wav(path: str, return_rate: bool = False):
+    """16-bit PCM wav -> mono (first channel) float32 in [-1, 1) like
+    torchaudio.load (processor.py:141-148).  Without `return_rate` the file must
+    be 16 kHz (use ASRModel.load_wav to resample)."""
     with wave.open(path, 'rb') as w:
         assert w.getsampwidth() == 2, 'only 16-bit PCM wav is supported'
         sr, nch = w.getframerate(), w.getnchannels()
         data = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
-    if sr != 16000:
-        raise NotImplementedError('only 16 kHz audio is supported')
     if nch > 1:
         data = data.reshape(-1, nch)[:, 0]
-    return (data.astype(np.float32) / 32768.0)
+    data = data.astype(np.float32) / 32768.0
+    if return_rate:
+        return data, sr
+    if sr != 16000:
+        raise NotImplementedError('read_wav: not 16 kHz; use ASRModel.load_wav')
+    return data
 
 
 def load_model(model_name_or_path: str, device='cuda') -> ASRModel:
