@@ -360,17 +360,16 @@ int gemm_f32(const GemmArgs& a, hipStream_t stream) {
   // shrinks with the problem so that the grid still covers the 256 CUs.
   //   1: 128x128, 2x4 waves   2: 128x128, 4x2 waves (64-wide wave tile: GLU)
   //   3: 64x128, 2x4 waves    4: 64x128, 2x2 waves (GLU)   5: 64x64, 2x2 waves
-  //   6: 128x128, 2x2 waves   7: 256x256, 4x2 waves (144 KB LDS, 1 block per CU)
+  //   6: 128x128, 2x2 waves
+  //   7: 256x256, 4x2 waves (144 KB LDS, 1 block per CU) -- only on request
+  //      (gemm_tile=7): +3.5 % on the isolated FFN-w1 shape (248 tiles, one
+  //      round), but -14 % inside the decode pipeline, where the other stream's
+  //      search kernel holds CUs and a 1-block-per-CU grid cannot rebalance
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
   const int64_t t64x128 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 128);
   int cfg;
   if (a.glu) cfg = t128 >= 224 ? 2 : 4;
   else if (conv) cfg = t128 >= 384 ? 6 : 4;  // K = 9C: the 4-wave block wins
-  // one 256x256 tile per CU in a single round (>= 85 % of the 256 CUs busy):
-  // +3.5 % on the FFN-w1 shape (7932x2048x256 -> 248 tiles), measured r01f
-  else if (a.K <= 512 && (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256) <= 256 &&
-           (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256) >= 218 && a.N % 256 == 0)
-    cfg = 7;
   else if (t128 >= 384) cfg = 1;
   else if (t64x128 >= 384) cfg = 3;
   else cfg = 5;
