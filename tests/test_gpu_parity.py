@@ -801,3 +801,45 @@ def test_recognize_cli_end_to_end(tmp_path):
             assert text == greedy_ref[key], key
             checked += 1
     assert checked >= 3
+
+
+def test_transcribe_cli_with_resampling_and_context(tmp_path, capsys):
+    """`python -m wenet_amd.bin.transcribe` on an 8 kHz wav in a model directory
+    (train.yaml / final.pt / units.txt): the printed text equals a direct decode
+    of the device-resampled, device-fbank features; a context list is accepted."""
+    import wave
+    import yaml
+    from wenet_amd.bin import transcribe as T
+    configs, sd, model = cached_model('tiny_causal', 0)
+    V = configs['output_dim']
+    syms = ['<blank>', '<unk>'] + [f't{i}' for i in range(2, V - 1)] + ['<sos/eos>']
+    (tmp_path / 'units.txt').write_text(''.join(f'{s} {i}\n' for i, s in enumerate(syms)))
+    cfg = dict(configs)
+    cfg['tokenizer'] = 'char'
+    cfg['tokenizer_conf'] = dict(symbol_table_path='units.txt', non_lang_syms_path=None,
+                                 connect_symbol=' ')
+    (tmp_path / 'train.yaml').write_text(yaml.safe_dump(cfg))
+    torch.save(sd, tmp_path / 'final.pt')
+    rng = np.random.RandomState(5)
+    n = 14000
+    x = 0.4 * np.sin(2 * np.pi * 330 * np.arange(n) / 8000.0) + 0.05 * rng.randn(n)
+    x16 = np.clip(x * 32768, -32768, 32767).astype(np.int16)
+    wav = tmp_path / 'a8k.wav'
+    with wave.open(str(wav), 'wb') as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(8000)
+        w.writeframes(x16.tobytes())
+    assert T.main([str(wav), '-m', str(tmp_path)]) == 0
+    text = capsys.readouterr().out.strip().splitlines()[-1]
+    pcm16k = model.resample(x16.astype(np.float32) / 32768.0, 8000, 16000)
+    assert pcm16k.shape[0] == 2 * n
+    feats, nfr = model.compute_fbank([pcm16k])
+    want = model.decode(['attention_rescoring'], feats, nfr)['attention_rescoring'][0]
+    assert text == ' '.join(syms[t] for t in want.tokens)
+    ctx = tmp_path / 'ctx.txt'
+    ctx.write_text('t5t6\nt7\n')  # chars 't','5',... are unknown symbols -> <unk> ids
+    assert T.main([str(wav), '-m', str(tmp_path), '--beam', '4', '--context_path',
+                   str(ctx), '--context_score', '2.0', '-t']) == 0
+    out = capsys.readouterr().out
+    assert 'tokens' in out and 'times' in out

@@ -109,3 +109,14 @@ def test_tokenizers_match_the_reference(tmp_path):
     ref, got = ref_init(dict(cfg)), init_tokenizer(cfg)
     ids = sp.encode('HELLO THE CAT')
     assert ref.detokenize(ids) == got.detokenize(ids)
+
+
+def test_transcribe_cli_args():
+    from wenet_amd.bin import transcribe as T
+    a = T.get_args(['a.wav', '-m', '/models/x'])
+    assert a.audio_file == 'a.wav' and a.model == '/models/x' and a.beam is None
+    assert a.context_score == 6.0 and a.device == 'cuda'
+    with pytest.raises(SystemExit):
+        T.get_args(['a.wav'])                      # no model download: -m is required
+    with pytest.raises(SystemExit):
+        T.get_args(['a.wav', '-m', 'x', '--device', 'cpu'])

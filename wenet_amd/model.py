@@ -140,6 +140,8 @@ class _Tokenizer:
     wenet/text/base_tokenizer.py:14 + char/bpe tokenizers (join the symbols;
     sentencepiece's word-boundary mark becomes a space)."""
 
+    bpe_path = None
+
     def __init__(self, units_file: str):
         self.id2sym = {}
         with open(units_file, 'r', encoding='utf8') as f:
@@ -147,6 +149,7 @@ class _Tokenizer:
                 arr = line.strip().split()
                 if len(arr) == 2:
                     self.id2sym[int(arr[1])] = arr[0]
+        self.symbol_table = {s: i for i, s in self.id2sym.items()}
 
     def detokenize(self, ids: List[int]) -> Tuple[str, List[str]]:
         tokens = [self.id2sym.get(int(i), '<unk>') for i in ids]
