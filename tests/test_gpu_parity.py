@@ -843,3 +843,59 @@ def test_transcribe_cli_with_resampling_and_context(tmp_path, capsys):
                    str(ctx), '--context_score', '2.0', '-t']) == 0
     out = capsys.readouterr().out
     assert 'tokens' in out and 'times' in out
+
+
+# --------------------------------------------------------------------------
+# beams above 16 (the general prefix-beam kernel, up to 64)
+
+
+@pytest.mark.parametrize('V,T,B,beam,ctx', [(40, 30, 4, 17, False), (67, 50, 3, 20, True),
+                                            (300, 40, 2, 32, False), (80, 25, 3, 64, True),
+                                            (5002, 20, 2, 50, False), (20, 60, 6, 20, True)])
+def test_prefix_beam_large_beams_bit_exact(V, T, B, beam, ctx):
+    """beam_size 17..64 runs the general kernel: n-best lists, order and time
+    stamps identical to the oracle, fp64 scores to 1e-9, with and without a
+    context graph."""
+    from wenet_amd import search as S
+    from wenet_amd import synthetic
+    from wenet_amd.context_graph import ContextGraph
+    O = _oracle()
+    logp, lens = synthetic.peaky_logprobs(B, (max(1, T // 2), T), V, 3.0, V + T + beam)
+    og = gg = None
+    if ctx:
+        rng = np.random.RandomState(beam)
+        phrases = [[int(t) for t in rng.randint(1, V, rng.randint(1, 5))] for _ in range(12)]
+        og = O.ContextGraph(phrases, 2.0)
+        gg = ContextGraph(context_list=phrases, context_score=2.0)
+    ref = O.ctc_prefix_beam_search(logp, lens, beam, 0, og)
+    got = S.ctc_prefix_beam_search(logp.cuda(), lens, beam, gg, 0)
+    for b in range(B):
+        _same_nbest(got[b], ref[b].nbest, ref[b].nbest_scores, ref[b].nbest_times,
+                    f'utt {b}')
+
+
+def test_large_beam_through_decode_and_rescoring():
+    """beam 24 end to end (prefix beam + attention rescoring of 24 hypotheses)
+    against the oracle on a small model."""
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('tiny_causal', 0)
+    feats, lens = S.make_features(3, (60, 150), seed=77)
+    kw = dict(beam_size=24, ctc_weight=0.5, reverse_weight=0.3, blank_penalty=3.0)
+    got = model.decode(['ctc_prefix_beam_search', 'attention_rescoring'], feats.cuda(),
+                       lens, **kw)
+    enc, mask = model._forward_encoder(feats.cuda(), lens)
+    enc_lens = mask.squeeze(1).sum(1).cpu()
+    logp = model.ctc_logprobs(enc, 3.0, 0, encoder_lens=enc_lens).cpu()
+    ref = O.ctc_prefix_beam_search(logp, enc_lens, 24, 0)
+    for b in range(3):
+        _same_nbest(got['ctc_prefix_beam_search'][b], ref[b].nbest, ref[b].nbest_scores,
+                    ref[b].nbest_times)
+    oref = O.attention_rescoring(configs, sd, ref, enc.cpu(), enc_lens, 0.5, 0.3,
+                                 *O.special_symbols(configs))
+    for b in range(3):
+        r = got['attention_rescoring'][b]
+        if list(r.tokens) == list(oref[b].tokens):
+            assert abs(r.score - oref[b].score) < 1e-3 * (len(r.tokens) + 1)
+    assert sum(list(got['attention_rescoring'][b].tokens) == list(oref[b].tokens)
+               for b in range(3)) >= 2

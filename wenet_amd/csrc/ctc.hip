@@ -665,6 +665,287 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
   }
 }
 
+// ===========================================================================
+// Large beams (17..64): the same per-entry formulation, written for generality
+// instead of latency.  One 1024-thread workgroup per utterance; the
+// <= 64 + 64*64 entries of a frame are dealt to the threads (<= 5 each), every
+// thread keeps only (total score, seq) of its entries, the `beam` survivors are
+// picked by `beam` rounds of a block-wide arg-max on (score desc, seq asc) --
+// exactly Python's stable sort order -- and only the survivors are evaluated in
+// full and written.  The default recipes (beam 10) never come here.
+constexpr int BIGB = 64;
+constexpr int BIG_THREADS = 1024;
+constexpr int BIG_WAVES = BIG_THREADS / 64;
+constexpr int BIG_EPT = (BIGB + BIGB * BIGB + BIG_THREADS - 1) / BIG_THREADS;
+
+struct BigHyp {
+  u64 hash[BIGB], par_hash[BIGB];
+  double s[BIGB], ns[BIGB], vs[BIGB], vns[BIGB], score[BIGB], vit[BIGB], cscore[BIGB];
+  int node[BIGB], last[BIGB], par[BIGB], depth[BIGB];
+  int ts[BIGB], tns[BIGB], tnsp[BIGB], tim[BIGB], cstate[BIGB];
+};
+
+struct BigEntry {
+  int valid;
+  double s, ns, vs, vns, cx;
+  int ts, tns_src, tns_op, tnsp;
+  int key, par, token, depth, seq, cs;
+  u64 hash, parh;
+};
+
+// Entry e of the frame: e < BIGB is the unchanged prefix H[e]; otherwise the
+// extension H[r] + topk[q] with (r, q) = divmod(e - BIGB, beam).  Same
+// arithmetic, same order rules as prefix_beam_kernel above.
+template <bool CTX>
+__device__ BigEntry big_eval(const BigHyp& H, int nb, int beam, int blank,
+                             const int* tk, const float* lq, int e, const CtxGraph& cg) {
+  BigEntry E;
+  E.valid = 0;
+  E.s = E.ns = E.vs = E.vns = NEG_INF; E.cx = 0.0;
+  E.ts = E.tns_src = E.tns_op = E.tnsp = 0;
+  E.key = E.par = E.token = -1; E.depth = 0; E.seq = 0x7fffffff; E.cs = 0;
+  E.hash = E.parh = 0;
+  if (e < BIGB) {
+    const int r = e;
+    if (r >= nb) return E;
+    const int Klast = H.last[r];
+    E.hash = H.hash[r]; E.parh = H.par_hash[r];
+    int qb = -1, ql = -1, rp = -1;
+    for (int q = 0; q < beam; ++q) {
+      if (tk[q] == blank) qb = q;
+      if (Klast >= 0 && tk[q] == Klast) ql = q;
+    }
+    for (int j = 0; j < nb; ++j)
+      if (H.hash[j] == E.parh) rp = j;
+    if (qb < 0 && ql < 0) return E;
+    E.valid = 1;
+    E.key = H.node[r]; E.par = H.par[r]; E.token = Klast; E.depth = H.depth[r];
+    if (qb >= 0) {
+      const double p = (double)lq[qb];
+      E.s = H.score[r] + p;
+      E.vs = H.vit[r] + p;
+      E.ts = H.tim[r];
+      E.seq = min(E.seq, (qb * nb + r) * 2);
+    }
+    if (ql >= 0) {
+      const double p = (double)lq[ql];
+      const int u = Klast;
+      const double xa = H.ns[r] + p, va = H.vns[r] + p;
+      const int Ktns = H.tns[r];
+      E.tnsp = H.tnsp[r];
+      E.seq = min(E.seq, (ql * nb + r) * 2);
+      double v = NEG_INF, ctp = NEG_INF;
+      int tsrc = 0, top = 0;
+      if (rp < 0) {
+        E.ns = xa;
+        if (v < va) { v = va; tsrc = Ktns; top = 2; }
+      } else {
+        double xb, vb; int tb, sub;
+        if (H.last[rp] == u) { xb = H.s[rp] + p; vb = H.vs[rp] + p; tb = H.ts[rp]; sub = 1; }
+        else { xb = H.score[rp] + p; vb = H.vit[rp] + p; tb = H.tim[rp]; sub = 0; }
+        E.seq = min(E.seq, (ql * nb + rp) * 2 + sub);
+        E.ns = log_add2_fast(xa, xb);
+        if (r < rp) {
+          if (v < va) { v = va; ctp = p; tsrc = Ktns; top = 2; }
+          if (v < vb) { v = vb; ctp = p; tsrc = tb; top = 1; }
+        } else {
+          if (v < vb) { v = vb; ctp = p; tsrc = tb; top = 1; }
+          if (v < va) {
+            v = va;
+            if (ctp < p) { ctp = p; tsrc = Ktns; top = 2; }
+          }
+        }
+      }
+      E.vns = v; E.tns_src = tsrc; E.tns_op = top;
+    }
+    if (CTX) {
+      int first = 0x7fffffff;
+      bool from_parent = false;
+      if (qb >= 0) first = qb * nb + r;
+      if (ql >= 0) {
+        first = min(first, ql * nb + r);
+        if (rp >= 0 && ql * nb + rp < first) from_parent = true;
+      }
+      if (from_parent) E.cx = H.cscore[rp] + ctx_step(cg, H.cstate[rp], Klast, &E.cs);
+      else { E.cx = H.cscore[r]; E.cs = H.cstate[r]; }
+    }
+    return E;
+  }
+  const int x = e - BIGB;
+  const int r = x / beam, q = x - r * beam;
+  if (r >= nb) return E;
+  const int u = tk[q];
+  if (u == blank) return E;
+  const u64 Ph = H.hash[r];
+  const u64 ch = prefix_hash(Ph, u);
+  for (int j = 0; j < nb; ++j)
+    if (H.hash[j] == ch) return E;  // lands on a beam member: that entry owns it
+  const double p = (double)lq[q];
+  double xx, v; int tb, sub;
+  if (u == H.last[r]) { xx = H.s[r] + p; v = H.vs[r] + p; tb = H.ts[r]; sub = 1; }
+  else { xx = H.score[r] + p; v = H.vit[r] + p; tb = H.tim[r]; sub = 0; }
+  E.valid = 1;
+  E.ns = xx;
+  if (v > NEG_INF) { E.vns = v; E.tns_src = tb; E.tns_op = 1; }
+  E.key = -1; E.par = H.node[r]; E.token = u; E.depth = H.depth[r] + 1;
+  E.hash = ch; E.parh = Ph;
+  E.seq = (q * nb + r) * 2 + sub;
+  if (CTX) E.cx = H.cscore[r] + ctx_step(cg, H.cstate[r], u, &E.cs);
+  return E;
+}
+
+struct BigKey { double s; int q; int e; };
+__device__ __forceinline__ bool big_better(const BigKey& a, const BigKey& b) {
+  // does b beat a?  larger score first, then the earlier dict insertion
+  return (b.s > a.s) || (b.s == a.s && b.q < a.q);
+}
+
+template <bool CTX>
+__global__ __launch_bounds__(BIG_THREADS) void prefix_beam_big_kernel(PrefixBeamArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = a.len[b], off = a.off[b];
+  const int beam = a.beam;
+  __shared__ BigHyp hyp[2];
+  __shared__ int tk[BIGB];
+  __shared__ float lq[BIGB];
+  __shared__ double w_s[2][BIG_WAVES];
+  __shared__ int w_q[2][BIG_WAVES], w_e[2][BIG_WAVES];
+
+  const int cap = a.max_len * beam + 1;
+  int* pool = a.pool + (int64_t)b * a.pool_stride;
+  int* n_parent = pool;
+  int* n_token = pool + cap;
+  int* t_prev = pool + 2 * cap;
+  int* t_val = pool + 3 * cap;
+  if (tid == 0) {
+    n_parent[0] = -1; n_token[0] = -1;
+    t_prev[0] = 0; t_val[0] = -1;
+    BigHyp& h = hyp[0];
+    h.hash[0] = ROOT_HASH; h.par_hash[0] = 0;
+    h.node[0] = 0; h.last[0] = -1; h.par[0] = -1; h.depth[0] = 0;
+    h.ts[0] = 0; h.tns[0] = 0; h.tnsp[0] = 0; h.tim[0] = 0;
+    h.s[0] = 0.0; h.ns[0] = NEG_INF; h.vs[0] = 0.0; h.vns[0] = 0.0;
+    h.score[0] = 0.0; h.vit[0] = 0.0;
+    h.cstate[0] = 0; h.cscore[0] = 0.0;
+  }
+  int cur = 0, nb = 1;
+  for (int t = 0; t < T; ++t) {
+    if (tid < beam) {
+      tk[tid] = a.topk_idx[(int64_t)(off + t) * a.k + tid];
+      lq[tid] = a.topk_val[(int64_t)(off + t) * a.k + tid];
+    }
+    __syncthreads();  // top-k of this frame, beam written by the previous frame
+    const BigHyp& H = hyp[cur];
+    const int n_ent = BIGB + nb * beam;
+    double ks[BIG_EPT];
+    int kq[BIG_EPT], kr[BIG_EPT];
+#pragma unroll
+    for (int i = 0; i < BIG_EPT; ++i) {
+      const int e = tid + i * BIG_THREADS;
+      ks[i] = NEG_INF; kq[i] = 0x7fffffff; kr[i] = -1;
+      if (e < n_ent) {
+        const BigEntry E = big_eval<CTX>(H, nb, beam, a.blank, tk, lq, e, a.cg);
+        if (E.valid) {
+          const double sc = log_add2_fast(E.s, E.ns);
+          ks[i] = CTX ? sc + E.cx : sc;   // total_score(), search.py:93-94
+          kq[i] = E.seq;
+        }
+      }
+    }
+    // `beam` rounds of block arg-max; every thread derives the same winner
+    int n_sel = 0;
+    for (int k = 0; k < beam; ++k) {
+      BigKey best; best.s = NEG_INF; best.q = 0x7fffffff; best.e = -1;
+#pragma unroll
+      for (int i = 0; i < BIG_EPT; ++i) {
+        BigKey c; c.s = ks[i]; c.q = kq[i]; c.e = tid + i * BIG_THREADS;
+        if (kq[i] != 0x7fffffff && (best.e < 0 || big_better(best, c))) best = c;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        BigKey c;
+        c.s = __shfl_xor(best.s, o, 64);
+        c.q = __shfl_xor(best.q, o, 64);
+        c.e = __shfl_xor(best.e, o, 64);
+        if (c.e >= 0 && (best.e < 0 || big_better(best, c))) best = c;
+      }
+      if (lane == 0) { w_s[k & 1][wave] = best.s; w_q[k & 1][wave] = best.q; w_e[k & 1][wave] = best.e; }
+      __syncthreads();
+      BigKey win; win.s = NEG_INF; win.q = 0x7fffffff; win.e = -1;
+      for (int w = 0; w < BIG_WAVES; ++w) {
+        BigKey c; c.s = w_s[k & 1][w]; c.q = w_q[k & 1][w]; c.e = w_e[k & 1][w];
+        if (c.e >= 0 && (win.e < 0 || big_better(win, c))) win = c;
+      }
+      if (win.e < 0) break;  // fewer valid entries than the beam (uniform)
+      n_sel = k + 1;
+      if ((win.e % BIG_THREADS) == tid) {
+        const int i = win.e / BIG_THREADS;
+#pragma unroll
+        for (int j = 0; j < BIG_EPT; ++j)
+          if (j == i) { kq[j] = 0x7fffffff; ks[j] = NEG_INF; kr[j] = k; }
+      }
+    }
+    // survivors: evaluate in full, write beam member `rank`
+#pragma unroll
+    for (int i = 0; i < BIG_EPT; ++i) {
+      if (kr[i] < 0) continue;
+      const int rank = kr[i];
+      const BigEntry E = big_eval<CTX>(H, nb, beam, a.blank, tk, lq, tid + i * BIG_THREADS, a.cg);
+      BigHyp& Hn = hyp[cur ^ 1];
+      const int slot = 1 + t * beam + rank;
+      int node = E.key;
+      if (E.key < 0) {
+        node = slot;
+        n_parent[slot] = E.par;
+        n_token[slot] = E.token;
+      }
+      int tns = 0, tnsp = 0;
+      if (E.tns_op == 1) {
+        t_prev[slot] = E.tns_src; t_val[slot] = t; tns = slot; tnsp = E.tns_src;
+      } else if (E.tns_op == 2) {
+        t_prev[slot] = E.tnsp; t_val[slot] = t; tns = slot; tnsp = E.tnsp;
+      }
+      Hn.node[rank] = node; Hn.par[rank] = E.par; Hn.last[rank] = E.token;
+      Hn.depth[rank] = E.depth;
+      Hn.hash[rank] = E.hash; Hn.par_hash[rank] = E.parh;
+      Hn.s[rank] = E.s; Hn.ns[rank] = E.ns; Hn.vs[rank] = E.vs; Hn.vns[rank] = E.vns;
+      Hn.ts[rank] = E.ts; Hn.tns[rank] = tns; Hn.tnsp[rank] = tnsp;
+      Hn.score[rank] = log_add2_fast(E.s, E.ns);
+      Hn.vit[rank] = E.vs > E.vns ? E.vs : E.vns;
+      Hn.tim[rank] = E.vs > E.vns ? E.ts : tns;
+      Hn.cscore[rank] = E.cx; Hn.cstate[rank] = E.cs;
+    }
+    nb = n_sel;
+    cur ^= 1;
+    __syncthreads();  // new beam complete; tk / lq free for the next frame
+  }
+  // ---- emit the n-best list (as prefix_beam_kernel) --------------------------
+  if (tid == 0) a.n_hyps[b] = nb;
+  if (tid < beam) {
+    const int64_t o = (int64_t)b * beam + tid;
+    if (tid < nb) {
+      const BigHyp& h = hyp[cur];
+      const int L = h.depth[tid];
+      a.hyp_lens[o] = L;
+      a.hyp_scores[o] = CTX ? h.score[tid] + (-a.cg.node_score[h.cstate[tid]])
+                            : h.score[tid];
+      int* tkn = a.hyp_tokens + o * a.max_len;
+      int* tm = a.hyp_times + o * a.max_len;
+      int node = h.node[tid];
+      for (int i = L - 1; i >= 0; --i) { tkn[i] = n_token[node]; node = n_parent[node]; }
+      int n_t = 0;
+      for (int y = h.tim[tid]; y != 0; y = t_prev[y]) ++n_t;
+      int y = h.tim[tid];
+      for (int i = n_t - 1; i >= 0; --i) { tm[i] = t_val[y]; y = t_prev[y]; }
+      a.hyp_tlens[o] = n_t;
+    } else {
+      a.hyp_lens[o] = 0;
+      a.hyp_tlens[o] = 0;
+      a.hyp_scores[o] = NEG_INF;
+    }
+  }
+}
+
 }  // namespace
 
 int ctc_logsoftmax_topk(const CtcRowArgs& a, hipStream_t s) {
@@ -708,9 +989,17 @@ int64_t prefix_beam_pool_ints(int max_len, int beam) {
 
 int ctc_prefix_beam(const PrefixBeamArgs& a, hipStream_t s) {
   WN_CHECK(a.B > 0, "prefix beam: empty batch");
-  WN_CHECK(a.beam >= 1 && a.beam <= MAXB,
-           "prefix beam: beam_size must be in [1, 16]");
+  WN_CHECK(a.beam >= 1 && a.beam <= BIGB,
+           "prefix beam: beam_size must be in [1, 64]");
   WN_CHECK(a.k == a.beam, "prefix beam: top-k width must equal the beam");
+  if (a.beam > MAXB) {  // large beams: the general kernel
+    if (a.cg.keys == nullptr)
+      hipLaunchKernelGGL((prefix_beam_big_kernel<false>), dim3(a.B), dim3(BIG_THREADS), 0, s, a);
+    else
+      hipLaunchKernelGGL((prefix_beam_big_kernel<true>), dim3(a.B), dim3(BIG_THREADS), 0, s, a);
+    WN_HIP(hipGetLastError());
+    return 0;
+  }
   static_assert(64 + MAXB * MAXB <= PB_THREADS, "one thread per entry");
   static_assert(PB_CHUNK * MAXB <= PB_THREADS, "one thread per staged top-k pair");
   const bool small = MAXB + a.beam * a.beam <= 128;
