@@ -63,6 +63,8 @@ typedef struct {
                                 1: conv1d2 (Conv1dSubsampling2, subsampling.py:117-171) */
   int32_t activation;        /* FFN activation: 0 swish/SiLU, 1 gelu (exact erf) */
   int32_t key_bias;          /* attention linear_k has a bias (Whisper: 0) */
+  int32_t cnn_norm;          /* conv-module norm: 0 layer_norm, 1 batch_norm (eval:
+                                running statistics; convolution.py:77-81) */
 } wn_config;
 
 /* One entry of the reference state_dict (fp32, host memory, C-contiguous). */

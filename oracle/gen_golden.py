@@ -47,6 +47,12 @@ CASES = [
     dict(case='librispeech_full', config='librispeech_bidecoder_large',
          wseed=0, batch=2, frames=(260, 330), fseed=11, beam=10, chunk=-1,
          left=-1, ctc_weight=0.5, reverse_weight=0.3),
+    dict(case='tiny_bn_full', config='tiny_bn', wseed=0, batch=4,
+         frames=(50, 180), fseed=13, beam=5, chunk=-1, left=-1, ctc_weight=0.5,
+         reverse_weight=0.0),
+    dict(case='aishell_conformer_full', config='aishell_conformer', wseed=0,
+         batch=2, frames=(200, 300), fseed=14, beam=10, chunk=-1, left=-1,
+         ctc_weight=0.5, reverse_weight=0.0),
     dict(case='wenetspeech_chunk16', config='wenetspeech_u2pp', wseed=0,
          batch=2, frames=(260, 330), fseed=12, beam=10, chunk=16, left=-1,
          ctc_weight=0.5, reverse_weight=0.3),

@@ -426,9 +426,25 @@ def mha(query, key, value, mask, sd, pfx, h):
     return _forward_attention(v, scores, mask, sd, pfx, h, d_k)
 
 
+def _conv_norm(x, sd, pfx, activation):
+    """The norm + activation in the middle of the conv module
+    (convolution.py:139-143) on x (B, C, T): LayerNorm over channels
+    (cnn_module_norm 'layer_norm') or eval-mode BatchNorm1d with its running
+    statistics ('batch_norm', the default; recognised by its buffers)."""
+    c = x.size(1)
+    if pfx + 'norm.running_mean' in sd:
+        return activation(F.batch_norm(x, sd[pfx + 'norm.running_mean'],
+                                       sd[pfx + 'norm.running_var'],
+                                       sd[pfx + 'norm.weight'], sd[pfx + 'norm.bias'],
+                                       False, 0.0, 1e-5))
+    y = F.layer_norm(x.transpose(1, 2), (c, ), sd[pfx + 'norm.weight'],
+                     sd[pfx + 'norm.bias'], 1e-5)
+    return activation(y).transpose(1, 2)
+
+
 def conv_module(x, mask_pad, sd, pfx, kernel_size, causal, activation):
     """ConvolutionModule.forward, wenet/models/transformer/convolution.py:98-153
-    with cnn_module_norm='layer_norm' and no streaming cache."""
+    without a streaming cache."""
     x = x.transpose(1, 2)
     if mask_pad.size(2) > 0:
         x = x.masked_fill(~mask_pad, 0.0)
@@ -442,10 +458,7 @@ def conv_module(x, mask_pad, sd, pfx, kernel_size, causal, activation):
     x = F.conv1d(x, sd[pfx + 'depthwise_conv.weight'],
                  sd[pfx + 'depthwise_conv.bias'],
                  padding=0 if causal else (kernel_size - 1) // 2, groups=c)
-    x = x.transpose(1, 2)
-    x = activation(F.layer_norm(x, (c, ), sd[pfx + 'norm.weight'],
-                                sd[pfx + 'norm.bias'], 1e-5))
-    x = x.transpose(1, 2)
+    x = _conv_norm(x, sd, pfx, activation)
     x = F.conv1d(x, sd[pfx + 'pointwise_conv2.weight'],
                  sd[pfx + 'pointwise_conv2.bias'])
     if mask_pad.size(2) > 0:
@@ -607,8 +620,7 @@ def conv_module_cached(x, sd, pfx, kernel_size, causal, activation, cache):
     x = F.conv1d(x, sd[pfx + 'depthwise_conv.weight'],
                  sd[pfx + 'depthwise_conv.bias'],
                  padding=0 if causal else (kernel_size - 1) // 2, groups=c)
-    x = activation(F.layer_norm(x.transpose(1, 2), (c, ), sd[pfx + 'norm.weight'],
-                                sd[pfx + 'norm.bias'], 1e-5)).transpose(1, 2)
+    x = _conv_norm(x, sd, pfx, activation)
     x = F.conv1d(x, sd[pfx + 'pointwise_conv2.weight'],
                  sd[pfx + 'pointwise_conv2.bias'])
     return x.transpose(1, 2), new_cache

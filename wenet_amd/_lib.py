@@ -19,7 +19,7 @@ class WnConfig(Structure):
         'has_cmvn', 'dec_heads', 'dec_ffn_dim', 'dec_layers', 'dec_r_layers',
         'bidirectional', 'sos', 'eos', 'max_pos')] + [('norm_eps', c_float)] + [
             (n, c_int32) for n in ('encoder_type', 'input_layer', 'activation',
-                                   'key_bias')]
+                                   'key_bias', 'cnn_norm')]
 
 
 class WnTensor(Structure):

@@ -181,7 +181,15 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs a) {
       for (int e = 0; e < E; ++e) acc.v[e] = fmaf(wk.v[e], cp.v[e], acc.v[e]);
     }
   }
-  ln_inplace<E>(acc, a.ln_w, a.ln_b, lane, a.eps);
+  if (a.norm_mode == 0) {
+    ln_inplace<E>(acc, a.ln_w, a.ln_b, lane, a.eps);
+  } else {
+    RowRegs<E> sc, sh;
+    sc.load(a.ln_w, lane);
+    sh.load(a.ln_b, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc.v[e] = fmaf(acc.v[e], sc.v[e], sh.v[e]);
+  }
 #pragma unroll
   for (int e = 0; e < E; ++e) acc.v[e] = silu_f(acc.v[e]);
   acc.store(a.y + (int64_t)row * a.ldy, lane);

@@ -37,6 +37,8 @@ struct DwConvArgs {
   const float* bias;    // [D]
   const float* cpad;    // [D] value of a padded (masked / left-pad) frame
   const float* ln_w; const float* ln_b;
+  int norm_mode = 0;    // 0: LayerNorm over channels (ln_w, ln_b); 1: per-channel
+                        // affine y = x * ln_w + ln_b (eval-mode BatchNorm1d)
   float* y; int ldy;
   const int* row_utt;   // [M] utterance of each row (-1: skip)
   const int* off;       // [B] first row of utterance

@@ -464,7 +464,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     WN_TRY(linear(L.pw1, t1, d, t2, d, M, s, ACT_NONE, nullptr, 0, 1.0f, true));
     DwConvArgs dw;
     dw.x = t2; dw.ldx = d; dw.wt = L.dw_wt; dw.bias = L.dw_b; dw.cpad = L.cpad;
-    dw.ln_w = L.conv_norm.w; dw.ln_b = L.conv_norm.b;
+    dw.ln_w = L.conv_norm.w; dw.ln_b = L.conv_norm.b; dw.norm_mode = c.cnn_norm;
     dw.y = t1; dw.ldy = d;
     dw.row_utt = m->d_row_utt.as<int>(); dw.off = m->d_off.as<int>();
     dw.len = m->d_len.as<int>();
@@ -562,7 +562,7 @@ int encoder_layers_chunk(wn_model* m, int R, int offset, int t1c, int next_start
     WN_TRY(linear(L.pw1, conv_in, d, glu, d, LR, s, ACT_NONE, nullptr, 0, 1.0f, true));
     DwConvArgs dw;
     dw.x = glu; dw.ldx = d; dw.wt = L.dw_wt; dw.bias = L.dw_b; dw.cpad = L.cpad;
-    dw.ln_w = L.conv_norm.w; dw.ln_b = L.conv_norm.b;
+    dw.ln_w = L.conv_norm.w; dw.ln_b = L.conv_norm.b; dw.norm_mode = c.cnn_norm;
     dw.y = xext; dw.ldy = d;
     dw.row_utt = m->ck_rowutt.as<int>(); dw.off = dd; dw.len = dd + 3;
     dw.M = LR; dw.D = d; dw.K = c.cnn_kernel; dw.causal = c.causal;
@@ -1014,8 +1014,28 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
   for (int i = 0; !tf && i < c.n_layers; ++i) {
     const std::string p = "encoder.encoders." + std::to_string(i);
     for (const char* n : {"norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff",
-                          "norm_final", "conv_module.norm"})
+                          "norm_final"})
       WN_TRY(stage_norm(src, hs, p + "." + n, d));
+    if (c.cnn_norm == 0) {
+      WN_TRY(stage_norm(src, hs, p + ".conv_module.norm", d));
+    } else {
+      // eval-mode BatchNorm1d (convolution.py:77-81,139-143) as a per-channel
+      // affine: y = x * scale + shift, scale = w / sqrt(running_var + eps),
+      // shift = b - running_mean * scale; staged in the norm's weight / bias slots
+      const std::string q = p + ".conv_module.norm";
+      WN_GET(bw, q + ".weight", d);
+      WN_GET(bb, q + ".bias", d);
+      WN_GET(bm, q + ".running_mean", d);
+      WN_GET(bv, q + ".running_var", d);
+      std::vector<float> sc(d), sh(d);
+      for (int ch = 0; ch < d; ++ch) {
+        const float inv = 1.0f / sqrtf(bv[ch] + c.norm_eps);
+        sc[ch] = bw[ch] * inv;
+        sh[ch] = bb[ch] - bm[ch] * sc[ch];
+      }
+      hs.add(q + ".weight", sc.data(), sc.size());
+      hs.add(q + ".bias", sh.data(), sh.size());
+    }
     for (const char* ff : {"feed_forward_macaron", "feed_forward"}) {
       WN_TRY(stage_linear(src, hs, p + "." + ff + ".w_1", F, d));
       WN_TRY(stage_linear(src, hs, p + "." + ff + ".w_2", d, F));

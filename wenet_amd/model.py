@@ -39,7 +39,7 @@ def config_from_yaml(configs: dict) -> _lib.WnConfig:
     if enc_type == 'conformer':
         checks = dict(input_layer='conv2d', pos_enc_layer_type='rel_pos',
                       selfattention_layer_type='rel_selfattn',
-                      activation_type='swish', cnn_module_norm='layer_norm',
+                      activation_type='swish',
                       normalize_before=True, use_cnn_module=True,
                       macaron_style=True)
         defaults = dict(input_layer='conv2d', pos_enc_layer_type='rel_pos',
@@ -99,6 +99,11 @@ def config_from_yaml(configs: dict) -> _lib.WnConfig:
     c.input_layer = 1 if ec.get('input_layer') == 'conv1d2' else 0
     c.activation = 1 if ec.get('activation_type', 'swish') == 'gelu' else 0
     c.key_bias = int(bool(ec.get('key_bias', True)))
+    cnn_norm = ec.get('cnn_module_norm', 'batch_norm')  # encoder.py default
+    if enc_type == 'conformer' and cnn_norm not in ('layer_norm', 'batch_norm'):
+        raise NotImplementedError(
+            f'encoder_conf.cnn_module_norm={cnn_norm!r} is outside the accelerated path')
+    c.cnn_norm = 1 if (enc_type == 'conformer' and cnn_norm == 'batch_norm') else 0
     if enc_type == 'transformer':
         c.cnn_kernel, c.causal = 1, 0
         # the Whisper decoder (learnable positions, tied embedding) is not on

@@ -183,6 +183,48 @@ CONFIGS = {
         'model_conf': dict(ctc_weight=0.3, lsm_weight=0.1,
                            length_normalized_loss=False),
     },
+    # examples/aishell/s0/conf/train_conformer.yaml:1-35: the offline recipe --
+    # symmetric conv (kernel 15), cnn_module_norm left at its default
+    # 'batch_norm', left-to-right decoder
+    'aishell_conformer': {
+        'input_dim': 80, 'output_dim': 4233,
+        'encoder': 'conformer',
+        'encoder_conf': dict(output_size=256, attention_heads=4,
+                             linear_units=2048, num_blocks=12, dropout_rate=0.1,
+                             positional_dropout_rate=0.1,
+                             attention_dropout_rate=0.0, input_layer='conv2d',
+                             normalize_before=True, cnn_module_kernel=15,
+                             use_cnn_module=True, activation_type='swish',
+                             pos_enc_layer_type='rel_pos',
+                             selfattention_layer_type='rel_selfattn'),
+        'decoder': 'transformer',
+        'decoder_conf': dict(attention_heads=4, linear_units=2048, num_blocks=6,
+                             dropout_rate=0.1, positional_dropout_rate=0.1,
+                             self_attention_dropout_rate=0.0,
+                             src_attention_dropout_rate=0.0),
+        'model_conf': dict(ctc_weight=0.3, lsm_weight=0.1,
+                           length_normalized_loss=False),
+    },
+    # miniature of it (batch_norm in the conv module)
+    'tiny_bn': {
+        'input_dim': 80, 'output_dim': 89,
+        'encoder': 'conformer',
+        'encoder_conf': dict(output_size=128, attention_heads=2,
+                             linear_units=160, num_blocks=2, dropout_rate=0.1,
+                             positional_dropout_rate=0.1,
+                             attention_dropout_rate=0.0, input_layer='conv2d',
+                             normalize_before=True, cnn_module_kernel=15,
+                             use_cnn_module=True, activation_type='swish',
+                             pos_enc_layer_type='rel_pos',
+                             selfattention_layer_type='rel_selfattn'),
+        'decoder': 'transformer',
+        'decoder_conf': dict(attention_heads=2, linear_units=128, num_blocks=2,
+                             dropout_rate=0.1, positional_dropout_rate=0.1,
+                             self_attention_dropout_rate=0.0,
+                             src_attention_dropout_rate=0.0),
+        'model_conf': dict(ctc_weight=0.3, lsm_weight=0.1,
+                           length_normalized_loss=False),
+    },
     # miniature of the offline recipe (symmetric conv, full attention,
     # left-to-right decoder only)
     'tiny_sym': {
@@ -329,6 +371,13 @@ def make_state_dict(configs: dict, seed: int = 0,
         sd[p + '.conv_module.depthwise_conv.bias'] = _uniform(
             seed, p + '.dw.b', (d, ), b)
         norm(p + '.conv_module.norm', d)
+        if ec.get('cnn_module_norm', 'batch_norm') == 'batch_norm':
+            # BatchNorm1d buffers (eval mode uses the running statistics)
+            sd[p + '.conv_module.norm.running_mean'] = _normal(
+                seed, p + '.bn.mean', (d, ), 0.3)
+            sd[p + '.conv_module.norm.running_var'] = (
+                0.5 + np.abs(_normal(seed, p + '.bn.var', (d, ), 0.5))).astype(np.float32)
+            sd[p + '.conv_module.norm.num_batches_tracked'] = np.asarray(1000, np.int64)
         b = 1.0 / math.sqrt(d)
         sd[p + '.conv_module.pointwise_conv2.weight'] = _uniform(
             seed, p + '.pw2.w', (d, d, 1), b)
