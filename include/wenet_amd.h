@@ -239,6 +239,18 @@ int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host
                            float reverse_weight, float* l2r_logp_host,
                            float* r2l_logp_host, void* stream);
 
+/* The decoder half of ASRModel.forward_attention_decoder (asr_model.py:453-547):
+ * one decoder (`which` 0: decoder / left_decoder, 1: right_decoder,
+ * decoder.py:146-201,430-463) over a PADDED batch of n_seq token rows for
+ * utterance `utt` of the current batch -> log_softmax over the vocabulary of
+ * every position, logp_dev (n_seq, max_len, vocab) on the device.  tokens_host
+ * (n_seq, max_len) are the decoder inputs ([sos] + hyp, eos-padded); lens_host
+ * the input lengths: keys past a row's length are masked, padded rows are
+ * computed like the reference computes them. */
+int wn_decoder_forward(wn_model* m, int32_t utt, int32_t which, int32_t n_seq,
+                       const int32_t* tokens_host, const int32_t* lens_host,
+                       int32_t max_len, float* logp_dev, void* stream);
+
 /* One step of attention_beam_search (search.py:252-371): for every running
  * hypothesis (its utterance index in the current batch, its tokens so far
  * starting with <sos>), log_softmax(output_layer(after_norm(decoder(...)[:, -1])))

@@ -899,3 +899,31 @@ def test_large_beam_through_decode_and_rescoring():
             assert abs(r.score - oref[b].score) < 1e-3 * (len(r.tokens) + 1)
     assert sum(list(got['attention_rescoring'][b].tokens) == list(oref[b].tokens)
                for b in range(3)) >= 2
+
+
+@pytest.mark.parametrize('config,rw', [('tiny_causal', 0.0), ('tiny_causal', 0.4),
+                                       ('tiny_sym', 0.3), ('tiny_bn', 0.0)])
+def test_forward_attention_decoder_vs_oracle(config, rw):
+    """ASRModel.forward_attention_decoder (asr_model.py:453-547): padded (N, L, V)
+    log-softmax outputs of the left and right decoders, every position."""
+    O = _oracle()
+    configs, sd, model = cached_model(config, 0)
+    sos, eos = O.special_symbols(configs)
+    g = torch.Generator().manual_seed(21)
+    V = configs['output_dim']
+    lens = torch.tensor([9, 4, 1, 6, 9])
+    hyps = torch.full((5, 9), eos, dtype=torch.long)
+    for i, n in enumerate(lens.tolist()):
+        hyps[i, 0] = sos
+        hyps[i, 1:n] = torch.randint(1, V - 1, (n - 1, ), generator=g)
+    enc = torch.randn(1, 31, configs['encoder_conf']['output_size'], generator=g)
+    got_l, got_r = model.forward_attention_decoder(hyps, lens, enc.cuda(), rw)
+    ref_l, ref_r = O.forward_attention_decoder(configs, sd, hyps, lens, enc, rw, sos, eos)
+    assert tuple(got_l.shape) == tuple(ref_l.shape)
+    assert (got_l.cpu() - ref_l).abs().max() < 2e-3
+    assert tuple(got_r.shape) == tuple(ref_r.shape)
+    assert (got_r.cpu() - ref_r).abs().max() < 2e-3
+    if rw > 0 and configs['decoder'] == 'bitransformer':
+        assert got_r.dim() == 3
+    else:
+        assert got_r.dim() == 0 and float(got_r) == 0.0

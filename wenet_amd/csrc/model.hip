@@ -1666,7 +1666,8 @@ namespace {
 // K/V projections of the encoder output are computed once per batch and layer
 // and reused by later calls (the autoregressive search calls this per step).
 int decoder_layers(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
-                   const int* d_tok, bool mem_cache, hipStream_t s) {
+                   const int* d_tok, bool mem_cache, hipStream_t s,
+                   const int* self_kvlen = nullptr) {
   const wn_config& c = m->cfg;
   const int d = c.d_model, Menc = m->rows;
   float* x = m->r_x.as<float>();
@@ -1693,6 +1694,10 @@ int decoder_layers(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
     a.O = t2; a.ldo = d;
     a.q_off = a.kv_off = m->r_qoff.as<int>();
     a.q_len = a.kv_len = m->r_qlen.as<int>();
+    // padded batches (wn_decoder_forward): keys past the sequence length are
+    // masked for every query, padded query rows included (mask.py make_pad_mask
+    // & subsequent_mask, decoder.py:171-177)
+    if (self_kvlen) a.kv_len = self_kvlen;
     a.n_seq = n_seq; a.n_heads = c.dec_heads; a.max_q_len = max_q;
     a.mask_mode = 1; a.scale = 0.125f;
     WN_TRY(attention(a, s));
@@ -1809,6 +1814,68 @@ int wn_decoder_next_topk(wn_model* m, int32_t n_seq, const int32_t* seq_utt_host
                         hipMemcpyDeviceToHost, s));
   WN_HIP(hipStreamSynchronize(s));
   return 0;
+}
+
+int wn_decoder_forward(wn_model* m, int32_t utt, int32_t which, int32_t n_seq,
+                       const int32_t* tokens_host, const int32_t* lens_host,
+                       int32_t max_len, float* logp_dev, void* stream) {
+  WN_CHECK(m && m->B > 0 && m->enc.p, "decoder forward: no current batch");
+  WN_CHECK(tokens_host && lens_host && logp_dev, "decoder forward: null argument");
+  WN_CHECK(utt >= 0 && utt < m->B && m->len[utt] > 0,
+           "decoder forward: utterance index / no encoder frames");
+  WN_CHECK(which == 0 || which == 1, "decoder forward: which must be 0 (left) or 1 (right)");
+  const Decoder& D = which == 0 ? m->left : m->right;
+  WN_CHECK(!D.layers.empty(), "decoder forward: the model has no such decoder");
+  WN_CHECK(n_seq > 0 && max_len > 0 && max_len <= m->cfg.max_pos,
+           "decoder forward: bad batch shape");
+  hipStream_t s = (hipStream_t)stream;
+  WN_HIP(hipSetDevice(m->device));
+  const wn_config& c = m->cfg;
+  const int d = c.d_model, V = c.vocab;
+  const int R = n_seq * max_len;
+  std::vector<int> tok(R), pos(R), qoff(n_seq), qlen(n_seq), kvoff(n_seq), kvlen(n_seq),
+      slen(n_seq);
+  for (int i = 0; i < n_seq; ++i) {
+    WN_CHECK(lens_host[i] >= 1 && lens_host[i] <= max_len, "decoder forward: length");
+    qoff[i] = i * max_len; qlen[i] = max_len; slen[i] = lens_host[i];
+    kvoff[i] = m->off[utt]; kvlen[i] = m->len[utt];
+    for (int j = 0; j < max_len; ++j) {
+      const int t = tokens_host[(size_t)i * max_len + j];
+      WN_CHECK(t >= 0 && t < V, "decoder forward: token id out of range");
+      tok[(size_t)i * max_len + j] = t;
+      pos[(size_t)i * max_len + j] = j;
+    }
+  }
+  WN_TRY(m->stage.begin((size_t)(2 * R + 5 * n_seq + 64) * sizeof(int) + 4096));
+  WN_TRY(upload_desc(m, m->r_tok, tok, s));
+  WN_TRY(upload_desc(m, m->r_pos, pos, s));
+  WN_TRY(upload_desc(m, m->r_qoff, qoff, s));
+  WN_TRY(upload_desc(m, m->r_qlen, qlen, s));
+  WN_TRY(upload_desc(m, m->r_kvoff, kvoff, s));
+  WN_TRY(upload_desc(m, m->r_kvlen, kvlen, s));
+  WN_TRY(upload_desc(m, m->r_tgt, slen, s));  // self-attention key lengths
+  WN_TRY(m->stage.end(s));
+  WN_TRY(m->r_x.ensure((size_t)R * d * sizeof(float)));
+  WN_TRY(m->r_t1.ensure((size_t)R * d * sizeof(float)));
+  WN_TRY(m->r_t2.ensure((size_t)R * d * sizeof(float)));
+  WN_TRY(m->r_qkv.ensure((size_t)R * 3 * d * sizeof(float)));
+  WN_TRY(m->r_h.ensure((size_t)R * c.dec_ffn_dim * sizeof(float)));
+  WN_TRY(m->r_mem.ensure((size_t)m->rows * 2 * d * sizeof(float)));
+  WN_TRY(m->r_logits.ensure((size_t)R * V * sizeof(float)));
+  WN_TRY(m->r_out.ensure((size_t)2 * R * sizeof(float)));
+  WN_TRY(decoder_layers(m, D, R, n_seq, max_len, m->r_tok.as<int>(), false, s,
+                        m->r_tgt.as<int>()));
+  float* t1 = m->r_t1.as<float>();
+  WN_TRY(ln(D.after, m->r_x.as<float>(), t1, R, d, c.norm_eps, s));
+  WN_TRY(linear(D.out, t1, d, m->r_logits.as<float>(), V, R, s));
+  // log_softmax over the vocabulary of every row (asr_model.py:543-546)
+  CtcRowArgs a;
+  a.logits = m->r_logits.as<float>(); a.ld = V; a.M = R; a.V = V; a.k = 1;
+  a.blank = 0; a.blank_penalty = 0.f;
+  a.topk_val = m->r_out.as<float>();
+  a.topk_idx = reinterpret_cast<int*>(m->r_out.as<float>() + R);
+  a.logp = logp_dev; a.ld_out = V;
+  return ctc_logsoftmax_topk(a, s);
 }
 
 int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host,

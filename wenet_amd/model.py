@@ -437,6 +437,53 @@ class ASRModel:
             'wn_ctc_logprobs')
         return out
 
+    def _decoder_forward(self, which: int, tokens: torch.Tensor, lens: torch.Tensor
+                         ) -> torch.Tensor:
+        tok = np.ascontiguousarray(tokens.detach().cpu().numpy().astype(np.int32))
+        ln = np.ascontiguousarray(torch.as_tensor(lens).detach().cpu().numpy()
+                                  .astype(np.int32))
+        n, L = tok.shape
+        out = torch.empty((n, L, self.vocab_size), dtype=torch.float32,
+                          device=self.device)
+        _lib.check(
+            self._L.wn_decoder_forward(self._h, 0, which, n, _lib.i32p(tok),
+                                       _lib.i32p(ln), L, out.data_ptr(),
+                                       _stream_ptr(self.device)),
+            'wn_decoder_forward')
+        return out
+
+    def forward_attention_decoder(self, hyps: torch.Tensor, hyps_lens: torch.Tensor,
+                                  encoder_out: torch.Tensor,
+                                  reverse_weight: float = 0
+                                  ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """asr_model.py:453-547: hyps (N, L) decoder inputs that already start
+        with sos (eos-padded), hyps_lens (N,), encoder_out (1, T', d) ->
+        (decoder_out, r_decoder_out), log-softmax over the vocabulary,
+        (N, L, V) on the device; r_decoder_out is the scalar 0 the reference
+        returns when the right-to-left decoder is not used."""
+        assert encoder_out.size(0) == 1
+        if self._cfg.dec_layers <= 0:
+            raise RuntimeError('the model has no attention decoder on the accelerated path')
+        self._set_encoder_out(encoder_out, [encoder_out.size(1)])
+        hyps_c = hyps.detach().cpu().long()
+        lens_c = torch.as_tensor(hyps_lens).detach().cpu().long()
+        decoder_out = self._decoder_forward(0, hyps_c, lens_c)
+        if reverse_weight > 0 and self.is_bidirectional_decoder():
+            # the reference's index arithmetic, asr_model.py:487-536
+            r_lens = lens_c - 1
+            r_hyps = hyps_c[:, 1:]
+            max_len = int(r_lens.max())
+            idx_range = torch.arange(0, max_len)
+            seq_mask = r_lens.unsqueeze(1) > idx_range
+            index = ((r_lens.unsqueeze(1) - 1) - idx_range) * seq_mask
+            r_hyps = torch.gather(r_hyps, 1, index)
+            r_hyps = torch.where(seq_mask, r_hyps, torch.tensor(self.eos))
+            r_hyps = torch.cat([hyps_c[:, 0:1], r_hyps], dim=1)
+            r_decoder_out = self._decoder_forward(1, r_hyps, lens_c)
+        else:
+            r_decoder_out = torch.tensor(0.0)
+        return decoder_out, r_decoder_out
+
     def _rescore(self, ctc_prefix_results: List[DecodeResult],
                  ctc_weight: float, reverse_weight: float):
         B = len(ctc_prefix_results)
