@@ -318,6 +318,18 @@ def main():
                 'traffic': None,
             },
         }
+        # HBM traffic of that kernel from the PMC passes (tools/gpu_pmc.sh; cannot
+        # be collected inside a timed run): bytes per launch, committed summary
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                           'pmc_roofline_kernel.json')
+        if wl is WORKLOADS.get('config2') and os.path.exists(pmc):
+            with open(pmc) as f:
+                rec = json.load(f)
+            line['roofline']['traffic'] = rec['hbm_bytes_per_launch']
+            line['roofline']['traffic_unit'] = 'bytes/launch (HBM read + write, PMC)'
+            line['roofline']['traffic_source'] = 'profiles/pmc_roofline_kernel.json'
+            line['roofline']['algorithmic_bytes'] = int(
+                4 * (enc_rows * d_model + ffn * d_model + enc_rows * ffn))
         if world == 1 and not whisper:
             line['end_to_end'] = end_to_end_leg(model, lens, device, total_audio,
                                                 ms_per_step)

@@ -9,9 +9,13 @@ the read column is the raw counter x 2 x 1024 and says so."""
 import collections
 import csv
 import glob
+import json
 import os
 import sqlite3
 import sys
+
+# the roofline kernel of bench.py: FFN w_1 GEMM (128x128 tile, 2x4 waves, SiLU)
+ROOFLINE_KERNEL = 'gemm_f32_kernel<128, 128, 2, 4, 1, false, false, false, 32, 1>'
 
 
 def load(dirname):
@@ -52,6 +56,19 @@ def main():
     for k, n, avg, tot, util, rd, wr, gbs in rows:
         print(f'| `{k[:110]}` | {n} | {avg:.1f} | {util:.3f} | {rd / 1e6:.1f} | '
               f'{wr / 1e6:.1f} | {gbs:.0f} |')
+    # machine-readable record of the roofline kernel: bench.py reports it as
+    # roofline.traffic (copy it to profiles/pmc_roofline_kernel.json)
+    for k, n, avg, tot, util, rd, wr, gbs in rows:
+        if ROOFLINE_KERNEL in k and rd == rd and wr == wr:
+            rec = dict(kernel=ROOFLINE_KERNEL, launches=n, avg_us=round(avg, 2),
+                       mfma_busy=round(util, 4), hbm_read_bytes_per_launch=int(rd),
+                       hbm_write_bytes_per_launch=int(wr),
+                       hbm_bytes_per_launch=int(rd + wr),
+                       method='rocprofv3 --pmc, separate passes for FETCH_SIZE and '
+                              'WRITE_SIZE (KiB; FETCH_SIZE x2 on gfx950), --streams 1')
+            with open(os.path.join(out, 'pmc_roofline_kernel.json'), 'w') as f:
+                json.dump(rec, f, indent=1)
+            break
 
 
 if __name__ == '__main__':
