@@ -30,7 +30,10 @@ import sys
 import time
 
 import numpy as np
-import torch
+# dmabuf IPC only on these hosts: RCCL needs this before the runtime starts
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -239,6 +239,8 @@ def main(argv=None):
     args = get_args(argv)
     logging.basicConfig(level=logging.INFO,
                         format='%(asctime)s %(levelname)s %(message)s')
+    # dmabuf IPC only on these hosts: RCCL needs this before the runtime starts
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch
     import yaml
     from wenet_amd.model import ASRModel
