@@ -927,3 +927,45 @@ def test_forward_attention_decoder_vs_oracle(config, rw):
         assert got_r.dim() == 3
     else:
         assert got_r.dim() == 0 and float(got_r) == 0.0
+
+
+# --------------------------------------------------------------------------
+# attention with the key range split over two wave groups (attn_split)
+
+
+@pytest.mark.parametrize('config,B,frames,chunk,left', [
+    ('tiny_causal', 7, (30, 700), -1, -1),
+    ('tiny_causal', 5, (30, 600), 8, 1),
+    ('tiny_causal', 4, (27, 400), 3, 0),
+    ('tiny_sym', 6, (7, 500), -1, -1),
+    ('tiny_bn', 3, (64, 333), -1, -1),
+    ('aishell_u2pp', 3, (500, 1100), 16, -1),
+])
+def test_attention_key_split_vs_oracle(config, B, frames, chunk, left):
+    """The key-split attention kernel forced on (attn_split = 2) for short and
+    long, ragged sequences, full / chunk / limited-left-context masks, and off
+    (attn_split = 1): both against the oracle's encoder output."""
+    from wenet_amd import _lib, synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=123)
+    with torch.no_grad():
+        ref, mask = O.encoder_forward(configs, sd, feats, lens, chunk, left)
+    ref_lens = mask.squeeze(1).sum(1).numpy()
+    L = _lib.lib()
+    outs = {}
+    try:
+        for mode in (2, 1):
+            _lib.check(L.wn_tune_set(b'attn_split', mode), 'tune')
+            enc, m = model._forward_encoder(feats.cuda(), lens, chunk, left)
+            outs[mode] = enc.cpu()
+            np.testing.assert_array_equal(m.squeeze(1).sum(1).cpu().numpy(), ref_lens)
+            for b in range(B):
+                nb = int(ref_lens[b])
+                if nb:
+                    err = (outs[mode][b, :nb] - ref[b, :nb]).abs().max().item()
+                    assert err < 2e-3, (config, 'attn_split', mode, 'utt', b, err)
+    finally:
+        L.wn_tune_set(b'attn_split', 0)
+    # the two kernels agree with each other far inside the oracle tolerance
+    assert (outs[1] - outs[2]).abs().max() < 5e-4

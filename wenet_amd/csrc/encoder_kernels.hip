@@ -228,18 +228,31 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs a) {
 constexpr int KT = 32;          // keys per tile
 constexpr int KSTR = 68;        // LDS row stride (floats): 64 + 4 pad
 
-template <int NW, bool RELPOS>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
+// KS = 2 ("key split"): the block has NW * 2 waves; waves [0, NW) take the first
+// half of the block's key tiles, waves [NW, 2 NW) the second half, for the SAME
+// NW * 32 queries, and the two partial (max, sum, O) states are merged through
+// LDS at the end.  Twice the waves per SIMD for the same staging traffic: with
+// one 32-query task per SIMD (config 2: 1062 tasks on 1024 SIMDs) every LDS /
+// MFMA latency of the dependent chain was exposed.  The LDS budget stays 52 KB
+// per block: one buffer per half instead of two buffers (two barriers per
+// iteration; the other resident waves cover them).
+template <int NW, bool RELPOS, int KS>
+__global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 2 : 1) void attention_kernel(AttnArgs a) {
   const int s = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (NW * 32);
   const int qlen = a.q_len[s];
   if (q0 >= qlen) return;
   const int kvlen = a.kv_len[s];
   const int qoff = a.q_off[s], kvoff = a.kv_off[s];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform
+  const int wave = wave_all % NW;   // query group
+  const int kh = wave_all / NW;     // key half (0 when KS == 1)
   const int hi = lane >> 5, li = lane & 31;
+  constexpr int NTHR = NW * KS * 64;
 
-  // double-buffered K / V / P tiles: [buf][matrix][KT * KSTR]
+  // K / V / P tiles: KS == 1: [2 buffers][matrix][KT * KSTR], double buffered;
+  //                  KS == 2: [2 halves][matrix][KT * KSTR], single buffered
   constexpr int NMAT = RELPOS ? 3 : 2;
   constexpr int MAT = KT * KSTR;
   __shared__ __attribute__((aligned(16))) float stile[2 * NMAT * MAT];
@@ -287,23 +300,27 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
     }
   }
   const int t_lo = blo / KT, t_hi = (bhi + KT - 1) / KT;
+  // iterations of the tile loop; half kh works on tile t_lo + kh * n_it + it
+  const int n_it = KS == 1 ? (t_hi - t_lo) : (t_hi - t_lo + 1) / 2;
 
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
 
-  // ---- tile staging: global -> registers (issued a whole tile ahead, so the
-  // HBM / L2 latency hides under the previous tile's MFMAs) -> LDS.
-  constexpr int NCH = KT * 16 / (NW * 64);  // float4 chunks per thread and matrix
+  // ---- tile staging: global -> registers (issued a whole iteration ahead, so
+  // the HBM / L2 latency hides under the MFMAs) -> LDS.  With KS == 2 one
+  // staging step moves the tiles of BOTH halves.
+  constexpr int NCH = KT * 16 * KS / NTHR;  // float4 chunks per thread and matrix
   f32x4 rK[NCH], rV[NCH], rP[RELPOS ? NCH : 1];
-  auto gload = [&](int kt) {
-    const int j0 = kt * KT;
+  auto gload = [&](int it) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * (NW * 64);
-      const int r = c >> 4, c4 = c & 15;
-      int j = j0 + r;
+      const int c = tid + i * NTHR;
+      const int half = KS == 1 ? 0 : c / (KT * 16);
+      const int w = c % (KT * 16);
+      const int r = w >> 4, c4 = w & 15;
+      int j = (t_lo + half * n_it + it) * KT + r;
       if (j > kvlen - 1) j = kvlen - 1;
       const int64_t grow = kvoff + j;
       rK[i] = *reinterpret_cast<const f32x4*>(a.K + grow * a.ldk + h * 64 + c4 * 4);
@@ -313,32 +330,40 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
                                                 c4 * 4);
     }
   };
-  auto lstore = [&](int buf) {
-    float* base = stile + buf * NMAT * MAT;
+  auto lstore = [&](int buf) {  // KS == 1: buffer index; KS == 2: ignored
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * (NW * 64);
-      const int r = c >> 4, c4 = c & 15;
+      const int c = tid + i * NTHR;
+      const int half = KS == 1 ? buf : c / (KT * 16);
+      const int w = c % (KT * 16);
+      const int r = w >> 4, c4 = w & 15;
+      float* base = stile + half * NMAT * MAT;
       *reinterpret_cast<f32x4*>(base + r * KSTR + c4 * 4) = rK[i];
       *reinterpret_cast<f32x4*>(base + MAT + r * KSTR + c4 * 4) = rV[i];
       if (RELPOS)
         *reinterpret_cast<f32x4*>(base + 2 * MAT + r * KSTR + c4 * 4) = rP[i];
     }
   };
-  if (t_lo < t_hi) {
-    gload(t_lo);
-    lstore(0);
+  if (n_it > 0) {
+    gload(0);
+    if (KS == 1) lstore(0);
   }
-  __syncthreads();
+  if (KS == 1) __syncthreads();
 
-  for (int kt = t_lo; kt < t_hi; ++kt) {
+  for (int it = 0; it < n_it; ++it) {
+    const int kt = t_lo + kh * n_it + it;   // this wave's tile (may be >= t_hi)
     const int j0 = kt * KT;
-    const int cur = (kt - t_lo) & 1;
+    const int cur = KS == 1 ? (it & 1) : kh;
     const float* sK = stile + cur * NMAT * MAT;
     const float* sV = sK + MAT;
     const float* sP = sK + 2 * MAT;
-    if (kt + 1 < t_hi) gload(kt + 1);
+    if (KS == 2) {
+      lstore(0);
+      __syncthreads();  // both halves' tiles visible
+    }
+    if (it + 1 < n_it) gload(it + 1);
 
+    if (KS == 1 || kt < t_hi) {
     // ---- S^T tile -------------------------------------------------------------
     f32x16 sc;
 #pragma unroll
@@ -402,11 +427,41 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[st], v0, o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[st], v1, o1, 0, 0, 0);
     }
-    if (kt + 1 < t_hi) lstore(cur ^ 1);
-    __syncthreads();  // next tile visible; this tile's buffer free for reuse
+    }
+    if (KS == 1 && it + 1 < n_it) lstore(cur ^ 1);
+    __syncthreads();  // KS == 1: next tile visible, this buffer free;
+                      // KS == 2: every wave is done with the tiles
+  }
+  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (KS == 2) {
+    // ---- merge the two key halves: half 1 parks (m, l, O) in LDS, half 0
+    // folds it in.  O rows are queries (r&3)+8(r>>2)+4hi, columns li / 32+li.
+    float* xm = stile + wave * (32 * 65 + 64);   // per query group: m[32] l[32] O[32][65]
+    float* xo = xm + 64;
+    if (kh == 1) {
+      if (hi == 0) { xm[li] = m_run; xm[32 + li] = l_tot; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        xo[qr * 65 + li] = o0[r];
+        xo[qr * 65 + 32 + li] = o1[r];
+      }
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    const float m1 = xm[li], l1 = xm[32 + li];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __expf(m_run - m), a1 = __expf(m1 - m);
+    l_tot = l_tot * a0 + l1 * a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float b0 = __shfl(a0, qr, 64), b1 = __shfl(a1, qr, 64);
+      o0[r] = o0[r] * b0 + xo[qr * 65 + li] * b1;
+      o1[r] = o1[r] * b0 + xo[qr * 65 + 32 + li] * b1;
+    }
   }
   // ---- normalise and store -------------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;  // fully-masked row -> 0
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -513,6 +568,8 @@ int dwconv_ln_silu(const DwConvArgs& a, hipStream_t s) {
   return 0;
 }
 
+int g_attn_split = 0;  // wn_tune_set("attn_split")
+
 int attention(const AttnArgs& a, hipStream_t s) {
   WN_CHECK(a.n_seq > 0 && a.n_heads > 0 && a.max_q_len > 0, "attention: empty");
   WN_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0,
@@ -520,10 +577,20 @@ int attention(const AttnArgs& a, hipStream_t s) {
   WN_CHECK(a.mask_mode != 2 || a.chunk_size > 0, "attention: chunk size");
   constexpr int NW = 2;
   dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 64);
-  if (a.P)
-    hipLaunchKernelGGL((attention_kernel<NW, true>), g, t, 0, s, a);
+  // key split for the encoder's self attention over long sequences: twice the
+  // waves for the same tiles (g_attn_split: 0 auto, 1 off, 2 on)
+  const bool split = g_attn_split == 2 ||
+                     (g_attn_split == 0 && a.P != nullptr && a.max_q_len >= 128);
+  if (split) {
+    dim3 t2(NW * 2 * 64);
+    if (a.P)
+      hipLaunchKernelGGL((attention_kernel<NW, true, 2>), g, t2, 0, s, a);
+    else
+      hipLaunchKernelGGL((attention_kernel<NW, false, 2>), g, t2, 0, s, a);
+  } else if (a.P)
+    hipLaunchKernelGGL((attention_kernel<NW, true, 1>), g, t, 0, s, a);
   else
-    hipLaunchKernelGGL((attention_kernel<NW, false>), g, t, 0, s, a);
+    hipLaunchKernelGGL((attention_kernel<NW, false, 1>), g, t, 0, s, a);
   WN_HIP(hipGetLastError());
   return 0;
 }

@@ -11,6 +11,7 @@ int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
 // y1 = LN(x; w1,b1), y2 = LN(y1; w2,b2) in one pass over contiguous [M][D] rows
 // (y1 may alias x).
 extern int g_ln_rows;
+extern int g_attn_split;
 int layernorm2(const float* x, const float* w1, const float* b1, const float* w2,
                const float* b2, float* y1, float* y2, int M, int D, float eps,
                hipStream_t s);

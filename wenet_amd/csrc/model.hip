@@ -1283,6 +1283,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "gemm_tile_conv") g_gemm_tile_conv = value;
   else if (k == "gemm_tile_glu") g_gemm_tile_glu = value;
   else if (k == "ln_rows") g_ln_rows = value;
+  else if (k == "attn_split") g_attn_split = value;
   else { set_error("wn_tune_set: unknown key " + k); return -1; }
   return 0;
 }
