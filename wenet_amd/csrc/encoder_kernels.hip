@@ -237,7 +237,7 @@ constexpr int KSTR = 68;        // LDS row stride (floats): 64 + 4 pad
 // per block: one buffer per half instead of two buffers (two barriers per
 // iteration; the other resident waves cover them).
 template <int NW, bool RELPOS, int KS>
-__global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 2 : 1) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kernel(AttnArgs a) {
   const int s = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (NW * 32);
   const int qlen = a.q_len[s];
@@ -344,9 +344,9 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 2 : 1) void attention_kerne
         *reinterpret_cast<f32x4*>(base + 2 * MAT + r * KSTR + c4 * 4) = rP[i];
     }
   };
-  if (n_it > 0) {
+  if (KS == 1 && n_it > 0) {
     gload(0);
-    if (KS == 1) lstore(0);
+    lstore(0);
   }
   if (KS == 1) __syncthreads();
 
@@ -358,10 +358,15 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 2 : 1) void attention_kerne
     const float* sV = sK + MAT;
     const float* sP = sK + 2 * MAT;
     if (KS == 2) {
+      // no register prefetch here: three waves per SIMD (<= 168 VGPRs, 3 blocks
+      // of 52 KB per CU) cover the load latency, and 768 block slots take the
+      // ~531 blocks of config 2 in ONE round
+      gload(it);
       lstore(0);
       __syncthreads();  // both halves' tiles visible
+    } else if (it + 1 < n_it) {
+      gload(it + 1);
     }
-    if (it + 1 < n_it) gload(it + 1);
 
     if (KS == 1 || kt < t_hi) {
     // ---- S^T tile -------------------------------------------------------------
