@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 _lib_mod = None
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md:42
 FRAMES = (800, 1200)  # 8..12 s of 10 ms frames, mean ~10 s
 BEAM = 10
 # BASELINE.json `configs`; the default (and the only one the driver runs) is
@@ -169,6 +170,11 @@ def main():
     ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS),
                     help='config2 = BASELINE.json configs[1] (the metric\'s '
                          'configuration, default); the others are extra data points')
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help='fp32 (default: the reference\'s dtype, the headline) or '
+                         'bf16 operands / fp32 accumulate (recognize.py --dtype bf16; '
+                         'the dtype BASELINE.json configs[4] names) -- an extra data '
+                         'point, never the headline line')
     ap.add_argument('--tune', default='',
                     help='experiments: comma list of key=value for wn_tune_set')
     args = ap.parse_args()
@@ -208,6 +214,8 @@ def main():
     configs = S.make_configs(CONFIG)
     sd = S.make_state_dict(configs, 0)
     model = ASRModel(configs, sd, device=device)
+    model.set_compute_dtype(args.dtype)  # before the pipeline clones the handle
+    bf16 = args.dtype == 'bf16'
 
     # global batch, sharded by length (weak scaling: 32 utterances per GPU)
     gfeats, glens = S.make_features(BATCH_PER_GPU * world, wl.get('frames', FRAMES),
@@ -297,11 +305,13 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': 'bf16 operands, f32 accumulate / activations' if bf16 else 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': wl['text'] + ', features resident in HBM, '
-                            'random-init weights',
+                'workload': (wl['text'].replace('fp32 (not the bf16 / fp8 the config '
+                                                'names)', 'bf16 GEMM operands (no fp8)')
+                             if bf16 else wl['text'])
+                            + ', features resident in HBM, random-init weights',
                 'global_batch': BATCH_PER_GPU * world,
                 'audio_seconds_per_step': round(total_audio, 1),
                 'encoder_frames_per_gpu': enc_rows,
@@ -310,12 +320,14 @@ def main():
             },
             'roofline': {
                 'bound': 'mfma',
-                'kernel': 'gemm_f32_kernel<128,128,2x4 waves,SiLU> (FFN w_1, '
+                'kernel': ('gemm_bf16_kernel' if bf16 else 'gemm_f32_kernel') +
+                          '<128,128,2x4 waves> (FFN w_1, '
                           f'M={enc_rows} N={ffn} K={d_model})',
                 'achieved': round(achieved, 2),
-                'peak': FP32_MFMA_PEAK_TFLOPS,
+                'peak': BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
-                'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                'frac': round(achieved / (BF16_MFMA_PEAK_TFLOPS if bf16
+                                          else FP32_MFMA_PEAK_TFLOPS), 4),
                 'launches': n_launch.value,
                 'avg_launch_us': round(ms.value * 1e3 / max(n_launch.value, 1), 2),
                 'traffic': None,
@@ -325,7 +337,7 @@ def main():
         # be collected inside a timed run): bytes per launch, committed summary
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
                            'pmc_roofline_kernel.json')
-        if wl is WORKLOADS.get('config2') and os.path.exists(pmc):
+        if wl is WORKLOADS.get('config2') and not bf16 and os.path.exists(pmc):
             with open(pmc) as f:
                 rec = json.load(f)
             line['roofline']['traffic'] = rec['hbm_bytes_per_launch']

@@ -21,7 +21,8 @@
  *  - the library owns the weights and a workspace arena that grows on demand;
  *    one wn_model per process/GPU (one process per GPU for multi-GPU);
  *  - all arithmetic is fp32 (fp64 for the prefix-beam bookkeeping, like the
- *    reference's Python floats); tokens / lengths are int32.
+ *    reference's Python floats) unless wn_model_set_precision() opts a handle
+ *    into bf16 operands; tokens / lengths are int32.
  */
 #ifndef WENET_AMD_H_
 #define WENET_AMD_H_
@@ -90,6 +91,24 @@ void wn_model_destroy(wn_model* m);
  * several batches running on different streams (wenet_amd/pipeline.py).
  * Handles may be used from different host threads, one thread per handle. */
 int wn_model_clone(const wn_model* src, wn_model** out);
+
+/* Operand precision of the handle's contractions: the reference's
+ * `recognize.py --dtype {fp32,bf16}` (wenet/bin/recognize.py:52-56,250-255: torch
+ * autocast around model.decode).
+ *   WN_PREC_F32  (default) fp32 operands on the fp32 matrix-core path: the parity
+ *                mode (identical greedy tokens, rescoring scores within 1e-3);
+ *   WN_PREC_BF16 every Linear / pointwise-conv / subsampling-conv contraction
+ *                rounds its two operands to bf16 (round to nearest even) and
+ *                accumulates in fp32; activations, LayerNorm, softmax, attention
+ *                scores, the depthwise conv, the searches and all tensors in HBM
+ *                stay fp32 (autocast additionally rounds every result to bf16,
+ *                so this mode is at least as precise as the reference's).
+ * Applies to later calls on this handle; clones inherit it.  The feature
+ * frontends (wn_fbank, wn_log_mel, wn_resample) always run in fp32. */
+#define WN_PREC_F32 0
+#define WN_PREC_BF16 1
+int wn_model_set_precision(wn_model* m, int32_t precision);
+int32_t wn_model_get_precision(const wn_model* m);
 
 /* A weight-less handle that only owns a workspace: enough for
  * wn_set_ctc_probs + the two CTC searches, i.e. for calling the reference's
@@ -270,6 +289,10 @@ int wn_decoder_next_topk(wn_model* m, int32_t n_seq, const int32_t* seq_utt_host
 int wn_op_gemm(const float* A_dev, const float* W_dev, const float* bias_dev,
                const float* resid_dev, float* C_dev, int32_t M, int32_t N,
                int32_t K, float alpha, int32_t act, void* stream);
+/* The same contraction with both operands rounded to bf16 (WN_PREC_BF16). */
+int wn_op_gemm_bf16(const float* A_dev, const float* W_dev, const float* bias_dev,
+                    const float* resid_dev, float* C_dev, int32_t M, int32_t N,
+                    int32_t K, float alpha, int32_t act, void* stream);
 /* out[i] = log_add(a[i], b[i]) (wenet/utils/common.py:302-310) in fp64 with the
  * routine the prefix beam search uses. */
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,
@@ -292,8 +315,8 @@ int wn_profile_collect(wn_model* m, int32_t* n_launches, double* total_ms,
 int wn_debug_set(wn_model* m, const char* key, int32_t value);
 
 /* Process-wide kernel tuning knob for A/B measurements (tools/bench_gemm.py):
- * "gemm_variant" (bit mask of experimental code paths), "gemm_tile" (force a
- * block tile).  Defaults (0) are the shipped configuration. */
+ * "gemm_variant" (bit mask of experimental code paths), "gemm_tile" /
+ * "gemm_tile_bf16" (force a block tile).  Defaults (0) are the shipped configuration. */
 int wn_tune_set(const char* key, int32_t value);
 
 #ifdef __cplusplus

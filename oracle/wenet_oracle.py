@@ -36,6 +36,59 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 import torch.nn.functional as F
+import contextlib
+
+_TORCH_F = F
+
+
+class _Bf16OperandFunctional:
+    """torch.nn.functional with the operand rounding of the product's
+    WN_PREC_BF16 mode (include/wenet_amd.h, `recognize.py --dtype bf16`,
+    wenet/bin/recognize.py:250-255,278-280): every contraction the product runs
+    on its GEMM kernels -- nn.Linear, kernel-1 / subsampling Conv1d, the
+    d -> d Conv2d of Conv2dSubsampling4 -- sees both operands rounded to bf16
+    (round to nearest even) and accumulates in fp32.  Everything else stays
+    fp32: the 1 -> d Conv2d and the depthwise Conv1d (not GEMMs in the product),
+    attention scores / softmax (torch.matmul is untouched), LayerNorm, and
+    `linear_pos` (projected once at model creation, in fp32)."""
+
+    def __init__(self, exempt_weights=()):
+        self._exempt = {w.data_ptr() for w in exempt_weights}
+
+    def __getattr__(self, name):
+        return getattr(_TORCH_F, name)
+
+    @staticmethod
+    def _r(t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    def linear(self, x, w, b=None):
+        if w.data_ptr() in self._exempt:
+            return _TORCH_F.linear(x, w, b)
+        return _TORCH_F.linear(self._r(x), self._r(w), b)
+
+    def conv1d(self, x, w, b=None, **kw):
+        if kw.get('groups', 1) != 1:
+            return _TORCH_F.conv1d(x, w, b, **kw)
+        return _TORCH_F.conv1d(self._r(x), self._r(w), b, **kw)
+
+    def conv2d(self, x, w, b=None, **kw):
+        if w.size(1) == 1:
+            return _TORCH_F.conv2d(x, w, b, **kw)
+        return _TORCH_F.conv2d(self._r(x), self._r(w), b, **kw)
+
+
+@contextlib.contextmanager
+def bf16_operands(sd=None):
+    """Run the oracle with the product's bf16-operand arithmetic (see
+    _Bf16OperandFunctional).  `sd`: the state_dict, to exempt `linear_pos`."""
+    global F
+    exempt = [v for k, v in (sd or {}).items() if k.endswith('linear_pos.weight')]
+    saved, F = F, _Bf16OperandFunctional(exempt)
+    try:
+        yield
+    finally:
+        F = saved
 
 # --------------------------------------------------------------------------
 # result record -- wenet/models/transformer/search.py:30-61

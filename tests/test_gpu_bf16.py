@@ -1,0 +1,258 @@
+"""GPU parity of the bf16-operand mode (WN_PREC_BF16, `recognize.py --dtype bf16`,
+BASELINE.json configs[4]): the bf16 matrix-core GEMM (csrc/gemm_bf16.hip) and the
+decode path running on it, against the oracle with the SAME operand rounding
+(oracle.wenet_oracle.bf16_operands: both operands of every GEMM-kernel
+contraction rounded to bf16 RNE, fp32 accumulation, everything else fp32).
+
+Tolerances:
+  single contraction   |err| <= 2e-6 * (|A| @ |W|^T)   (fp32 accumulation order only)
+  encoder layers       |err| <= 4e-3 * scale per layer (an activation that sits on a
+                       bf16 rounding boundary may round the other way on the GPU:
+                       one bf16 ulp = 0.4 % of that element)
+  decode               greedy tokens identical wherever the oracle's top-1 margin
+                       exceeds 5e-2; rescoring scores within 2e-2 * (L+1)
+The bf16 mode is NOT the parity mode against the fp32 reference (that is the
+default fp32 path); its distance from fp32 is reported, not bounded tightly.
+"""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import cached_model, compare_nbest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import wenet_oracle as O
+    return O
+
+
+def _r(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _gemm_bf16(A, W, bias=None, resid=None, alpha=1.0, act=0):
+    from wenet_amd import _lib
+    L = _lib.lib()
+    M, K = A.shape
+    N = W.shape[0]
+    C = torch.empty((M, N), dtype=torch.float32, device='cuda')
+    _lib.check(L.wn_op_gemm_bf16(_ptr(A), _ptr(W), _ptr(bias), _ptr(resid), _ptr(C),
+                                 M, N, K, alpha, act,
+                                 torch.cuda.current_stream().cuda_stream), 'gemm_bf16')
+    torch.cuda.synchronize()
+    return C
+
+
+@pytest.mark.parametrize('M,N,K', [
+    (128, 128, 32), (1, 1, 32), (77, 67, 64), (300, 200, 96), (300, 256, 256),
+    (7936, 2048, 256), (7936, 256, 2048), (513, 4233, 256), (2000, 768, 256),
+    (129, 130, 2432), (3000, 1280, 5120), (3000, 5120, 1280), (4097, 384, 160)])
+def test_gemm_bf16_plain_asymmetric(M, N, K):
+    """Both K-tile widths (K % 64 == 0 and not), every block shape, ragged M / N."""
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)  # asymmetric operands (transpose check)
+    ref = _r(A) @ _r(W).T
+    got = _gemm_bf16(A.cuda(), W.cuda()).cpu().double()
+    scale = (A.abs().double() @ W.abs().double().T).max().item()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-6 * scale, (err, scale)
+    # ... and the operands really were rounded: the exact product is further away
+    exact = A.double() @ W.double().T
+    assert (got - exact).abs().max().item() > 5 * err + 1e-9 * scale
+
+
+def test_gemm_bf16_identity_detects_transposed_store():
+    K = 64
+    A = torch.eye(K)
+    W = torch.arange(96 * K, dtype=torch.float32).reshape(96, K) / 100.0
+    got = _gemm_bf16(A.cuda(), W.cuda()).cpu()
+    want = W.to(torch.bfloat16).to(torch.float32).T.contiguous()
+    torch.testing.assert_close(got, want, rtol=0, atol=0)
+
+
+def test_gemm_bf16_rounding_is_nearest_even():
+    """Operand values half way between two bf16 numbers (the tie) and just off
+    it: the kernel's conversion must agree with torch's (RNE) on every one."""
+    base = torch.tensor([1.0, 1.5, 3.0, 100.0, 0.007]).to(torch.bfloat16).float()
+    ulp = torch.tensor([2.0 ** -7, 2.0 ** -7, 2.0 ** -6, 2.0 ** -1, 2.0 ** -15])
+    vals = []
+    for j in range(8):
+        lo = base + j * ulp                     # a bf16 number
+        vals += [lo + ulp / 2, lo + ulp / 2 * 1.001, lo + ulp / 2 * 0.999]
+    v = torch.cat(vals)
+    v = torch.cat([v, -v])
+    K = 32 * ((v.numel() + 31) // 32)
+    A = torch.zeros(K, K)
+    A[torch.arange(v.numel()), torch.arange(v.numel())] = v
+    W = torch.eye(K)
+    got = _gemm_bf16(A.cuda(), W.cuda()).cpu()
+    want = A.to(torch.bfloat16).to(torch.float32)
+    torch.testing.assert_close(got, want, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
+@pytest.mark.parametrize('use_resid', [False, True])
+@pytest.mark.parametrize('K', [96, 128])
+def test_gemm_bf16_epilogues(act, use_resid, K):
+    g = torch.Generator().manual_seed(act * 2 + int(use_resid) + K)
+    M, N = 333, 200
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g) if use_resid else None
+    y = (_r(A) @ _r(W).T).float() + bias
+    if act == 1:
+        y = torch.nn.functional.silu(y)
+    elif act == 2:
+        y = torch.relu(y)
+    elif act == 3:
+        y = torch.nn.functional.gelu(y)
+    y = 0.5 * y
+    if use_resid:
+        y = y + resid
+    got = _gemm_bf16(A.cuda(), W.cuda(), bias.cuda(),
+                     resid.cuda() if use_resid else None, 0.5, act).cpu()
+    torch.testing.assert_close(got, y, rtol=1e-5, atol=2e-5)
+
+
+def _set_dtype(model, dtype):
+    model.set_compute_dtype(dtype)
+    assert model.compute_dtype == dtype
+
+
+@pytest.mark.parametrize('config,B,frames,chunk,left', [
+    ('tiny_causal', 6, (30, 260), -1, -1),
+    ('tiny_causal', 4, (30, 200), 8, 1),
+    ('tiny_sym', 5, (7, 180), -1, -1),
+    ('tiny_bn', 4, (20, 150), -1, -1),
+    ('whisper_tiny_like', 4, (3, 140), -1, -1),
+])
+def test_bf16_encoder_layers_vs_oracle(config, B, frames, chunk, left):
+    """Every encoder layer output of the bf16 mode against the oracle with the same
+    operand rounding (GLU, implicit-GEMM conv, gathered-row conv, residual and
+    activation epilogues of the bf16 kernels all sit on this path)."""
+    from wenet_amd import _lib, synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=91, feat_dim=configs['input_dim'])
+    with torch.no_grad():
+        ref32, _, layers32 = O.encoder_forward(configs, sd, feats, lens, chunk, left,
+                                               return_layers=True)
+        with O.bf16_operands(sd):
+            ref, mask, layers = O.encoder_forward(configs, sd, feats, lens, chunk,
+                                                  left, return_layers=True)
+    ref_lens = mask.squeeze(1).sum(1).numpy()
+    L = _lib.lib()
+    _set_dtype(model, 'bf16')
+    try:
+        for n in range(len(layers)):
+            _lib.check(L.wn_debug_set(model._h, b'n_layers', n), 'dbg')
+            _lib.check(L.wn_debug_set(model._h, b'skip_after_norm', 1), 'dbg')
+            enc, m = model._forward_encoder(feats.cuda(), lens, chunk, left)
+            enc = enc.cpu()
+            worst, apart = 0.0, 0.0
+            for b in range(B):
+                nb = int(ref_lens[b])
+                if nb:
+                    scale = max(layers[n][b, :nb].abs().max().item(), 1.0)
+                    worst = max(worst, (enc[b, :nb] - layers[n][b, :nb]).abs().max().item() / scale)
+                    apart = max(apart, (layers32[n][b, :nb] - layers[n][b, :nb]).abs().max().item() / scale)
+            assert worst < 4e-3, (config, 'layer', n, worst)
+            # the emulation and fp32 differ by far more than GPU vs emulation,
+            # so this test does tell the two arithmetic modes apart
+            if n == len(layers) - 1:
+                assert apart > 3 * worst, (config, apart, worst)
+    finally:
+        L.wn_debug_set(model._h, b'n_layers', -1)
+        L.wn_debug_set(model._h, b'skip_after_norm', 0)
+        _set_dtype(model, 'fp32')
+
+
+@pytest.mark.parametrize('config,B,frames,chunk', [
+    ('tiny_causal', 6, (40, 260), -1), ('tiny_causal', 4, (40, 200), 8),
+    ('tiny_sym', 5, (20, 180), -1), ('tiny_bn', 4, (30, 150), -1)])
+def test_bf16_decode_vs_oracle(config, B, frames, chunk):
+    """decode() in the bf16 mode (CTC head, both searches, the rescoring decoder)
+    against the oracle's decode() under the same operand rounding."""
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=17, feat_dim=configs['input_dim'])
+    methods = ['ctc_greedy_search', 'ctc_prefix_beam_search', 'attention_rescoring']
+    kw = dict(beam_size=4, decoding_chunk_size=chunk, ctc_weight=0.5,
+              reverse_weight=0.3 if configs.get('decoder') == 'bitransformer' else 0.0)
+    with O.bf16_operands(sd):
+        want = O.decode(configs, sd, methods, feats, lens, **kw)
+        with torch.no_grad():
+            enc, mask = O.encoder_forward(configs, sd, feats, lens, chunk, -1)
+            logp = O.ctc_logprobs(sd, enc)
+    top2 = logp.topk(2, dim=-1).values
+    margin = (top2[..., 0] - top2[..., 1])
+    enc_lens = mask.squeeze(1).sum(1)
+    _set_dtype(model, 'bf16')
+    try:
+        got = model.decode(methods, feats.cuda(), lens, **kw)
+    finally:
+        _set_dtype(model, 'fp32')
+    for b in range(B):
+        n = int(enc_lens[b])
+        if n and margin[b, :n].min().item() > 5e-2:
+            assert got['ctc_greedy_search'][b].tokens == want['ctc_greedy_search'][b].tokens
+        w = want['ctc_prefix_beam_search'][b]
+        compare_nbest(got['ctc_prefix_beam_search'][b], w.nbest, w.nbest_scores,
+                      w.nbest_times, score_atol=2e-2, what=f'{config}[{b}]')
+        r, wr = got['attention_rescoring'][b], want['attention_rescoring'][b]
+        if list(r.tokens) == list(wr.tokens):
+            assert abs(r.score - wr.score) < 2e-2 * (len(wr.tokens) + 1), (config, b)
+
+
+def test_bf16_is_a_per_handle_switch_and_fp32_comes_back_bit_exact():
+    """fp32 -> bf16 -> fp32 on one handle: the two fp32 runs are bit-identical, the
+    bf16 run is not; clones inherit the mode of their source at clone time."""
+    from wenet_amd import synthetic as S
+    configs, sd, model = cached_model('tiny_causal', 0)
+    feats, lens = S.make_features(3, (50, 120), seed=3, feat_dim=configs['input_dim'])
+    a, _ = model._forward_encoder(feats.cuda(), lens)
+    a = a.clone()
+    _set_dtype(model, 'bf16')
+    try:
+        b, _ = model._forward_encoder(feats.cuda(), lens)
+        b = b.clone()
+        twin = model.clone()
+        assert twin.compute_dtype == 'bf16'
+        c, _ = twin._forward_encoder(feats.cuda(), lens)
+        assert torch.equal(b, c)
+    finally:
+        _set_dtype(model, 'fp32')
+    d, _ = model._forward_encoder(feats.cuda(), lens)
+    assert torch.equal(a, d)
+    assert not torch.equal(a, b)
+    assert (a - b).abs().max().item() < 0.2 * max(1.0, a.abs().max().item())
+    with pytest.raises(ValueError):
+        model.set_compute_dtype('fp16')
+
+
+def test_bf16_whisper_golden_stays_close_to_the_fp32_reference():
+    """Whisper-tiny-like encoder in bf16 against the REAL reference's committed fp32
+    output: reported distance, bounded loosely (bf16 operands: ~3 significant
+    digits per product)."""
+    from golden_util import build_inputs, load_case
+    meta, arrays = load_case('whisperenc_tiny')
+    configs, sd, model = cached_model(meta['config'], meta['wseed'])
+    _, _, feats, lens = build_inputs(meta)
+    _set_dtype(model, 'bf16')
+    try:
+        enc, mask = model._forward_encoder(feats.cuda(), lens)
+    finally:
+        _set_dtype(model, 'fp32')
+    enc = enc.cpu().numpy()
+    for b, n in enumerate(arrays['enc_lens']):
+        ref = arrays['enc_out'][b, :n]
+        err = np.abs(enc[b, :n] - ref).max()
+        assert err < 6e-2 * max(1.0, np.abs(ref).max()), (b, err)

@@ -3,6 +3,7 @@
 B=32 x ~10 s -> M = 7932 encoder rows), through the C ABI (wn_op_gemm).
 
     python tools/bench_gemm.py [--reps 30] [--only w1] [--variants 0,1]
+    python tools/bench_gemm.py --bf16 --tiles 0,1,7 --only wh_w1,wh_w2,w1
 
 Prints TFLOP/s per shape and variant (variants = wn_tune_set("gemm_variant")),
 interleaved within one process.
@@ -30,6 +31,11 @@ SHAPES = {
     'sub_out': (M, 256, 4864, 0, False),
     'w1_512': (M, 2048, 512, 1, False),
     'w2_512': (M, 512, 2048, 0, True),
+    # Whisper-large-v3 encoder, batch 16 x 1500 frames (BASELINE configs[4])
+    'wh_w1': (24000, 5120, 1280, 3, False),
+    'wh_w2': (24000, 1280, 5120, 0, True),
+    'wh_qkv': (24000, 3840, 1280, 0, False),
+    'wh_out': (24000, 1280, 1280, 0, True),
 }
 
 
@@ -39,8 +45,12 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--variants', default='0')
     ap.add_argument('--tiles', default='0')
+    ap.add_argument('--bf16', action='store_true',
+                    help='bf16-operand kernels (wn_op_gemm_bf16, gemm_tile_bf16)')
     args = ap.parse_args()
     L = _lib.lib()
+    op = L.wn_op_gemm_bf16 if args.bf16 else L.wn_op_gemm
+    tile_key = b'gemm_tile_bf16' if args.bf16 else b'gemm_tile'
     dev = torch.device('cuda', 0)
     variants = [(int(t), int(v)) for t in args.tiles.split(',')
                 for v in args.variants.split(',')]
@@ -56,13 +66,13 @@ def main():
         C = torch.empty(m, n, device=dev)
 
         def run():
-            _lib.check(L.wn_op_gemm(A.data_ptr(), W.data_ptr(), bias.data_ptr(),
-                                    R.data_ptr() if resid else None,
-                                    C.data_ptr(), m, n, k, 1.0, act, None), name)
+            _lib.check(op(A.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                          R.data_ptr() if resid else None,
+                          C.data_ptr(), m, n, k, 1.0, act, None), name)
         res = {}
         for rnd in range(3):
             for v in variants:
-                L.wn_tune_set(b'gemm_tile', v[0])
+                L.wn_tune_set(tile_key, v[0])
                 L.wn_tune_set(b'gemm_variant', v[1])
                 for _ in range(3):
                     run()
@@ -82,7 +92,7 @@ def main():
             print(f'{name:8s} M={m} N={n} K={k} tile/variant {v}: {us:8.2f} us  '
                   f'{tf:6.1f} TF/s  (rounds {[round(x, 1) for x in res[v]]})', flush=True)
             out[f'{name}/t{v[0]}v{v[1]}'] = dict(us=us, tflops=tf)
-    L.wn_tune_set(b'gemm_tile', 0)
+    L.wn_tune_set(tile_key, 0)
     L.wn_tune_set(b'gemm_variant', 0)
     print(json.dumps(out))
 

@@ -30,6 +30,7 @@ class WnTensor(Structure):
 # every symbol include/wenet_amd.h declares
 EXPORTS = [
     'wn_last_error', 'wn_version', 'wn_model_create', 'wn_model_destroy', 'wn_model_clone',
+    'wn_model_set_precision', 'wn_model_get_precision', 'wn_op_gemm_bf16',
     'wn_workspace_create', 'wn_resample_length', 'wn_resample', 'wn_fbank', 'wn_log_mel', 'wn_encode', 'wn_encode_chunk', 'wn_set_encoder_out',
     'wn_ctc_logprobs', 'wn_set_ctc_probs', 'wn_ctc_greedy_search',
     'wn_set_context_graph', 'wn_ctc_prefix_beam_search', 'wn_attention_rescoring', 'wn_decoder_forward', 'wn_decoder_next_topk', 'wn_op_gemm',
@@ -85,6 +86,9 @@ def lib():
     L.wn_decoder_next_topk.argtypes = [vp, i32, pi32, pi32, pi32, i32, i32,
                                        POINTER(f32), pi32, vp]
     L.wn_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]
+    L.wn_op_gemm_bf16.argtypes = L.wn_op_gemm.argtypes
+    L.wn_model_set_precision.argtypes = [vp, i32]
+    L.wn_model_get_precision.argtypes = [vp]
     L.wn_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
     L.wn_op_log_add.argtypes = [vp, vp, vp, i32, vp]
     L.wn_debug_set.argtypes = [vp, c_char_p, i32]
@@ -92,7 +96,8 @@ def lib():
     L.wn_profile_enable.argtypes = [vp, i32]
     L.wn_profile_collect.argtypes = [vp, pi32, pf64, pf64]
     for n in EXPORTS:
-        if n not in ('wn_last_error', 'wn_version', 'wn_model_destroy'):
+        if n not in ('wn_last_error', 'wn_version', 'wn_model_destroy',
+                     'wn_resample_length'):
             getattr(L, n).restype = i32
     _lib = L
     return L

@@ -44,7 +44,9 @@ def get_args(argv=None):
                    help='device index (default: LOCAL_RANK, else 0)')
     p.add_argument('--device', default='cuda', choices=['cuda'],
                    help='only the MI355X path exists; there is no CPU fallback')
-    p.add_argument('--dtype', default='fp32', choices=['fp32'])
+    p.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
+                   help="model's compute dtype (recognize.py:52-56): bf16 = bf16 "
+                   'operands, fp32 accumulate, on the bf16 matrix cores')
     p.add_argument('--num_workers', type=int, default=4,
                    help='host threads reading wav files ahead of the GPU')
     p.add_argument('--checkpoint', required=True, help='checkpoint model (.pt)')
@@ -265,6 +267,7 @@ def main(argv=None):
     blank_id = get_blank_id(configs, tokenizer.symbol_table)
     logging.info('blank_id is %d', blank_id)
     model = ASRModel(configs, load_state(configs, args.checkpoint), device)
+    model.set_compute_dtype(args.dtype)
 
     context_graph = None
     if 'decoding-graph' in args.context_bias_mode:

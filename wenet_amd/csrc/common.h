@@ -88,10 +88,20 @@ struct GemmArgs {
 
 int gemm_f32(const GemmArgs& a, hipStream_t stream);
 
+// Operand precision of the calling host thread's GEMMs (wn_model_set_precision):
+// 0 = fp32 operands (gemm.hip, the default and the parity mode), 1 = operands
+// rounded to bf16 on the way into LDS, fp32 accumulate (gemm_bf16.hip).  Set by
+// the C-ABI entry points from their handle (PrecisionScope in model.hip); one
+// host thread drives one handle, so a thread-local is the handle's state.
+enum GemmPrecision { PREC_F32 = 0, PREC_BF16 = 1 };
+extern thread_local int t_gemm_prec;
+int gemm_bf16(const GemmArgs& a, hipStream_t stream);  // called by gemm_f32
+
 // Tuning knobs (wn_tune_set): experiments / A-B runs only, defaults are the
 // shipped configuration.
 extern int g_gemm_variant;  // bit mask, see gemm.hip
 extern int g_gemm_tile_conv, g_gemm_tile_glu;
 extern int g_gemm_tile;     // 0 auto, else force a block configuration (gemm.hip)
+extern int g_gemm_tile_bf16;  // same for the bf16-operand kernels (gemm_bf16.hip)
 
 }  // namespace wn

@@ -24,6 +24,7 @@
 //    the A panel is fetched into one L2, not eight.
 //  * epilogue fused: bias, SiLU/ReLU, alpha, residual add, GLU.
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace wn {
 
@@ -31,14 +32,9 @@ int g_gemm_variant = 0;
 int g_gemm_tile = 0;
 int g_gemm_tile_conv = 0;
 int g_gemm_tile_glu = 0;
+thread_local int t_gemm_prec = PREC_F32;
 
 namespace {
-
-__device__ __forceinline__ float silu_fast(float x) {
-  // x * sigmoid(x) on v_exp_f32 / v_rcp_f32 (each ~1 ulp); __frcp_rn would be
-  // the correctly rounded division sequence (v_div_scale / fmas / fixup)
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
 
 constexpr int BK = 32;  // K granularity every problem must respect
 
@@ -58,14 +54,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TILE = (BM + BN) * LDS_STRIDE;  // floats per buffer: A then W
 
-  // ---- XCD-aware tile assignment (bijective for any grid size) -----------
-  const int nblk = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk / 8, r = nblk % 8;
-    const int xcd = bid % 8, slot = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
+  // ---- XCD-aware tile assignment (gemm_epilogue.h) -------------------------
+  const int bid = xcd_block_order(blockIdx.x, tiles_m * tiles_n);
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -200,86 +190,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
     }
   }
 
-  // ---- epilogue ------------------------------------------------------------
-  // C/D layout of the 32x32 MFMA: col = lane & 31,
-  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  const int col_in = lane & 31;
-  const int row_hi = (lane >> 5) * 4;
-  if constexpr (GLU) {
-    const int ncol_out = p.N / 2;
-    const int cbase = n0 + wn_ * WTN;  // permuted column of the 'a' half
-    const int ca = cbase + col_in, cg = cbase + 32 + col_in;
-    const int cout = cbase / 2 + col_in;
-    const bool cok = cg < p.N;
-    const float ba = (p.bias && cok) ? p.bias[ca] : 0.0f;
-    const float bg = (p.bias && cok) ? p.bias[cg] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int row0 = m0 + wm * WTM + i * 32 + row_hi;
-      float* cp = p.C + (int64_t)row0 * p.ldc + cout;
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float a = acc[i][0][r] + ba;
-        const float g = acc[i][1][r] + bg;
-        v[r] = (variant & 1) ? a * sigmoid_f(g)
-                             : a * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dr = (r & 3) + 8 * (r >> 2);
-        if (row0 + dr < p.M && cok) cp[dr * p.ldc] = v[r];
-      }
-    }
-    (void)ncol_out;
-    return;
-  }
-  // Values first (no branches, so the 16 results of a tile overlap their
-  // exp / rcp latencies), then the stores; only the ragged last tiles pay for
-  // per-row predicates.
-  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);  // block-uniform
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + wn_ * WTN + j * 32 + col_in;
-    const bool cok = col < p.N;
-    const float b = (p.bias && cok) ? p.bias[col] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int row0 = m0 + wm * WTM + i * 32 + row_hi;
-      float* cp = p.C + (int64_t)row0 * p.ldc + col;
-      const float* rp = RESID ? p.resid + (int64_t)row0 * p.ldr + col : nullptr;
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float x = acc[i][j][r] + b;
-        if (ACT == ACT_SILU) x = (variant & 1) ? silu_f(x) : silu_fast(x);
-        if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
-        if (ACT == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-        v[r] = x * p.alpha;
-      }
-      if (full) {
-        if (RESID) {
-          float rr[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rr[r] = rp[((r & 3) + 8 * (r >> 2)) * p.ldr];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += rr[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cp[((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dr = (r & 3) + 8 * (r >> 2);
-          if (row0 + dr < p.M && cok) {
-            float x = v[r];
-            if (RESID) x += rp[dr * p.ldr];
-            cp[dr * p.ldc] = x;
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<BM, BN, WGM, WGN, ACT, RESID, GLU>(p, acc, m0, n0, wm, wn_, lane,
+                                                   variant);
 }
 
 template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
@@ -355,6 +267,7 @@ int gemm_f32(const GemmArgs& a, hipStream_t stream) {
     WN_CHECK(a.lda % 4 == 0, "gemm: lda must be a multiple of 4 floats");
   }
   if (a.glu) WN_CHECK(a.N % 64 == 0, "gemm(GLU): N must be a multiple of 64");
+  if (t_gemm_prec == PREC_BF16) return gemm_bf16(a, stream);
   // Tile choice (measured on M = 7932 rows, profiles/): 8 waves per block hide
   // the barrier / LDS latency of the short K loops better than 4; the block
   // shrinks with the problem so that the grid still covers the 256 CUs.

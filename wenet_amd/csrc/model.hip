@@ -277,6 +277,7 @@ struct wn_model {
   bool prof_on = false;
   unsigned prof_seq = 0;
   double prof_flops = 0.0;
+  int prec = PREC_F32;       // GEMM operand precision (wn_model_set_precision)
   int dbg_layers = -1;       // run only the first n encoder layers
   int dbg_skip_after_norm = 0;
   // fbank tables
@@ -293,6 +294,14 @@ struct wn_model {
 };
 
 namespace {
+
+// Makes the handle's GEMM operand precision current for the calling thread for
+// the duration of one C-ABI call (every GEMM launch reads t_gemm_prec).
+struct PrecisionScope {
+  int saved;
+  explicit PrecisionScope(const wn_model* m) : saved(t_gemm_prec) { t_gemm_prec = m->prec; }
+  ~PrecisionScope() { t_gemm_prec = saved; }
+};
 
 int upload_desc(wn_model* m, DevBuf& buf, const std::vector<int>& v,
                 hipStream_t s) {
@@ -1215,6 +1224,7 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   std::unique_ptr<wn_model> m(new wn_model());
   m->cfg = src->cfg;
   m->device = src->device;
+  m->prec = src->prec;
   // weights, projected position tables and fbank tables are read-only: share
   m->weights = src->weights;
   m->pos_tabs = src->pos_tabs;
@@ -1239,6 +1249,16 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   *out = m.release();
   return 0;
 }
+
+int wn_model_set_precision(wn_model* m, int32_t precision) {
+  WN_CHECK(m, "wn_model_set_precision: null model");
+  WN_CHECK(precision == PREC_F32 || precision == PREC_BF16,
+           "wn_model_set_precision: 0 (fp32) or 1 (bf16 operands, fp32 accumulate)");
+  m->prec = precision;
+  return 0;
+}
+
+int32_t wn_model_get_precision(const wn_model* m) { return m ? m->prec : -1; }
 
 int wn_profile_enable(wn_model* m, int32_t on) {
   WN_CHECK(m, "wn_profile_enable: null model");
@@ -1282,6 +1302,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "gemm_tile") g_gemm_tile = value;
   else if (k == "gemm_tile_conv") g_gemm_tile_conv = value;
   else if (k == "gemm_tile_glu") g_gemm_tile_glu = value;
+  else if (k == "gemm_tile_bf16") g_gemm_tile_bf16 = value;
   else if (k == "ln_rows") g_ln_rows = value;
   else if (k == "attn_split") g_attn_split = value;
   else { set_error("wn_tune_set: unknown key " + k); return -1; }
@@ -1303,6 +1324,7 @@ int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host
               int32_t B, int32_t T, int32_t chunk, int32_t left,
               float* enc_out_dev, int32_t* enc_lens_host, void* stream) {
   WN_CHECK(m && feats_dev && feat_lens_host, "wn_encode: null argument");
+  PrecisionScope prec_scope(m);
   WN_CHECK(!m->layers.empty() || !m->tf_layers.empty(),
            "wn_encode: this handle has no weights");
   WN_CHECK(B > 0, "wn_encode: empty batch");
@@ -1345,6 +1367,7 @@ int wn_encode_chunk(wn_model* m, const float* feats_dev, int32_t time, int32_t o
                     float* new_att_cache_dev, float* new_cnn_cache_dev,
                     int32_t* chunk_out, int32_t* new_cache_t1_out, void* stream) {
   WN_CHECK(m && feats_dev && out_dev, "wn_encode_chunk: null argument");
+  PrecisionScope prec_scope(m);
   WN_CHECK(!m->layers.empty() && m->cfg.encoder_type == 0,
            "wn_encode_chunk: needs a Conformer encoder");
   WN_CHECK(time >= 7, "wn_encode_chunk: at least 7 frames are needed by Conv2dSubsampling4");
@@ -1403,6 +1426,7 @@ int wn_ctc_logprobs(wn_model* m, int32_t topk, int32_t blank_id,
                     float blank_penalty, float* logp_dev, int32_t Tp,
                     void* stream) {
   WN_CHECK(m && m->B > 0, "wn_ctc_logprobs: no current batch (call wn_encode)");
+  PrecisionScope prec_scope(m);
   WN_CHECK(m->ctc.w, "wn_ctc_logprobs: this handle has no weights");
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));
@@ -1752,6 +1776,7 @@ int wn_decoder_next_topk(wn_model* m, int32_t n_seq, const int32_t* seq_utt_host
                          int32_t max_len, int32_t topk, float* logp_host,
                          int32_t* idx_host, void* stream) {
   WN_CHECK(m && m->B > 0 && m->enc.p, "decoder step: no current batch");
+  PrecisionScope prec_scope(m);
   WN_CHECK(!m->left.layers.empty(), "decoder step: the model has no attention decoder");
   WN_CHECK(n_seq > 0 && seq_utt_host && seq_lens_host && tokens_host && logp_host &&
                idx_host && max_len > 0, "decoder step: bad argument");
@@ -1822,6 +1847,7 @@ int wn_decoder_forward(wn_model* m, int32_t utt, int32_t which, int32_t n_seq,
                        const int32_t* tokens_host, const int32_t* lens_host,
                        int32_t max_len, float* logp_dev, void* stream) {
   WN_CHECK(m && m->B > 0 && m->enc.p, "decoder forward: no current batch");
+  PrecisionScope prec_scope(m);
   WN_CHECK(tokens_host && lens_host && logp_dev, "decoder forward: null argument");
   WN_CHECK(utt >= 0 && utt < m->B && m->len[utt] > 0,
            "decoder forward: utterance index / no encoder frames");
@@ -1886,6 +1912,7 @@ int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host
                            float reverse_weight, float* l2r_logp_host,
                            float* r2l_logp_host, void* stream) {
   WN_CHECK(m && m->B > 0 && m->enc.p, "rescoring: no current batch");
+  PrecisionScope prec_scope(m);
   WN_CHECK(!m->left.layers.empty(), "rescoring: the model has no attention decoder");
   WN_CHECK(n_hyps_host && hyp_lens_host && hyp_tokens_host && l2r_logp_host &&
                r2l_logp_host, "rescoring: null argument");
@@ -1978,6 +2005,16 @@ int wn_op_gemm(const float* A, const float* W, const float* bias,
   g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N;
   g.alpha = alpha; g.act = act;
   return gemm_f32(g, (hipStream_t)stream);
+}
+
+int wn_op_gemm_bf16(const float* A, const float* W, const float* bias,
+                    const float* resid, float* C, int32_t M, int32_t N, int32_t K,
+                    float alpha, int32_t act, void* stream) {
+  const int saved = t_gemm_prec;
+  t_gemm_prec = PREC_BF16;
+  const int r = wn_op_gemm(A, W, bias, resid, C, M, N, K, alpha, act, stream);
+  t_gemm_prec = saved;
+  return r;
 }
 
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,

@@ -232,6 +232,26 @@ class ASRModel:
                 pass
             self._h = None
 
+    # ---- compute dtype (recognize.py --dtype, recognize.py:52-56,250-255) ----
+    _DTYPES = {'fp32': 0, 'float32': 0, torch.float32: 0,
+               'bf16': 1, 'bfloat16': 1, torch.bfloat16: 1}
+
+    def set_compute_dtype(self, dtype) -> 'ASRModel':
+        """'fp32' (default, the parity mode) or 'bf16': every Linear / pointwise
+        conv / subsampling conv rounds its operands to bf16 and accumulates in
+        fp32 on the bf16 matrix cores (wn_model_set_precision).  The reference
+        gets the same effect from torch autocast around model.decode; 'fp16' is
+        not offered (no fp16 kernels)."""
+        if dtype not in self._DTYPES:
+            raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {dtype!r}")
+        _lib.check(self._L.wn_model_set_precision(self._h, self._DTYPES[dtype]),
+                   'wn_model_set_precision')
+        return self
+
+    @property
+    def compute_dtype(self) -> str:
+        return 'bf16' if self._L.wn_model_get_precision(self._h) == 1 else 'fp32'
+
     # torch.nn.Module-flavoured no-ops so reference driver code keeps working
     def eval(self):
         return self
