@@ -237,10 +237,16 @@ int dispatch_tile(const GemmArgs& a, bool conv, hipStream_t stream) {
   //   1: 128x128, 2x4 waves   2: 128x128, 4x2 waves (64-wide wave tile: GLU)
   //   4: 64x128, 2x2 waves (GLU, conv)   5: 64x64, 2x2 waves
   //   7: 256x256, 4x2 waves (144 KB LDS, one block per CU, K tile 64 only)
+  // Measured (tools/bench_gemm.py --bf16, profiles/r01g_gemm_bf16_tiles.txt):
+  // 256x256 wins by 28-47 % once it fills the chip for more than ~2 rounds or
+  // the K loop is long (M=24000: N=5120/3840 K=1280, N=1280 K=5120), loses 4 %
+  // at 470 tiles with K=1280, and badly when it cannot cover the CUs.
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
+  const int64_t t256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
   int cfg;
   if (a.glu) cfg = t128 >= 224 ? 2 : 4;
   else if (conv) cfg = t128 >= 224 ? 1 : 4;
+  else if (BKT == 64 && t256 >= 256 && (t256 >= 1024 || a.K >= 2048)) cfg = 7;
   else cfg = t128 >= 224 ? 1 : 5;
   const int forced = g_gemm_tile_bf16;
   if (forced > 0) {
