@@ -49,8 +49,12 @@ class _Bf16OperandFunctional:
     d -> d Conv2d of Conv2dSubsampling4 -- sees both operands rounded to bf16
     (round to nearest even) and accumulates in fp32.  Everything else stays
     fp32: the 1 -> d Conv2d and the depthwise Conv1d (not GEMMs in the product),
-    attention scores / softmax (torch.matmul is untouched), LayerNorm, and
-    `linear_pos` (projected once at model creation, in fp32)."""
+    softmax, LayerNorm, and `linear_pos` (projected once at model creation, in
+    fp32).  The attention matmuls round their operands too (`_mm` below): q (+
+    pos_bias_u / v), k, the projected position rows, the probabilities and v --
+    what torch.matmul does under autocast.  The product rounds the UN-normalised
+    online-softmax probabilities, the oracle the normalised ones: same relative
+    rounding, not bit-identical."""
 
     def __init__(self, exempt_weights=()):
         self._exempt = {w.data_ptr() for w in exempt_weights}
@@ -78,17 +82,30 @@ class _Bf16OperandFunctional:
         return _TORCH_F.conv2d(self._r(x), self._r(w), b, **kw)
 
 
+_MM_ROUND = False  # bf16_operands(): attention matmuls round their operands
+
+
+def _mm(a, b):
+    """torch.matmul of the attention score / context products."""
+    if _MM_ROUND:
+        a = a.to(torch.bfloat16).to(torch.float32)
+        b = b.to(torch.bfloat16).to(torch.float32)
+    return torch.matmul(a, b)
+
+
 @contextlib.contextmanager
-def bf16_operands(sd=None):
+def bf16_operands(sd=None, attention=True):
     """Run the oracle with the product's bf16-operand arithmetic (see
     _Bf16OperandFunctional).  `sd`: the state_dict, to exempt `linear_pos`."""
-    global F
+    global F, _MM_ROUND
     exempt = [v for k, v in (sd or {}).items() if k.endswith('linear_pos.weight')]
     saved, F = F, _Bf16OperandFunctional(exempt)
+    saved_mm, _MM_ROUND = _MM_ROUND, bool(attention)
     try:
         yield
     finally:
         F = saved
+        _MM_ROUND = saved_mm
 
 # --------------------------------------------------------------------------
 # result record -- wenet/models/transformer/search.py:30-61
@@ -437,7 +454,7 @@ def _forward_attention(value, scores, mask, sd, pfx, h, d_k):
         attn = torch.softmax(scores.float(), dim=-1).masked_fill(m, 0.0)
     else:
         attn = torch.softmax(scores.float(), dim=-1)
-    x = torch.matmul(attn, value)
+    x = _mm(attn, value)
     x = x.transpose(-3, -2).contiguous()
     x = x.view(x.size()[:-2] + (h * d_k, ))
     return F.linear(x, sd[pfx + 'linear_out.weight'],
@@ -464,8 +481,8 @@ def rel_pos_mha(x, mask, pos_emb, sd, pfx, h):
     p = p.view(pos_emb.size(0), -1, h, d_k).transpose(1, 2)
     q_u = (q + sd[pfx + 'pos_bias_u']).transpose(1, 2)
     q_v = (q + sd[pfx + 'pos_bias_v']).transpose(1, 2)
-    matrix_bd = torch.matmul(q_v, p.transpose(-2, -1))
-    matrix_ac = torch.matmul(q_u, k.transpose(-2, -1))
+    matrix_bd = _mm(q_v, p.transpose(-2, -1))
+    matrix_ac = _mm(q_u, k.transpose(-2, -1))
     scores = (matrix_ac + matrix_bd) / math.sqrt(d_k)
     return _forward_attention(v, scores, mask, sd, pfx, h, d_k)
 
@@ -475,7 +492,7 @@ def mha(query, key, value, mask, sd, pfx, h):
     caches, wenet/models/transformer/attention.py:247-304,456-520."""
     d_k = query.size(-1) // h
     q, k, v = _qkv(query, key, value, sd, pfx, h)
-    scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(d_k)
+    scores = _mm(q, k.transpose(-2, -1)) / math.sqrt(d_k)
     return _forward_attention(v, scores, mask, sd, pfx, h, d_k)
 
 
@@ -645,8 +662,8 @@ def rel_pos_mha_cached(x, pos_emb, sd, pfx, h, k_cache, v_cache):
     p = p.view(pos_emb.size(0), -1, h, d_k).transpose(1, 2)
     q_u = (q + sd[pfx + 'pos_bias_u']).transpose(1, 2)
     q_v = (q + sd[pfx + 'pos_bias_v']).transpose(1, 2)
-    scores = (torch.matmul(q_u, k.transpose(-2, -1)) +
-              torch.matmul(q_v, p.transpose(-2, -1))) / math.sqrt(d_k)
+    scores = (_mm(q_u, k.transpose(-2, -1)) +
+              _mm(q_v, p.transpose(-2, -1))) / math.sqrt(d_k)
     out = _forward_attention(v, scores, torch.ones((0, 0, 0), dtype=torch.bool),
                              sd, pfx, h, d_k)
     return out, (k, v)

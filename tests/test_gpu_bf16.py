@@ -6,9 +6,11 @@ contraction rounded to bf16 RNE, fp32 accumulation, everything else fp32).
 
 Tolerances:
   single contraction   |err| <= 2e-6 * (|A| @ |W|^T)   (fp32 accumulation order only)
-  encoder layers       |err| <= 4e-3 * scale per layer (an activation that sits on a
+  encoder layers       |err| <= 6e-3 * scale per layer (an activation that sits on a
                        bf16 rounding boundary may round the other way on the GPU:
-                       one bf16 ulp = 0.4 % of that element)
+                       one bf16 ulp = 0.4 % of that element; the attention kernel
+                       rounds un-normalised online-softmax probabilities, the oracle
+                       normalised ones)
   decode stages        fed identical inputs: CTC log-probs <= 5e-3, rescoring scores
                        <= 3e-2, n-best lists identical on the same log-probs
 The bf16 mode is NOT the parity mode against the fp32 reference (that is the
@@ -132,6 +134,8 @@ def _set_dtype(model, dtype):
     ('tiny_sym', 5, (7, 180), -1, -1),
     ('tiny_bn', 4, (20, 150), -1, -1),
     ('whisper_tiny_like', 4, (3, 140), -1, -1),
+    ('whisper_tiny_like', 2, (780, 900), -1, -1),     # 4 waves per attention block
+    ('whisper_tiny_like', 2, (2050, 2600), -1, -1),   # 8 waves per attention block
 ])
 def test_bf16_encoder_layers_vs_oracle(config, B, frames, chunk, left):
     """Every encoder layer output of the bf16 mode against the oracle with the same
@@ -163,7 +167,7 @@ def test_bf16_encoder_layers_vs_oracle(config, B, frames, chunk, left):
                     scale = max(layers[n][b, :nb].abs().max().item(), 1.0)
                     worst = max(worst, (enc[b, :nb] - layers[n][b, :nb]).abs().max().item() / scale)
                     apart = max(apart, (layers32[n][b, :nb] - layers[n][b, :nb]).abs().max().item() / scale)
-            assert worst < 4e-3, (config, 'layer', n, worst)
+            assert worst < 6e-3, (config, 'layer', n, worst)
             # the emulation and fp32 differ by far more than GPU vs emulation,
             # so this test does tell the two arithmetic modes apart
             if n == len(layers) - 1:
@@ -230,6 +234,36 @@ def test_bf16_decode_stages_vs_oracle(config, B, frames, chunk):
         n = int(enc_lens[b])
         if n and margin[b, :n].min().item() > 0.2:
             assert got['ctc_greedy_search'][b].tokens == ref_greedy[b].tokens
+
+
+@pytest.mark.parametrize('nw', [2, 4, 8])
+@pytest.mark.parametrize('config,chunk,left', [('tiny_causal', 8, 1), ('tiny_causal', -1, -1),
+                                               ('tiny_sym', -1, -1)])
+def test_bf16_attention_block_shapes(nw, config, chunk, left):
+    """Every block shape of the bf16 attention kernel (2 / 4 / 8 query groups per
+    block) under the full, chunk and left-context masks, rel-pos variant, ragged
+    lengths that leave partial query groups and partial key tiles."""
+    from wenet_amd import _lib, synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(4, (300, 700), seed=29, feat_dim=configs['input_dim'])
+    with torch.no_grad(), O.bf16_operands(sd):
+        ref, mask = O.encoder_forward(configs, sd, feats, lens, chunk, left)
+    ref_lens = mask.squeeze(1).sum(1).numpy()
+    L = _lib.lib()
+    _set_dtype(model, 'bf16')
+    try:
+        _lib.check(L.wn_tune_set(b'attn_bf16_nw', nw), 'tune')
+        enc, _ = model._forward_encoder(feats.cuda(), lens, chunk, left)
+    finally:
+        L.wn_tune_set(b'attn_bf16_nw', 0)
+        _set_dtype(model, 'fp32')
+    enc = enc.cpu()
+    for b in range(4):
+        nb = int(ref_lens[b])
+        scale = max(ref[b, :nb].abs().max().item(), 1.0)
+        err = (enc[b, :nb] - ref[b, :nb]).abs().max().item() / scale
+        assert err < 6e-3, (config, nw, b, err)
 
 
 def test_bf16_is_a_per_handle_switch_and_fp32_comes_back_bit_exact():

@@ -1,0 +1,318 @@
+// Multi-head attention (d_k = 64) with bf16 operands on the bf16 matrix cores --
+// the WN_PREC_BF16 twin of attention_kernel (encoder_kernels.hip): same
+// arguments, masks, online softmax in fp32 and fp32 output; Q (+ pos_bias_u/v),
+// K, the projected position rows and the probabilities / V are rounded to bf16
+// (RNE) where they enter an MFMA.  Under the reference's autocast
+// (wenet/bin/recognize.py:278-280) torch.matmul(q, k^T) and torch.matmul(attn, v)
+// (wenet/models/transformer/attention.py:133-178,364-438) run with bf16 operands
+// as well; the softmax there and here is fp32.
+//
+// One block = NW waves, each wave owns 32 query rows of one (sequence, head);
+// the block shares every 32-key K / V (/ P) tile, staged global (fp32) ->
+// registers -> bf16 LDS one tile ahead (double-buffered, one barrier per tile).
+// Per tile and wave:
+//   S^T = K (Q+u)^T [+ P (Q+v)^T]   4 (8) x v_mfma_f32_32x32x16_bf16
+//       lane l holds, for ITS query (l & 31), keys (r&3) + 8(r>>2) + 4(l>>5)
+//   online softmax on the lane's 16 scores (max / sum: one exchange with lane^32)
+//   O += P V                         4 x v_mfma_f32_32x32x16_bf16
+//       the lane's probabilities r = 8j .. 8j+7 ARE the A fragment of MFMA j
+//       (k slot (hi, e) <-> key 16j + 4hi + (e&3) + 8(e>>2)); V is stored
+//       TRANSPOSED in LDS, Vt[dim][slot], slot = 16j + 8hi + e, so the B fragment
+//       (8 keys of one dim) is one 16-byte read.
+// With 16x the MFMA rate the softmax VALU work (16 scores per lane and tile)
+// bounds the kernel; NW grows with the sequence length so that the fp32 K / V
+// stream from L2 is shared by more queries (64 B/clk/CU budget).
+#include "kernels.h"
+
+namespace wn {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KT = 32;     // keys per tile
+constexpr int KSTR = 72;   // K / P tile row stride (bf16): 64 dims + 16 B pad
+constexpr int VSTR = 40;   // Vt row stride (bf16): 32 key slots + 16 B pad
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+  r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+  r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+  return r;
+}
+
+template <int NW, bool RELPOS>
+__global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attention_bf16_kernel(AttnArgs a) {
+  const int s = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (NW * 32);
+  const int qlen = a.q_len[s];
+  if (q0 >= qlen) return;
+  const int kvlen = a.kv_len[s];
+  const int qoff = a.q_off[s], kvoff = a.kv_off[s];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  constexpr int NTHR = NW * 64;
+
+  // LDS: [2 buffers][K tile | Vt tile | P tile]
+  constexpr int KMAT = KT * KSTR;        // bf16 elements
+  constexpr int VMAT = 64 * VSTR;
+  constexpr int BUF = KMAT + VMAT + (RELPOS ? KMAT : 0);
+  __shared__ __attribute__((aligned(16))) __bf16 stile[2 * BUF];
+
+  // ---- this lane's query row: dims kk*16 + hi*8 .. +7, kk = 0..3 ------------
+  const int qi = q0 + wave * 32 + li;
+  const int qc = qi < qlen ? qi : qlen - 1;
+  bf16x8 qu[4], qv[RELPOS ? 4 : 1];
+  {
+    const float* qp = a.Q + (int64_t)(qoff + qc) * a.ldq + h * 64 + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + kk * 16);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + kk * 16 + 4);
+      if (RELPOS) {
+        const float* bu = a.bias_u + h * 64 + kk * 16 + hi * 8;
+        const float* bv = a.bias_v + h * 64 + kk * 16 + hi * 8;
+        qu[kk] = pack8(x0 + *reinterpret_cast<const f32x4*>(bu),
+                       x1 + *reinterpret_cast<const f32x4*>(bu + 4));
+        qv[kk] = pack8(x0 + *reinterpret_cast<const f32x4*>(bv),
+                       x1 + *reinterpret_cast<const f32x4*>(bv + 4));
+      } else {
+        qu[kk] = pack8(x0, x1);
+      }
+    }
+  }
+  // key window of this query: [jmin, jmax)
+  int jmin = 0, jmax = kvlen;
+  if (a.mask_mode == 1) {
+    jmax = min(kvlen, qi + 1);
+  } else if (a.mask_mode == 2) {
+    const int c = qi / a.chunk_size;
+    jmax = min(kvlen, (c + 1) * a.chunk_size);
+    if (a.left_chunks >= 0) jmin = max((c - a.left_chunks) * a.chunk_size, 0);
+  }
+  // key range of the whole block (uniform)
+  int blo = 0, bhi = kvlen;
+  {
+    const int qlast = min(q0 + NW * 32, qlen) - 1;
+    if (a.mask_mode == 1) {
+      bhi = min(kvlen, qlast + 1);
+    } else if (a.mask_mode == 2) {
+      bhi = min(kvlen, (qlast / a.chunk_size + 1) * a.chunk_size);
+      if (a.left_chunks >= 0)
+        blo = max((q0 / a.chunk_size - a.left_chunks) * a.chunk_size, 0);
+    }
+  }
+  const int t_lo = blo / KT, t_hi = (bhi + KT - 1) / KT;
+  const int n_it = t_hi - t_lo;
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+
+  // ---- tile staging ---------------------------------------------------------
+  // K (and P): 32 rows x 16 float4 chunks, natural mapping (coalesced rows).
+  // V: 16 key pairs x 16 float4 chunks; an item loads the same 4 dims of keys
+  // 2m, 2m+1 (adjacent slots of Vt) and writes 4 packed bf16 pairs.
+  constexpr int NCK = (KT * 16 + NTHR - 1) / NTHR;   // K chunks per thread
+  constexpr int NCV = (KT * 8 + NTHR - 1) / NTHR;    // V items per thread
+  f32x4 rK[NCK], rP[RELPOS ? NCK : 1], rV0[NCV], rV1[NCV];
+  auto gload = [&](int it) {
+    const int jt = (t_lo + it) * KT;
+#pragma unroll
+    for (int i = 0; i < NCK; ++i) {
+      const int c = tid + i * NTHR;
+      if (KT * 16 % NTHR == 0 || c < KT * 16) {
+        const int r = c >> 4, c4 = c & 15;
+        int j = jt + r;
+        if (j > kvlen - 1) j = kvlen - 1;
+        rK[i] = *reinterpret_cast<const f32x4*>(a.K + (int64_t)(kvoff + j) * a.ldk +
+                                                h * 64 + c4 * 4);
+        if (RELPOS)
+          rP[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)j * a.ldp + h * 64 +
+                                                  c4 * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCV; ++i) {
+      const int c = tid + i * NTHR;
+      if (KT * 8 % NTHR == 0 || c < KT * 8) {
+        const int m = c & 15, c4 = c >> 4;
+        int j0 = jt + 2 * m, j1 = j0 + 1;
+        if (j0 > kvlen - 1) j0 = kvlen - 1;
+        if (j1 > kvlen - 1) j1 = kvlen - 1;
+        rV0[i] = *reinterpret_cast<const f32x4*>(a.V + (int64_t)(kvoff + j0) * a.ldv +
+                                                 h * 64 + c4 * 4);
+        rV1[i] = *reinterpret_cast<const f32x4*>(a.V + (int64_t)(kvoff + j1) * a.ldv +
+                                                 h * 64 + c4 * 4);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    __bf16* base = stile + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < NCK; ++i) {
+      const int c = tid + i * NTHR;
+      if (KT * 16 % NTHR == 0 || c < KT * 16) {
+        const int r = c >> 4, c4 = c & 15;
+        bf16x4 k4;
+        k4[0] = (__bf16)rK[i][0]; k4[1] = (__bf16)rK[i][1];
+        k4[2] = (__bf16)rK[i][2]; k4[3] = (__bf16)rK[i][3];
+        *reinterpret_cast<bf16x4*>(base + r * KSTR + c4 * 4) = k4;
+        if (RELPOS) {
+          bf16x4 p4;
+          p4[0] = (__bf16)rP[i][0]; p4[1] = (__bf16)rP[i][1];
+          p4[2] = (__bf16)rP[i][2]; p4[3] = (__bf16)rP[i][3];
+          *reinterpret_cast<bf16x4*>(base + KMAT + VMAT + r * KSTR + c4 * 4) = p4;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCV; ++i) {
+      const int c = tid + i * NTHR;
+      if (KT * 8 % NTHR == 0 || c < KT * 8) {
+        const int m = c & 15, c4 = c >> 4;
+        const int k = 2 * m;                       // tile-local key of rV0
+        const int k16 = k & 15;
+        const int slot = (k >> 4) * 16 + ((k16 >> 2) & 1) * 8 + (k16 & 3) +
+                         4 * (k16 >> 3);          // even; key k+1 is slot+1
+        __bf16* vt = base + KMAT + (c4 * 4) * VSTR + slot;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          bf16x2 pr;
+          pr[0] = (__bf16)rV0[i][d];
+          pr[1] = (__bf16)rV1[i][d];
+          *reinterpret_cast<bf16x2*>(vt + d * VSTR) = pr;
+        }
+      }
+    }
+  };
+  if (n_it > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+
+  for (int it = 0; it < n_it; ++it) {
+    const int j0 = (t_lo + it) * KT;
+    const int cur = it & 1;
+    const __bf16* sK = stile + cur * BUF;
+    const __bf16* sV = sK + KMAT;
+    const __bf16* sP = sK + KMAT + VMAT;
+    if (it + 1 < n_it) gload(it + 1);
+
+    // ---- S^T tile -----------------------------------------------------------
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    {
+      const __bf16* kf = sK + li * KSTR + hi * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 fk = *reinterpret_cast<const bf16x8*>(kf + kk * 16);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, qu[kk], sc, 0, 0, 0);
+      }
+      if (RELPOS) {
+        const __bf16* pf = sP + li * KSTR + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bf16x8 fp = *reinterpret_cast<const bf16x8*>(pf + kk * 16);
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp, qv[kk], sc, 0, 0, 0);
+        }
+      }
+    }
+    // ---- online softmax on this lane's query ----------------------------------
+    float tmax = -1e30f;
+    bool ok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      ok[r] = (j >= jmin) && (j < jmax);
+      sc[r] *= a.scale;
+      if (ok[r]) tmax = fmaxf(tmax, sc[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = ok[r] ? __expf(sc[r] - m_new) : 0.f;
+      sc[r] = p;
+      psum += p;
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    // rescale the running output: its rows are queries (r&3)+8(r>>2)+4hi
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * hi, 64);
+        o0[r] *= ar;
+        o1[r] *= ar;
+      }
+    }
+    // ---- O += P V ---------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 pa;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pa[e] = (__bf16)sc[8 * j + e];
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(sV + li * VSTR + j * 16 + hi * 8);
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(sV + (32 + li) * VSTR + j * 16 +
+                                                         hi * 8);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, v0, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, v1, o1, 0, 0, 0);
+    }
+    if (it + 1 < n_it) lstore(cur ^ 1);
+    __syncthreads();  // next tile visible, this buffer free
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  // ---- normalise and store ---------------------------------------------------
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;  // fully-masked row -> 0
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    const float ir = __shfl(inv, qr, 64);
+    const int qrow = q0 + wave * 32 + qr;
+    if (qrow < qlen) {
+      float* op = a.O + (int64_t)(qoff + qrow) * a.ldo + h * 64;
+      op[li] = o0[r] * ir;
+      op[32 + li] = o1[r] * ir;
+    }
+  }
+}
+
+template <int NW>
+int launch(const AttnArgs& a, hipStream_t s) {
+  dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 64);
+  if (a.P)
+    hipLaunchKernelGGL((attention_bf16_kernel<NW, true>), g, t, 0, s, a);
+  else
+    hipLaunchKernelGGL((attention_bf16_kernel<NW, false>), g, t, 0, s, a);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int g_attn_bf16_nw = 0;  // wn_tune_set("attn_bf16_nw"): 0 auto, else 2 / 4 / 8
+
+int attention_bf16(const AttnArgs& a, hipStream_t s) {
+  // argument checks are attention()'s (the only caller)
+  WN_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldp % 4 == 0,
+           "attention(bf16): strides must be multiples of 4 floats");
+  int nw = g_attn_bf16_nw;
+  if (nw != 2 && nw != 4 && nw != 8)
+    nw = a.max_q_len >= 1024 ? 8 : a.max_q_len >= 384 ? 4 : 2;
+  switch (nw) {
+    case 8: return launch<8>(a, s);
+    case 4: return launch<4>(a, s);
+    default: return launch<2>(a, s);
+  }
+}
+
+}  // namespace wn

@@ -574,12 +574,14 @@ int dwconv_ln_silu(const DwConvArgs& a, hipStream_t s) {
 }
 
 int g_attn_split = 0;  // wn_tune_set("attn_split")
+int g_attn_bf16 = 1;   // wn_tune_set("attn_bf16")
 
 int attention(const AttnArgs& a, hipStream_t s) {
   WN_CHECK(a.n_seq > 0 && a.n_heads > 0 && a.max_q_len > 0, "attention: empty");
   WN_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0,
            "attention: strides must be multiples of 4 floats");
   WN_CHECK(a.mask_mode != 2 || a.chunk_size > 0, "attention: chunk size");
+  if (t_gemm_prec == PREC_BF16 && g_attn_bf16 != 0) return attention_bf16(a, s);
   constexpr int NW = 2;
   dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 64);
   // key split for the encoder's self attention over long sequences: twice the

@@ -66,6 +66,11 @@ struct AttnArgs {
   float scale = 0.125f;
 };
 int attention(const AttnArgs& a, hipStream_t s);
+// The same with bf16 MFMA operands (attention_bf16.hip); attention() routes here
+// when the calling thread's precision is PREC_BF16 (and g_attn_bf16 != 0).
+int attention_bf16(const AttnArgs& a, hipStream_t s);
+extern int g_attn_bf16;      // 1 (default): bf16 mode uses the bf16 attention kernel
+extern int g_attn_bf16_nw;   // 0 auto, else waves (32-query groups) per block
 
 // CTC head tail: per row log-softmax statistics + top-k (descending, lower
 // index first on ties) (+ optionally the full log-prob row).

@@ -1305,6 +1305,8 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "gemm_tile_bf16") g_gemm_tile_bf16 = value;
   else if (k == "ln_rows") g_ln_rows = value;
   else if (k == "attn_split") g_attn_split = value;
+  else if (k == "attn_bf16") g_attn_bf16 = value;
+  else if (k == "attn_bf16_nw") g_attn_bf16_nw = value;
   else { set_error("wn_tune_set: unknown key " + k); return -1; }
   return 0;
 }
