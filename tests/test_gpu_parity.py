@@ -969,3 +969,84 @@ def test_attention_key_split_vs_oracle(config, B, frames, chunk, left):
         L.wn_tune_set(b'attn_split', 0)
     # the two kernels agree with each other far inside the oracle tolerance
     assert (outs[1] - outs[2]).abs().max() < 5e-4
+
+
+def test_recognize_cli_shard_list_equals_raw_list(tmp_path):
+    """--data_type shard (tar shards of <key>.wav / <key>.txt, one plain and one
+    gzip-compressed) writes the same result files as --data_type raw on the same
+    audio; a raw list with start / end decodes the segment; --dtype bf16 runs the
+    same command on the bf16 matrix cores."""
+    import io
+    import json
+    import tarfile
+    import wave
+    import yaml
+    from wenet_amd.bin import recognize as R
+    configs, sd, model = cached_model('tiny_causal', 0)
+    V = configs['output_dim']
+    units = tmp_path / 'units.txt'
+    syms = ['<blank>', '<unk>'] + [f't{i}' for i in range(2, V - 1)] + ['<sos/eos>']
+    units.write_text(''.join(f'{s} {i}\n' for i, s in enumerate(syms)))
+    cfg = dict(configs)
+    cfg['tokenizer'] = 'char'
+    cfg['tokenizer_conf'] = dict(symbol_table_path=str(units), non_lang_syms_path=None,
+                                 connect_symbol=' ')
+    cfg['dataset_conf'] = dict(fbank_conf=dict(num_mel_bins=80, frame_length=25,
+                                               frame_shift=10, dither=0.0))
+    (tmp_path / 'train.yaml').write_text(yaml.safe_dump(cfg))
+    torch.save(sd, tmp_path / 'final.pt')
+    rng = np.random.RandomState(5)
+    keys, blobs = [], {}
+    for i in range(5):
+        n = int(rng.randint(16000, 36000))
+        t = np.arange(n) / 16000.0
+        x = 0.3 * np.sin(2 * np.pi * (180 + 70 * i) * t) + 0.05 * rng.randn(n)
+        path = tmp_path / f'u{i}.wav'
+        with wave.open(str(path), 'wb') as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(np.clip(x * 32768, -32768, 32767).astype(np.int16).tobytes())
+        keys.append(f'utt{i}')
+        blobs[f'utt{i}'] = path.read_bytes()
+    raw = tmp_path / 'raw.list'
+    raw.write_text(''.join(json.dumps(dict(key=k, wav=str(tmp_path / f'u{i}.wav'), txt='')) +
+                           '\n' for i, k in enumerate(keys)))
+    for name, mode, ks in (('s0.tar', 'w', keys[:3]), ('s1.tar.gz', 'w:gz', keys[3:])):
+        with tarfile.open(tmp_path / name, mode) as t:
+            for k in ks:
+                for ext, payload in (('wav', blobs[k]), ('txt', b'x')):
+                    ti = tarfile.TarInfo(f'{k}.{ext}')
+                    ti.size = len(payload)
+                    t.addfile(ti, io.BytesIO(payload))
+    shard = tmp_path / 'shard.list'
+    shard.write_text(f"{tmp_path / 's0.tar'}\n{tmp_path / 's1.tar.gz'}\n")
+    modes = ['ctc_greedy_search', 'attention_rescoring']
+
+    def run(lst, out, *extra):
+        rc = R.main(['--config', str(tmp_path / 'train.yaml'), '--checkpoint',
+                     str(tmp_path / 'final.pt'), '--test_data', str(lst), '--result_dir',
+                     str(out), '--batch_size', '2', '--beam_size', '3', '--ctc_weight',
+                     '0.5', '--modes'] + modes + list(extra))
+        assert rc == 0
+        return {m: (out / m / 'text').read_text().splitlines() for m in modes}
+    a = run(raw, tmp_path / 'o_raw')
+    b = run(shard, tmp_path / 'o_shard', '--data_type', 'shard')
+    assert a == b and len(a['ctc_greedy_search']) == 5
+    # segment: the first second of utt0 == decoding a file that holds only that
+    with wave.open(str(tmp_path / 'u0.wav'), 'rb') as w:
+        head = w.readframes(16000)
+    with wave.open(str(tmp_path / 'head.wav'), 'wb') as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(head)
+    seg = tmp_path / 'seg.list'
+    seg.write_text(json.dumps(dict(key='s', wav=str(tmp_path / 'u0.wav'), start=0.0, end=1.0))
+                   + '\n')
+    whole = tmp_path / 'head.list'
+    whole.write_text(json.dumps(dict(key='s', wav=str(tmp_path / 'head.wav'))) + '\n')
+    assert run(seg, tmp_path / 'o_seg') == run(whole, tmp_path / 'o_head')
+    c = run(raw, tmp_path / 'o_bf16', '--dtype', 'bf16')
+    assert [ln.split(' ')[0] for ln in c['ctc_greedy_search']] == \
+        [ln.split(' ')[0] for ln in a['ctc_greedy_search']]

@@ -17,8 +17,11 @@ def test_args_reject_modes_outside_the_path():
     assert a.modes == ['ctc_greedy_search', 'attention_rescoring'] and a.batch_size == 16
     with pytest.raises(SystemExit):
         R.get_args(base + ['--modes', 'rnnt_greedy_search'])
+    assert R.get_args(base + ['--modes', 'attention', '--data_type', 'shard']
+                      ).data_type == 'shard'
     with pytest.raises(SystemExit):
-        R.get_args(base + ['--modes', 'attention', '--data_type', 'shard'])
+        R.get_args(base + ['--modes', 'attention', '--dtype', 'fp16'])
+    assert R.get_args(base + ['--modes', 'attention', '--dtype', 'bf16']).dtype == 'bf16'
 
 
 def test_data_list_batches_and_order(tmp_path):
@@ -32,6 +35,124 @@ def test_data_list_batches_and_order(tmp_path):
     # processor.padding: longest first, ties keep list order
     assert R.padding_order([50, 80, 50, 90, 80]) == [3, 1, 4, 0, 2]
     p.write_text('{"wav": "x"}\n')
+    with pytest.raises(ValueError):
+        R.read_data_list(str(p))
+
+
+def _wav_bytes(samples, rate, tag, bits, nch=1, extensible=False, extra_chunk=True):
+    """A RIFF/WAVE image of `samples` ((n, nch) float in [-1, 1))."""
+    import struct
+    import numpy as np
+    x = np.asarray(samples, dtype=np.float64).reshape(-1, nch)
+    if tag == 1 and bits == 8:
+        raw = np.clip(np.round(x * 128 + 128), 0, 255).astype(np.uint8).tobytes()
+    elif tag == 1 and bits == 16:
+        raw = np.round(x * 32768).clip(-32768, 32767).astype('<i2').tobytes()
+    elif tag == 1 and bits == 24:
+        v = np.round(x * (1 << 23)).clip(-(1 << 23), (1 << 23) - 1).astype(np.int64)
+        v = np.where(v < 0, v + (1 << 24), v).reshape(-1)
+        raw = b''.join(int(t).to_bytes(3, 'little') for t in v)
+    elif tag == 1 and bits == 32:
+        raw = np.round(x * 2147483648.0).clip(-2 ** 31, 2 ** 31 - 1).astype('<i4').tobytes()
+    elif tag == 3 and bits == 32:
+        raw = x.astype('<f4').tobytes()
+    else:
+        raw = x.astype('<f8').tobytes()
+    block = nch * bits // 8
+    if extensible:
+        guid = struct.pack('<H', tag) + bytes.fromhex('000000001000800000aa00389b71')
+        fmt = struct.pack('<HHIIHHHHI', 0xFFFE, nch, rate, rate * block, block, bits,
+                          22, bits, 0) + guid
+    else:
+        fmt = struct.pack('<HHIIHH', tag, nch, rate, rate * block, block, bits)
+    chunks = b'fmt ' + struct.pack('<I', len(fmt)) + fmt
+    if extra_chunk:
+        chunks += b'LIST' + struct.pack('<I', 5) + b'hello' + b'\0'  # odd size + pad
+    chunks += b'data' + struct.pack('<I', len(raw)) + raw
+    return b'RIFF' + struct.pack('<I', 4 + len(chunks)) + b'WAVE' + chunks
+
+
+def test_read_wav_formats_segments_and_bytes(tmp_path):
+    """decode_wav (processor.py:125-153): every linear wav encoding with
+    torchaudio.load's normalisation, first channel of multi-channel files, byte
+    strings (shard members) and `start` / `end` segments."""
+    import io
+    import wave
+    import numpy as np
+    from wenet_amd.model import read_wav
+    rng = np.random.Generator(np.random.PCG64(3))
+    x = (rng.random((4000, 2)) * 1.8 - 0.9)
+    x16 = np.round(x * 32768) / 32768          # exactly representable in s16
+    for tag, bits, tol in [(1, 16, 0), (1, 24, 0), (1, 32, 0), (3, 32, 1e-7), (3, 64, 1e-7),
+                           (1, 8, 1 / 128)]:
+        for ext in (False, True):
+            buf = _wav_bytes(x16, 16000, tag, bits, nch=2, extensible=ext)
+            got = read_wav(buf)
+            assert got.dtype == np.float32 and got.shape == (4000, )
+            assert np.abs(got - x16[:, 0]).max() <= tol + 1e-9, (tag, bits, ext)
+    # the stdlib writer's s16 file, from a path, a file object, with a rate
+    p = tmp_path / 'a.wav'
+    with wave.open(str(p), 'wb') as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(8000)
+        w.writeframes(np.round(x16[:, 1] * 32768).astype('<i2').tobytes())
+    got, sr = read_wav(str(p), return_rate=True)
+    assert sr == 8000 and np.array_equal(got, x16[:, 1].astype(np.float32))
+    got2, _ = read_wav(io.BytesIO(p.read_bytes()), return_rate=True)
+    assert np.array_equal(got, got2)
+    with pytest.raises(NotImplementedError):
+        read_wav(str(p))                         # 8 kHz without return_rate
+    seg, _ = read_wav(str(p), return_rate=True, start=0.1, end=0.25)
+    assert np.array_equal(seg, got[800:2000])
+    with pytest.raises(ValueError):
+        read_wav(b'OggS' + bytes(64))
+    with pytest.raises(NotImplementedError):
+        read_wav(_wav_bytes(x16, 16000, 1, 16).replace(b'\x01\x00\x01\x00', b'\x11\x00\x01\x00', 1))
+
+
+def test_shard_list_reads_tar_members_lazily(tmp_path):
+    """tar_file_and_group (datapipes.py:365-427): <key>.wav + <key>.txt groups in
+    member order; plain tars are read by offset, compressed ones through tarfile."""
+    import io
+    import tarfile
+    import numpy as np
+    from wenet_amd.model import read_wav
+    waves = {f'utt{i}': _wav_bytes(np.full((100 + i, 1), i / 10.0), 16000, 1, 16)
+             for i in range(5)}
+
+    def build(path, mode, keys, with_orphan=False):
+        with tarfile.open(path, mode) as t:
+            for k in keys:
+                for ext, payload in (('txt', ('text ' + k).encode()), ('wav', waves[k])):
+                    ti = tarfile.TarInfo(f'{k}.{ext}')
+                    ti.size = len(payload)
+                    t.addfile(ti, io.BytesIO(payload))
+            if with_orphan:  # a transcript without audio is dropped
+                ti = tarfile.TarInfo('orphan.txt')
+                ti.size = 1
+                t.addfile(ti, io.BytesIO(b'x'))
+    build(tmp_path / 's0.tar', 'w', ['utt0', 'utt1', 'utt2'], with_orphan=True)
+    build(tmp_path / 's1.tar.gz', 'w:gz', ['utt3', 'utt4'])
+    lst = tmp_path / 'shards.list'
+    lst.write_text(f"{tmp_path / 's0.tar'}\nfile://{tmp_path / 's1.tar.gz'}\n\n")
+    entries = R.read_data_list(str(lst), 'shard')
+    assert [k for k, _ in entries] == ['utt0', 'utt1', 'utt2', 'utt3', 'utt4']
+    assert entries[0][1].offset is not None and entries[3][1].offset is None
+    for k, m in entries:
+        assert m.read() == waves[k]
+        assert len(read_wav(m.read())) == 100 + int(k[3:])
+    lst.write_text('https://example.com/s.tar\n')
+    with pytest.raises(ValueError):
+        R.read_data_list(str(lst), 'shard')
+
+
+def test_raw_list_segments(tmp_path):
+    p = tmp_path / 'd.list'
+    p.write_text(json.dumps(dict(key='a', wav='/w/a.wav', start=1.5, end=2.0)) + '\n' +
+                 json.dumps(dict(key='b', wav='/w/b.wav')) + '\n')
+    assert R.read_data_list(str(p)) == [('a', ('/w/a.wav', 1.5, 2.0)), ('b', '/w/b.wav')]
+    p.write_text(json.dumps(dict(key='a', wav='/w/a.wav', start=1.5)) + '\n')
     with pytest.raises(ValueError):
         R.read_data_list(str(p))
 

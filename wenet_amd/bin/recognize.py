@@ -73,8 +73,6 @@ def get_args(argv=None):
     for m in args.modes:
         if m not in MODES:
             p.error(f'mode {m!r} is not on the accelerated path (have: {MODES})')
-    if args.data_type != 'raw':
-        p.error("only --data_type raw (a list of wav files) is supported")
     return args
 
 
@@ -96,19 +94,87 @@ def override_config(configs: dict, items: Sequence[str]) -> dict:
     return configs
 
 
-def read_data_list(path: str) -> List[Tuple[str, str]]:
-    """`raw` lists (processor.parse_raw, processor.py:104-122): one JSON object
-    per line with `key`, `wav` (and `txt`, unused here)."""
+AUDIO_FORMAT_SETS = {'flac', 'mp3', 'm4a', 'ogg', 'opus', 'wav', 'wma'}  # processor.py:39
+
+
+class TarMember:
+    """One audio file inside a shard: read lazily by the reader threads."""
+
+    __slots__ = ('tar', 'name', 'offset', 'size')
+
+    def __init__(self, tar, name, offset, size):
+        self.tar, self.name, self.offset, self.size = tar, name, offset, size
+
+    def read(self) -> bytes:
+        if self.offset is not None:        # plain tar: the member's bytes lie as-is
+            with open(self.tar, 'rb') as f:
+                f.seek(self.offset)
+                return f.read(self.size)
+        import tarfile
+        with tarfile.open(self.tar, 'r:*') as t:   # compressed tar
+            return t.extractfile(self.name).read()
+
+
+def read_data_list(path: str, data_type: str = 'raw') -> List[Tuple[str, object]]:
+    """(key, audio source) of every utterance in list order.
+
+    `raw` lists (processor.parse_json + decode_wav, processor.py:66-70,125-153):
+    one JSON object per line with `key`, `wav` and optionally `start` / `end`
+    (seconds; a segment of the file); `txt` is unused here.  The source is the
+    path, or (path, start, end).
+
+    `shard` lists (datapipes.py:365-427 tar_file_and_group): one LOCAL tar path
+    (or file:// URL) per line; inside, consecutive members `<key>.<audio ext>` and
+    `<key>.txt` form one utterance (an utterance without audio is dropped, like
+    the reference's `valid` flag).  The source is a TarMember.  Remote URLs
+    (the reference pipes them through wget) are refused: no network on this path."""
     out = []
     with open(path, 'r', encoding='utf8') as f:
-        for ln, line in enumerate(f, 1):
-            line = line.strip()
+        lines = [ln.strip() for ln in f]
+    if data_type == 'raw':
+        for ln, line in enumerate(lines, 1):
             if not line:
                 continue
             obj = json.loads(line)
             if 'key' not in obj or 'wav' not in obj:
                 raise ValueError(f'{path}:{ln}: need "key" and "wav"')
-            out.append((obj['key'], obj['wav']))
+            if 'start' in obj:
+                if 'end' not in obj:
+                    raise ValueError(f'{path}:{ln}: "start" without "end"')
+                out.append((obj['key'], (obj['wav'], float(obj['start']),
+                                         float(obj['end']))))
+            else:
+                out.append((obj['key'], obj['wav']))
+        return out
+    import tarfile
+    from urllib.parse import urlparse
+    for ln, line in enumerate(lines, 1):
+        if not line:
+            continue
+        pr = urlparse(line)
+        if pr.scheme not in ('', 'file'):
+            raise ValueError(f'{path}:{ln}: only local shards are supported, got {line}')
+        tar_path = pr.path if pr.scheme == 'file' else line
+        with open(tar_path, 'rb') as fh:
+            plain = fh.read(262)[257:262] == b'ustar'  # else: compressed (or v7) tar
+        with tarfile.open(tar_path, 'r:*') as t:
+            prev, member = None, None
+            for ti in t:
+                if not ti.isfile():
+                    continue
+                pos = ti.name.rfind('.')
+                assert pos > 0, f'{tar_path}: member {ti.name!r} has no extension'
+                prefix, postfix = ti.name[:pos], ti.name[pos + 1:]
+                if prev is not None and prefix != prev:
+                    if member is not None:
+                        out.append((prev, member))
+                    member = None
+                if postfix in AUDIO_FORMAT_SETS:
+                    member = TarMember(tar_path, ti.name,
+                                       ti.offset_data if plain else None, ti.size)
+                prev = prefix
+            if prev is not None and member is not None:
+                out.append((prev, member))
     return out
 
 
@@ -181,8 +247,12 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
     import torch
     from wenet_amd.model import read_wav
 
-    def read16k(path):  # host threads read; rates other than 16 kHz go through
-        return read_wav(path, return_rate=True)  # the device resampler below
+    def read16k(src):  # host threads read; rates other than 16 kHz go through
+        if isinstance(src, TarMember):          # the device resampler below
+            return read_wav(src.read(), return_rate=True)
+        if isinstance(src, tuple):              # (path, start, end) segment
+            return read_wav(src[0], return_rate=True, start=src[1], end=src[2])
+        return read_wav(src, return_rate=True)
     from wenet_amd.pipeline import DecodePipeline
     kw = dict(beam_size=args.beam_size,
               decoding_chunk_size=args.decoding_chunk_size,
@@ -276,7 +346,8 @@ def main(argv=None):
                                      configs['tokenizer_conf'].get('bpe_path'),
                                      args.context_graph_score)
 
-    batches = static_batches(read_data_list(args.test_data), args.batch_size)
+    batches = static_batches(read_data_list(args.test_data, args.data_type),
+                             args.batch_size)
     mine = list(range(rank, len(batches), world))
     files = {}
     for mode in args.modes:

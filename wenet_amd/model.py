@@ -17,7 +17,6 @@ import ctypes
 import json
 import math
 import os
-import wave
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -724,17 +723,77 @@ class ASRModel:
         return result
 
 
-def read_wav(path: str, return_rate: bool = False):
-    """16-bit PCM wav -> mono (first channel) float32 in [-1, 1) like
-    torchaudio.load (processor.py:141-148).  Without `return_rate` the file must
-    be 16 kHz (use ASRModel.load_wav to resample)."""
-    with wave.open(path, 'rb') as w:
-        assert w.getsampwidth() == 2, 'only 16-bit PCM wav is supported'
-        sr, nch = w.getframerate(), w.getnchannels()
-        data = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+def _parse_riff_wave(buf: bytes):
+    """RIFF/WAVE container -> (format tag, channels, rate, bits, data bytes).
+    PCM (1), IEEE float (3) and WAVE_FORMAT_EXTENSIBLE (0xFFFE, sub-format in
+    the GUID's first two bytes); unknown chunks (LIST, fact, ...) are skipped."""
+    import struct
+    if len(buf) < 12 or buf[:4] != b'RIFF' or buf[8:12] != b'WAVE':
+        raise ValueError('not a RIFF/WAVE file')
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(buf):
+        cid, size = buf[pos:pos + 4], struct.unpack('<I', buf[pos + 4:pos + 8])[0]
+        body = buf[pos + 8:pos + 8 + size]
+        if cid == b'fmt ':
+            tag, nch, rate, _, _, bits = struct.unpack('<HHIIHH', body[:16])
+            if tag == 0xFFFE and len(body) >= 26:
+                tag = struct.unpack('<H', body[24:26])[0]
+            fmt = (tag, nch, rate, bits)
+        elif cid == b'data':
+            data = body  # a truncated file yields the samples that are there
+            if fmt is not None:
+                break
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None:
+        raise ValueError('wav file without fmt / data chunk')
+    return fmt + (data, )
+
+
+def read_wav(path, return_rate: bool = False, start: Optional[float] = None,
+             end: Optional[float] = None):
+    """wav file (path, bytes or file object) -> mono (first channel,
+    processor.singal_channel) float32 in [-1, 1) with torchaudio.load's
+    normalisation (processor.decode_wav, processor.py:125-153): u8 -> (x-128)/128,
+    s16 / s24 / s32 -> x / 2^(bits-1), float32 / float64 as stored.  `start` /
+    `end` (seconds) select a segment like the raw lists' `start` / `end` keys.
+    Without `return_rate` the file must be 16 kHz (use ASRModel.load_wav to
+    resample).  Compressed containers (flac, mp3, ...) are not decoded."""
+    if isinstance(path, (bytes, bytearray, memoryview)):
+        buf = bytes(path)
+    elif hasattr(path, 'read'):
+        buf = path.read()
+    else:
+        with open(path, 'rb') as f:
+            buf = f.read()
+    tag, nch, sr, bits, raw = _parse_riff_wave(buf)
+    frame = nch * (bits // 8)
+    raw = raw[:len(raw) - len(raw) % max(frame, 1)]
+    if tag == 1 and bits == 16:
+        data = np.frombuffer(raw, dtype='<i2').astype(np.float32) / 32768.0
+    elif tag == 1 and bits == 8:
+        data = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif tag == 1 and bits == 24:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v >= 1 << 23, v - (1 << 24), v)
+        data = v.astype(np.float32) / float(1 << 23)
+    elif tag == 1 and bits == 32:
+        data = (np.frombuffer(raw, dtype='<i4').astype(np.float64) / 2147483648.0
+                ).astype(np.float32)
+    elif tag == 3 and bits == 32:
+        data = np.frombuffer(raw, dtype='<f4').astype(np.float32)
+    elif tag == 3 and bits == 64:
+        data = np.frombuffer(raw, dtype='<f8').astype(np.float32)
+    else:
+        raise NotImplementedError(
+            f'wav format tag {tag} with {bits} bits is not supported (PCM 8/16/24/32, '
+            'IEEE float 32/64)')
     if nch > 1:
-        data = data.reshape(-1, nch)[:, 0]
-    data = data.astype(np.float32) / 32768.0
+        data = np.ascontiguousarray(data.reshape(-1, nch)[:, 0])
+    if start is not None:
+        assert end is not None  # processor.py:139
+        s0, s1 = int(start * sr), int(end * sr)
+        data = data[s0:s1]
     if return_rate:
         return data, sr
     if sr != 16000:
