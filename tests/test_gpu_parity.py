@@ -1050,3 +1050,49 @@ def test_recognize_cli_shard_list_equals_raw_list(tmp_path):
     c = run(raw, tmp_path / 'o_bf16', '--dtype', 'bf16')
     assert [ln.split(' ')[0] for ln in c['ctc_greedy_search']] == \
         [ln.split(' ')[0] for ln in a['ctc_greedy_search']]
+
+
+def test_busy_handle_is_refused_not_corrupted():
+    """One host thread per wn_model handle: a second thread that enters a handle
+    while a call is running gets a RuntimeError (status -3), and the first
+    thread's results are unaffected.  (A feature-frontend call racing a decode on
+    the same handle used to corrupt the descriptor staging buffer.)"""
+    import threading
+    from wenet_amd import synthetic as S
+    configs, sd, model = cached_model('aishell_u2pp', 0)
+    feats, lens = S.make_features(8, (300, 500), seed=77)
+    fd = feats.cuda()
+    want = model.decode(['ctc_prefix_beam_search'], fd, lens, beam_size=5)
+    wave = (np.random.RandomState(1).rand(16000) * 0.2 - 0.1).astype(np.float32)
+    stop, errors, n_ok = threading.Event(), [], [0]
+
+    def intruder():
+        torch.cuda.set_device(model.device)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            while not stop.is_set():
+                try:
+                    model.compute_fbank([wave])
+                    n_ok[0] += 1
+                except RuntimeError as e:
+                    errors.append(str(e))
+    t = threading.Thread(target=intruder)
+    t.start()
+    try:
+        got, mine = [], []
+        for _ in range(6):
+            try:
+                got.append(model.decode(['ctc_prefix_beam_search'], fd, lens, beam_size=5))
+            except RuntimeError as e:   # the intruder held the handle at entry
+                mine.append(str(e))
+    finally:
+        stop.set()
+        t.join()
+    for e in errors + mine:
+        assert 'in use by another host thread' in e, e
+    assert got, 'every decode lost the race'
+    for g in got:
+        for b in range(8):
+            assert g['ctc_prefix_beam_search'][b].tokens == \
+                want['ctc_prefix_beam_search'][b].tokens
+            assert g['ctc_prefix_beam_search'][b].nbest_scores == \
+                want['ctc_prefix_beam_search'][b].nbest_scores

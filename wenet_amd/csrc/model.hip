@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <memory>
 #include <string>
@@ -278,6 +279,11 @@ struct wn_model {
   unsigned prof_seq = 0;
   double prof_flops = 0.0;
   int prec = PREC_F32;       // GEMM operand precision (wn_model_set_precision)
+  // one host thread per handle: the workspace, the descriptor staging and the
+  // current batch are per-handle state.  Entry points take this flag and fail
+  // loudly (status -3) instead of corrupting the staging buffer when a second
+  // thread enters the same handle (use wn_model_clone for a second thread).
+  std::atomic<bool> busy{false};
   int dbg_layers = -1;       // run only the first n encoder layers
   int dbg_skip_after_norm = 0;
   // fbank tables
@@ -297,6 +303,23 @@ namespace {
 
 // Makes the handle's GEMM operand precision current for the calling thread for
 // the duration of one C-ABI call (every GEMM launch reads t_gemm_prec).
+struct HandleGuard {
+  wn_model* m;
+  bool ok;
+  explicit HandleGuard(wn_model* m_) : m(m_), ok(false) {
+    bool expected = false;
+    ok = m->busy.compare_exchange_strong(expected, true, std::memory_order_acquire);
+  }
+  ~HandleGuard() { if (ok) m->busy.store(false, std::memory_order_release); }
+};
+#define WN_ENTER(m)                                                              \
+  HandleGuard handle_guard(m);                                                   \
+  if (!handle_guard.ok) {                                                        \
+    ::wn::set_error("this wn_model handle is in use by another host thread; "    \
+                    "one thread per handle (wn_model_clone gives a second one)"); \
+    return -3;                                                                   \
+  }
+
 struct PrecisionScope {
   int saved;
   explicit PrecisionScope(const wn_model* m) : saved(t_gemm_prec) { t_gemm_prec = m->prec; }
@@ -1326,6 +1349,7 @@ int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host
               int32_t B, int32_t T, int32_t chunk, int32_t left,
               float* enc_out_dev, int32_t* enc_lens_host, void* stream) {
   WN_CHECK(m && feats_dev && feat_lens_host, "wn_encode: null argument");
+  WN_ENTER(m);
   PrecisionScope prec_scope(m);
   WN_CHECK(!m->layers.empty() || !m->tf_layers.empty(),
            "wn_encode: this handle has no weights");
@@ -1369,6 +1393,7 @@ int wn_encode_chunk(wn_model* m, const float* feats_dev, int32_t time, int32_t o
                     float* new_att_cache_dev, float* new_cnn_cache_dev,
                     int32_t* chunk_out, int32_t* new_cache_t1_out, void* stream) {
   WN_CHECK(m && feats_dev && out_dev, "wn_encode_chunk: null argument");
+  WN_ENTER(m);
   PrecisionScope prec_scope(m);
   WN_CHECK(!m->layers.empty() && m->cfg.encoder_type == 0,
            "wn_encode_chunk: needs a Conformer encoder");
@@ -1408,6 +1433,7 @@ int wn_set_encoder_out(wn_model* m, const float* enc_out_dev,
                        void* stream) {
   WN_CHECK(m && enc_out_dev && enc_lens_host && B > 0 && Tp > 0,
            "wn_set_encoder_out: bad argument");
+  WN_ENTER(m);
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));
   std::vector<int> off(B), len(B);
@@ -1428,6 +1454,7 @@ int wn_ctc_logprobs(wn_model* m, int32_t topk, int32_t blank_id,
                     float blank_penalty, float* logp_dev, int32_t Tp,
                     void* stream) {
   WN_CHECK(m && m->B > 0, "wn_ctc_logprobs: no current batch (call wn_encode)");
+  WN_ENTER(m);
   PrecisionScope prec_scope(m);
   WN_CHECK(m->ctc.w, "wn_ctc_logprobs: this handle has no weights");
   hipStream_t s = (hipStream_t)stream;
@@ -1513,6 +1540,7 @@ int wn_set_ctc_probs(wn_model* m, const float* logp_dev, const int32_t* lens_hos
                      void* stream) {
   WN_CHECK(m && logp_dev && lens_host && B > 0 && Tp > 0 && V > 0,
            "wn_set_ctc_probs: bad argument");
+  WN_ENTER(m);
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));
   const int k = std::max(1, topk);
@@ -1537,6 +1565,7 @@ int wn_set_ctc_probs(wn_model* m, const float* logp_dev, const int32_t* lens_hos
 int wn_ctc_greedy_search(wn_model* m, int32_t blank_id, int32_t* tokens_host,
                          int32_t* tok_lens_host, int32_t max_len, void* stream) {
   WN_CHECK(m && m->ctc_valid, "greedy: no CTC posteriors (call wn_ctc_logprobs)");
+  WN_ENTER(m);
   WN_CHECK(tokens_host && tok_lens_host, "greedy: null output");
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));
@@ -1564,6 +1593,7 @@ int wn_set_context_graph(wn_model* m, int32_t n_nodes, const int32_t* fail,
                          const int32_t* edge_from, const int32_t* edge_token,
                          const int32_t* edge_to, void* stream) {
   WN_CHECK(m, "context graph: null model");
+  WN_ENTER(m);
   if (n_nodes <= 0) {
     m->ctx = CtxGraph();
     m->ctx_buf.reset();
@@ -1636,6 +1666,7 @@ int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
                               int32_t* hyp_times_host, double* hyp_scores_host,
                               int32_t max_len, void* stream) {
   WN_CHECK(m && m->ctc_valid, "prefix beam: no CTC posteriors");
+  WN_ENTER(m);
   WN_CHECK(m->ctc_k == beam, "prefix beam: wn_ctc_logprobs must be called with topk == beam");
   WN_CHECK(n_hyps_host && hyp_lens_host && hyp_tlens_host && hyp_tokens_host &&
                hyp_times_host && hyp_scores_host, "prefix beam: null output");
@@ -1778,6 +1809,7 @@ int wn_decoder_next_topk(wn_model* m, int32_t n_seq, const int32_t* seq_utt_host
                          int32_t max_len, int32_t topk, float* logp_host,
                          int32_t* idx_host, void* stream) {
   WN_CHECK(m && m->B > 0 && m->enc.p, "decoder step: no current batch");
+  WN_ENTER(m);
   PrecisionScope prec_scope(m);
   WN_CHECK(!m->left.layers.empty(), "decoder step: the model has no attention decoder");
   WN_CHECK(n_seq > 0 && seq_utt_host && seq_lens_host && tokens_host && logp_host &&
@@ -1849,6 +1881,7 @@ int wn_decoder_forward(wn_model* m, int32_t utt, int32_t which, int32_t n_seq,
                        const int32_t* tokens_host, const int32_t* lens_host,
                        int32_t max_len, float* logp_dev, void* stream) {
   WN_CHECK(m && m->B > 0 && m->enc.p, "decoder forward: no current batch");
+  WN_ENTER(m);
   PrecisionScope prec_scope(m);
   WN_CHECK(tokens_host && lens_host && logp_dev, "decoder forward: null argument");
   WN_CHECK(utt >= 0 && utt < m->B && m->len[utt] > 0,
@@ -1914,6 +1947,7 @@ int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host
                            float reverse_weight, float* l2r_logp_host,
                            float* r2l_logp_host, void* stream) {
   WN_CHECK(m && m->B > 0 && m->enc.p, "rescoring: no current batch");
+  WN_ENTER(m);
   PrecisionScope prec_scope(m);
   WN_CHECK(!m->left.layers.empty(), "rescoring: the model has no attention decoder");
   WN_CHECK(n_hyps_host && hyp_lens_host && hyp_tokens_host && l2r_logp_host &&
@@ -2043,6 +2077,7 @@ int64_t wn_resample_length(int64_t n_in, int32_t orig_freq, int32_t new_freq) {
 int wn_resample(wn_model* m, const float* pcm_dev, int64_t n_in, int32_t orig_freq,
                 int32_t new_freq, float* out_dev, int64_t n_out, void* stream) {
   WN_CHECK(m && pcm_dev && out_dev, "wn_resample: null argument");
+  WN_ENTER(m);
   WN_CHECK(orig_freq > 0 && new_freq > 0 && n_in > 0, "wn_resample: bad rate or length");
   WN_CHECK(n_out == wn_resample_length(n_in, orig_freq, new_freq),
            "wn_resample: n_out must be wn_resample_length(n_in, orig, new)");
@@ -2091,6 +2126,7 @@ int wn_fbank(wn_model* m, const float* pcm_dev, const int64_t* sample_off_host,
              int32_t* n_frames_host, void* stream) {
   WN_CHECK(m && pcm_dev && sample_off_host && feats_dev && n_frames_host && B > 0,
            "wn_fbank: bad argument");
+  WN_ENTER(m);
   WN_CHECK(m->fbank_ok, "wn_fbank: no Kaldi fbank for this feature dimension "
                         "(Whisper models use log-mel, processor.py:320-369)");
   hipStream_t s = (hipStream_t)stream;
@@ -2159,6 +2195,7 @@ int wn_log_mel(wn_model* m, const float* pcm_dev, const int64_t* sample_off_host
                int32_t* n_frames_host, void* stream) {
   WN_CHECK(m && pcm_dev && sample_off_host && feats_dev && n_frames_host && B > 0,
            "wn_log_mel: bad argument");
+  WN_ENTER(m);
   WN_CHECK(n_mels >= 1 && n_mels <= 256, "wn_log_mel: num_mel_bins");
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));

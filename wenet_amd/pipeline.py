@@ -18,6 +18,13 @@ order on its stream.
 One host thread per stream drives the C ABI (ctypes drops the GIL inside the
 calls); the reference's own multi-process sharding (tools/decode.sh:65-83) is
 the precedent for running independent decodes side by side.
+
+A wn_model handle belongs to one host thread at a time (its workspace, descriptor
+staging and current batch are per-handle state), so the pipeline works on its OWN
+clones only and never on the caller's handle: the caller keeps using `model`
+(compute_fbank, resample, a direct decode()) from its thread while batches are
+in flight.  The library enforces this: a second thread entering a busy handle
+gets status -3 instead of corrupting it.
 """
 import concurrent.futures
 import queue
@@ -34,8 +41,7 @@ class DecodePipeline:
     def __init__(self, model: ASRModel, n_streams: int = 2):
         assert n_streams >= 1
         self.device = model.device
-        self.models: List[ASRModel] = [model] + [model.clone()
-                                                 for _ in range(n_streams - 1)]
+        self.models: List[ASRModel] = [model.clone() for _ in range(n_streams)]
         self.streams = [torch.cuda.Stream(device=self.device)
                         for _ in range(n_streams)]
         self._free = queue.SimpleQueue()
