@@ -539,3 +539,79 @@ def test_forward_attention_decoder_matches_live_reference(config, rw):
     o_l, o_r = O.forward_attention_decoder(configs, sd, hyps, lens, enc, rw, sos, eos)
     assert r_l.shape == o_l.shape and (r_l - o_l).abs().max() < 1e-5
     assert r_r.shape == o_r.shape and (r_r - o_r).abs().max() < 1e-5
+
+
+# --------------------------------------------------------------------------
+# bf16-operand emulation (the product's WN_PREC_BF16 mode; tests/test_gpu_bf16.py
+# compares the GPU against it)
+
+
+def test_bf16_operand_emulation_is_scoped_and_selective():
+    """bf16_operands() changes exactly the GEMM-kernel contractions and the
+    attention products, leaves the module as it found it, and is idempotent on
+    operands that are already bf16 numbers."""
+    from wenet_amd import synthetic as S
+    configs = S.make_configs('tiny_causal')
+    sd = S.make_state_dict(configs, 0)
+    feats, lens = S.make_features(3, (40, 120), seed=5)
+    with torch.no_grad():
+        a, _ = O.encoder_forward(configs, sd, feats, lens)
+        with O.bf16_operands(sd):
+            b, _ = O.encoder_forward(configs, sd, feats, lens)
+            assert O._MM_ROUND and not isinstance(O.F, type(torch.nn.functional))
+        c, _ = O.encoder_forward(configs, sd, feats, lens)
+        with O.bf16_operands(sd, attention=False):
+            d, _ = O.encoder_forward(configs, sd, feats, lens)
+    assert torch.equal(a, c) and O.F is torch.nn.functional and not O._MM_ROUND
+    assert not torch.equal(a, b) and not torch.equal(b, d)
+    rel = (a - b).abs().max() / a.abs().max()
+    assert 1e-4 < rel < 5e-2, rel          # bf16 operands: ~3 significant digits
+    # selective: depthwise conv, the 1 -> d Conv2d and linear_pos stay fp32
+    x = torch.randn(2, 8, 20)
+    w = torch.randn(8, 1, 3)
+    with O.bf16_operands(sd):
+        assert torch.equal(O.F.conv1d(x, w, None, groups=8),
+                           torch.nn.functional.conv1d(x, w, None, groups=8))
+        img, k1 = torch.randn(1, 1, 9, 9), torch.randn(4, 1, 3, 3)
+        assert torch.equal(O.F.conv2d(img, k1, None, stride=2),
+                           torch.nn.functional.conv2d(img, k1, None, stride=2))
+        wp = sd['encoder.encoders.0.self_attn.linear_pos.weight']
+        pe = torch.randn(5, wp.shape[1])
+        assert torch.equal(O.F.linear(pe, wp), torch.nn.functional.linear(pe, wp))
+        # rounding is idempotent: bf16-valued operands give the exact fp32 product
+        xb = torch.randn(7, 16).to(torch.bfloat16).float()
+        wb = torch.randn(5, 16).to(torch.bfloat16).float()
+        assert torch.equal(O.F.linear(xb, wb), torch.nn.functional.linear(xb, wb))
+        assert torch.equal(O._mm(xb, wb.T), torch.matmul(xb, wb.T))
+
+
+@needs_reference
+@pytest.mark.parametrize('config', ['tiny_causal', 'tiny_sym'])
+def test_bf16_operand_mode_is_at_least_as_close_to_fp32_as_reference_autocast(config):
+    """The reference's `--dtype bf16` is torch autocast around decode()
+    (wenet/bin/recognize.py:250-255,278-280), which rounds operands AND results of
+    every linear / conv / matmul to bf16.  The product's bf16 mode rounds operands
+    only; its emulation must sit closer to the fp32 encoder output than the real
+    reference under CPU autocast does, and the two must agree to bf16 accuracy."""
+    from oracle import _ref_harness, gen_golden
+    from wenet_amd import synthetic as S
+    _ref_harness.install()
+    configs = S.make_configs(config)
+    sd = S.make_state_dict(configs, 3)
+    model = gen_golden.build_reference_model(configs, sd)
+    feats, lens = S.make_features(4, (60, 200), seed=8)
+    with torch.no_grad():
+        ref32, mask = model._forward_encoder(feats, lens)
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            ref_ac, _ = model._forward_encoder(feats, lens)
+        with O.bf16_operands(sd):
+            emu, _ = O.encoder_forward(configs, sd, feats, lens)
+    n = mask.squeeze(1).sum(1)
+    d_ac = max((ref_ac[b, :n[b]].float() - ref32[b, :n[b]]).abs().max().item()
+               for b in range(4))
+    d_emu = max((emu[b, :n[b]] - ref32[b, :n[b]]).abs().max().item() for b in range(4))
+    d_x = max((emu[b, :n[b]] - ref_ac[b, :n[b]].float()).abs().max().item()
+              for b in range(4))
+    scale = ref32.abs().max().item()
+    assert d_emu <= d_ac, (d_emu, d_ac)
+    assert d_emu < 4e-2 * scale and d_x < 8e-2 * scale, (d_emu, d_x, scale)
