@@ -102,10 +102,12 @@ int wn_model_clone(const wn_model* src, wn_model** out);
  *                mode (identical greedy tokens, rescoring scores within 1e-3);
  *   WN_PREC_BF16 every Linear / pointwise-conv / subsampling-conv contraction
  *                rounds its two operands to bf16 (round to nearest even) and
- *                accumulates in fp32; activations, LayerNorm, softmax, attention
- *                scores, the depthwise conv, the searches and all tensors in HBM
- *                stay fp32 (autocast additionally rounds every result to bf16,
- *                so this mode is at least as precise as the reference's).
+ *                accumulates in fp32; the attention products likewise; LayerNorm,
+ *                softmax, the depthwise conv and the searches stay fp32
+ *                (autocast additionally rounds every result to bf16, so this
+ *                mode is at least as precise as the reference's).  Tensors that
+ *                only feed such a contraction may be KEPT as bf16 in HBM -- same
+ *                values, the contraction rounds them first thing.
  * Applies to later calls on this handle; clones inherit it.  The feature
  * frontends (wn_fbank, wn_log_mel, wn_resample) always run in fp32. */
 #define WN_PREC_F32 0
@@ -296,6 +298,14 @@ int wn_op_gemm(const float* A_dev, const float* W_dev, const float* bias_dev,
 int wn_op_gemm_bf16(const float* A_dev, const float* W_dev, const float* bias_dev,
                     const float* resid_dev, float* C_dev, int32_t M, int32_t N,
                     int32_t K, float alpha, int32_t act, void* stream);
+/* The bf16-STORAGE form of that contraction (the kernel the bf16 mode runs on
+ * LayerNorm outputs / FFN hidden / attention context, which it keeps as bf16 in
+ * HBM): A and W are rounded to bf16 images first, the GEMM reads those; C is fp32
+ * (M, N) or, with c_bf16 != 0 and no residual, a bf16 (M, N) matrix. */
+int wn_op_gemm_bf16_stored(const float* A_dev, const float* W_dev, const float* bias_dev,
+                           const float* resid_dev, void* C_dev, int32_t M, int32_t N,
+                           int32_t K, float alpha, int32_t act, int32_t c_bf16,
+                           void* stream);
 /* out[i] = log_add(a[i], b[i]) (wenet/utils/common.py:302-310) in fp64 with the
  * routine the prefix beam search uses. */
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,

@@ -25,6 +25,20 @@ from gpu_util import cached_model, compare_nbest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=['convert', 'stored'])
+def bf16_store(request):
+    """Every test runs in both forms of the bf16 mode: operands converted on the fly
+    from fp32 tensors (0) and the bf16-STORAGE form (1: LayerNorm output, FFN hidden
+    and attention context kept as bf16, bf16 image of the weight slab).  The two
+    are the same arithmetic -- rounding is idempotent -- so the expectations are
+    identical."""
+    from wenet_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.wn_tune_set(b'bf16_store', request.param), 'tune')
+    yield request.param
+    L.wn_tune_set(b'bf16_store', 0)
+
+
 def _oracle():
     from oracle import wenet_oracle as O
     return O
@@ -121,6 +135,80 @@ def test_gemm_bf16_epilogues(act, use_resid, K):
     got = _gemm_bf16(A.cuda(), W.cuda(), bias.cuda(),
                      resid.cuda() if use_resid else None, 0.5, act).cpu()
     torch.testing.assert_close(got, y, rtol=1e-5, atol=2e-5)
+
+
+def _gemm_stored(A, W, bias=None, resid=None, alpha=1.0, act=0, c_bf16=False):
+    from wenet_amd import _lib
+    L = _lib.lib()
+    M, K = A.shape
+    N = W.shape[0]
+    C = torch.empty((M, N), dtype=torch.bfloat16 if c_bf16 else torch.float32,
+                    device='cuda')
+    _lib.check(L.wn_op_gemm_bf16_stored(_ptr(A), _ptr(W), _ptr(bias), _ptr(resid), _ptr(C),
+                                        M, N, K, alpha, act, int(c_bf16),
+                                        torch.cuda.current_stream().cuda_stream),
+               'gemm_bf16_stored')
+    torch.cuda.synchronize()
+    return C
+
+
+@pytest.mark.parametrize('M,N,K', [
+    (128, 128, 32), (1, 1, 32), (77, 67, 64), (300, 200, 96), (300, 256, 256),
+    (7936, 2048, 256), (7936, 256, 2048), (513, 4233, 256), (129, 130, 2432),
+    (3000, 1280, 5120), (6000, 5120, 1280), (4097, 384, 160), (2100, 1280, 128)])
+def test_gemm_bf16_stored_plain(M, N, K, bf16_store):
+    """The bf16-storage GEMM (A, W bf16 in HBM, prefetch distance 2): every block
+    shape incl. 256x256, both K-tile widths, odd / even K-tile counts, ragged M / N;
+    fp32 and bf16 C."""
+    if bf16_store == 0:
+        pytest.skip('one run is enough for the raw operator')
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K + 1)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    ref = _r(A) @ _r(W).T
+    scale = (A.abs().double() @ W.abs().double().T).max().item()
+    got = _gemm_stored(A.cuda(), W.cuda()).cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-6 * scale, (err, scale)
+    # identical to the convert-on-the-fly kernel up to accumulation order
+    conv = _gemm_bf16(A.cuda(), W.cuda()).cpu().double()
+    assert (got - conv).abs().max().item() <= 4e-6 * scale
+    got16 = _gemm_stored(A.cuda(), W.cuda(), c_bf16=True).cpu()
+    assert got16.dtype == torch.bfloat16
+    want16 = ref.float().to(torch.bfloat16).float()
+    # a value on a bf16 tie may round either way after an accumulation-order change
+    assert (got16.float() - want16).abs().max().item() <= \
+        2.0 ** -7 * ref.abs().max().item() + 4e-6 * scale
+
+
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
+@pytest.mark.parametrize('mode', ['plain', 'resid', 'c_bf16'])
+@pytest.mark.parametrize('K', [96, 128])
+def test_gemm_bf16_stored_epilogues(act, mode, K, bf16_store):
+    if bf16_store == 0:
+        pytest.skip('one run is enough for the raw operator')
+    g = torch.Generator().manual_seed(act * 3 + K + len(mode))
+    M, N = 333, 200
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g) if mode == 'resid' else None
+    y = (_r(A) @ _r(W).T).float() + bias
+    if act == 1:
+        y = torch.nn.functional.silu(y)
+    elif act == 2:
+        y = torch.relu(y)
+    elif act == 3:
+        y = torch.nn.functional.gelu(y)
+    y = 0.5 * y
+    if resid is not None:
+        y = y + resid
+    got = _gemm_stored(A.cuda(), W.cuda(), bias.cuda(),
+                       resid.cuda() if resid is not None else None, 0.5, act,
+                       c_bf16=(mode == 'c_bf16')).cpu()
+    if mode == 'c_bf16':
+        torch.testing.assert_close(got.float(), y, rtol=2.0 ** -7, atol=1e-3)
+    else:
+        torch.testing.assert_close(got, y, rtol=1e-5, atol=2e-5)
 
 
 def _set_dtype(model, dtype):

@@ -279,9 +279,16 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
     const float ir = __shfl(inv, qr, 64);
     const int qrow = q0 + wave * 32 + qr;
     if (qrow < qlen) {
-      float* op = a.O + (int64_t)(qoff + qrow) * a.ldo + h * 64;
-      op[li] = o0[r] * ir;
-      op[32 + li] = o1[r] * ir;
+      if (a.o_bf16) {  // bf16-storage mode: the context only feeds the out-proj GEMM
+        __bf16* op = reinterpret_cast<__bf16*>(a.O) + (int64_t)(qoff + qrow) * a.ldo +
+                     h * 64;
+        op[li] = (__bf16)(o0[r] * ir);
+        op[32 + li] = (__bf16)(o1[r] * ir);
+      } else {
+        float* op = a.O + (int64_t)(qoff + qrow) * a.ldo + h * 64;
+        op[li] = o0[r] * ir;
+        op[32 + li] = o1[r] * ir;
+      }
     }
   }
 }

@@ -84,6 +84,11 @@ struct GemmArgs {
   const int64_t* a_row_off = nullptr;
   int conv_C = 0;
   int64_t conv_sy = 0, conv_sx = 0;
+  // bf16-storage form of the bf16 mode (gemm_bf16s.hip): A is a bf16 matrix (A
+  // reinterpreted, lda in bf16 elements); C is written as bf16 (ldc in elements).
+  // Needs the bf16 image of the weight slab (t_wslab_*), plain A, no residual
+  // with bf16 C.
+  bool a_bf16 = false, c_bf16 = false;
 };
 
 int gemm_f32(const GemmArgs& a, hipStream_t stream);
@@ -96,6 +101,16 @@ int gemm_f32(const GemmArgs& a, hipStream_t stream);
 enum GemmPrecision { PREC_F32 = 0, PREC_BF16 = 1 };
 extern thread_local int t_gemm_prec;
 int gemm_bf16(const GemmArgs& a, hipStream_t stream);  // called by gemm_f32
+// bf16 image of the calling handle's weight slab (PrecisionScope): W pointers
+// inside [t_wslab_f32, t_wslab_f32 + t_wslab_elems) map to t_wslab_bf16 + offset.
+extern thread_local const float* t_wslab_f32;
+extern thread_local const void* t_wslab_bf16;
+extern thread_local int64_t t_wslab_elems;
+int gemm_bf16_stored(const GemmArgs& a, const void* Wh, hipStream_t stream);
+int convert_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t s);
+// 1: in the bf16 mode the GEMM-only tensors (LayerNorm output, FFN hidden,
+// attention context) are stored as bf16 (wn_tune_set("bf16_store"))
+extern int g_bf16_store;
 
 // Tuning knobs (wn_tune_set): experiments / A-B runs only, defaults are the
 // shipped configuration.

@@ -117,6 +117,57 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(
   r.store(y2 + (int64_t)row * D, lane);
 }
 
+// bf16-storage form of the bf16 mode: the normalised row only ever feeds a GEMM,
+// whose first step rounds it to bf16 anyway, so it is WRITTEN as bf16 (half the
+// bytes out, half the bytes into the GEMM, identical arithmetic).
+template <int E>
+__device__ __forceinline__ void store_row_bf16(const RowRegs<E>& r, __bf16* p, int lane) {
+  constexpr int VEC = RowRegs<E>::VEC;
+  typedef __bf16 hvec_t __attribute__((ext_vector_type(VEC)));
+#pragma unroll
+  for (int j = 0; j < E / VEC; ++j) {
+    if constexpr (VEC == 1) {
+      p[j * 64 + lane] = (__bf16)r.v[j];
+    } else {
+      hvec_t t;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) t[e] = (__bf16)r.v[j * VEC + e];
+      *reinterpret_cast<hvec_t*>(p + j * 64 * VEC + lane * VEC) = t;
+    }
+  }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void layernorm_bf16out_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ w,
+    const float* __restrict__ b, __bf16* __restrict__ y, int ldy, int M, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  RowRegs<E> r;
+  r.load(x + (int64_t)row * ldx, lane);
+  ln_inplace<E>(r, w, b, lane, eps);
+  store_row_bf16<E>(r, y + (int64_t)row * ldy, lane);
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void layernorm2_bf16out_kernel(
+    const float* __restrict__ x, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2,
+    const float* __restrict__ b2, float* __restrict__ y1, __bf16* __restrict__ y2,
+    int M, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  constexpr int D = E * 64;
+  RowRegs<E> r;
+  r.load(x + (int64_t)row * D, lane);
+  ln_inplace<E>(r, w1, b1, lane, eps);
+  r.store(y1 + (int64_t)row * D, lane);
+  ln_inplace<E>(r, w2, b2, lane, eps);
+  store_row_bf16<E>(r, y2 + (int64_t)row * D, lane);
+}
+
 // ===========================================================================
 // GlobalCMVN (cmvn.py:36-47) + Conv2d(1, C, 3, stride 2) + ReLU
 // (subsampling.py:188-190).  One block per (utterance, T1 frame): the three
@@ -499,9 +550,28 @@ __global__ void copy_rows_kernel(const float* src, int lds, const int* src_rows,
 int g_ln_rows = 0;  // wn_tune_set("ln_rows"): 0 auto, 1 or 2 rows per wave
 
 int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
-              int ldy, int M, int D, float eps, hipStream_t s) {
+              int ldy, int M, int D, float eps, hipStream_t s, bool y_bf16) {
   WN_CHECK(M > 0, "layernorm: empty");
   WN_CHECK(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: row stride % 4");
+  if (y_bf16) {  // y is a bf16 matrix, ldy in bf16 elements
+    dim3 gh(cdiv(M, 4)), th(256);
+    __bf16* yh = reinterpret_cast<__bf16*>(y);
+#define WN_LNH(E)                                                                  \
+  case E * 64:                                                                    \
+    hipLaunchKernelGGL((layernorm_bf16out_kernel<E>), gh, th, 0, s, x, ldx, w, b,  \
+                       yh, ldy, M, eps);                                          \
+    break;
+    switch (D) {
+      WN_LNH(1) WN_LNH(2) WN_LNH(3) WN_LNH(4) WN_LNH(6) WN_LNH(8) WN_LNH(10)
+      WN_LNH(12) WN_LNH(16) WN_LNH(20)
+      default:
+        set_error("layernorm: unsupported width " + std::to_string(D));
+        return -1;
+    }
+#undef WN_LNH
+    WN_HIP(hipGetLastError());
+    return 0;
+  }
   // two rows per wave: only on request (no gain measured)
   const bool two = g_ln_rows == 2;
   dim3 g(cdiv(M, two ? 8 : 4)), t(256);
@@ -528,9 +598,26 @@ int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
 
 int layernorm2(const float* x, const float* w1, const float* b1, const float* w2,
                const float* b2, float* y1, float* y2, int M, int D, float eps,
-               hipStream_t s) {
+               hipStream_t s, bool y2_bf16) {
   WN_CHECK(M > 0, "layernorm2: empty");
   dim3 g(cdiv(M, 4)), t(256);
+  if (y2_bf16) {
+    __bf16* yh = reinterpret_cast<__bf16*>(y2);
+#define WN_LN2H(E)                                                                 \
+  case E * 64:                                                                    \
+    hipLaunchKernelGGL(layernorm2_bf16out_kernel<E>, g, t, 0, s, x, w1, b1, w2,   \
+                       b2, y1, yh, M, eps);                                       \
+    break;
+    switch (D) {
+      WN_LN2H(1) WN_LN2H(2) WN_LN2H(4) WN_LN2H(8) WN_LN2H(12) WN_LN2H(16) WN_LN2H(20)
+      default:
+        set_error("layernorm2: unsupported width " + std::to_string(D));
+        return -1;
+    }
+#undef WN_LN2H
+    WN_HIP(hipGetLastError());
+    return 0;
+  }
 #define WN_LN2(E)                                                               \
   case E * 64:                                                                  \
     hipLaunchKernelGGL(layernorm2_kernel<E>, g, t, 0, s, x, w1, b1, w2, b2, y1, \

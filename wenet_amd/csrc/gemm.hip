@@ -268,6 +268,7 @@ int gemm_f32(const GemmArgs& a, hipStream_t stream) {
   }
   if (a.glu) WN_CHECK(a.N % 64 == 0, "gemm(GLU): N must be a multiple of 64");
   if (t_gemm_prec == PREC_BF16) return gemm_bf16(a, stream);
+  WN_CHECK(!a.a_bf16 && !a.c_bf16, "gemm: bf16 operands need the bf16 mode");
   // Tile choice (measured on M = 7932 rows, profiles/): 8 waves per block hide
   // the barrier / LDS latency of the short K loops better than 4; the block
   // shrinks with the problem so that the grid still covers the 256 CUs.

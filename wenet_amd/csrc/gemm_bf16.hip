@@ -273,9 +273,21 @@ int dispatch_tile(const GemmArgs& a, bool conv, hipStream_t stream) {
 }  // namespace
 
 int g_gemm_tile_bf16 = 0;
+int g_bf16_store = 0;
+thread_local const float* t_wslab_f32 = nullptr;
+thread_local const void* t_wslab_bf16 = nullptr;
+thread_local int64_t t_wslab_elems = 0;
 
 int gemm_bf16(const GemmArgs& a, hipStream_t stream) {
   // argument checks are gemm_f32's (the only caller)
+  if (a.a_bf16) {
+    WN_CHECK(t_wslab_bf16 && a.W >= t_wslab_f32 && a.W < t_wslab_f32 + t_wslab_elems,
+             "gemm(bf16 stored): W is not inside the handle's converted weight slab");
+    const char* wh = reinterpret_cast<const char*>(t_wslab_bf16) +
+                     (a.W - t_wslab_f32) * 2;
+    return gemm_bf16_stored(a, wh, stream);
+  }
+  WN_CHECK(!a.c_bf16, "gemm(bf16): bf16 C needs bf16 A");
   const bool conv = a.a_row_off != nullptr;
   const bool k64 = a.K % 64 == 0 && (!conv || a.conv_C % 64 == 0);
   return k64 ? dispatch_tile<64>(a, conv, stream) : dispatch_tile<32>(a, conv, stream);

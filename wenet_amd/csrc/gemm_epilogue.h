@@ -15,12 +15,16 @@ __device__ __forceinline__ float silu_fast(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
-template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU>
+// CH: C is a bf16 matrix (p.C reinterpreted, p.ldc in bf16 elements) -- the
+// bf16-storage mode's FFN hidden tensor; only without residual / GLU.
+template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
+          bool CH = false>
 __device__ __forceinline__ void gemm_epilogue(
     const GemmArgs& p, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0,
     int n0, int wm, int wn_, int lane, int variant) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
+  static_assert(!CH || (!RESID && !GLU), "bf16 C: plain / activation epilogues only");
   const int col_in = lane & 31;
   const int row_hi = (lane >> 5) * 4;
   if constexpr (GLU) {
@@ -73,7 +77,14 @@ __device__ __forceinline__ void gemm_epilogue(
           if (ACT == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
           v[r] = x * p.alpha;
         }
-        if (full) {
+        if constexpr (CH) {
+          __bf16* hp = reinterpret_cast<__bf16*>(p.C) + (int64_t)row0 * p.ldc + col;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (full || (row0 + dr < p.M && cok)) hp[dr * p.ldc] = (__bf16)v[r];
+          }
+        } else if (full) {
           if (RESID) {
             float rr[16];
 #pragma unroll

@@ -5,8 +5,9 @@
 namespace wn {
 
 // y[r,:] = LayerNorm(x[r,:]) * w + b, one wave per row; D in {64..1024, %64}.
+// y_bf16: y is a bf16 matrix (ldy in bf16 elements) -- bf16-storage mode.
 int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
-              int ldy, int M, int D, float eps, hipStream_t s);
+              int ldy, int M, int D, float eps, hipStream_t s, bool y_bf16 = false);
 
 // y1 = LN(x; w1,b1), y2 = LN(y1; w2,b2) in one pass over contiguous [M][D] rows
 // (y1 may alias x).
@@ -14,7 +15,7 @@ extern int g_ln_rows;
 extern int g_attn_split;
 int layernorm2(const float* x, const float* w1, const float* b1, const float* w2,
                const float* b2, float* y1, float* y2, int M, int D, float eps,
-               hipStream_t s);
+               hipStream_t s, bool y2_bf16 = false);
 
 // GlobalCMVN + Conv2d(1->C,3,stride 2) + ReLU over the padded (B,T,F) frame
 // tensor, written packed channels-last: out[(t1_off[b]+t1)*F1 + f1][c].
@@ -61,6 +62,7 @@ struct AttnArgs {
   const int* q_off; const int* q_len;   // [n_seq]
   const int* kv_off; const int* kv_len; // [n_seq]
   int n_seq, n_heads, max_q_len;
+  bool o_bf16 = false; // bf16 kernel only: O is a bf16 matrix (ldo in elements)
   int mask_mode = 0;   // 0: keys < kv_len; 1: causal; 2: chunk window
   int chunk_size = 0, left_chunks = -1;
   float scale = 0.125f;

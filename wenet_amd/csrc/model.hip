@@ -227,6 +227,8 @@ struct wn_model {
   int device = 0;
   // immutable after create, shared by wn_model_clone()d handles
   std::shared_ptr<DevBuf> weights = std::make_shared<DevBuf>();  // one slab for every weight
+  int64_t n_weight_elems = 0;            // floats in the slab
+  std::shared_ptr<DevBuf> weights_bf16;  // bf16 image of the slab (bf16 mode, lazily)
   std::map<std::string, const float*> w; // name -> device pointer
   // re-laid-out subsampling weights
   const float* conv1_w = nullptr; const float* conv1_b = nullptr;
@@ -322,33 +324,57 @@ struct HandleGuard {
 
 struct PrecisionScope {
   int saved;
-  explicit PrecisionScope(const wn_model* m) : saved(t_gemm_prec) { t_gemm_prec = m->prec; }
-  ~PrecisionScope() { t_gemm_prec = saved; }
+  const float* s_f32; const void* s_bf16; int64_t s_elems;
+  explicit PrecisionScope(const wn_model* m)
+      : saved(t_gemm_prec), s_f32(t_wslab_f32), s_bf16(t_wslab_bf16),
+        s_elems(t_wslab_elems) {
+    t_gemm_prec = m->prec;
+    const bool img = m->prec == PREC_BF16 && m->weights_bf16 && m->weights_bf16->p;
+    t_wslab_f32 = img ? m->weights->as<float>() : nullptr;
+    t_wslab_bf16 = img ? m->weights_bf16->p : nullptr;
+    t_wslab_elems = img ? m->n_weight_elems : 0;
+  }
+  ~PrecisionScope() {
+    t_gemm_prec = saved;
+    t_wslab_f32 = s_f32; t_wslab_bf16 = s_bf16; t_wslab_elems = s_elems;
+  }
 };
+
+// bf16-storage form of the bf16 mode: LayerNorm output, FFN hidden and attention
+// context are written as bf16 (their only consumers are GEMMs that round them to
+// bf16 first thing), the GEMMs read the bf16 image of the weight slab.
+bool bf16_store_active() {
+  return t_gemm_prec == PREC_BF16 && g_bf16_store != 0 && g_attn_bf16 != 0 &&
+         t_wslab_bf16 != nullptr;
+}
 
 int upload_desc(wn_model* m, DevBuf& buf, const std::vector<int>& v,
                 hipStream_t s) {
   return m->stage.put(buf, v.data(), v.size() * sizeof(int), s);
 }
 
+// a_bf16 / c_bf16: A / C are bf16 matrices in the same buffers (lda / ldc stay the
+// element counts) -- only under bf16_store_active().
 int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M,
            hipStream_t s, int act = ACT_NONE, const float* resid = nullptr,
-           int ldr = 0, float alpha = 1.0f, bool glu = false) {
+           int ldr = 0, float alpha = 1.0f, bool glu = false, bool a_bf16 = false,
+           bool c_bf16 = false) {
   GemmArgs g;
   g.A = A; g.W = l.w; g.bias = l.b; g.C = C; g.resid = resid;
   g.M = M; g.N = l.out; g.K = l.in; g.lda = lda; g.ldc = ldc; g.ldr = ldr;
   g.alpha = alpha; g.act = act; g.glu = glu;
+  g.a_bf16 = a_bf16; g.c_bf16 = c_bf16;
   return gemm_f32(g, s);
 }
 
 // FFN w_1 GEMM (SiLU epilogue), optionally bracketed by HIP events
 int ffn_w1(wn_model* m, const Linear& l, const float* A, float* C, int M,
-           hipStream_t s, int act = ACT_SILU) {
+           hipStream_t s, int act = ACT_SILU, bool h16 = false) {
   // every hipEventRecord pair costs ~10 us of idle GPU around the launch
   // (measured in the rocprofv3 trace), so only every 6th launch is bracketed:
   // an unbiased sample of the average launch duration (4 per 12-layer pass)
   if (!m->prof_on || (m->prof_seq++ % 6) != 0)
-    return linear(l, A, l.in, C, l.out, M, s, act);
+    return linear(l, A, l.in, C, l.out, M, s, act, nullptr, 0, 1.0f, false, h16, h16);
   if (m->prof_used + 2 > m->prof_ev.size()) {
     for (int i = 0; i < 64; ++i) {
       hipEvent_t e;
@@ -357,7 +383,7 @@ int ffn_w1(wn_model* m, const Linear& l, const float* A, float* C, int M,
     }
   }
   WN_HIP(hipEventRecord(m->prof_ev[m->prof_used], s));
-  WN_TRY(linear(l, A, l.in, C, l.out, M, s, act));
+  WN_TRY(linear(l, A, l.in, C, l.out, M, s, act, nullptr, 0, 1.0f, false, h16, h16));
   WN_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], s));
   m->prof_used += 2;
   m->prof_flops += 2.0 * M * (double)l.out * l.in;
@@ -365,8 +391,8 @@ int ffn_w1(wn_model* m, const Linear& l, const float* A, float* C, int M,
 }
 
 int ln(const Norm& n, const float* x, float* y, int M, int D, float eps,
-       hipStream_t s) {
-  return layernorm(x, D, n.w, n.b, y, D, M, D, eps, s);
+       hipStream_t s, bool y_bf16 = false) {
+  return layernorm(x, D, n.w, n.b, y, D, M, D, eps, s, y_bf16);
 }
 
 // ---- set the per-utterance row layout of the current batch -----------------
@@ -469,31 +495,36 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
   }
   const int n_run = m->dbg_layers >= 0 ? std::min(m->dbg_layers, c.n_layers)
                                       : c.n_layers;
+  // bf16-storage mode: the LayerNorm outputs (t1), the FFN hidden (hb) and the
+  // attention context (t2) hold bf16; the GLU output / depthwise-conv tensors
+  // stay fp32 (the depthwise kernel is fp32)
+  const bool h16 = bf16_store_active();
   for (int li = 0; li < n_run; ++li) {
     const EncLayer& L = m->layers[li];
     // x += 0.5 * FFN_macaron(LN(x))                 encoder_layer.py:220-228
     // (for li > 0 the previous layer's tail already left LN(x) in t1)
-    if (li == 0) WN_TRY(ln(L.norm_ff_mac, x, t1, M, d, eps, s));
-    WN_TRY(ffn_w1(m, L.ffm1, t1, hb, M, s));
-    WN_TRY(linear(L.ffm2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 0.5f));
+    if (li == 0) WN_TRY(ln(L.norm_ff_mac, x, t1, M, d, eps, s, h16));
+    WN_TRY(ffn_w1(m, L.ffm1, t1, hb, M, s, ACT_SILU, h16));
+    WN_TRY(linear(L.ffm2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 0.5f, false, h16));
     // x += MHA(LN(x))                               encoder_layer.py:230-238
-    WN_TRY(ln(L.norm_mha, x, t1, M, d, eps, s));
-    WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s));
+    WN_TRY(ln(L.norm_mha, x, t1, M, d, eps, s, h16));
+    WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s, ACT_NONE, nullptr, 0, 1.0f, false,
+                  h16));
     AttnArgs a;
     a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d;
     a.ldq = a.ldk = a.ldv = 3 * d;
     a.P = L.pos_tab; a.ldp = d; a.bias_u = L.bias_u; a.bias_v = L.bias_v;
-    a.O = t2; a.ldo = d;
+    a.O = t2; a.ldo = d; a.o_bf16 = h16;
     a.q_off = a.kv_off = m->d_off.as<int>();
     a.q_len = a.kv_len = m->d_len.as<int>();
     a.n_seq = m->B; a.n_heads = c.n_heads; a.max_q_len = max_len;
     a.mask_mode = mask_mode; a.chunk_size = cs; a.left_chunks = lc;
     a.scale = 1.0f / sqrtf(64.0f);
     WN_TRY(attention(a, s));
-    WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d));
+    WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d, 1.0f, false, h16));
     // x += Conv(LN(x))                              encoder_layer.py:240-251
-    WN_TRY(ln(L.norm_conv, x, t1, M, d, eps, s));
-    WN_TRY(linear(L.pw1, t1, d, t2, d, M, s, ACT_NONE, nullptr, 0, 1.0f, true));
+    WN_TRY(ln(L.norm_conv, x, t1, M, d, eps, s, h16));
+    WN_TRY(linear(L.pw1, t1, d, t2, d, M, s, ACT_NONE, nullptr, 0, 1.0f, true, h16));
     DwConvArgs dw;
     dw.x = t2; dw.ldx = d; dw.wt = L.dw_wt; dw.bias = L.dw_b; dw.cpad = L.cpad;
     dw.ln_w = L.conv_norm.w; dw.ln_b = L.conv_norm.b; dw.norm_mode = c.cnn_norm;
@@ -505,13 +536,13 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     WN_TRY(dwconv_ln_silu(dw, s));
     WN_TRY(linear(L.pw2, t1, d, x, d, M, s, ACT_NONE, x, d));
     // x += 0.5 * FFN(LN(x)); x = LN(x)              encoder_layer.py:253-263
-    WN_TRY(ln(L.norm_ff, x, t1, M, d, eps, s));
-    WN_TRY(ffn_w1(m, L.ff1, t1, hb, M, s));
-    WN_TRY(linear(L.ff2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 0.5f));
+    WN_TRY(ln(L.norm_ff, x, t1, M, d, eps, s, h16));
+    WN_TRY(ffn_w1(m, L.ff1, t1, hb, M, s, ACT_SILU, h16));
+    WN_TRY(linear(L.ff2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 0.5f, false, h16));
     if (li + 1 < n_run) {
       const EncLayer& Ln = m->layers[li + 1];
       WN_TRY(layernorm2(x, L.norm_final.w, L.norm_final.b, Ln.norm_ff_mac.w,
-                        Ln.norm_ff_mac.b, x, t1, M, d, eps, s));
+                        Ln.norm_ff_mac.b, x, t1, M, d, eps, s, h16));
     } else {
       WN_TRY(ln(L.norm_final, x, x, M, d, eps, s));
     }
@@ -624,26 +655,28 @@ int transformer_layers(wn_model* m, hipStream_t s) {
   int max_len = 0;
   for (int b = 0; b < m->B; ++b) max_len = std::max(max_len, m->len[b]);
   const int act = c.activation == 1 ? ACT_GELU : ACT_SILU;
+  const bool h16 = bf16_store_active();  // t1, t2, hb hold bf16 (see there)
   const int n_run = m->dbg_layers >= 0 ? std::min(m->dbg_layers, c.n_layers)
                                       : c.n_layers;
   for (int li = 0; li < n_run; ++li) {
     const TfLayer& L = m->tf_layers[li];
-    WN_TRY(ln(L.n1, x, t1, M, d, eps, s));
-    WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s));
+    WN_TRY(ln(L.n1, x, t1, M, d, eps, s, h16));
+    WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s, ACT_NONE, nullptr, 0, 1.0f, false,
+                  h16));
     AttnArgs a;
     a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d;
     a.ldq = a.ldk = a.ldv = 3 * d;
-    a.O = t2; a.ldo = d;
+    a.O = t2; a.ldo = d; a.o_bf16 = h16;
     a.q_off = a.kv_off = m->d_off.as<int>();
     a.q_len = a.kv_len = m->d_len.as<int>();
     a.n_seq = m->B; a.n_heads = c.n_heads; a.max_q_len = max_len;
     a.mask_mode = 0;
     a.scale = 1.0f / sqrtf(64.0f);
     WN_TRY(attention(a, s));
-    WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d));
-    WN_TRY(ln(L.n2, x, t1, M, d, eps, s));
-    WN_TRY(ffn_w1(m, L.ff1, t1, hb, M, s, act));
-    WN_TRY(linear(L.ff2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d));
+    WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d, 1.0f, false, h16));
+    WN_TRY(ln(L.n2, x, t1, M, d, eps, s, h16));
+    WN_TRY(ffn_w1(m, L.ff1, t1, hb, M, s, act, h16));
+    WN_TRY(linear(L.ff2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 1.0f, false, h16));
   }
   WN_TRY(m->enc.ensure((size_t)std::max(M, 1) * d * sizeof(float)));
   if (m->dbg_skip_after_norm) {
@@ -1124,6 +1157,7 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
   }
   // ---- upload ---------------------------------------------------------------
   WN_TRY(m->weights->ensure(hs.data.size() * sizeof(float)));
+  m->n_weight_elems = (int64_t)hs.data.size();
   WN_HIP(hipMemcpy(m->weights->p, hs.data.data(), hs.data.size() * sizeof(float),
                    hipMemcpyHostToDevice));
   const float* base = m->weights->as<float>();
@@ -1250,6 +1284,8 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->prec = src->prec;
   // weights, projected position tables and fbank tables are read-only: share
   m->weights = src->weights;
+  m->n_weight_elems = src->n_weight_elems;
+  m->weights_bf16 = src->weights_bf16;
   m->pos_tabs = src->pos_tabs;
   m->fb_tab_i = src->fb_tab_i;
   m->w = src->w;
@@ -1277,6 +1313,17 @@ int wn_model_set_precision(wn_model* m, int32_t precision) {
   WN_CHECK(m, "wn_model_set_precision: null model");
   WN_CHECK(precision == PREC_F32 || precision == PREC_BF16,
            "wn_model_set_precision: 0 (fp32) or 1 (bf16 operands, fp32 accumulate)");
+  if (precision == PREC_BF16 && !m->weights_bf16 && m->n_weight_elems > 0) {
+    // one-time bf16 image of the weight slab for the bf16-storage GEMMs (same
+    // element offsets; clones made afterwards share it)
+    WN_HIP(hipSetDevice(m->device));
+    auto img = std::make_shared<DevBuf>();
+    WN_TRY(img->ensure((size_t)m->n_weight_elems * 2));
+    WN_TRY(convert_f32_to_bf16(m->weights->as<float>(), img->p, m->n_weight_elems,
+                               nullptr));
+    WN_HIP(hipStreamSynchronize(nullptr));
+    m->weights_bf16 = img;
+  }
   m->prec = precision;
   return 0;
 }
@@ -1329,6 +1376,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "ln_rows") g_ln_rows = value;
   else if (k == "attn_split") g_attn_split = value;
   else if (k == "attn_bf16") g_attn_bf16 = value;
+  else if (k == "bf16_store") g_bf16_store = value;
   else if (k == "attn_bf16_nw") g_attn_bf16_nw = value;
   else { set_error("wn_tune_set: unknown key " + k); return -1; }
   return 0;
@@ -2051,6 +2099,28 @@ int wn_op_gemm_bf16(const float* A, const float* W, const float* bias,
   const int r = wn_op_gemm(A, W, bias, resid, C, M, N, K, alpha, act, stream);
   t_gemm_prec = saved;
   return r;
+}
+
+int wn_op_gemm_bf16_stored(const float* A, const float* W, const float* bias,
+                           const float* resid, void* C, int32_t M, int32_t N, int32_t K,
+                           float alpha, int32_t act, int32_t c_bf16, void* stream) {
+  // test hook of the bf16-storage GEMM: A and W are converted to bf16 images in
+  // scratch buffers first (the model path gets them from its producers / the
+  // converted weight slab)
+  WN_CHECK(A && W && C && M > 0 && N > 0 && K > 0, "gemm(bf16 stored): null / empty");
+  WN_CHECK(K % 32 == 0, "gemm: K must be a multiple of 32");
+  static thread_local DevBuf a16, w16;
+  hipStream_t s = (hipStream_t)stream;
+  WN_TRY(a16.ensure((size_t)M * K * 2));
+  WN_TRY(w16.ensure((size_t)N * K * 2));
+  WN_TRY(convert_f32_to_bf16(A, a16.p, (int64_t)M * K, s));
+  WN_TRY(convert_f32_to_bf16(W, w16.p, (int64_t)N * K, s));
+  GemmArgs g;
+  g.A = a16.as<float>(); g.W = W; g.bias = bias; g.resid = resid;
+  g.C = reinterpret_cast<float*>(C);
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N;
+  g.alpha = alpha; g.act = act; g.a_bf16 = true; g.c_bf16 = c_bf16 != 0;
+  return gemm_bf16_stored(g, w16.p, s);
 }
 
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,
