@@ -36,7 +36,7 @@ def bf16_store(request):
     L = _lib.lib()
     _lib.check(L.wn_tune_set(b'bf16_store', request.param), 'tune')
     yield request.param
-    L.wn_tune_set(b'bf16_store', 0)
+    L.wn_tune_set(b'bf16_store', 1)  # the shipped default
 
 
 def _oracle():

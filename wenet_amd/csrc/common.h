@@ -108,8 +108,9 @@ extern thread_local const void* t_wslab_bf16;
 extern thread_local int64_t t_wslab_elems;
 int gemm_bf16_stored(const GemmArgs& a, const void* Wh, hipStream_t stream);
 int convert_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t s);
-// 1: in the bf16 mode the GEMM-only tensors (LayerNorm output, FFN hidden,
-// attention context) are stored as bf16 (wn_tune_set("bf16_store"))
+// 1 (default): in the bf16 mode the GEMM-only tensors (LayerNorm output, FFN
+// hidden, attention context) are stored as bf16; 0: every tensor stays fp32 and
+// the GEMMs convert on the fly (wn_tune_set("bf16_store"), A/B and tests)
 extern int g_bf16_store;
 
 // Tuning knobs (wn_tune_set): experiments / A-B runs only, defaults are the
