@@ -12,7 +12,7 @@
  *
  * Conventions
  *  - every function returns 0 on success, <0 on error (-1 bad argument, -2 HIP
- *    error, -3 handle busy); wn_last_error() gives the thread-local message;
+ *    error, -3 missing / mis-shaped weight, -4 handle busy); wn_last_error() gives the thread-local message;
  *  - `*_dev` pointers are device (HBM) pointers owned by the caller (e.g. a
  *    torch-ROCm tensor's data_ptr()); `*_host` pointers are host memory;
  *  - `stream` is a hipStream_t (0 = default stream).  Launches are
@@ -22,7 +22,7 @@
  *    one wn_model per process/GPU (one process per GPU for multi-GPU);
  *  - a handle is used by ONE host thread at a time (workspace, descriptor
  *    staging and current batch are per-handle state): a second thread that
- *    enters a busy handle gets -3 and must use its own wn_model_clone();
+ *    enters a busy handle gets -4 and must use its own wn_model_clone();
  *  - all arithmetic is fp32 (fp64 for the prefix-beam bookkeeping, like the
  *    reference's Python floats) unless wn_model_set_precision() opts a handle
  *    into bf16 operands; tokens / lengths are int32.

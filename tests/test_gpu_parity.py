@@ -1054,7 +1054,7 @@ def test_recognize_cli_shard_list_equals_raw_list(tmp_path):
 
 def test_busy_handle_is_refused_not_corrupted():
     """One host thread per wn_model handle: a second thread that enters a handle
-    while a call is running gets a RuntimeError (status -3), and the first
+    while a call is running gets a RuntimeError (status -4), and the first
     thread's results are unaffected.  (A feature-frontend call racing a decode on
     the same handle used to corrupt the descriptor staging buffer.)"""
     import threading

@@ -108,7 +108,7 @@ def lib():
 def check(status: int, what: str = ''):
     if status != 0:
         msg = lib().wn_last_error().decode('utf8', 'replace')
-        if status == -3:
+        if status == -4:  # handle busy (one host thread per handle)
             raise RuntimeError(f'{what}: {msg}')
         if status == -1 and ('must not be 0' in msg or 'null' in msg):
             raise AssertionError(f'{what}: {msg}')

@@ -26,6 +26,9 @@ namespace {
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;             // owns its allocation
+  DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { if (p) (void)hipFree(p); }
   int ensure(size_t bytes) {
     if (bytes <= cap) return 0;
@@ -47,6 +50,9 @@ struct Stager {
   size_t cap = 0, used = 0;
   hipEvent_t ev = nullptr;
   bool pending = false;
+  Stager() = default;
+  Stager(const Stager&) = delete;
+  Stager& operator=(const Stager&) = delete;
   ~Stager() {
     if (host) (void)hipHostFree(host);
     if (ev) (void)hipEventDestroy(ev);
@@ -283,7 +289,7 @@ struct wn_model {
   int prec = PREC_F32;       // GEMM operand precision (wn_model_set_precision)
   // one host thread per handle: the workspace, the descriptor staging and the
   // current batch are per-handle state.  Entry points take this flag and fail
-  // loudly (status -3) instead of corrupting the staging buffer when a second
+  // loudly (status -4) instead of corrupting the staging buffer when a second
   // thread enters the same handle (use wn_model_clone for a second thread).
   std::atomic<bool> busy{false};
   int dbg_layers = -1;       // run only the first n encoder layers
@@ -319,7 +325,7 @@ struct HandleGuard {
   if (!handle_guard.ok) {                                                        \
     ::wn::set_error("this wn_model handle is in use by another host thread; "    \
                     "one thread per handle (wn_model_clone gives a second one)"); \
-    return -3;                                                                   \
+    return -4;                                                                   \
   }
 
 struct PrecisionScope {

@@ -24,7 +24,7 @@ staging and current batch are per-handle state), so the pipeline works on its OW
 clones only and never on the caller's handle: the caller keeps using `model`
 (compute_fbank, resample, a direct decode()) from its thread while batches are
 in flight.  The library enforces this: a second thread entering a busy handle
-gets status -3 instead of corrupting it.
+gets status -4 instead of corrupting it.
 """
 import concurrent.futures
 import queue
