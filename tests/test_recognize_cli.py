@@ -22,6 +22,14 @@ def test_args_reject_modes_outside_the_path():
     with pytest.raises(SystemExit):
         R.get_args(base + ['--modes', 'attention', '--dtype', 'fp16'])
     assert R.get_args(base + ['--modes', 'attention', '--dtype', 'bf16']).dtype == 'bf16'
+    # the reference's transducer / HLG options are accepted (unused by these modes)
+    a = R.get_args(base + ['--modes', 'attention_rescoring', '--attn_weight', '0.3',
+                           '--transducer_weight', '0.2', '--lm_scale', '0.7', '--hlg', 'x',
+                           '--search_ctc_weight', '0.5', '--use_lora', 'False'])
+    assert a.attn_weight == 0.3 and a.search_ctc_weight == 0.5 and not a.use_lora
+    assert R.get_args(base + ['--modes', 'attention']).search_ctc_weight == 1.0
+    with pytest.raises(SystemExit):
+        R.get_args(base + ['--modes', 'attention', '--use_lora', 'True'])
 
 
 def test_data_list_batches_and_order(tmp_path):

@@ -69,7 +69,23 @@ def get_args(argv=None):
     p.add_argument('--context_graph_score', type=float, default=0.0)
     p.add_argument('--streams', type=int, default=2,
                    help='decode() calls in flight on the GPU')
+    # Options of the reference's command line (recognize.py:86-190) that only its
+    # transducer / HLG / LoRA modes read.  They are accepted so that existing decode
+    # scripts run unchanged; the four modes on this path never look at them, exactly
+    # as in the reference.  LoRA would change the weights and is refused.
+    for name in ('--search_ctc_weight', '--search_transducer_weight',
+                 '--transducer_weight', '--attn_weight', '--lm_scale', '--decoder_scale',
+                 '--r_decoder_scale'):
+        p.add_argument(name, type=float, default=1.0 if name.startswith('--search_ctc')
+                       else 0.0, help='(transducer / HLG modes only: unused here)')
+    p.add_argument('--word', default='', help='(HLG modes only: unused here)')
+    p.add_argument('--hlg', default='', help='(HLG modes only: unused here)')
+    p.add_argument('--use_lora', type=lambda v: str(v).lower() in ('1', 'true', 'yes'),
+                   default=False)
+    p.add_argument('--lora_ckpt_path', default=None)
     args = p.parse_args(argv)
+    if args.use_lora:
+        p.error('--use_lora: LoRA checkpoints are not supported on the accelerated path')
     for m in args.modes:
         if m not in MODES:
             p.error(f'mode {m!r} is not on the accelerated path (have: {MODES})')
