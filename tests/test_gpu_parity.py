@@ -1058,6 +1058,7 @@ def test_busy_handle_is_refused_not_corrupted():
     thread's results are unaffected.  (A feature-frontend call racing a decode on
     the same handle used to corrupt the descriptor staging buffer.)"""
     import threading
+    import time
     from wenet_amd import synthetic as S
     configs, sd, model = cached_model('aishell_u2pp', 0)
     feats, lens = S.make_features(8, (300, 500), seed=77)
@@ -1075,11 +1076,13 @@ def test_busy_handle_is_refused_not_corrupted():
                     n_ok[0] += 1
                 except RuntimeError as e:
                     errors.append(str(e))
+                time.sleep(0.001)  # leave the handle free most of the time: every
+                # decode() needs it free at each of its 3 entries to succeed
     t = threading.Thread(target=intruder)
     t.start()
     try:
         got, mine = [], []
-        for _ in range(6):
+        for _ in range(12):
             try:
                 got.append(model.decode(['ctc_prefix_beam_search'], fd, lens, beam_size=5))
             except RuntimeError as e:   # the intruder held the handle at entry
