@@ -1,6 +1,6 @@
 """ctypes binding of oracle/_ref/libref_fbank.so -- the REFERENCE's own C++
-fbank (runtime/core/frontend/fbank.h) built by oracle/Makefile.  Test
-infrastructure only."""
+fbank (runtime/core/frontend/fbank.h) and wav reader (frontend/wav.h) built by
+oracle/Makefile.  Test infrastructure only."""
 import ctypes
 import os
 
@@ -36,3 +36,20 @@ def ref_fbank(waveform: np.ndarray, num_bins: int = 80, sample_rate: int = 16000
                          frame_shift, out.ctypes.data, max_frames)
     assert got >= 0, 'ref_fbank: output buffer too small'
     return out[:got]
+
+
+def ref_wav_read(path: str):
+    """The reference's WavReader: (interleaved raw integer sample values as
+    float32, channels, sample rate, bits per sample)."""
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.ref_wav_read.restype = ctypes.c_int
+    lib.ref_wav_read.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int,
+                                 ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                 ctypes.POINTER(ctypes.c_int)]
+    cap = max(1, os.path.getsize(path))
+    out = np.zeros((cap, ), dtype=np.float32)
+    ch, sr, bits = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    n = lib.ref_wav_read(path.encode(), out.ctypes.data, cap, ctypes.byref(ch),
+                         ctypes.byref(sr), ctypes.byref(bits))
+    assert n >= 0, f'ref_wav_read failed ({n})'
+    return out[:n], ch.value, sr.value, bits.value

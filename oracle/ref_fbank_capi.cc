@@ -22,3 +22,22 @@ extern "C" int ref_fbank(const float* wave_s16_scale, int n_samples, int num_bin
     for (int b = 0; b < num_bins; ++b) out[t * num_bins + b] = feat[t][b];
   return n;
 }
+
+// The REFERENCE's own wav reader (runtime/core/frontend/wav.h:59-134): interleaved
+// samples as raw integer values.  Pins wenet_amd.model.read_wav (PCM16 / PCM32, mono
+// and multi-channel, files with extra chunks).  Returns the number of interleaved
+// values, or a negative count if `out` is too small; -1: the reader refused the file.
+#include "frontend/wav.h"
+
+extern "C" int ref_wav_read(const char* path, float* out, int max_values, int* channels,
+                            int* sample_rate, int* bits) {
+  wenet::WavReader r;
+  if (!r.Open(path)) return -1;
+  *channels = r.num_channel();
+  *sample_rate = r.sample_rate();
+  *bits = r.bits_per_sample();
+  const int n = r.num_samples() * r.num_channel();
+  if (n > max_values) return -n;
+  for (int i = 0; i < n; ++i) out[i] = r.data()[i];
+  return n;
+}

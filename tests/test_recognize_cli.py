@@ -74,8 +74,10 @@ def _wav_bytes(samples, rate, tag, bits, nch=1, extensible=False, extra_chunk=Tr
     else:
         fmt = struct.pack('<HHIIHH', tag, nch, rate, rate * block, block, bits)
     chunks = b'fmt ' + struct.pack('<I', len(fmt)) + fmt
-    if extra_chunk:
+    if extra_chunk is True:
         chunks += b'LIST' + struct.pack('<I', 5) + b'hello' + b'\0'  # odd size + pad
+    elif extra_chunk:  # an even-sized chunk of that many bytes
+        chunks += b'LIST' + struct.pack('<I', int(extra_chunk)) + bytes(int(extra_chunk))
     chunks += b'data' + struct.pack('<I', len(raw)) + raw
     return b'RIFF' + struct.pack('<I', 4 + len(chunks)) + b'WAVE' + chunks
 
@@ -249,3 +251,42 @@ def test_transcribe_cli_args():
         T.get_args(['a.wav'])                      # no model download: -m is required
     with pytest.raises(SystemExit):
         T.get_args(['a.wav', '-m', 'x', '--device', 'cpu'])
+
+
+def test_read_wav_matches_the_reference_wav_reader(tmp_path):
+    """Audio in against the REFERENCE's own reader
+    (runtime/core/frontend/wav.h:59-134, built from where it lies into
+    oracle/_ref): identical samples for PCM16 / PCM32, mono and stereo, with and
+    without extra chunks between `fmt ` and `data`, and the reference's own test
+    file."""
+    import numpy as np
+    from oracle import ref_fbank as RF
+    from wenet_amd.model import read_wav
+    if not RF.available():
+        pytest.skip('oracle/_ref/libref_fbank.so not built (needs /root/reference)')
+    rng = np.random.Generator(np.random.PCG64(9))
+    x = rng.random((3000, 2)) * 1.6 - 0.8
+    for bits, scale in ((16, 32768.0), (32, 2147483648.0)):
+        for nch in (1, 2):
+            # (an odd-sized chunk with its pad byte, which read_wav handles per the
+            # RIFF rules, sends the reference's chunk loop out of step: even only)
+            for extra in (False, 26):
+                p = tmp_path / f'w{bits}_{nch}_{int(extra)}.wav'
+                p.write_bytes(_wav_bytes(x[:, :nch], 22050, 1, bits, nch=nch,
+                                         extra_chunk=extra))
+                ref, ch, sr, b = RF.ref_wav_read(str(p))
+                got, rate = read_wav(str(p), return_rate=True)
+                assert (ch, sr, b) == (nch, 22050, bits) and rate == 22050
+                ref0 = ref.reshape(-1, nch)[:, 0]      # first channel (singal_channel)
+                assert len(got) == len(ref0) == 3000
+                # both are float32 views of the same integers (PCM32 exceeds the
+                # 24-bit mantissa: compare after the same float32 rounding)
+                np.testing.assert_array_equal(
+                    (got.astype(np.float64) * scale).astype(np.float32),
+                    ref0.astype(np.float32))
+    ref_file = '/root/reference/test/resources/aishell-BAC009S0724W0121.wav'
+    if os.path.exists(ref_file):
+        ref, ch, sr, b = RF.ref_wav_read(ref_file)
+        got, rate = read_wav(ref_file, return_rate=True)
+        assert (ch, sr, b, rate) == (1, 16000, 16, 16000)
+        np.testing.assert_array_equal(got * np.float32(32768.0), ref)
