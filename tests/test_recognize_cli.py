@@ -290,3 +290,47 @@ def test_read_wav_matches_the_reference_wav_reader(tmp_path):
         got, rate = read_wav(ref_file, return_rate=True)
         assert (ch, sr, b, rate) == (1, 16000, 16, 16000)
         np.testing.assert_array_equal(got * np.float32(32768.0), ref)
+
+
+def test_compute_feature_follows_feats_type():
+    """load_feature (cli/model.py:47-66): the feature function is chosen by
+    dataset_conf.feats_type and gets its <type>_conf.  Dispatch only -- the
+    kernels behind it are covered by the GPU tests."""
+    import numpy as np
+    import torch
+    from wenet_amd.model import ASRModel
+    calls = []
+
+    class Fake(ASRModel):
+        def __init__(self, configs):
+            self.configs = configs
+
+        def __del__(self):
+            pass
+
+        def load_wav(self, wav_file):
+            return np.zeros(1600, np.float32)
+
+        def compute_fbank(self, waves):
+            calls.append(('fbank', len(waves)))
+            return torch.zeros(1, 9, 80), torch.tensor([8])
+
+        def compute_log_mel_spectrogram(self, waves, **kw):
+            calls.append(('log_mel', kw))
+            return torch.zeros(1, 10, kw['num_mel_bins']), torch.tensor([10])
+
+    assert Fake({}).compute_feature('a.wav').shape == (8, 80)
+    assert Fake({'dataset_conf': {'feats_type': 'fbank'}}).compute_feature('a').shape == (8, 80)
+    m = Fake({'dataset_conf': {'feats_type': 'log_mel_spectrogram',
+                               'log_mel_spectrogram_conf': {
+                                   'num_mel_bins': 128, 'padding': 0, 'pad_or_trim': True,
+                                   'max_duration': 30, 'n_fft': 400, 'hop_length': 160}}})
+    assert m.compute_feature('a').shape == (10, 128)
+    assert calls[-1] == ('log_mel', dict(num_mel_bins=128, padding=0, pad_or_trim=True,
+                                         max_duration=30))
+    with pytest.raises(NotImplementedError):
+        Fake({'dataset_conf': {'feats_type': 'mfcc'}}).compute_feature('a')
+    with pytest.raises(NotImplementedError):
+        Fake({'dataset_conf': {'feats_type': 'log_mel_spectrogram',
+                               'log_mel_spectrogram_conf': {'hop_length': 128}}}
+             ).compute_feature('a')

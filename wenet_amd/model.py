@@ -707,8 +707,28 @@ class ASRModel:
         return wav if rate == 16000 else self.resample(wav, rate, 16000)
 
     def compute_feature(self, wav_file: str) -> torch.Tensor:
-        """cli/model.py:59-66: decode_wav -> resample -> compute_fbank."""
-        feats, lens = self.compute_fbank([self.load_wav(wav_file)])
+        """cli/model.py:47-66 (load_feature): decode_wav -> resample -> the
+        feature function `dataset_conf.feats_type` names with its `<type>_conf`
+        -- `fbank` (default) or `log_mel_spectrogram` (the Whisper recipes);
+        `mfcc` is not on this path."""
+        dc = self.configs.get('dataset_conf') or {}
+        feats_type = dc.get('feats_type', 'fbank')
+        if feats_type == 'fbank':
+            feats, lens = self.compute_fbank([self.load_wav(wav_file)])
+        elif feats_type == 'log_mel_spectrogram':
+            conf = dc.get('log_mel_spectrogram_conf') or {}
+            if conf.get('n_fft', 400) != 400 or conf.get('hop_length', 160) != 160:
+                raise NotImplementedError(
+                    'log_mel_spectrogram: n_fft 400 / hop_length 160 only')
+            feats, lens = self.compute_log_mel_spectrogram(
+                [self.load_wav(wav_file)],
+                num_mel_bins=conf.get('num_mel_bins', 80),
+                padding=conf.get('padding', 0),
+                pad_or_trim=conf.get('pad_or_trim', False),
+                max_duration=conf.get('max_duration', 30))
+        else:
+            raise NotImplementedError(
+                f'feats_type {feats_type!r}: fbank and log_mel_spectrogram only')
         return feats[0, :int(lens[0])]
 
     def transcribe(self, wav: str) -> DecodeResult:
