@@ -188,6 +188,25 @@ def test_override_config_and_feature_checks():
     cfg['dataset_conf']['fbank_conf']['frame_shift'] = 20
     with pytest.raises(NotImplementedError):
         R.check_feature_conf(cfg)
+    # the Whisper recipes' frontend (examples/aishell/whisper/conf/finetune_whisper_largev3.yaml)
+    wcfg = {'input_dim': 128, 'dataset_conf': {
+        'feats_type': 'log_mel_spectrogram',
+        'log_mel_spectrogram_conf': {'hop_length': 160, 'n_fft': 400, 'num_mel_bins': 128,
+                                     'padding': 0}}}
+    R.check_feature_conf(wcfg)
+
+    class M:
+        configs = wcfg
+        compute_fbank = staticmethod(lambda waves: ('fbank', waves))
+        compute_log_mel_spectrogram = staticmethod(lambda waves, **kw: ('log_mel', kw))
+    assert R.feature_function(M, wcfg)(['w']) == (
+        'log_mel', dict(num_mel_bins=128, padding=0, pad_or_trim=False, max_duration=30))
+    assert R.feature_function(M, cfg)(['w']) == ('fbank', ['w'])
+    wcfg['dataset_conf']['log_mel_spectrogram_conf']['num_mel_bins'] = 80
+    with pytest.raises(NotImplementedError):
+        R.check_feature_conf(wcfg)
+    with pytest.raises(NotImplementedError):
+        R.check_feature_conf({'dataset_conf': {'feats_type': 'mfcc'}})
 
 
 def test_tokenizer_char_and_bpe_detokenize():

@@ -207,16 +207,39 @@ def padding_order(n_frames: Sequence[int]) -> List[int]:
 
 
 def check_feature_conf(configs: dict):
+    """The feature recipes this path computes on the device: Kaldi fbank (25 ms /
+    10 ms, input_dim bins) and the Whisper log-mel (n_fft 400, hop 160)."""
     dc = configs.get('dataset_conf', {})
-    if dc.get('feats_type', 'fbank') != 'fbank':
-        raise NotImplementedError('recognize: fbank features only')
-    fc = dc.get('fbank_conf', {})
-    if (fc.get('num_mel_bins', 80) != configs.get('input_dim', 80)
-            or fc.get('frame_length', 25) != 25 or fc.get('frame_shift', 10) != 10):
-        raise NotImplementedError('recognize: fbank must be 25 ms / 10 ms frames with '
-                                  'input_dim mel bins')
+    feats_type = dc.get('feats_type', 'fbank')
+    if feats_type == 'log_mel_spectrogram':
+        lc = dc.get('log_mel_spectrogram_conf', {})
+        if (lc.get('n_fft', 400) != 400 or lc.get('hop_length', 160) != 160
+                or lc.get('num_mel_bins', 80) != configs.get('input_dim', 80)):
+            raise NotImplementedError('recognize: log_mel_spectrogram must be n_fft 400 / '
+                                      'hop_length 160 with input_dim mel bins')
+    elif feats_type != 'fbank':
+        raise NotImplementedError('recognize: fbank or log_mel_spectrogram features only')
+    else:
+        fc = dc.get('fbank_conf', {})
+        if (fc.get('num_mel_bins', 80) != configs.get('input_dim', 80)
+                or fc.get('frame_length', 25) != 25 or fc.get('frame_shift', 10) != 10):
+            raise NotImplementedError('recognize: fbank must be 25 ms / 10 ms frames with '
+                                      'input_dim mel bins')
     if dc.get('resample_conf', {}).get('resample_rate', 16000) != 16000:
         raise NotImplementedError('recognize: 16 kHz models only')
+
+
+def feature_function(model, configs: dict):
+    """waveform list -> (padded features in HBM, lengths): dataset_conf.feats_type
+    with its conf, like the reference's dataset pipeline (dataset.py:100-118)."""
+    dc = configs.get('dataset_conf', {})
+    if dc.get('feats_type', 'fbank') == 'log_mel_spectrogram':
+        lc = dc.get('log_mel_spectrogram_conf', {})
+        kw = dict(num_mel_bins=lc.get('num_mel_bins', 80), padding=lc.get('padding', 0),
+                  pad_or_trim=lc.get('pad_or_trim', False),
+                  max_duration=lc.get('max_duration', 30))
+        return lambda waves: model.compute_log_mel_spectrogram(waves, **kw)
+    return model.compute_fbank
 
 
 def format_line(key: str, text: str) -> str:
@@ -279,6 +302,7 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
               blank_id=blank_id, blank_penalty=args.blank_penalty,
               length_penalty=args.length_penalty)
     max_fmt = max(len(m) for m in args.modes)
+    compute_features = feature_function(model, model.configs)
     depth = max(2, 2 * args.streams)  # batches of wav data read ahead
     readers = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, args.num_workers))
 
@@ -309,7 +333,7 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
             if pos + depth < len(order):
                 nxt = order[pos + depth]
                 pending_wavs[nxt] = load(nxt)
-            feats, n_frames = model.compute_fbank(waves)
+            feats, n_frames = compute_features(waves)
             perm = padding_order(n_frames.tolist())
             idx = torch.as_tensor(perm, dtype=torch.long)
             feats = feats.index_select(0, idx.to(feats.device))
