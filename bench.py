@@ -14,6 +14,10 @@ sorted by length and dealt round-robin; results are gathered with one RCCL
 all_gather inside the timed region).  Weights are random-init (sharpened CTC
 head, wenet_amd/synthetic.py), inputs synthetic.
 
+`--workload configN` / `--dtype bf16` measure the other BASELINE configs and the
+opt-in bf16-operand mode (recognize.py --dtype bf16) as extra data points; the
+default line (config2, fp32 = the reference's dtype) is the headline.
+
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     : the FFN w_1 GEMM (fp32 MFMA), achieved = algorithmic FLOP of
                  its launches / their HIP-event durations inside the timed
