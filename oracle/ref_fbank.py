@@ -38,6 +38,17 @@ def ref_fbank(waveform: np.ndarray, num_bins: int = 80, sample_rate: int = 16000
     return out[:got]
 
 
+def has_wav_reader() -> bool:
+    """The built library exports ref_wav_read (a library built before that entry
+    point existed does not: rebuild with `make -C oracle`)."""
+    if not available():
+        return False
+    try:
+        return hasattr(ctypes.CDLL(LIB_PATH), 'ref_wav_read')
+    except OSError:
+        return False
+
+
 def ref_wav_read(path: str):
     """The reference's WavReader: (interleaved raw integer sample values as
     float32, channels, sample rate, bits per sample)."""

@@ -281,8 +281,13 @@ def test_read_wav_matches_the_reference_wav_reader(tmp_path):
     import numpy as np
     from oracle import ref_fbank as RF
     from wenet_amd.model import read_wav
-    if not RF.available():
-        pytest.skip('oracle/_ref/libref_fbank.so not built (needs /root/reference)')
+    if not RF.has_wav_reader() and os.path.isdir('/root/reference/runtime/core'):
+        import subprocess  # a library from before ref_wav_read existed: rebuild it
+        subprocess.run(['make', '-s', '-C', os.path.join(os.path.dirname(
+            os.path.dirname(os.path.abspath(__file__))), 'oracle')], check=False)
+    if not RF.has_wav_reader():
+        pytest.skip('oracle/_ref/libref_fbank.so without ref_wav_read '
+                    '(needs /root/reference: make -C oracle)')
     rng = np.random.Generator(np.random.PCG64(9))
     x = rng.random((3000, 2)) * 1.6 - 0.8
     for bits, scale in ((16, 32768.0), (32, 2147483648.0)):
