@@ -1101,15 +1101,11 @@ def is_bidirectional(configs) -> bool:
     return configs.get('decoder', 'bitransformer') == 'bitransformer'
 
 
-def forward_attention_decoder(configs, sd, hyps, hyps_lens, encoder_out,
-                              reverse_weight: float = 0.0, sos: int = 2,
-                              eos: int = 2):
-    """ASRModel.forward_attention_decoder asr_model.py:453-547."""
-    assert encoder_out.size(0) == 1
-    num_hyps = hyps.size(0)
-    encoder_out = encoder_out.repeat(num_hyps, 1, 1)
-    encoder_mask = torch.ones(num_hyps, 1, encoder_out.size(1),
-                              dtype=torch.bool)
+def reverse_hyps(hyps, hyps_lens, eos: int):
+    """Input of the right-to-left decoder, asr_model.py:485-536: hyps (N, L) start
+    with sos and are eos-padded, hyps_lens count the sos; every hypothesis is
+    reversed behind its sos and re-padded with eos (worked example in the
+    reference's comments, pinned in tests/test_oracle.py)."""
     r_hyps_lens = hyps_lens - 1
     r_hyps = hyps[:, 1:]
     max_len = torch.max(r_hyps_lens)
@@ -1120,7 +1116,19 @@ def forward_attention_decoder(configs, sd, hyps, hyps_lens, encoder_out,
     index = index * seq_mask
     r_hyps = torch.gather(r_hyps, 1, index)
     r_hyps = torch.where(seq_mask, r_hyps, eos)
-    r_hyps = torch.cat([hyps[:, 0:1], r_hyps], dim=1)
+    return torch.cat([hyps[:, 0:1], r_hyps], dim=1)
+
+
+def forward_attention_decoder(configs, sd, hyps, hyps_lens, encoder_out,
+                              reverse_weight: float = 0.0, sos: int = 2,
+                              eos: int = 2):
+    """ASRModel.forward_attention_decoder asr_model.py:453-547."""
+    assert encoder_out.size(0) == 1
+    num_hyps = hyps.size(0)
+    encoder_out = encoder_out.repeat(num_hyps, 1, 1)
+    encoder_mask = torch.ones(num_hyps, 1, encoder_out.size(1),
+                              dtype=torch.bool)
+    r_hyps = reverse_hyps(hyps, hyps_lens, eos)
     dc = configs['decoder_conf']
     if is_bidirectional(configs):
         lp, nl = 'decoder.left_decoder.', dc.get('num_blocks', 6)

@@ -615,3 +615,34 @@ def test_bf16_operand_mode_is_at_least_as_close_to_fp32_as_reference_autocast(co
     scale = ref32.abs().max().item()
     assert d_emu <= d_ac, (d_emu, d_ac)
     assert d_emu < 4e-2 * scale and d_x < 8e-2 * scale, (d_emu, d_x, scale)
+
+
+def test_reverse_hyps_worked_example_of_the_reference():
+    """The worked example in the reference's own comments
+    (wenet/models/transformer/asr_model.py:487-536): hyps
+    [[sos,1,2,3],[sos,9,8,4],[sos,2,eos,eos]] with lens [4,4,2] ->
+    [[sos,3,2,1],[sos,4,8,9],[sos,2,eos,eos]] -- oracle and product host code."""
+    from wenet_amd.model import reverse_hyps as product_reverse
+    sos = eos = 11
+    hyps = torch.tensor([[sos, 1, 2, 3], [sos, 9, 8, 4], [sos, 2, eos, eos]])
+    lens = torch.tensor([4, 4, 2])
+    want = [[sos, 3, 2, 1], [sos, 4, 8, 9], [sos, 2, eos, eos]]
+    assert O.reverse_hyps(hyps, lens, eos).tolist() == want
+    assert product_reverse(hyps, lens, eos).tolist() == want
+    # reversing twice restores every hypothesis (padding stays eos)
+    assert O.reverse_hyps(O.reverse_hyps(hyps, lens, eos), lens, eos).tolist() == hyps.tolist()
+    g = torch.Generator().manual_seed(4)
+    for _ in range(20):
+        n, L = int(torch.randint(1, 6, (1, ), generator=g)), int(torch.randint(2, 9, (1, ), generator=g))
+        lens = torch.randint(2, L + 1, (n, ), generator=g)
+        lens[0] = L
+        h = torch.randint(20, 90, (n, L), generator=g)
+        h[:, 0] = sos
+        for i in range(n):
+            h[i, int(lens[i]):] = eos
+        a, b = O.reverse_hyps(h, lens, eos), product_reverse(h, lens, eos)
+        assert a.tolist() == b.tolist()
+        for i in range(n):
+            k = int(lens[i])
+            assert a[i, 1:k].tolist() == h[i, 1:k].flip(0).tolist()
+            assert a[i, k:].tolist() == [eos] * (L - k)

@@ -161,6 +161,21 @@ class _Tokenizer:
         return text, tokens
 
 
+def reverse_hyps(hyps: torch.Tensor, hyps_lens: torch.Tensor, eos: int) -> torch.Tensor:
+    """Decoder input of the right-to-left decoder (asr_model.py:485-536): `hyps`
+    (N, L) start with sos and are eos-padded, `hyps_lens` count the sos; each
+    hypothesis is reversed behind its sos and padded with eos again."""
+    r_lens = hyps_lens - 1
+    r_hyps = hyps[:, 1:]
+    max_len = int(r_lens.max())
+    idx_range = torch.arange(0, max_len)
+    seq_mask = r_lens.unsqueeze(1) > idx_range
+    index = ((r_lens.unsqueeze(1) - 1) - idx_range) * seq_mask
+    r_hyps = torch.gather(r_hyps, 1, index)
+    r_hyps = torch.where(seq_mask, r_hyps, torch.tensor(eos))
+    return torch.cat([hyps[:, 0:1], r_hyps], dim=1)
+
+
 class ASRModel:
     """GPU-resident Conformer CTC/attention model with the reference's
     inference API."""
@@ -488,16 +503,7 @@ class ASRModel:
         lens_c = torch.as_tensor(hyps_lens).detach().cpu().long()
         decoder_out = self._decoder_forward(0, hyps_c, lens_c)
         if reverse_weight > 0 and self.is_bidirectional_decoder():
-            # the reference's index arithmetic, asr_model.py:487-536
-            r_lens = lens_c - 1
-            r_hyps = hyps_c[:, 1:]
-            max_len = int(r_lens.max())
-            idx_range = torch.arange(0, max_len)
-            seq_mask = r_lens.unsqueeze(1) > idx_range
-            index = ((r_lens.unsqueeze(1) - 1) - idx_range) * seq_mask
-            r_hyps = torch.gather(r_hyps, 1, index)
-            r_hyps = torch.where(seq_mask, r_hyps, torch.tensor(self.eos))
-            r_hyps = torch.cat([hyps_c[:, 0:1], r_hyps], dim=1)
+            r_hyps = reverse_hyps(hyps_c, lens_c, self.eos)
             r_decoder_out = self._decoder_forward(1, r_hyps, lens_c)
         else:
             r_decoder_out = torch.tensor(0.0)
