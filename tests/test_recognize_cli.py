@@ -358,3 +358,43 @@ def test_compute_feature_follows_feats_type():
         Fake({'dataset_conf': {'feats_type': 'log_mel_spectrogram',
                                'log_mel_spectrogram_conf': {'hop_length': 128}}}
              ).compute_feature('a')
+
+
+@needs_reference
+def test_every_reference_recipe_is_accepted_or_refused_cleanly():
+    """The reference's own construction test (test/wenet/utils/test_init_model.py:
+    every examples/*/*/conf/*.yaml builds) mirrored for this path: each recipe either
+    maps to a wn_config or is refused with NotImplementedError naming the key -- never
+    a crash, never a silent mis-configuration.  The BASELINE recipes are accepted."""
+    import glob
+    import yaml
+    from wenet_amd.model import config_from_yaml
+    accepted, refused = [], {}
+    paths = sorted(glob.glob('/root/reference/examples/*/*/conf/*.yaml'))
+    assert len(paths) > 50
+    for p in paths:
+        with open(p) as f:
+            c = yaml.load(f, Loader=yaml.FullLoader)
+        if not isinstance(c, dict) or 'encoder_conf' not in c:
+            continue
+        c.setdefault('input_dim', 80)
+        c.setdefault('output_dim', 5000)
+        name = p.split('examples/')[1]
+        try:
+            cfg = config_from_yaml(c)
+        except NotImplementedError as e:
+            refused[name] = str(e)
+            continue
+        accepted.append(name)
+        assert cfg.d_model % 64 == 0 and cfg.n_layers > 0 and cfg.vocab == c['output_dim']
+    for must in ('aishell/s0/conf/train_u2++_conformer.yaml',
+                 'aishell/s0/conf/train_conformer.yaml',
+                 'librispeech/s0/conf/train_conformer_bidecoder_large.yaml',
+                 'wenetspeech/s0/conf/train_u2++_conformer.yaml',
+                 'aishell/whisper/conf/finetune_whisper_largev3.yaml'):
+        assert must in accepted, (must, refused.get(must))
+    for name, why in refused.items():
+        assert 'outside the accelerated path' in why, (name, why)
+    for family in ('rnnt', 'paraformer'):
+        assert not [a for a in accepted if f'/{family}/' in a], family
+    assert len(accepted) >= 25 and len(refused) >= 20

@@ -34,6 +34,13 @@ def config_from_yaml(configs: dict) -> _lib.WnConfig:
     """train.yaml dict -> wn_config (keys as init_model.py:100-181 reads them)."""
     ec = configs['encoder_conf']
     dc = configs.get('decoder_conf') or {}
+    # init_model.py:36-50 WENET_MODEL_CLASSES: the CTC / attention-decoder family
+    # (ASRModel and its subclasses) is on this path; transducer, paraformer, ...
+    # have other decoders and decode methods.
+    model_type = configs.get('model', 'asr_model')
+    if model_type not in ('asr_model', 'whisper', 'k2_model', 'ctl_model'):
+        raise NotImplementedError(
+            f'model {model_type!r} is outside the accelerated path (asr_model family)')
     enc_type = configs.get('encoder', 'conformer')
     if enc_type == 'conformer':
         checks = dict(input_layer='conv2d', pos_enc_layer_type='rel_pos',
