@@ -9,27 +9,38 @@ Conformer decode path on MI355X (BASELINE.json `metric`).
 One step = one `ASRModel.decode()` pass over one batch of synthetic fbank
 features that are already resident in HBM: BASELINE.json configs[1]
 (AIShell u2++ Conformer 12L/4h/256d, batch 32 x ~10 s, ctc_prefix_beam_search,
-beam 10) on every GPU (weak scaling: the global batch is 32 x N utterances,
-sorted by length and dealt round-robin; results are gathered with one RCCL
-all_gather inside the timed region).  Weights are random-init (sharpened CTC
-head, wenet_amd/synthetic.py), inputs synthetic.
+beam 10) on every GPU (weak scaling: 32 utterances per GPU -- group g of the
+global batch is `synthetic.make_bench_group(workload, g)` -- sorted by length and
+dealt in snake order; results are gathered with one RCCL all_gather inside the
+timed region).  Weights are random-init (sharpened CTC head,
+wenet_amd/synthetic.py), inputs synthetic.
 
-`--workload configN` / `--dtype bf16` measure the other BASELINE configs and the
-opt-in bf16-operand mode (recognize.py --dtype bf16) as extra data points; the
-default line (config2, fp32 = the reference's dtype) is the headline.
+Timing: W warm-up steps, then ROUNDS of exactly K steps, each round bracketed by a
+barrier + torch.cuda.synchronize() on both sides and max-reduced over the ranks;
+rounds repeat until they cover >= 2 s, and `value` / `ms_per_step` are the MEDIAN
+round (`rounds` carries min / max).  After the timed rounds the tokens the last
+timed step produced are compared with what the REAL reference produced on the same
+batch (tests/golden/bench_*.npz): `verified`.
+
+`--workload configN` / `--dtype bf16|fp8` measure the other BASELINE configs and
+the opt-in reduced-precision modes as extra data points; the default line
+(config2, fp32 = the reference's dtype) is the headline.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     : the FFN w_1 GEMM (fp32 MFMA), achieved = algorithmic FLOP of
-                 its launches / their HIP-event durations inside the timed
-                 region, peak 157.3 TF (MI355X_MICROARCH.md);
+  roofline     : the FFN w_1 GEMM (MFMA), achieved = algorithmic FLOP of its
+                 launches / their HIP-event durations inside the timed rounds,
+                 peak from MI355X_MICROARCH.md; `whole_decode_frac` = all encoder +
+                 CTC-head contraction FLOPs of the batch / step time / peak;
   cpu_baseline : the oracle (torch-CPU restatement of the reference decode,
-                 kind "port") timed on this box's host cores on a bounded
-                 sample of the same workload.
+                 kind "port") timed on this box's host cores on the whole batch;
+                 profiles/cpu_port_vs_reference.json calibrates the port against
+                 the real reference's ASRModel.decode.
 """
 import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -43,40 +54,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 _lib_mod = None
-FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md:42
-FRAMES = (800, 1200)  # 8..12 s of 10 ms frames, mean ~10 s
-BEAM = 10
-# BASELINE.json `configs`; the default (and the only one the driver runs) is
-# configs[1], the configuration the metric is quoted on.
-WORKLOADS = {
-    'config2': dict(config='aishell_u2pp', batch=32, method='ctc_prefix_beam_search',
-                    kw={}, text='BASELINE.json configs[1]: AIShell u2++ conformer '
-                    '12L/4head/256d fbank80, batch 32 x ~10 s per GPU (8-12 s '
-                    'ragged), ctc_prefix_beam_search beam 10'),
-    'config3': dict(config='librispeech_bidecoder_large', batch=64,
-                    method='attention_rescoring',
-                    kw=dict(ctc_weight=0.5, reverse_weight=0.3),
-                    text='BASELINE.json configs[2]: LibriSpeech conformer '
-                    'bidecoder-large 12L/8head/512d fbank80, batch 64 x ~10 s per GPU, '
-                    'attention_rescoring beam 10, ctc_weight 0.5, reverse_weight 0.3'),
-    'config4': dict(config='wenetspeech_u2pp', batch=32,
-                    method='ctc_prefix_beam_search',
-                    kw=dict(decoding_chunk_size=16, num_decoding_left_chunks=-1),
-                    text='BASELINE.json configs[3]: WenetSpeech u2++ conformer '
-                    '12L/8head/512d, decoding_chunk_size 16 (chunk-mask streaming), '
-                    'batch 32 x ~10 s per GPU, ctc_prefix_beam_search beam 10'),
-    'config5': dict(config='whisper_largev3', batch=16, method='ctc_greedy_search',
-                    kw={}, frames=(3000, 3000), feat_dim=128,
-                    text='BASELINE.json configs[4]: Whisper-large-v3 encoder '
-                    '32L/20head/1280d, 128 mel bins, 30 s windows, batch 16 per GPU, '
-                    'fp32 (not the bf16 / fp8 the config names), + a 307-way CTC head '
-                    'and greedy search'),
-}
-CONFIG = 'aishell_u2pp'
-BATCH_PER_GPU = 32
-METHOD = 'ctc_prefix_beam_search'
-DECODE_KW = {}
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md:41-43
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'fp8': 5000.0}
+MIN_TIMED_SECONDS = 2.0
+MAX_ROUNDS = 400
 
 
 def audio_seconds(n_frames) -> float:
@@ -84,45 +65,87 @@ def audio_seconds(n_frames) -> float:
     return float(sum(((int(t) - 1) * 160 + 400) / 16000.0 for t in n_frames))
 
 
-def cpu_baseline(configs, sd, feats, lens):
-    """Oracle decode (same method / beam) on a bounded sample of the batch on
-    the host cores.  torch-CPU with one thread per hardware thread collapses on
-    these small GEMMs (256 threads: <1 audio-s/s), so a short calibration picks
-    the best of a few thread counts first; `cores` is what was used."""
+def contraction_flops(configs, feat_lens) -> float:
+    """Algorithmic FLOPs (2 x MAC) of every contraction of the encoder + CTC head
+    for utterances of `feat_lens` frames -- SURVEY.md section 8(d)'s per-unit figure
+    (11.776 GMAC for one 998-frame AIShell utterance), evaluated per utterance."""
+    ec = configs['encoder_conf']
+    d, F, L = ec['output_size'], ec['linear_units'], ec['num_blocks']
+    V = configs['output_dim']
+    mac = 0.0
+    if configs.get('encoder') == 'transformer':   # Whisper-style encoder
+        fd = configs['input_dim']
+        for t in feat_lens:
+            t = int(t)
+            tp = (t - 1) // 2 + 1
+            mac += t * 3 * fd * d + tp * 3 * d * d            # Conv1dSubsampling2
+            mac += L * (4 * tp * d * d + 2 * tp * d * F + 2 * tp * tp * d)
+            mac += tp * d * V
+        return 2.0 * mac
+    K = ec['cnn_module_kernel']
+    fd = configs['input_dim']
+    f1 = (fd - 1) // 2
+    f2 = (f1 - 1) // 2
+    for t in feat_lens:
+        t = int(t)
+        t1 = (t - 1) // 2
+        tp = (t1 - 1) // 2
+        mac += t1 * f1 * d * 9 + tp * f2 * d * 9 * d + tp * f2 * d * d   # subsampling
+        per_layer = (2 * 2 * tp * d * F            # two FFNs
+                     + 4 * tp * d * d              # q, k, v, out
+                     + tp * d * d                  # linear_pos
+                     + 3 * tp * tp * d             # ac + bd + pv
+                     + tp * d * 2 * d + tp * d * K + tp * d * d)  # conv module
+        mac += L * per_layer + tp * d * V
+    return 2.0 * mac
+
+
+def cpu_baseline(configs, sd, feats, lens, method, kw, beam):
+    """Oracle decode (same method / beam) of the WHOLE batch on the host cores.
+    torch-CPU with one thread per hardware thread collapses on these small GEMMs
+    (256 threads: < 1 audio-s/s), so a short calibration picks the best of a few
+    thread counts first; `cores` is what was used."""
     from oracle import wenet_oracle as O
     ncores = os.cpu_count() or 1
-    n = min(8, feats.shape[0])
-    f = feats[:n, :int(lens[:n].max())].contiguous()
-    l = lens[:n]
     best_t, best_dt = 1, float('inf')
     for nt in sorted({min(ncores, c) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(nt)
         with torch.no_grad():
-            O.encoder_forward(configs, sd, f[:2], l[:2])  # warm-up
+            O.encoder_forward(configs, sd, feats[:2], lens[:2])  # warm-up
             t0 = time.time()
-            O.encoder_forward(configs, sd, f[:2], l[:2])
+            O.encoder_forward(configs, sd, feats[:2], lens[:2])
             dt = time.time() - t0
         if dt < best_dt:
             best_t, best_dt = nt, dt
     torch.set_num_threads(best_t)
-    O.decode(configs, sd, [METHOD], f[:1], l[:1], beam_size=BEAM, **DECODE_KW)  # warm-up
-    reps, t0 = 0, time.time()
-    while True:
-        O.decode(configs, sd, [METHOD], f, l, beam_size=BEAM, **DECODE_KW)
-        reps += 1
-        if time.time() - t0 > 12.0 or reps >= 3:
-            break
-    dt = (time.time() - t0) / reps
-    return {
-        'value': round(audio_seconds(l.tolist()) / dt, 2),
+    O.decode(configs, sd, [method], feats[:1], lens[:1], beam_size=beam, **kw)  # warm-up
+    ts = []
+    t_start = time.time()
+    while len(ts) < 3 and (not ts or time.time() - t_start < 20.0):
+        t0 = time.time()
+        O.decode(configs, sd, [method], feats, lens, beam_size=beam, **kw)
+        ts.append(time.time() - t0)
+    dt = statistics.median(ts)
+    out = {
+        'value': round(audio_seconds(lens.tolist()) / dt, 2),
         'unit': 'audio_s/s',
         'cores': torch.get_num_threads(),
         'kind': 'port',
-        'sample': f'{n} utterances of the same batch ({audio_seconds(l.tolist()):.0f} s '
-                  f'audio), {METHOD} beam {BEAM}, oracle/wenet_oracle.py '
-                  f'(torch-CPU fp32 + Python prefix beam), mean of {reps} runs, '
-                  f'best of 8/16/32/64 threads on {ncores} hardware threads',
+        'sample': f'the whole batch: {feats.shape[0]} utterances '
+                  f'({audio_seconds(lens.tolist()):.0f} s audio), {method} beam {beam}, '
+                  f'oracle/wenet_oracle.py (torch-CPU fp32 + Python prefix beam), median '
+                  f'of {len(ts)} runs, best of 8/16/32/64 threads on {ncores} hardware '
+                  f'threads',
     }
+    cal = os.path.join(ROOT, 'profiles', 'cpu_port_vs_reference.json')
+    if os.path.exists(cal):
+        with open(cal) as f:
+            c = json.load(f)
+        out['port_over_reference_speed'] = c.get('port_over_reference_speed')
+        out['calibration'] = ('profiles/cpu_port_vs_reference.json: port vs the real '
+                              'reference ASRModel.decode on the same batch, '
+                              f"{c.get('threads')} threads, build container")
+    return out
 
 
 def end_to_end_leg(model, lens, device, total_audio, ms_per_step):
@@ -163,29 +186,32 @@ def end_to_end_leg(model, lens, device, total_audio, ms_per_step):
 
 
 def main():
+    from wenet_amd import synthetic as S
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--min-seconds', type=float, default=MIN_TIMED_SECONDS,
+                    help='rounds of --steps steps are repeated until they cover this')
     ap.add_argument('--streams', type=int, default=2,
                     help='decodes kept in flight per GPU (wenet_amd/pipeline.py); '
                          '1 = plain back-to-back ASRModel.decode() calls')
-    ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS),
+    ap.add_argument('--workload', default='config2', choices=sorted(S.BENCH_WORKLOADS),
                     help='config2 = BASELINE.json configs[1] (the metric\'s '
                          'configuration, default); the others are extra data points')
-    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
-                    help='fp32 (default: the reference\'s dtype, the headline) or '
-                         'bf16 operands / fp32 accumulate (recognize.py --dtype bf16; '
-                         'the dtype BASELINE.json configs[4] names) -- an extra data '
-                         'point, never the headline line')
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp8'],
+                    help='fp32 (default: the reference\'s dtype, the headline); bf16 = '
+                         'bf16 operands / fp32 accumulate (recognize.py --dtype bf16); '
+                         'fp8 = bf16 mode with e4m3 FFN GEMMs (BASELINE.json '
+                         'configs[4]) -- extra data points, never the headline line')
     ap.add_argument('--tune', default='',
                     help='experiments: comma list of key=value for wn_tune_set')
     args = ap.parse_args()
-    global CONFIG, BATCH_PER_GPU, METHOD, DECODE_KW
-    wl = WORKLOADS[args.workload]
-    CONFIG, BATCH_PER_GPU, METHOD, DECODE_KW = (wl['config'], wl['batch'],
+    wl = S.BENCH_WORKLOADS[args.workload]
+    config, batch_per_gpu, method, decode_kw = (wl['config'], wl['batch'],
                                                 wl['method'], wl['kw'])
+    beam = S.BENCH_BEAM
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -208,22 +234,21 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=device)
 
-    from wenet_amd import _lib, dist as wdist, synthetic as S
+    from wenet_amd import _lib, dist as wdist, verify
     global _lib_mod
     _lib_mod = _lib
     for kv in filter(None, args.tune.split(',')):
         k, v = kv.split('=')
         _lib.check(_lib.lib().wn_tune_set(k.encode(), int(v)), 'tune')
     from wenet_amd.model import ASRModel
-    configs = S.make_configs(CONFIG)
+    configs = S.make_configs(config)
     sd = S.make_state_dict(configs, 0)
     model = ASRModel(configs, sd, device=device)
     model.set_compute_dtype(args.dtype)  # before the pipeline clones the handle
-    bf16 = args.dtype == 'bf16'
+    reduced = args.dtype != 'fp32'
 
-    # global batch, sharded by length (weak scaling: 32 utterances per GPU)
-    gfeats, glens = S.make_features(BATCH_PER_GPU * world, wl.get('frames', FRAMES),
-                                    seed=1234, feat_dim=wl.get('feat_dim', 80))
+    # global batch, sharded by length (weak scaling: `batch` utterances per GPU)
+    gfeats, glens = S.make_bench_batch(args.workload, world)
     mine = wdist.shard_indices(glens.tolist(), world, rank)
     lens = glens[mine]
     feats = gfeats[mine, :int(lens.max())].contiguous()
@@ -238,7 +263,7 @@ def main():
 
     def finish(res):
         rec = wdist.pack_results(mine, [r.tokens for r in res],
-                                 [r.score for r in res], BATCH_PER_GPU, max_tok,
+                                 [r.score for r in res], batch_per_gpu, max_tok,
                                  'cpu' if share_gpu else device)
         return wdist.gather_results(rec, world)
 
@@ -246,11 +271,11 @@ def main():
         """n decode passes over the batch, `--streams` of them in flight; the
         per-step result gather (one all_gather) stays on the main thread, in
         step order."""
-        futs = [pipe.submit([METHOD], feats_dev, lens, beam_size=BEAM, **DECODE_KW)
+        futs = [pipe.submit([method], feats_dev, lens, beam_size=beam, **decode_kw)
                 for _ in range(n)]
         out = None
         for f in futs:
-            out = finish(f.result()[METHOD])
+            out = finish(f.result()[method])
         return out
 
     def barrier():
@@ -259,15 +284,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device='cpu' if share_gpu else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     out = run_steps(args.warmup)
     L = _lib.lib()
     for mdl in pipe.models:
         _lib.check(L.wn_profile_enable(mdl._h, 1), 'profile')
-    barrier()
-    t0 = time.perf_counter()
-    out = run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    round_s = []
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        out = run_steps(args.steps)   # EXACTLY --steps steps per timed round
+        barrier()
+        round_s.append(max_over_ranks(time.perf_counter() - t0))
+        # every rank sees the same max-reduced times, so they stop together
+        if sum(round_s) >= args.min_seconds or len(round_s) >= MAX_ROUNDS:
+            break
     n_launch, ms, flops = ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
     tot_launch, tot_ms, tot_flops = 0, 0.0, 0.0
     for mdl in pipe.models:
@@ -278,28 +316,33 @@ def main():
         tot_launch += n_launch.value
         tot_ms += ms.value
         tot_flops += flops.value
-    n_launch.value, ms.value, flops.value = tot_launch, tot_ms, tot_flops
     pipe.close()
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64,
-                         device='cpu' if share_gpu else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert len(out) == BATCH_PER_GPU * world, 'result gather lost utterances'
+    assert len(out) == batch_per_gpu * world, 'result gather lost utterances'
 
     if rank == 0:
+        dt = statistics.median(round_s)
         ms_per_step = dt / args.steps * 1e3
         value = total_audio * args.steps / dt
-        achieved = (flops.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
+        achieved = (tot_flops / (tot_ms * 1e-3)) / 1e12 if tot_ms > 0 else 0.0
         d_model = configs['encoder_conf']['output_size']
         enc_rows = (int(sum((int(t) + 1) // 2 for t in lens.tolist())) if whisper
                     else int(sum(max(0, (int(t) - 7) // 4 + 1) for t in lens.tolist())))
         ffn = configs['encoder_conf']['linear_units']
+        peak = PEAK_TFLOPS[args.dtype]
+        whole_flops = contraction_flops(configs, glens.tolist())
+        # the FFN GEMMs run in e4m3 in the fp8 mode, everything else in bf16: the
+        # whole-decode fraction is priced against the bf16 peak there
+        whole_peak = PEAK_TFLOPS['bf16'] if args.dtype == 'fp8' else peak
+        dtype_txt = {'fp32': 'f32',
+                     'bf16': 'bf16 operands, f32 accumulate / activations',
+                     'fp8': 'e4m3 FFN GEMM operands (per-row / per-channel scales), '
+                            'bf16 elsewhere, f32 accumulate'}[args.dtype]
+        kern = {'fp32': 'gemm_f32_kernel', 'bf16': 'gemm_bf16s_kernel',
+                'fp8': 'gemm_fp8_kernel'}[args.dtype]
         line = {
             'metric': ('audio-seconds/sec (RTF^-1), Whisper-large-v3 encoder, '
                        if whisper else
-                       'audio-seconds/sec (RTF^-1), 12L Conformer fbank80, ') + METHOD,
+                       'audio-seconds/sec (RTF^-1), 12L Conformer fbank80, ') + method,
             'value': round(value, 1),
             'unit': 'audio_s/s',
             'n_gpus': world,
@@ -309,51 +352,70 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'bf16 operands, f32 accumulate / activations' if bf16 else 'f32',
+            'dtype': dtype_txt,
             'data': 'synthetic',
             'config': {
-                'workload': (wl['text'].replace('fp32 (not the bf16 / fp8 the config '
-                                                'names)', 'bf16 GEMM operands (no fp8)')
-                             if bf16 else wl['text'])
-                            + ', features resident in HBM, random-init weights',
-                'global_batch': BATCH_PER_GPU * world,
+                'workload': wl['text'] + ', features resident in HBM, random-init weights',
+                'global_batch': batch_per_gpu * world,
                 'audio_seconds_per_step': round(total_audio, 1),
                 'encoder_frames_per_gpu': enc_rows,
                 'parallelism': f'utterance-sharded x{world}, one all_gather of results',
                 'decodes_in_flight_per_gpu': max(1, args.streams),
             },
+            'rounds': {
+                'n': len(round_s),
+                'steps_per_round': args.steps,
+                'timed_seconds': round(sum(round_s), 3),
+                'ms_per_step_median': round(ms_per_step, 3),
+                'ms_per_step_min': round(min(round_s) / args.steps * 1e3, 3),
+                'ms_per_step_max': round(max(round_s) / args.steps * 1e3, 3),
+                'note': 'each round = exactly --steps steps between barrier + '
+                        'synchronize brackets, max over ranks; value = median round',
+            },
             'roofline': {
                 'bound': 'mfma',
-                'kernel': ('gemm_bf16_kernel' if bf16 else 'gemm_f32_kernel') +
-                          '<128,128,2x4 waves> (FFN w_1, '
-                          f'M={enc_rows} N={ffn} K={d_model})',
+                'kernel': f'{kern} (FFN w_1, M={enc_rows} N={ffn} K={d_model})',
                 'achieved': round(achieved, 2),
-                'peak': BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS,
+                'peak': peak,
                 'unit': 'TFLOP/s',
-                'frac': round(achieved / (BF16_MFMA_PEAK_TFLOPS if bf16
-                                          else FP32_MFMA_PEAK_TFLOPS), 4),
-                'launches': n_launch.value,
-                'avg_launch_us': round(ms.value * 1e3 / max(n_launch.value, 1), 2),
+                'frac': round(achieved / peak, 4),
+                'launches': tot_launch,
+                'avg_launch_us': round(tot_ms * 1e3 / max(tot_launch, 1), 2),
                 'traffic': None,
+                'whole_decode_tflops': round(whole_flops / world / (ms_per_step * 1e-3)
+                                             / 1e12, 2),
+                'whole_decode_frac': round(whole_flops / world / (ms_per_step * 1e-3)
+                                           / 1e12 / whole_peak, 4),
+                'whole_decode_note': 'encoder + CTC-head contraction FLOPs of one GPU\'s '
+                                     'batch (SURVEY.md 8d formula) / ms_per_step / peak',
             },
         }
         # HBM traffic of that kernel from the PMC passes (tools/gpu_pmc.sh; cannot
         # be collected inside a timed run): bytes per launch, committed summary
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                           'pmc_roofline_kernel.json')
-        if wl is WORKLOADS.get('config2') and not bf16 and os.path.exists(pmc):
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_roofline_kernel.json')
+        if args.workload == 'config2' and not reduced and os.path.exists(pmc):
             with open(pmc) as f:
                 rec = json.load(f)
             line['roofline']['traffic'] = rec['hbm_bytes_per_launch']
             line['roofline']['traffic_unit'] = 'bytes/launch (HBM read + write, PMC)'
-            line['roofline']['traffic_source'] = 'profiles/pmc_roofline_kernel.json'
+            line['roofline']['traffic_source'] = ('profiles/pmc_roofline_kernel.json, '
+                                                  'visit ' + str(rec.get('visit', 'r01d')))
             line['roofline']['algorithmic_bytes'] = int(
                 4 * (enc_rows * d_model + ffn * d_model + enc_rows * ffn))
+        # what the timed steps produced vs the real reference's answer
+        ver = verify.verify_bench_output(args.workload, world, out, method)
+        line['verified'] = ver.pop('verified')
+        line['verify'] = ver
+        if reduced and line['verified'] is False:
+            # reduced-precision modes are not bit-comparable with the fp32 reference
+            line['verify']['note'] = ('reduced-precision run: token identity with the '
+                                      'fp32 reference is reported, not required')
         if world == 1 and not whisper:
             line['end_to_end'] = end_to_end_leg(model, lens, device, total_audio,
                                                 ms_per_step)
         if not args.no_cpu_baseline and world == 1 and not whisper:
-            line['cpu_baseline'] = cpu_baseline(configs, sd, feats, lens)
+            line['cpu_baseline'] = cpu_baseline(configs, sd, feats, lens, method,
+                                                decode_kw, beam)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

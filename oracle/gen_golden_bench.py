@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Goldens of the REAL reference on the BASELINE.json-shaped batches that
+bench.py times (tests/golden/bench_*.npz).  Runs only in the build container.
+
+    python oracle/gen_golden_bench.py [case ...]
+
+Cases (the batch is `synthetic.make_bench_batch(workload, world)`, i.e. exactly
+what `bench.py --workload configN` decodes on one GPU; weights seed 0):
+  bench_config2       AIShell u2++ 256d, B=32 x 800-1200 frames, beam 10
+                      (BASELINE.json configs[1]; greedy, prefix beam, rescoring)
+  bench_config3       LibriSpeech bidecoder-large 512d, B=64, attention_rescoring
+                      ctc_weight 0.5 / reverse_weight 0.3 (configs[2])
+  bench_config4       WenetSpeech u2++ 512d, decoding_chunk_size 16, B=32 (configs[3])
+  bench_config2_w8    the 8 x 32 utterances `bench.py --gpus 8` deals over the
+                      ranks (groups 1..7: 1-best / 2-best only, a few KB)
+
+Stored per case (no encoder output tensor: ~1-2 MB each):
+  ctc_topk_val/idx    top-10 CTC log-probs of every valid frame (packed rows)
+  enc_lens, row_off   frames per utterance / first packed row
+  enc_sample          encoder output of utterances 0 and B-1, every 4th frame
+  meta (json)         greedy tokens, n-best lists + fp64 scores + times, the
+                      rescoring winner and ALL per-hypothesis rescoring scores
+
+The per-hypothesis rescoring scores are computed from the decoder outputs the
+reference's own `attention_rescoring` (search.py:374-458) obtained from
+`forward_attention_decoder` (captured by wrapping the bound method), with the
+reference's formula; the generator asserts that their arg-max and maximum equal
+what the reference returned.
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import _ref_harness  # noqa: E402
+from oracle.gen_golden import build_reference_model  # noqa: E402
+
+TOPK = 10
+
+
+def hyp_scores_from_capture(cap, pre, eos, ctc_weight, reverse_weight):
+    """search.py:421-449 on the captured (decoder_out, r_decoder_out)."""
+    decoder_out, r_decoder_out = cap
+    out = []
+    for i, hyp in enumerate(pre.nbest):
+        score = 0.0
+        for j, w in enumerate(hyp):
+            score += decoder_out[i][j][w]
+        score += decoder_out[i][len(hyp)][eos]
+        if reverse_weight > 0 and r_decoder_out.dim() > 0:
+            r_score = 0.0
+            for j, w in enumerate(hyp):
+                r_score += r_decoder_out[i][len(hyp) - j - 1][w]
+            r_score += r_decoder_out[i][len(hyp)][eos]
+            score = score * (1 - reverse_weight) + r_score * reverse_weight
+        score += pre.nbest_scores[i] * ctc_weight
+        out.append(float(score))
+    return out
+
+
+def run_group(model, feats, lens, beam, chunk, left, ctc_weight, reverse_weight,
+              rescoring=True, detail=True):
+    """Reference decode of one padded batch -> dict of arrays + json-able meta."""
+    from wenet.models.transformer import search as ref_search
+    methods = ['ctc_greedy_search', 'ctc_prefix_beam_search']
+    captured = []
+    if rescoring:
+        methods.append('attention_rescoring')
+        orig = model.forward_attention_decoder
+
+        def spy(*a, **k):
+            r = orig(*a, **k)
+            captured.append((r[0].detach().clone(), r[1].detach().clone()))
+            return r
+        model.forward_attention_decoder = spy
+    with torch.no_grad():
+        enc, mask = model._forward_encoder(feats, lens, chunk, left)
+        enc_lens = mask.squeeze(1).sum(1)
+        logp = model.ctc_logprobs(enc)
+        res = model.decode(methods, feats, lens, beam_size=beam,
+                           decoding_chunk_size=chunk, num_decoding_left_chunks=left,
+                           ctc_weight=ctc_weight, reverse_weight=reverse_weight)
+    if rescoring:
+        del model.forward_attention_decoder  # back to the class's bound method
+    B = feats.size(0)
+    meta = {}
+    meta['greedy'] = [list(map(int, r.tokens)) for r in res['ctc_greedy_search']]
+    nb = beam if detail else 2
+    meta['prefix'] = [
+        dict(nbest=[list(map(int, h)) for h in r.nbest[:nb]],
+             nbest_scores=[float(s) for s in r.nbest_scores[:nb]],
+             nbest_times=[list(map(int, t)) for t in r.nbest_times[:nb]] if detail else [])
+        for r in res['ctc_prefix_beam_search']
+    ]
+    if rescoring:
+        assert len(captured) == B
+        eos = model.eos_symbol()
+        meta['rescoring'] = []
+        for b in range(B):
+            pre = res['ctc_prefix_beam_search'][b]
+            r = res['attention_rescoring'][b]
+            allsc = hyp_scores_from_capture(captured[b], pre, eos, ctc_weight,
+                                            reverse_weight)
+            best = int(np.argmax(allsc))
+            assert list(pre.nbest[best]) == list(r.tokens), (b, best)
+            assert abs(allsc[best] - r.score) <= 1e-5 * max(1.0, abs(r.score)), \
+                (b, allsc[best], r.score)
+            meta['rescoring'].append(dict(
+                tokens=list(map(int, r.tokens)), score=float(r.score),
+                confidence=float(r.confidence), best_index=best, all_scores=allsc,
+                tokens_confidence=[float(x) for x in r.tokens_confidence]))
+    arrays = {}
+    if detail:
+        el = enc_lens.tolist()
+        topv, topi = logp.topk(TOPK, dim=-1)
+        arrays['enc_lens'] = enc_lens.numpy().astype(np.int32)
+        arrays['row_off'] = np.concatenate([[0], np.cumsum(el)[:-1]]).astype(np.int32)
+        arrays['ctc_topk_val'] = np.concatenate(
+            [topv[b, :el[b]].numpy() for b in range(B)]).astype(np.float32)
+        arrays['ctc_topk_idx'] = np.concatenate(
+            [topi[b, :el[b]].numpy() for b in range(B)]).astype(np.int16)
+        arrays['enc_sample_utts'] = np.asarray([0, B - 1], dtype=np.int32)
+        arrays['enc_sample'] = np.concatenate(
+            [enc[b, :el[b]:4].numpy() for b in (0, B - 1)]).astype(np.float32)
+    return arrays, meta
+
+
+def save(path, arrays, meta):
+    arrays = dict(arrays)
+    arrays['meta'] = np.frombuffer(json.dumps(meta).encode('utf8'), dtype=np.uint8)
+    np.savez_compressed(path, **arrays)
+    print(path, os.path.getsize(path) // 1024, 'KiB')
+
+
+def run_case(workload, outdir, world=1):
+    from wenet_amd import synthetic as S
+    wl = S.BENCH_WORKLOADS[workload]
+    configs = S.make_configs(wl['config'])
+    sd = S.make_state_dict(configs, 0)
+    model = build_reference_model(configs, sd)
+    kw = wl['kw']
+    chunk = kw.get('decoding_chunk_size', -1)
+    left = kw.get('num_decoding_left_chunks', -1)
+    cw = kw.get('ctc_weight', 0.5)
+    rw = kw.get('reverse_weight', 0.3 if configs['decoder'] == 'bitransformer' else 0.0)
+    base = dict(workload=workload, config=wl['config'], wseed=0, batch=wl['batch'],
+                beam=S.BENCH_BEAM, chunk=chunk, left=left, ctc_weight=cw,
+                reverse_weight=rw)
+    if world == 1:
+        feats, lens = S.make_bench_batch(workload, 1)
+        arrays, meta = run_group(model, feats, lens, S.BENCH_BEAM, chunk, left, cw, rw)
+        meta.update(base, world=1, lens=lens.tolist())
+        save(os.path.join(outdir, f'bench_{workload}.npz'), arrays, meta)
+        return
+    # N > 1: utterance groups of `batch` (group g = seed 1234 + g); the reference
+    # decodes each group as one padded batch (the model is causal, so the result of
+    # an utterance does not depend on its batch)
+    assert configs['encoder_conf'].get('causal', False), 'grouped goldens need a causal model'
+    groups = []
+    for g in range(world):
+        feats, lens = S.make_bench_group(workload, g)
+        _, meta = run_group(model, feats, lens, S.BENCH_BEAM, chunk, left, cw, rw,
+                            rescoring=False, detail=False)
+        groups.append(dict(lens=lens.tolist(), greedy=meta['greedy'],
+                           prefix=meta['prefix']))
+        print('group', g, 'done', flush=True)
+    meta = dict(base, world=world, groups=groups)
+    save(os.path.join(outdir, f'bench_{workload}_w{world}.npz'), {}, meta)
+
+
+def main():
+    _ref_harness.install()
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    outdir = os.path.join(ROOT, 'tests', 'golden')
+    want = sys.argv[1:] or ['bench_config2', 'bench_config3', 'bench_config4',
+                            'bench_config2_w8']
+    for name in want:
+        parts = name.split('_')
+        world = int(parts[2][1:]) if len(parts) > 2 else 1
+        run_case(parts[1], outdir, world)
+
+
+if __name__ == '__main__':
+    main()

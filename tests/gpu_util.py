@@ -51,3 +51,111 @@ def compare_nbest(got, ref_nbest, ref_scores, ref_times, score_atol=2e-3,
 def frame_margins(logp: torch.Tensor):
     top2 = logp.topk(2, dim=-1).values
     return (top2[..., 0] - top2[..., 1])
+
+
+# ---------------------------------------------------------------------------
+# Margin-aware parity rules (north_star: identical CTC 1-best tokens for greedy,
+# rescoring scores within 1e-3).  The reference's and the GPU's log-probs differ by
+# fp32 summation order (<= LOGP_TOL); a frame whose reference top-1 margin is
+# below FRAME_EPS may legitimately flip to the reference's second choice.  The
+# rules are per FRAME, never per utterance, and every check reports how much it
+# actually compared.
+FRAME_EPS = 1e-3     # top-1 margin under which a frame may flip to the runner-up
+LOGP_TOL = 5e-4      # |GPU - reference| on the top-k CTC log-probs
+NBEST_TOL = 2e-3     # fp64 prefix-beam score, sum of ~T' log-probs
+RESCORE_TOL = 1e-3   # north_star: attention-rescoring scores within 1e-3
+
+
+def collapse(path, blank=0):
+    """ctc_utils.remove_duplicates_and_blank (ctc_utils.py:23-33)."""
+    out, prev = [], None
+    for t in path:
+        t = int(t)
+        if t != prev and t != blank:
+            out.append(t)
+        prev = t
+    return out
+
+
+def greedy_frame_check(got_top1, ref_topk_idx, ref_topk_val, got_tokens, ref_tokens,
+                       what='', eps=FRAME_EPS):
+    """Per-frame greedy rule for ONE utterance.
+    got_top1 [n] GPU arg-max per frame; ref_topk_idx/val [n][>=2] of the reference.
+      * every frame with reference margin > eps: identical arg-max (strict);
+      * a frame under eps: the GPU arg-max is the reference's top-1 or top-2;
+      * the GPU token list is the collapse of its own arg-max path, and with no
+        flipped frame it IS the reference's token list.
+    Returns (n_frames, n_strict, n_flips)."""
+    got_top1 = np.asarray(got_top1).astype(np.int64)
+    idx = np.asarray(ref_topk_idx).astype(np.int64)
+    val = np.asarray(ref_topk_val)
+    n = len(got_top1)
+    assert idx.shape[0] == n, (what, idx.shape, n)
+    margin = val[:, 0] - val[:, 1]
+    strict = margin > eps
+    bad = strict & (got_top1 != idx[:, 0])
+    assert not bad.any(), (f'{what}: arg-max differs on frames with reference margin > '
+                           f'{eps}', np.nonzero(bad)[0][:8].tolist(),
+                           margin[bad][:8].tolist())
+    loose = ~strict
+    ok2 = (got_top1 == idx[:, 0]) | (got_top1 == idx[:, 1])
+    assert ok2[loose].all(), f'{what}: low-margin frame outside the reference top-2'
+    flips = int((got_top1 != idx[:, 0]).sum())
+    assert list(got_tokens) == collapse(got_top1), f'{what}: tokens != collapse(arg-max)'
+    if flips == 0:
+        assert list(got_tokens) == list(ref_tokens), f'{what}: greedy tokens differ'
+    return n, int(strict.sum()), flips
+
+
+def nbest_check(got, ref_nbest, ref_scores, ref_times, what='', tol=NBEST_TOL):
+    """Prefix-beam n-best of one utterance against the reference's (from slightly
+    different log-probs).  A reference hypothesis may be absent from the GPU list
+    only if it sits within 2*tol of the reference's pruning edge (its last score);
+    present ones must carry the reference's score (tol) and identical time stamps;
+    the 1-best is the reference's unless the reference's top-2 gap is under 2*tol.
+    Returns (n_ref_hyps, n_compared)."""
+    g_nbest = [list(x) for x in got.nbest]
+    r_nbest = [list(x) for x in ref_nbest]
+    assert len(g_nbest) == len(r_nbest), (what, len(g_nbest), len(r_nbest))
+    compared = 0
+    for i, h in enumerate(r_nbest):
+        if h not in g_nbest:
+            assert ref_scores[i] - ref_scores[-1] < 2 * tol, \
+                f'{what}: reference hyp #{i} missing, {ref_scores[i] - ref_scores[-1]:.2e} above the beam edge'
+            continue
+        j = g_nbest.index(h)
+        assert abs(got.nbest_scores[j] - ref_scores[i]) < tol, \
+            (what, i, got.nbest_scores[j], ref_scores[i])
+        if ref_times is not None and len(ref_times) > i:
+            assert list(got.nbest_times[j]) == list(ref_times[i]), (what, i)
+        if j != i:
+            lo, hi = min(i, j), max(i, j)
+            assert abs(ref_scores[lo] - ref_scores[hi]) < 2 * tol, \
+                f'{what}: order differs beyond tolerance ({i} vs {j})'
+        compared += 1
+    if len(ref_scores) < 2 or ref_scores[0] - ref_scores[1] > 2 * tol:
+        assert list(got.tokens) == r_nbest[0], f'{what}: 1-best differs'
+    else:
+        assert list(got.tokens) in r_nbest[:2], f'{what}: 1-best outside the tied pair'
+    return len(r_nbest), compared
+
+
+def rescoring_check(got, got_pre, ref, ref_pre_nbest, what='', tol=RESCORE_TOL):
+    """attention_rescoring of one utterance: the score of EVERY hypothesis both
+    n-best lists hold within `tol` ABSOLUTE of the reference's
+    (`ref['all_scores'][i]` belongs to `ref_pre_nbest[i]`); the winner is the
+    reference's whenever the reference's top-2 rescoring gap exceeds 2*tol.
+    Returns (n_hyps_compared, max_abs_err)."""
+    g_nbest = [list(x) for x in got_pre.nbest]
+    r_nbest = [list(x) for x in ref_pre_nbest]
+    errs = []
+    for i, h in enumerate(r_nbest):
+        if h in g_nbest:
+            errs.append(abs(got.all_scores[g_nbest.index(h)] - ref['all_scores'][i]))
+    assert errs, f'{what}: no common hypothesis'
+    assert max(errs) < tol, (f'{what}: rescoring score off by {max(errs):.3e}', errs)
+    rs = sorted(ref['all_scores'], reverse=True)
+    if len(rs) < 2 or rs[0] - rs[1] > 2 * tol:
+        assert list(got.tokens) == list(ref['tokens']), f'{what}: rescoring winner differs'
+        assert abs(got.score - ref['score']) < tol, (what, got.score, ref['score'])
+    return len(errs), max(errs)

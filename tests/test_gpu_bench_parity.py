@@ -1,0 +1,97 @@
+"""Parity AT THE BASELINE.json CONFIGURATIONS: the exact batches bench.py times
+(synthetic.make_bench_batch) through the C ABI against what the REAL reference
+produced on them (tests/golden/bench_*.npz, oracle/gen_golden_bench.py).
+
+  config2  AIShell u2++ 256d, B=32 x 8-12 s, prefix beam 10      (configs[1], the headline)
+  config3  LibriSpeech bidecoder-large 512d, B=64, rescoring 0.5 / 0.3   (configs[2])
+  config4  WenetSpeech u2++ 512d, decoding_chunk_size 16, B=32           (configs[3])
+
+Rules (tests/gpu_util.py): per-FRAME greedy identity (strict above a 1e-3 margin,
+top-2 below; >= 95 % of frames strictly compared, flips counted and printed),
+n-best lists with fp64 scores within 2e-3 and identical time stamps, EVERY
+hypothesis' rescoring score within 1e-3 absolute and the reference's winner.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load_case
+from gpu_util import (FRAME_EPS, LOGP_TOL, cached_model, greedy_frame_check,
+                      nbest_check, rescoring_check)
+
+pytestmark = pytest.mark.gpu
+
+METHODS = ['ctc_greedy_search', 'ctc_prefix_beam_search', 'attention_rescoring']
+
+
+@pytest.mark.parametrize('workload', ['config2', 'config3', 'config4'])
+def test_bench_batch_vs_reference(workload):
+    from wenet_amd import synthetic as S
+    meta, arr = load_case(f'bench_{workload}')
+    configs, sd, model = cached_model(meta['config'], meta['wseed'])
+    feats, lens = S.make_bench_batch(workload, 1)
+    assert lens.tolist() == meta['lens']
+    B = meta['batch']
+    kw = dict(beam_size=meta['beam'], decoding_chunk_size=meta['chunk'],
+              num_decoding_left_chunks=meta['left'], ctc_weight=meta['ctc_weight'],
+              reverse_weight=meta['reverse_weight'])
+    fd = feats.cuda()
+    enc, mask = model._forward_encoder(fd, lens, meta['chunk'], meta['left'])
+    enc_lens = mask.squeeze(1).sum(1).cpu()
+    np.testing.assert_array_equal(enc_lens.numpy(), arr['enc_lens'])
+    # encoder drift on the sampled utterances (every 4th frame of utterances 0, B-1)
+    r = 0
+    enc_err = 0.0
+    for b in arr['enc_sample_utts'].tolist():
+        got = enc[b, :int(enc_lens[b]):4].cpu().numpy()
+        ref = arr['enc_sample'][r:r + got.shape[0]]
+        r += got.shape[0]
+        enc_err = max(enc_err, float(np.abs(got - ref).max()))
+    assert enc_err < 2e-3, enc_err
+    logp = model.ctc_logprobs(enc, encoder_lens=enc_lens)
+    K = arr['ctc_topk_val'].shape[1]
+    topv, topi = logp.topk(K, dim=-1)
+    topv, topi = topv.cpu().numpy(), topi.cpu().numpy()
+    res = model.decode(METHODS, fd, lens, **kw)
+    n_frames = n_strict = n_flips = 0
+    logp_err = 0.0
+    nb_total = nb_cmp = rs_cmp = 0
+    rs_err = 0.0
+    for b in range(B):
+        o, n = int(arr['row_off'][b]), int(arr['enc_lens'][b])
+        rv, ri = arr['ctc_topk_val'][o:o + n], arr['ctc_topk_idx'][o:o + n]
+        logp_err = max(logp_err, float(np.abs(topv[b, :n] - rv).max()))
+        f, s, fl = greedy_frame_check(topi[b, :n, 0], ri, rv,
+                                      res['ctc_greedy_search'][b].tokens,
+                                      meta['greedy'][b], what=f'{workload}[{b}]')
+        n_frames += f; n_strict += s; n_flips += fl
+        g = meta['prefix'][b]
+        t, c = nbest_check(res['ctc_prefix_beam_search'][b], g['nbest'],
+                           g['nbest_scores'], g['nbest_times'], what=f'{workload}[{b}]')
+        nb_total += t; nb_cmp += c
+        c, e = rescoring_check(res['attention_rescoring'][b],
+                               res['ctc_prefix_beam_search'][b], meta['rescoring'][b],
+                               g['nbest'], what=f'{workload}[{b}]')
+        rs_cmp += c; rs_err = max(rs_err, e)
+    print(f'\n[{workload}] utterances {B}, frames {n_frames}, strictly compared '
+          f'{n_strict} ({100.0 * n_strict / n_frames:.2f} %), arg-max flips on '
+          f'sub-{FRAME_EPS:g} frames {n_flips}; max |d logp| {logp_err:.2e}, encoder '
+          f'{enc_err:.2e}; n-best hyps compared {nb_cmp}/{nb_total}; rescoring hyps '
+          f'compared {rs_cmp}, max |d score| {rs_err:.2e}')
+    assert logp_err < LOGP_TOL, logp_err
+    assert n_strict >= 0.95 * n_frames
+
+
+def test_bench_verify_helper_matches_goldens():
+    """bench.py's own output check (wenet_amd/verify.py) on a real decode."""
+    from wenet_amd import synthetic as S, verify
+    configs, sd, model = cached_model('aishell_u2pp', 0)
+    feats, lens = S.make_bench_batch('config2', 1)
+    res = model.decode(['ctc_prefix_beam_search'], feats.cuda(), lens,
+                       beam_size=S.BENCH_BEAM)['ctc_prefix_beam_search']
+    rep = verify.verify_bench_output('config2', 1, [(i, list(r.tokens), r.score)
+                                                    for i, r in enumerate(res)])
+    assert rep['verified'] is True, rep
+    assert rep['utterances'] == 32 and rep['identical'] + rep['near_tie'] == 32
+    bad = [(i, [1, 2, 3], 0.0) for i in range(32)]
+    assert verify.verify_bench_output('config2', 1, bad)['verified'] is False

@@ -7,8 +7,11 @@ fbank) and end to end.
 Tolerances (fp32 path, different summation order than torch-CPU):
   encoder output       |err| <= 2e-3 on unit-variance activations
   CTC log-probs        |err| <= 5e-3 (logits are sharpened x12)
-  greedy tokens        identical wherever the oracle's top-1 margin > 2e-2
-  prefix-beam scores   |err| <= 2e-3, rescoring scores |err| <= 1e-3 * (L+1)
+  greedy tokens        per FRAME (tests/gpu_util.py): identical arg-max on every frame
+                       whose reference top-1 margin > 1e-3, reference top-2 below it,
+                       >= 95 % of frames strictly compared, flips counted
+  prefix-beam scores   |err| <= 2e-3; rescoring scores |err| <= 1e-3 ABSOLUTE for
+                       every hypothesis, the reference's winner required
 Bit-exact (same log-prob tensor fed to both): greedy tokens, n-best token
 lists, n-best time stamps; fp64 n-best scores to 1e-9.
 """
@@ -21,7 +24,8 @@ from golden_util import (attention_case_names, build_inputs, case_names,
                          context_case_names, context_search_case_names, load_case,
                          stream_case_names,
                          whisper_case_names)
-from gpu_util import cached_model, compare_nbest, frame_margins
+from gpu_util import (cached_model, compare_nbest, frame_margins, greedy_frame_check,
+                      nbest_check, rescoring_check)
 
 pytestmark = pytest.mark.gpu
 
@@ -57,20 +61,30 @@ def test_golden_case(name):
                        num_decoding_left_chunks=meta['left'],
                        ctc_weight=meta['ctc_weight'],
                        reverse_weight=meta['reverse_weight'])
-    ref_margin = arrays['ctc_topk_val'][..., 0] - arrays['ctc_topk_val'][..., 1]
+    top1 = logp.argmax(-1).cpu().numpy()
+    n_frames = n_strict = n_flips = 0
     for b in range(meta['batch']):
         n = arrays['enc_lens'][b]
-        if ref_margin[b, :n].min() > 2e-2:
-            assert res['ctc_greedy_search'][b].tokens == meta['greedy'][b]
+        f, st, fl = greedy_frame_check(
+            top1[b, :n], arrays['ctc_topk_idx'][b, :n], arrays['ctc_topk_val'][b, :n],
+            res['ctc_greedy_search'][b].tokens, meta['greedy'][b], what=f'{name}[{b}]')
+        n_frames += f; n_strict += st; n_flips += fl
         g = meta['prefix'][b]
-        compare_nbest(res['ctc_prefix_beam_search'][b], g['nbest'],
-                      g['nbest_scores'], g['nbest_times'], what=f'{name}[{b}]')
+        nbest_check(res['ctc_prefix_beam_search'][b], g['nbest'],
+                    g['nbest_scores'], g['nbest_times'], what=f'{name}[{b}]')
+        # the reference fixture holds the winner only: its score is compared
+        # whenever the GPU picked the same hypothesis, and it MUST pick it unless
+        # the GPU's own top-2 rescoring gap is inside the tolerance
         r, gr = res['attention_rescoring'][b], meta['rescoring'][b]
+        gs = sorted(r.all_scores, reverse=True)
+        if len(gs) < 2 or gs[0] - gs[1] > 2e-3:
+            assert list(r.tokens) == gr['tokens'], (name, b)
         if list(r.tokens) == gr['tokens']:
-            tol = 1e-3 * (len(gr['tokens']) + 1)
-            assert abs(r.score - gr['score']) < tol, (name, b, r.score, gr['score'])
+            assert abs(r.score - gr['score']) < 1e-3, (name, b, r.score, gr['score'])
             np.testing.assert_allclose(r.tokens_confidence,
                                        gr['tokens_confidence'], atol=2e-3)
+    print(f'\n[{name}] frames {n_frames}, strictly compared {n_strict}, flips {n_flips}')
+    assert n_strict >= 0.95 * n_frames
 
 
 @pytest.mark.parametrize('name', whisper_case_names())
@@ -91,14 +105,21 @@ def test_whisper_encoder_golden_case(name):
         assert err < 2e-3 * max(1.0, np.abs(ref).max()), (name, b, err)
     res = model.decode(['ctc_greedy_search', 'ctc_prefix_beam_search'],
                        feats.cuda(), lens, beam_size=meta['beam'])
-    ref_margin = arrays['ctc_topk_val'][..., 0] - arrays['ctc_topk_val'][..., 1]
+    logp = model.ctc_logprobs(torch.from_numpy(enc).cuda(),
+                              encoder_lens=torch.from_numpy(enc_lens))
+    top1 = logp.argmax(-1).cpu().numpy()
+    n_frames = n_strict = 0
     for b in range(meta['batch']):
         n = arrays['enc_lens'][b]
-        if ref_margin[b, :n].min() > 2e-2:
-            assert res['ctc_greedy_search'][b].tokens == meta['greedy'][b]
+        f, st, _ = greedy_frame_check(
+            top1[b, :n], arrays['ctc_topk_idx'][b, :n], arrays['ctc_topk_val'][b, :n],
+            res['ctc_greedy_search'][b].tokens, meta['greedy'][b], what=f'{name}[{b}]',
+            eps=2e-3)   # unit-scale 1280-wide activations: logp error ~1e-3
+        n_frames += f; n_strict += st
         g = meta['prefix'][b]
-        compare_nbest(res['ctc_prefix_beam_search'][b], g['nbest'],
-                      g['nbest_scores'], g['nbest_times'], what=f'{name}[{b}]')
+        nbest_check(res['ctc_prefix_beam_search'][b], g['nbest'],
+                    g['nbest_scores'], g['nbest_times'], what=f'{name}[{b}]')
+    assert n_strict >= 0.95 * n_frames
     with pytest.raises((RuntimeError, NotImplementedError, AssertionError)):
         model.decode(['attention_rescoring'], feats.cuda(), lens, beam_size=2)
 
@@ -268,7 +289,7 @@ def test_rescoring_vs_oracle_on_same_hyps():
     from wenet_amd import search as S, synthetic as SY
     O = _oracle()
     for config, rw in [('tiny_causal', 0.3), ('tiny_sym', 0.0),
-                       ('aishell_u2pp', 0.4)]:
+                       ('aishell_u2pp', 0.4), ('librispeech_bidecoder_large', 0.3)]:
         configs, sd, model = cached_model(config, 0)
         feats, lens = SY.make_features(3, (200, 330), seed=19)
         with torch.no_grad():
@@ -298,20 +319,26 @@ def test_end_to_end_vs_oracle_ragged_batch():
                        ctc_weight=0.5, reverse_weight=0.3)
     with torch.no_grad():
         enc, mask = O.encoder_forward(configs, sd, feats, lens)
-        margins = frame_margins(O.ctc_logprobs(sd, enc))
+        ref_logp = O.ctc_logprobs(sd, enc)
+    rv, ri = ref_logp.topk(2, dim=-1)
     enc_lens = mask.squeeze(1).sum(1)
+    genc, _ = model._forward_encoder(feats.cuda(), lens)
+    top1 = model.ctc_logprobs(genc, encoder_lens=enc_lens).argmax(-1).cpu().numpy()
+    n_frames = n_strict = 0
     for b in range(6):
-        if margins[b, :enc_lens[b]].min() > 2e-2:
-            assert got['ctc_greedy_search'][b].tokens == \
-                ref['ctc_greedy_search'][b].tokens
+        n = int(enc_lens[b])
+        f, st, _ = greedy_frame_check(top1[b, :n], ri[b, :n].numpy(), rv[b, :n].numpy(),
+                                      got['ctc_greedy_search'][b].tokens,
+                                      ref['ctc_greedy_search'][b].tokens, what=f'e2e[{b}]')
+        n_frames += f; n_strict += st
         rp = ref['ctc_prefix_beam_search'][b]
-        compare_nbest(got['ctc_prefix_beam_search'][b], rp.nbest,
-                      rp.nbest_scores, rp.nbest_times, what=f'e2e[{b}]')
-        if list(got['attention_rescoring'][b].tokens) == \
-                list(ref['attention_rescoring'][b].tokens):
-            L = len(ref['attention_rescoring'][b].tokens)
-            assert abs(got['attention_rescoring'][b].score -
-                       ref['attention_rescoring'][b].score) < 1e-3 * (L + 1)
+        nbest_check(got['ctc_prefix_beam_search'][b], rp.nbest,
+                    rp.nbest_scores, rp.nbest_times, what=f'e2e[{b}]')
+        rr = ref['attention_rescoring'][b]
+        rescoring_check(got['attention_rescoring'][b], got['ctc_prefix_beam_search'][b],
+                        dict(all_scores=rr.all_scores, tokens=list(rr.tokens),
+                             score=rr.score), rp.nbest, what=f'e2e[{b}]')
+    assert n_strict >= 0.95 * n_frames
 
 
 def test_padding_invariance_property():
@@ -401,11 +428,14 @@ def test_simulate_streaming_vs_reference_cache_path(name):
                        simulate_streaming=True)
     assert res['ctc_greedy_search'][0].tokens == meta['greedy']
     g = meta['prefix']
-    compare_nbest(res['ctc_prefix_beam_search'][0], g['nbest'], g['nbest_scores'],
-                  g['nbest_times'], what=name)
+    nbest_check(res['ctc_prefix_beam_search'][0], g['nbest'], g['nbest_scores'],
+                g['nbest_times'], what=name)
     r = res['attention_rescoring'][0]
+    gs = sorted(r.all_scores, reverse=True)
+    if len(gs) < 2 or gs[0] - gs[1] > 2e-3:
+        assert list(r.tokens) == meta['rescoring']['tokens'], name
     if list(r.tokens) == meta['rescoring']['tokens']:
-        assert abs(r.score - meta['rescoring']['score']) < 1e-3 * (len(r.tokens) + 1)
+        assert abs(r.score - meta['rescoring']['score']) < 1e-3
     # the reference's preconditions
     two = torch.cat([feats, feats]).cuda()
     with pytest.raises(AssertionError):

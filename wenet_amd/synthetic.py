@@ -577,3 +577,61 @@ def peaky_logprobs(batch: int, frames, vocab: int, peak: float, seed: int):
     x.scatter_add_(2, hot, torch.full(hot.shape, float(peak)))
     x[..., 0] += 1.0
     return torch.log_softmax(x, dim=-1), lens.to(torch.int32)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json `configs` as bench.py workloads.  bench.py, the `-m gpu` parity
+# tests at these sizes and oracle/gen_golden_bench.py (which runs the REAL
+# reference on them) all take the batch from here, so the committed goldens
+# (tests/golden/bench_*.npz) are the reference's answer to exactly the batch the
+# benchmark times.
+BENCH_BEAM = 10
+BENCH_FRAMES = (800, 1200)   # 8..12 s of 10 ms frames, mean ~10 s
+BENCH_WORKLOADS = {
+    'config2': dict(config='aishell_u2pp', batch=32, method='ctc_prefix_beam_search',
+                    kw={}, text='BASELINE.json configs[1]: AIShell u2++ conformer '
+                    '12L/4head/256d fbank80, batch 32 x ~10 s per GPU (8-12 s '
+                    'ragged), ctc_prefix_beam_search beam 10'),
+    'config3': dict(config='librispeech_bidecoder_large', batch=64,
+                    method='attention_rescoring',
+                    kw=dict(ctc_weight=0.5, reverse_weight=0.3),
+                    text='BASELINE.json configs[2]: LibriSpeech conformer '
+                    'bidecoder-large 12L/8head/512d fbank80, batch 64 x ~10 s per GPU, '
+                    'attention_rescoring beam 10, ctc_weight 0.5, reverse_weight 0.3'),
+    'config4': dict(config='wenetspeech_u2pp', batch=32,
+                    method='ctc_prefix_beam_search',
+                    kw=dict(decoding_chunk_size=16, num_decoding_left_chunks=-1),
+                    text='BASELINE.json configs[3]: WenetSpeech u2++ conformer '
+                    '12L/8head/512d, decoding_chunk_size 16 (chunk-mask streaming), '
+                    'batch 32 x ~10 s per GPU, ctc_prefix_beam_search beam 10'),
+    'config5': dict(config='whisper_largev3', batch=16, method='ctc_greedy_search',
+                    kw={}, frames=(3000, 3000), feat_dim=128,
+                    text='BASELINE.json configs[4]: Whisper-large-v3 encoder '
+                    '32L/20head/1280d, 128 mel bins, 30 s windows, batch 16 per GPU, '
+                    '+ a 307-way CTC head and greedy search'),
+}
+
+
+def make_bench_group(workload: str, group: int = 0):
+    """Utterance group `group` of a bench workload: `batch` utterances, seed
+    1234 + group.  Group 0 is the whole batch of a 1-GPU run."""
+    wl = BENCH_WORKLOADS[workload]
+    return make_features(wl['batch'], wl.get('frames', BENCH_FRAMES),
+                         seed=1234 + group, feat_dim=wl.get('feat_dim', 80))
+
+
+def make_bench_batch(workload: str, world: int = 1):
+    """Global batch of `bench.py --workload W --gpus world`: groups 0..world-1
+    back to back (global index = group * batch + index in group), zero-padded to
+    the longest utterance.  Weak scaling: `batch` utterances per GPU."""
+    groups = [make_bench_group(workload, g) for g in range(world)]
+    if world == 1:
+        return groups[0]
+    tmax = max(int(f.size(1)) for f, _ in groups)
+    feats = torch.zeros((sum(f.size(0) for f, _ in groups), tmax, groups[0][0].size(2)),
+                        dtype=torch.float32)
+    r = 0
+    for f, _ in groups:
+        feats[r:r + f.size(0), :f.size(1)] = f
+        r += f.size(0)
+    return feats, torch.cat([l for _, l in groups])
