@@ -306,6 +306,15 @@ int wn_op_gemm_bf16_stored(const float* A_dev, const float* W_dev, const float* 
                            const float* resid_dev, void* C_dev, int32_t M, int32_t N,
                            int32_t K, float alpha, int32_t act, int32_t c_bf16,
                            void* stream);
+/* The reduced-precision GEMM kernels on operands that are ALREADY in their storage
+ * type in HBM (what the model path hands them): dtype 1 = bf16 A (M, K) and W (N, K);
+ * dtype 2 = OCP e4m3 A and W with per-row fp32 scales a_scale (M) / w_scale (N)
+ * (C = epi(a_scale[m] * w_scale[n] * sum_k A W)).  Scales are ignored for bf16.
+ * Micro-benchmarks and the operator tests call this; C as wn_op_gemm_bf16_stored. */
+int wn_op_gemm_lowp(const void* A_dev, const void* W_dev, const float* a_scale_dev,
+                    const float* w_scale_dev, const float* bias_dev,
+                    const float* resid_dev, void* C_dev, int32_t M, int32_t N, int32_t K,
+                    float alpha, int32_t act, int32_t c_bf16, int32_t dtype, void* stream);
 /* out[i] = log_add(a[i], b[i]) (wenet/utils/common.py:302-310) in fp64 with the
  * routine the prefix beam search uses. */
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,

@@ -181,6 +181,77 @@ def test_gemm_bf16_stored_plain(M, N, K, bf16_store):
         2.0 ** -7 * ref.abs().max().item() + 4e-6 * scale
 
 
+def _gemm_lowp_bf16(A16, W16, bias=None, resid=None, alpha=1.0, act=0, c_bf16=False):
+    from wenet_amd import _lib
+    L = _lib.lib()
+    M, K = A16.shape
+    N = W16.shape[0]
+    C = torch.empty((M, N), dtype=torch.bfloat16 if c_bf16 else torch.float32, device='cuda')
+    _lib.check(L.wn_op_gemm_lowp(_ptr(A16), _ptr(W16), None, None, _ptr(bias), _ptr(resid),
+                                 _ptr(C), M, N, K, alpha, act, 1 if c_bf16 else 0, 1,
+                                 torch.cuda.current_stream().cuda_stream), 'gemm_lowp')
+    torch.cuda.synchronize()
+    return C
+
+
+@pytest.mark.parametrize('M,N,K,act,mode', [
+    (512, 512, 128, 0, 'plain'),        # 2 K tiles: prologue + one pair
+    (700, 520, 192, 1, 'plain'),        # ragged M and N, odd K-tile count
+    (256, 256, 1280, 3, 'c_bf16'),
+    (3000, 1280, 5120, 0, 'resid'),     # Whisper w_2
+    (2900, 5120, 1280, 3, 'c_bf16'),    # Whisper w_1 (GELU, bf16 hidden)
+    (1500, 3840, 1280, 0, 'plain'),     # Whisper QKV
+    (1000, 264, 320, 2, 'resid'),       # N not a multiple of 32
+])
+def test_gemm_bf16_pipelined(M, N, K, act, mode, bf16_store):
+    """gemm_bf16p_kernel (256x256, direct-to-LDS DMA, counted vmcnt, staggered waves,
+    operand-swapped MFMA): against the fp64 product of the bf16 operands, bitwise equal
+    to itself over repeated launches (race screen: the LDS ring is ordered only by the
+    counted waits and barriers), and equal to the register-staged kernel up to
+    accumulation order."""
+    if bf16_store == 0:
+        pytest.skip('one run is enough for the raw operator')
+    from wenet_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + act)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * 0.3).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g) if mode == 'resid' else None
+    acc = A.double() @ W.double().T
+    y = acc.float() + bias
+    if act == 1:
+        y = torch.nn.functional.silu(y)
+    elif act == 2:
+        y = torch.relu(y)
+    elif act == 3:
+        y = torch.nn.functional.gelu(y)
+    y = 0.5 * y
+    if resid is not None:
+        y = y + resid
+    scale = (A.abs().double() @ W.abs().double().T).max().item()
+    args = (A.cuda(), W.cuda(), bias.cuda(), resid.cuda() if resid is not None else None,
+            0.5, act, mode == 'c_bf16')
+    try:
+        _lib.check(L.wn_tune_set(b'gemm_tile_bf16', 8), 'tune')
+        got = _gemm_lowp_bf16(*args)
+        for _ in range(4):
+            again = _gemm_lowp_bf16(*args)
+            assert torch.equal(got, again), 'pipelined GEMM is not deterministic (race?)'
+        _lib.check(L.wn_tune_set(b'gemm_tile_bf16', 1), 'tune')
+        other = _gemm_lowp_bf16(*args)
+    finally:
+        L.wn_tune_set(b'gemm_tile_bf16', 0)
+    got, other = got.cpu().float(), other.cpu().float()
+    if mode == 'c_bf16':
+        tol = 2.0 ** -7 * y.abs().max().item() + 4e-6 * scale
+        assert (got - y).abs().max().item() <= tol
+        assert (got - other).abs().max().item() <= tol
+    else:
+        assert (got - y).abs().max().item() <= 3e-6 * scale + 2e-5
+        assert (got - other).abs().max().item() <= 4e-6 * scale + 2e-5
+
+
 @pytest.mark.parametrize('act', [0, 1, 2, 3])
 @pytest.mark.parametrize('mode', ['plain', 'resid', 'c_bf16'])
 @pytest.mark.parametrize('K', [96, 128])

@@ -36,6 +36,8 @@ SHAPES = {
     'wh_w2': (24000, 1280, 5120, 0, True),
     'wh_qkv': (24000, 3840, 1280, 0, False),
     'wh_out': (24000, 1280, 1280, 0, True),
+    'wh_w2n': (24000, 1280, 5120, 0, False),   # w_2 without the residual (variants)
+    'sq8k': (8192, 8192, 8192, 0, False),
 }
 
 
@@ -47,10 +49,15 @@ def main():
     ap.add_argument('--tiles', default='0')
     ap.add_argument('--bf16', action='store_true',
                     help='bf16-operand kernels (wn_op_gemm_bf16, gemm_tile_bf16)')
+    ap.add_argument('--lowp', default='', choices=['', 'bf16', 'fp8'],
+                    help='operands already stored as bf16 / e4m3 (wn_op_gemm_lowp): the '
+                         'kernels the bf16 / fp8 modes run; tiles via gemm_tile_bf16 '
+                         '(1 = 128x128, 7 = 256x256 register-staged, 8 = 256x256 pipelined)')
+    ap.add_argument('--c-bf16', action='store_true', help='--lowp: bf16 C (no residual)')
     args = ap.parse_args()
     L = _lib.lib()
     op = L.wn_op_gemm_bf16 if args.bf16 else L.wn_op_gemm
-    tile_key = b'gemm_tile_bf16' if args.bf16 else b'gemm_tile'
+    tile_key = b'gemm_tile_bf16' if (args.bf16 or args.lowp) else b'gemm_tile'
     dev = torch.device('cuda', 0)
     variants = [(int(t), int(v)) for t in args.tiles.split(',')
                 for v in args.variants.split(',')]
@@ -64,8 +71,31 @@ def main():
         bias = torch.rand(n, generator=g).to(dev)
         R = torch.rand(m, n, generator=g).to(dev) if resid else None
         C = torch.empty(m, n, device=dev)
+        if args.lowp:
+            if args.c_bf16:
+                resid, R = False, None
+            C = torch.empty(m, n, device=dev,
+                            dtype=torch.bfloat16 if args.c_bf16 else torch.float32)
+            if args.lowp == 'bf16':
+                A2, W2, sa, sw, dt = A.to(torch.bfloat16), W.to(torch.bfloat16), None, None, 1
+            else:
+                sa = (A.abs().amax(1) / 448.0).clamp_min(1e-12)
+                sw = (W.abs().amax(1) / 448.0).clamp_min(1e-12)
+                A2 = (A / sa[:, None]).to(torch.float8_e4m3fn)
+                W2 = (W / sw[:, None]).to(torch.float8_e4m3fn)
+                dt = 2
+
+        def run_lowp():
+            _lib.check(L.wn_op_gemm_lowp(A2.data_ptr(), W2.data_ptr(),
+                                         sa.data_ptr() if sa is not None else None,
+                                         sw.data_ptr() if sw is not None else None,
+                                         bias.data_ptr(), R.data_ptr() if resid else None,
+                                         C.data_ptr(), m, n, k, 1.0, act,
+                                         1 if args.c_bf16 else 0, dt, None), name)
 
         def run():
+            if args.lowp:
+                return run_lowp()
             _lib.check(op(A.data_ptr(), W.data_ptr(), bias.data_ptr(),
                           R.data_ptr() if resid else None,
                           C.data_ptr(), m, n, k, 1.0, act, None), name)

@@ -107,6 +107,9 @@ extern thread_local const float* t_wslab_f32;
 extern thread_local const void* t_wslab_bf16;
 extern thread_local int64_t t_wslab_elems;
 int gemm_bf16_stored(const GemmArgs& a, const void* Wh, hipStream_t stream);
+// 256x256 direct-to-LDS pipelined kernel for the large shapes (gemm_bf16p.hip)
+bool gemm_bf16p_supported(const GemmArgs& a);
+int gemm_bf16_pipelined(const GemmArgs& a, const void* Wh, hipStream_t stream);
 int convert_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t s);
 // 1 (default): in the bf16 mode the GEMM-only tensors (LayerNorm output, FFN
 // hidden, attention context) are stored as bf16; 0: every tensor stays fp32 and

@@ -271,6 +271,13 @@ int gemm_bf16_stored(const GemmArgs& a, const void* Wh, hipStream_t stream) {
                (int64_t)a.N * a.K * 2 < (int64_t(1) << 32),
            "gemm(bf16 stored): operand larger than the 32-bit byte offsets (4 GiB)");
   const __bf16* W = reinterpret_cast<const __bf16*>(Wh);
+  // large shapes: the 256x256 direct-to-LDS pipelined kernel (gemm_bf16p.hip);
+  // gemm_tile_bf16 = 8 forces it, any other forced tile keeps this file's kernels
+  {
+    const int64_t t256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
+    const bool want = g_gemm_tile_bf16 == 8 || (g_gemm_tile_bf16 == 0 && t256 >= 192);
+    if (want && gemm_bf16p_supported(a)) return gemm_bf16_pipelined(a, Wh, stream);
+  }
   return a.K % 64 == 0 ? dispatch_tile<64>(a, W, a.c_bf16, stream)
                        : dispatch_tile<32>(a, W, a.c_bf16, stream);
 }

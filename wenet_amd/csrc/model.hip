@@ -2129,6 +2129,23 @@ int wn_op_gemm_bf16_stored(const float* A, const float* W, const float* bias,
   return gemm_bf16_stored(g, w16.p, s);
 }
 
+int wn_op_gemm_lowp(const void* A, const void* W, const float* a_scale,
+                    const float* w_scale, const float* bias, const float* resid, void* C,
+                    int32_t M, int32_t N, int32_t K, float alpha, int32_t act,
+                    int32_t c_bf16, int32_t dtype, void* stream) {
+  WN_CHECK(A && W && C && M > 0 && N > 0 && K > 0, "gemm(lowp): null / empty");
+  WN_CHECK(K % 32 == 0, "gemm: K must be a multiple of 32");
+  GemmArgs g;
+  g.A = reinterpret_cast<const float*>(A); g.W = nullptr; g.bias = bias; g.resid = resid;
+  g.C = reinterpret_cast<float*>(C);
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N;
+  g.alpha = alpha; g.act = act; g.a_bf16 = true; g.c_bf16 = c_bf16 != 0;
+  if (dtype == 1) return gemm_bf16_stored(g, W, (hipStream_t)stream);
+  (void)a_scale; (void)w_scale;
+  set_error("gemm(lowp): unknown dtype");
+  return -1;
+}
+
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,
                   int32_t n, void* stream) {
   return log_add_pairs(a_dev, b_dev, out_dev, n, (hipStream_t)stream);
