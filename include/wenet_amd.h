@@ -108,10 +108,19 @@ int wn_model_clone(const wn_model* src, wn_model** out);
  *                mode is at least as precise as the reference's).  Tensors that
  *                only feed such a contraction may be KEPT as bf16 in HBM -- same
  *                values, the contraction rounds them first thing.
+ *   WN_PREC_FP8  WN_PREC_BF16, and the two GEMMs of every encoder feed-forward module
+ *                (w_1, w_2, positionwise_feed_forward.py:50-58) on OCP MXFP8 operands:
+ *                e4m3 elements with one power-of-two (E8M0) scale per 32 consecutive
+ *                k, for activations (quantised by the LayerNorm / by the w_1
+ *                epilogue) and weights (quantised once here), multiplied on the
+ *                block-scaled fp8 matrix cores with fp32 accumulation -- BASELINE.json
+ *                configs[4] "MFMA fp8 FFN".  Shapes too small to fill the chip with
+ *                256 x 256 tiles stay on the bf16 kernels.
  * Applies to later calls on this handle; clones inherit it.  The feature
  * frontends (wn_fbank, wn_log_mel, wn_resample) always run in fp32. */
 #define WN_PREC_F32 0
 #define WN_PREC_BF16 1
+#define WN_PREC_FP8 2
 int wn_model_set_precision(wn_model* m, int32_t precision);
 int32_t wn_model_get_precision(const wn_model* m);
 
@@ -308,13 +317,21 @@ int wn_op_gemm_bf16_stored(const float* A_dev, const float* W_dev, const float* 
                            void* stream);
 /* The reduced-precision GEMM kernels on operands that are ALREADY in their storage
  * type in HBM (what the model path hands them): dtype 1 = bf16 A (M, K) and W (N, K);
- * dtype 2 = OCP e4m3 A and W with per-row fp32 scales a_scale (M) / w_scale (N)
- * (C = epi(a_scale[m] * w_scale[n] * sum_k A W)).  Scales are ignored for bf16.
- * Micro-benchmarks and the operator tests call this; C as wn_op_gemm_bf16_stored. */
-int wn_op_gemm_lowp(const void* A_dev, const void* W_dev, const float* a_scale_dev,
-                    const float* w_scale_dev, const float* bias_dev,
-                    const float* resid_dev, void* C_dev, int32_t M, int32_t N, int32_t K,
-                    float alpha, int32_t act, int32_t c_bf16, int32_t dtype, void* stream);
+ * dtype 2 = OCP MXFP8: e4m3 A and W with one E8M0 block scale per 32 consecutive k of a
+ * row, scales as dwords [K/128][pitch = M resp. N] (the 4 bytes of a dword = the 4 k
+ * blocks of one 128-wide K tile), exactly what wn_op_mx_quantize writes.  c_mode 0: fp32
+ * C (M, N); 1: bf16 C (bf16 operands, no residual); 2: MXFP8 C (MXFP8 operands, no
+ * residual) with its block scales [N/128][M] in c_scale_dev.  Micro-benchmarks and the
+ * operator tests call this. */
+int wn_op_gemm_lowp(const void* A_dev, const void* W_dev, const void* a_scale_dev,
+                    const void* w_scale_dev, const float* bias_dev,
+                    const float* resid_dev, void* C_dev, void* c_scale_dev, int32_t M,
+                    int32_t N, int32_t K, float alpha, int32_t act, int32_t c_mode,
+                    int32_t dtype, void* stream);
+/* x (rows, K) fp32 -> MXFP8: q (rows, K) e4m3 bytes + scale dwords [K/128][rows]
+ * (block rule: the smallest power of two 2^e with amax <= 448 * 2^e; csrc/mxfp8.h). */
+int wn_op_mx_quantize(const float* x_dev, int32_t rows, int32_t K, void* q_dev,
+                      void* scale_dev, void* stream);
 /* out[i] = log_add(a[i], b[i]) (wenet/utils/common.py:302-310) in fp64 with the
  * routine the prefix beam search uses. */
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,

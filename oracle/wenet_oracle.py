@@ -56,8 +56,9 @@ class _Bf16OperandFunctional:
     online-softmax probabilities, the oracle the normalised ones: same relative
     rounding, not bit-identical."""
 
-    def __init__(self, exempt_weights=()):
+    def __init__(self, exempt_weights=(), mx_weights=()):
         self._exempt = {w.data_ptr() for w in exempt_weights}
+        self._mx = {w.data_ptr() for w in mx_weights}
 
     def __getattr__(self, name):
         return getattr(_TORCH_F, name)
@@ -69,6 +70,8 @@ class _Bf16OperandFunctional:
     def linear(self, x, w, b=None):
         if w.data_ptr() in self._exempt:
             return _TORCH_F.linear(x, w, b)
+        if w.data_ptr() in self._mx:   # WN_PREC_FP8: MXFP8 operands for the FFN GEMMs
+            return _TORCH_F.linear(mx_round(x), mx_round(w), b)
         return _TORCH_F.linear(self._r(x), self._r(w), b)
 
     def conv1d(self, x, w, b=None, **kw):
@@ -93,13 +96,50 @@ def _mm(a, b):
     return torch.matmul(a, b)
 
 
+def mx_quantize(x: torch.Tensor):
+    """OCP MXFP8 quantisation along the last dim (a multiple of 32): e4m3 elements
+    (torch.float8_e4m3fn, round to nearest even) and one biased E8M0 scale byte per
+    32 consecutive elements.  Block rule of the product (csrc/mxfp8.h), restated: the
+    smallest power of two 2^e with amax <= 448 * 2^e:  amax = m 2^x, 1 <= m < 2  ->
+    e = x - 8 + (m > 1.75), biased E = e + 127 clamped to [0, 253]; elements =
+    RNE_e4m3(v * 2^-e).  Returns (q float8 [..., K], E uint8 [..., K/32])."""
+    x = x.to(torch.float32)
+    K = x.shape[-1]
+    assert K % 32 == 0
+    xb = x.reshape(*x.shape[:-1], K // 32, 32)
+    amax = xb.abs().amax(-1).contiguous()
+    bits = amax.view(torch.int32)
+    E = (((bits >> 23) & 0xff) - 8 + ((bits & 0x7fffff) > 0x600000).to(torch.int32))
+    E = E.clamp(0, 253)
+    inv = ((254 - E) << 23).to(torch.int32).view(torch.float32)
+    q = (xb * inv.unsqueeze(-1)).to(torch.float8_e4m3fn)
+    return q.reshape(x.shape), E.to(torch.uint8)
+
+
+def mx_dequantize(q: torch.Tensor, E: torch.Tensor) -> torch.Tensor:
+    K = q.shape[-1]
+    scale = torch.pow(torch.tensor(2.0, dtype=torch.float64), E.to(torch.float64) - 127.0)
+    v = q.to(torch.float32).to(torch.float64).reshape(*q.shape[:-1], K // 32, 32)
+    return (v * scale.unsqueeze(-1)).reshape(q.shape).to(torch.float32)
+
+
+def mx_round(x: torch.Tensor) -> torch.Tensor:
+    """x -> the fp32 values its MXFP8 image represents (exact: e4m3 x power of two)."""
+    return mx_dequantize(*mx_quantize(x))
+
+
 @contextlib.contextmanager
-def bf16_operands(sd=None, attention=True):
+def bf16_operands(sd=None, attention=True, fp8_ffn=False):
     """Run the oracle with the product's bf16-operand arithmetic (see
-    _Bf16OperandFunctional).  `sd`: the state_dict, to exempt `linear_pos`."""
+    _Bf16OperandFunctional).  `sd`: the state_dict, to exempt `linear_pos`.
+    fp8_ffn: the WN_PREC_FP8 mode -- the FFN GEMMs (w_1, w_2 of every encoder layer)
+    see MXFP8 operands instead (BASELINE.json configs[4])."""
     global F, _MM_ROUND
     exempt = [v for k, v in (sd or {}).items() if k.endswith('linear_pos.weight')]
-    saved, F = F, _Bf16OperandFunctional(exempt)
+    mx = [v for k, v in (sd or {}).items()
+          if fp8_ffn and k.startswith('encoder.') and
+          k.endswith(('w_1.weight', 'w_2.weight'))]
+    saved, F = F, _Bf16OperandFunctional(exempt, mx)
     saved_mm, _MM_ROUND = _MM_ROUND, bool(attention)
     try:
         yield

@@ -188,7 +188,7 @@ def _gemm_lowp_bf16(A16, W16, bias=None, resid=None, alpha=1.0, act=0, c_bf16=Fa
     N = W16.shape[0]
     C = torch.empty((M, N), dtype=torch.bfloat16 if c_bf16 else torch.float32, device='cuda')
     _lib.check(L.wn_op_gemm_lowp(_ptr(A16), _ptr(W16), None, None, _ptr(bias), _ptr(resid),
-                                 _ptr(C), M, N, K, alpha, act, 1 if c_bf16 else 0, 1,
+                                 _ptr(C), None, M, N, K, alpha, act, 1 if c_bf16 else 0, 1,
                                  torch.cuda.current_stream().cuda_stream), 'gemm_lowp')
     torch.cuda.synchronize()
     return C

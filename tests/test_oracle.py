@@ -646,3 +646,26 @@ def test_reverse_hyps_worked_example_of_the_reference():
             k = int(lens[i])
             assert a[i, 1:k].tolist() == h[i, 1:k].flip(0).tolist()
             assert a[i, k:].tolist() == [eos] * (L - k)
+
+
+def test_mx_quantize_rule_known_answers():
+    """MXFP8 block rule of the fp8 mode (csrc/mxfp8.h, restated in the oracle): the
+    smallest power of two 2^e with amax <= 448 * 2^e; elements RNE to e4m3."""
+    x = torch.zeros(4, 32)
+    x[0, 0] = 448.0            # exactly representable with e = 0
+    x[1, 0] = 449.0            # just above: e = 1
+    x[2, 0] = 56.0             # 1.75 * 2^5 -> e = -3 (boundary stays inside)
+    x[2, 1] = 1.0
+    x[3, :] = 0.0              # all-zero block: E = 0, elements 0
+    q, E = O.mx_quantize(x)
+    assert E[:, 0].tolist() == [127, 128, 124, 0]
+    d = O.mx_dequantize(q, E)
+    assert d[0, 0] == 448.0 and d[1, 0] == 448.0   # 224.5 -> RNE 224 -> x 2
+    assert d[2, 0] == 56.0 and d[2, 1] == 1.0
+    assert float(d[3].abs().max()) == 0.0
+    # round trip is idempotent and within half an e4m3 ulp of the block maximum's scale
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn(7, 96, generator=g) * 5
+    r = O.mx_round(y)
+    assert torch.equal(O.mx_round(r), r)
+    assert ((r - y).abs() <= 0.0625 * y.abs() + 2.0 ** -9 * y.abs().amax()).all()

@@ -53,7 +53,8 @@ def main():
                     help='operands already stored as bf16 / e4m3 (wn_op_gemm_lowp): the '
                          'kernels the bf16 / fp8 modes run; tiles via gemm_tile_bf16 '
                          '(1 = 128x128, 7 = 256x256 register-staged, 8 = 256x256 pipelined)')
-    ap.add_argument('--c-bf16', action='store_true', help='--lowp: bf16 C (no residual)')
+    ap.add_argument('--c-bf16', action='store_true',
+                    help='--lowp: C in the operand type (bf16 / MXFP8; no residual)')
     args = ap.parse_args()
     L = _lib.lib()
     op = L.wn_op_gemm_bf16 if args.bf16 else L.wn_op_gemm
@@ -78,20 +79,29 @@ def main():
                             dtype=torch.bfloat16 if args.c_bf16 else torch.float32)
             if args.lowp == 'bf16':
                 A2, W2, sa, sw, dt = A.to(torch.bfloat16), W.to(torch.bfloat16), None, None, 1
+                cmode = 1 if args.c_bf16 else 0
             else:
-                sa = (A.abs().amax(1) / 448.0).clamp_min(1e-12)
-                sw = (W.abs().amax(1) / 448.0).clamp_min(1e-12)
-                A2 = (A / sa[:, None]).to(torch.float8_e4m3fn)
-                W2 = (W / sw[:, None]).to(torch.float8_e4m3fn)
+                def mxq(x):
+                    r, kk = x.shape
+                    q = torch.empty((r, kk), dtype=torch.uint8, device=dev)
+                    sc = torch.zeros((kk // 128, r), dtype=torch.int32, device=dev)
+                    _lib.check(L.wn_op_mx_quantize(x.data_ptr(), r, kk, q.data_ptr(),
+                                                   sc.data_ptr(), None), 'mxq')
+                    return q, sc
+                (A2, sa), (W2, sw) = mxq(A), mxq(W)
                 dt = 2
+                cmode = 2 if args.c_bf16 else 0
+                if args.c_bf16:
+                    C = torch.empty(m, n, device=dev, dtype=torch.uint8)
+            csc = torch.zeros(((n + 127) // 128, m), dtype=torch.int32, device=dev)
 
         def run_lowp():
             _lib.check(L.wn_op_gemm_lowp(A2.data_ptr(), W2.data_ptr(),
                                          sa.data_ptr() if sa is not None else None,
                                          sw.data_ptr() if sw is not None else None,
                                          bias.data_ptr(), R.data_ptr() if resid else None,
-                                         C.data_ptr(), m, n, k, 1.0, act,
-                                         1 if args.c_bf16 else 0, dt, None), name)
+                                         C.data_ptr(), csc.data_ptr(), m, n, k, 1.0, act,
+                                         cmode, dt, None), name)
 
         def run():
             if args.lowp:

@@ -89,6 +89,15 @@ struct GemmArgs {
   // Needs the bf16 image of the weight slab (t_wslab_*), plain A, no residual
   // with bf16 C.
   bool a_bf16 = false, c_bf16 = false;
+  // MXFP8 form (gemm_bf16p.hip, ET = 1): A is an e4m3 matrix (lda in elements) with
+  // block scales a_scale, W comes with w_scale; scales are dwords [K/128][pitch]
+  // (4 E8M0 bytes of the 4 k blocks of a K tile, K-tile-major).  c_mx: C is written as
+  // MXFP8 (ldc in elements) with its block scales in c_scale (the k blocks of the
+  // next GEMM).
+  bool fp8 = false, c_mx = false;
+  const unsigned* a_scale = nullptr; const unsigned* w_scale = nullptr;
+  unsigned* c_scale = nullptr;
+  int a_scale_pitch = 0, w_scale_pitch = 0, c_scale_pitch = 0;
 };
 
 int gemm_f32(const GemmArgs& a, hipStream_t stream);
@@ -110,6 +119,11 @@ int gemm_bf16_stored(const GemmArgs& a, const void* Wh, hipStream_t stream);
 // 256x256 direct-to-LDS pipelined kernel for the large shapes (gemm_bf16p.hip)
 bool gemm_bf16p_supported(const GemmArgs& a);
 int gemm_bf16_pipelined(const GemmArgs& a, const void* Wh, hipStream_t stream);
+int gemm_mxfp8(const GemmArgs& a, const void* Wq, hipStream_t stream);
+// fp32 [rows][ld] -> e4m3 [rows][K] + block scales [K/128][pitch] dwords
+int mx_quantize(const float* x, int ld, int rows, int K, void* q, unsigned* scale, int pitch,
+                hipStream_t s);
+enum { PREC_FP8 = 2 };  // bf16 mode with MXFP8 FFN GEMMs (wn_model_set_precision)
 int convert_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t s);
 // 1 (default): in the bf16 mode the GEMM-only tensors (LayerNorm output, FFN
 // hidden, attention context) are stored as bf16; 0: every tensor stays fp32 and

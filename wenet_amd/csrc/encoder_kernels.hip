@@ -2,6 +2,7 @@
 // conv, the depthwise-conv core of the Conformer conv module, and the
 // relative-position multi-head attention (online softmax, fp32 MFMA).
 #include "kernels.h"
+#include "mxfp8.h"
 
 namespace wn {
 
@@ -148,6 +149,40 @@ __global__ __launch_bounds__(256) void layernorm_bf16out_kernel(
   r.load(x + (int64_t)row * ldx, lane);
   ln_inplace<E>(r, w, b, lane, eps);
   store_row_bf16<E>(r, y + (int64_t)row * ldy, lane);
+}
+
+// MXFP8 form of the fp8 mode (WN_PREC_FP8): the normalised row feeds the FFN w_1 GEMM
+// as e4m3 elements + one E8M0 scale per 32 columns (csrc/mxfp8.h).  A lane holds 4
+// consecutive columns per 256-column chunk, 8 lanes one MX block.
+template <int E>
+__global__ __launch_bounds__(256) void layernorm_mx_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ w,
+    const float* __restrict__ b, unsigned char* __restrict__ q, unsigned* __restrict__ scale,
+    int pitch, int M, float eps) {
+  static_assert(E % 4 == 0, "MX LayerNorm: 4 columns per lane and chunk");
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  constexpr int D = E * 64;
+  RowRegs<E> r;
+  r.load(x + (int64_t)row * ldx, lane);
+  ln_inplace<E>(r, w, b, lane, eps);
+#pragma unroll
+  for (int j = 0; j < E / 4; ++j) {
+    const float* v = r.v + 4 * j;
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const int Eb = mx_e8m0(amax);
+    const float inv = mx_inv_scale(Eb);
+    const int c = j * 256 + lane * 4;
+    *reinterpret_cast<int*>(q + (int64_t)row * D + c) =
+        mx_pack4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+    if ((lane & 7) == 0)
+      reinterpret_cast<unsigned char*>(scale)[((int64_t)(c >> 7) * pitch + row) * 4 +
+                                              ((c >> 5) & 3)] = (unsigned char)Eb;
+  }
 }
 
 template <int E>
@@ -548,6 +583,28 @@ __global__ void copy_rows_kernel(const float* src, int lds, const int* src_rows,
 }  // namespace
 
 int g_ln_rows = 0;  // wn_tune_set("ln_rows"): 0 auto, 1 or 2 rows per wave
+
+int layernorm_mx(const float* x, int ldx, const float* w, const float* b, void* q,
+                 unsigned* scale, int pitch, int M, int D, float eps, hipStream_t s) {
+  WN_CHECK(M > 0 && ldx % 4 == 0 && D % 256 == 0 && pitch >= M,
+           "layernorm_mx: width must be a multiple of 256");
+  dim3 g(cdiv(M, 4)), t(256);
+  unsigned char* qq = reinterpret_cast<unsigned char*>(q);
+#define WN_LNM(E)                                                                   \
+  case E * 64:                                                                      \
+    hipLaunchKernelGGL((layernorm_mx_kernel<E>), g, t, 0, s, x, ldx, w, b, qq, scale, \
+                       pitch, M, eps);                                              \
+    break;
+  switch (D) {
+    WN_LNM(4) WN_LNM(8) WN_LNM(12) WN_LNM(16) WN_LNM(20)
+    default:
+      set_error("layernorm_mx: unsupported width " + std::to_string(D));
+      return -1;
+  }
+#undef WN_LNM
+  WN_HIP(hipGetLastError());
+  return 0;
+}
 
 int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
               int ldy, int M, int D, float eps, hipStream_t s, bool y_bf16) {

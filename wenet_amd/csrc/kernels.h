@@ -9,6 +9,11 @@ namespace wn {
 int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
               int ldy, int M, int D, float eps, hipStream_t s, bool y_bf16 = false);
 
+// y = LayerNorm(x) written as MXFP8: q (M, D) e4m3 bytes + block scales
+// [D/128][pitch] dwords (csrc/mxfp8.h); D % 256 == 0.
+int layernorm_mx(const float* x, int ldx, const float* w, const float* b, void* q,
+                 unsigned* scale, int pitch, int M, int D, float eps, hipStream_t s);
+
 // y1 = LN(x; w1,b1), y2 = LN(y1; w2,b2) in one pass over contiguous [M][D] rows
 // (y1 may alias x).
 extern int g_ln_rows;

@@ -235,6 +235,13 @@ struct wn_model {
   std::shared_ptr<DevBuf> weights = std::make_shared<DevBuf>();  // one slab for every weight
   int64_t n_weight_elems = 0;            // floats in the slab
   std::shared_ptr<DevBuf> weights_bf16;  // bf16 image of the slab (bf16 mode, lazily)
+  // MXFP8 images of the FFN weights (fp8 mode, lazily): fp32 weight pointer ->
+  // (e4m3 [N][K], block scales [K/128][N] dwords); clones share it
+  struct MxW { const void* q; const unsigned* scale; };
+  std::shared_ptr<DevBuf> weights_mx;
+  std::shared_ptr<std::map<const float*, MxW>> mx_at;
+  bool fp8_ffn = false;                  // WN_PREC_FP8: prec == PREC_BF16 + MXFP8 FFN GEMMs
+  DevBuf mx_sa, mx_sh;                   // block scales of the LN output / FFN hidden
   std::map<std::string, const float*> w; // name -> device pointer
   // re-laid-out subsampling weights
   const float* conv1_w = nullptr; const float* conv1_b = nullptr;
@@ -328,12 +335,19 @@ struct HandleGuard {
     return -4;                                                                   \
   }
 
+thread_local const std::map<const float*, wn_model::MxW>* t_mx = nullptr;
+// fp8 mode: smallest number of 256 x 256 tiles of an FFN GEMM pair for which the MXFP8
+// kernels are used (below it the bf16 kernels fill the chip better); tests set 0
+int g_fp8_min_tiles = 192;
+
 struct PrecisionScope {
   int saved;
   const float* s_f32; const void* s_bf16; int64_t s_elems;
+  const std::map<const float*, wn_model::MxW>* s_mx;
   explicit PrecisionScope(const wn_model* m)
       : saved(t_gemm_prec), s_f32(t_wslab_f32), s_bf16(t_wslab_bf16),
-        s_elems(t_wslab_elems) {
+        s_elems(t_wslab_elems), s_mx(t_mx) {
+    t_mx = (m->fp8_ffn && m->mx_at) ? m->mx_at.get() : nullptr;
     t_gemm_prec = m->prec;
     const bool img = m->prec == PREC_BF16 && m->weights_bf16 && m->weights_bf16->p;
     t_wslab_f32 = img ? m->weights->as<float>() : nullptr;
@@ -343,6 +357,7 @@ struct PrecisionScope {
   ~PrecisionScope() {
     t_gemm_prec = saved;
     t_wslab_f32 = s_f32; t_wslab_bf16 = s_bf16; t_wslab_elems = s_elems;
+    t_mx = s_mx;
   }
 };
 
@@ -375,7 +390,7 @@ int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M,
 
 // FFN w_1 GEMM (SiLU epilogue), optionally bracketed by HIP events
 int ffn_w1(wn_model* m, const Linear& l, const float* A, float* C, int M,
-           hipStream_t s, int act = ACT_SILU, bool h16 = false) {
+           hipStream_t s, int act, bool h16) {
   // every hipEventRecord pair costs ~10 us of idle GPU around the launch
   // (measured in the rocprofv3 trace), so only every 6th launch is bracketed:
   // an unbiased sample of the average launch duration (4 per 12-layer pass)
@@ -399,6 +414,71 @@ int ffn_w1(wn_model* m, const Linear& l, const float* A, float* C, int M,
 int ln(const Norm& n, const float* x, float* y, int M, int D, float eps,
        hipStream_t s, bool y_bf16 = false) {
   return layernorm(x, D, n.w, n.b, y, D, M, D, eps, s, y_bf16);
+}
+
+// x += alpha * w_2(act(w_1(LN(x)))) -- one feed-forward module
+// (positionwise_feed_forward.py:50-58 inside encoder_layer.py:220-228 / :253-261 /
+// encoder_layer.py:117-125).  `ln_done`: t1 already holds LN(x) (fused earlier).
+// fp8 mode (WN_PREC_FP8) and shapes the pipelined kernel takes: the LayerNorm writes
+// MXFP8, w_1 reads it and writes the hidden tensor as MXFP8 again (block scales from
+// its epilogue), w_2 reads that and adds into the fp32 residual stream.
+int ffn_w1(wn_model* m, const Linear& l, const float* A, float* C, int M, hipStream_t s,
+           int act, bool h16);
+int ffn_module(wn_model* m, const Norm& nrm, const Linear& w1, const Linear& w2, int act,
+               float alpha, bool ln_done, bool h16, hipStream_t s) {
+  const wn_config& c = m->cfg;
+  const int d = c.d_model, M = m->rows;
+  float* x = m->x.as<float>();
+  float* t1 = m->t1.as<float>();
+  float* hb = m->hbuf.as<float>();
+  bool mx = false;
+  const wn_model::MxW *q1 = nullptr, *q2 = nullptr;
+  if (t_mx && h16 && !ln_done) {
+    auto i1 = t_mx->find(w1.w), i2 = t_mx->find(w2.w);
+    const int64_t t256 = (int64_t)cdiv(M, 256) * cdiv(std::min(w1.out, w2.out), 256);
+    if (i1 != t_mx->end() && i2 != t_mx->end() && d % 256 == 0 && w1.out % 128 == 0 &&
+        t256 >= g_fp8_min_tiles) {
+      mx = true; q1 = &i1->second; q2 = &i2->second;
+    }
+  }
+  if (!mx) {
+    if (!ln_done) WN_TRY(ln(nrm, x, t1, M, d, c.norm_eps, s, h16));
+    WN_TRY(ffn_w1(m, w1, t1, hb, M, s, act, h16));
+    return linear(w2, hb, w1.out, x, d, M, s, ACT_NONE, x, d, alpha, false, h16);
+  }
+  const int pitch = cdiv(M, 256) * 256;
+  WN_TRY(m->mx_sa.ensure((size_t)(d / 128) * pitch * 4));
+  WN_TRY(m->mx_sh.ensure((size_t)(w1.out / 128) * pitch * 4));
+  WN_TRY(layernorm_mx(x, d, nrm.w, nrm.b, t1, m->mx_sa.as<unsigned>(), pitch, M, d,
+                      c.norm_eps, s));
+  GemmArgs g;
+  g.A = t1; g.bias = w1.b; g.C = hb; g.M = M; g.N = w1.out; g.K = d;
+  g.lda = d; g.ldc = w1.out; g.act = act; g.fp8 = true; g.c_mx = true;
+  g.a_scale = m->mx_sa.as<unsigned>(); g.a_scale_pitch = pitch;
+  g.w_scale = q1->scale; g.w_scale_pitch = w1.out;
+  g.c_scale = m->mx_sh.as<unsigned>(); g.c_scale_pitch = pitch;
+  const bool bracket = m->prof_on && (m->prof_seq++ % 6) == 0;
+  if (bracket) {
+    if (m->prof_used + 2 > m->prof_ev.size())
+      for (int i = 0; i < 64; ++i) {
+        hipEvent_t e;
+        WN_HIP(hipEventCreate(&e));
+        m->prof_ev.push_back(e);
+      }
+    WN_HIP(hipEventRecord(m->prof_ev[m->prof_used], s));
+  }
+  WN_TRY(gemm_mxfp8(g, q1->q, s));
+  if (bracket) {
+    WN_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], s));
+    m->prof_used += 2;
+    m->prof_flops += 2.0 * M * (double)w1.out * d;
+  }
+  GemmArgs h;
+  h.A = hb; h.bias = w2.b; h.C = x; h.resid = x; h.M = M; h.N = d; h.K = w1.out;
+  h.lda = w1.out; h.ldc = d; h.ldr = d; h.alpha = alpha; h.fp8 = true;
+  h.a_scale = m->mx_sh.as<unsigned>(); h.a_scale_pitch = pitch;
+  h.w_scale = q2->scale; h.w_scale_pitch = d;
+  return gemm_mxfp8(h, q2->q, s);
 }
 
 // ---- set the per-utterance row layout of the current batch -----------------
@@ -509,9 +589,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     const EncLayer& L = m->layers[li];
     // x += 0.5 * FFN_macaron(LN(x))                 encoder_layer.py:220-228
     // (for li > 0 the previous layer's tail already left LN(x) in t1)
-    if (li == 0) WN_TRY(ln(L.norm_ff_mac, x, t1, M, d, eps, s, h16));
-    WN_TRY(ffn_w1(m, L.ffm1, t1, hb, M, s, ACT_SILU, h16));
-    WN_TRY(linear(L.ffm2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 0.5f, false, h16));
+    WN_TRY(ffn_module(m, L.norm_ff_mac, L.ffm1, L.ffm2, ACT_SILU, 0.5f, li > 0, h16, s));
     // x += MHA(LN(x))                               encoder_layer.py:230-238
     WN_TRY(ln(L.norm_mha, x, t1, M, d, eps, s, h16));
     WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s, ACT_NONE, nullptr, 0, 1.0f, false,
@@ -542,9 +620,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     WN_TRY(dwconv_ln_silu(dw, s));
     WN_TRY(linear(L.pw2, t1, d, x, d, M, s, ACT_NONE, x, d));
     // x += 0.5 * FFN(LN(x)); x = LN(x)              encoder_layer.py:253-263
-    WN_TRY(ln(L.norm_ff, x, t1, M, d, eps, s, h16));
-    WN_TRY(ffn_w1(m, L.ff1, t1, hb, M, s, ACT_SILU, h16));
-    WN_TRY(linear(L.ff2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 0.5f, false, h16));
+    WN_TRY(ffn_module(m, L.norm_ff, L.ff1, L.ff2, ACT_SILU, 0.5f, false, h16, s));
     if (li + 1 < n_run) {
       const EncLayer& Ln = m->layers[li + 1];
       WN_TRY(layernorm2(x, L.norm_final.w, L.norm_final.b, Ln.norm_ff_mac.w,
@@ -680,9 +756,7 @@ int transformer_layers(wn_model* m, hipStream_t s) {
     a.scale = 1.0f / sqrtf(64.0f);
     WN_TRY(attention(a, s));
     WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d, 1.0f, false, h16));
-    WN_TRY(ln(L.n2, x, t1, M, d, eps, s, h16));
-    WN_TRY(ffn_w1(m, L.ff1, t1, hb, M, s, act, h16));
-    WN_TRY(linear(L.ff2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 1.0f, false, h16));
+    WN_TRY(ffn_module(m, L.n2, L.ff1, L.ff2, act, 1.0f, false, h16, s));
   }
   WN_TRY(m->enc.ensure((size_t)std::max(M, 1) * d * sizeof(float)));
   if (m->dbg_skip_after_norm) {
@@ -1292,6 +1366,7 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->weights = src->weights;
   m->n_weight_elems = src->n_weight_elems;
   m->weights_bf16 = src->weights_bf16;
+  m->weights_mx = src->weights_mx; m->mx_at = src->mx_at; m->fp8_ffn = src->fp8_ffn;
   m->pos_tabs = src->pos_tabs;
   m->fb_tab_i = src->fb_tab_i;
   m->w = src->w;
@@ -1317,9 +1392,10 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
 
 int wn_model_set_precision(wn_model* m, int32_t precision) {
   WN_CHECK(m, "wn_model_set_precision: null model");
-  WN_CHECK(precision == PREC_F32 || precision == PREC_BF16,
-           "wn_model_set_precision: 0 (fp32) or 1 (bf16 operands, fp32 accumulate)");
-  if (precision == PREC_BF16 && !m->weights_bf16 && m->n_weight_elems > 0) {
+  WN_CHECK(precision == PREC_F32 || precision == PREC_BF16 || precision == PREC_FP8,
+           "wn_model_set_precision: 0 (fp32), 1 (bf16 operands, fp32 accumulate) or 2 "
+           "(bf16 + MXFP8 feed-forward GEMMs)");
+  if (precision != PREC_F32 && !m->weights_bf16 && m->n_weight_elems > 0) {
     // one-time bf16 image of the weight slab for the bf16-storage GEMMs (same
     // element offsets; clones made afterwards share it)
     WN_HIP(hipSetDevice(m->device));
@@ -1330,11 +1406,45 @@ int wn_model_set_precision(wn_model* m, int32_t precision) {
     WN_HIP(hipStreamSynchronize(nullptr));
     m->weights_bf16 = img;
   }
-  m->prec = precision;
+  if (precision == PREC_FP8 && !m->mx_at) {
+    // one-time MXFP8 images of the feed-forward weights (w_1, w_2 of every encoder
+    // layer): e4m3 [N][K] + block scales [K/128][N]
+    WN_HIP(hipSetDevice(m->device));
+    std::vector<const Linear*> ws;
+    for (const auto& L : m->layers) { ws.push_back(&L.ffm1); ws.push_back(&L.ffm2);
+                                      ws.push_back(&L.ff1); ws.push_back(&L.ff2); }
+    for (const auto& L : m->tf_layers) { ws.push_back(&L.ff1); ws.push_back(&L.ff2); }
+    size_t bytes = 0;
+    for (const Linear* l : ws)
+      if (l->w && l->in % 128 == 0)
+        bytes += ((size_t)l->out * l->in + 255) / 256 * 256 + (size_t)(l->in / 128) * l->out * 4;
+    auto buf = std::make_shared<DevBuf>();
+    auto at = std::make_shared<std::map<const float*, wn_model::MxW>>();
+    if (bytes > 0) {
+      WN_TRY(buf->ensure(bytes));
+      char* p = buf->as<char>();
+      for (const Linear* l : ws) {
+        if (!l->w || l->in % 128 != 0) continue;
+        char* q = p;
+        p += ((size_t)l->out * l->in + 255) / 256 * 256;
+        unsigned* sc = reinterpret_cast<unsigned*>(p);
+        p += (size_t)(l->in / 128) * l->out * 4;
+        WN_TRY(mx_quantize(l->w, l->in, l->out, l->in, q, sc, l->out, nullptr));
+        (*at)[l->w] = wn_model::MxW{q, sc};
+      }
+      WN_HIP(hipStreamSynchronize(nullptr));
+    }
+    m->weights_mx = buf;
+    m->mx_at = at;
+  }
+  m->prec = precision == PREC_F32 ? PREC_F32 : PREC_BF16;
+  m->fp8_ffn = precision == PREC_FP8;
   return 0;
 }
 
-int32_t wn_model_get_precision(const wn_model* m) { return m ? m->prec : -1; }
+int32_t wn_model_get_precision(const wn_model* m) {
+  return m ? (m->fp8_ffn ? (int32_t)PREC_FP8 : m->prec) : -1;
+}
 
 int wn_profile_enable(wn_model* m, int32_t on) {
   WN_CHECK(m, "wn_profile_enable: null model");
@@ -1384,6 +1494,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "attn_bf16") g_attn_bf16 = value;
   else if (k == "bf16_store") g_bf16_store = value;
   else if (k == "attn_bf16_nw") g_attn_bf16_nw = value;
+  else if (k == "fp8_min_tiles") g_fp8_min_tiles = value;
   else { set_error("wn_tune_set: unknown key " + k); return -1; }
   return 0;
 }
@@ -2129,21 +2240,40 @@ int wn_op_gemm_bf16_stored(const float* A, const float* W, const float* bias,
   return gemm_bf16_stored(g, w16.p, s);
 }
 
-int wn_op_gemm_lowp(const void* A, const void* W, const float* a_scale,
-                    const float* w_scale, const float* bias, const float* resid, void* C,
+int wn_op_gemm_lowp(const void* A, const void* W, const void* a_scale, const void* w_scale,
+                    const float* bias, const float* resid, void* C, void* c_scale,
                     int32_t M, int32_t N, int32_t K, float alpha, int32_t act,
-                    int32_t c_bf16, int32_t dtype, void* stream) {
+                    int32_t c_mode, int32_t dtype, void* stream) {
   WN_CHECK(A && W && C && M > 0 && N > 0 && K > 0, "gemm(lowp): null / empty");
   WN_CHECK(K % 32 == 0, "gemm: K must be a multiple of 32");
   GemmArgs g;
   g.A = reinterpret_cast<const float*>(A); g.W = nullptr; g.bias = bias; g.resid = resid;
   g.C = reinterpret_cast<float*>(C);
   g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N;
-  g.alpha = alpha; g.act = act; g.a_bf16 = true; g.c_bf16 = c_bf16 != 0;
-  if (dtype == 1) return gemm_bf16_stored(g, W, (hipStream_t)stream);
-  (void)a_scale; (void)w_scale;
+  g.alpha = alpha; g.act = act;
+  if (dtype == 1) {
+    WN_CHECK(c_mode == 0 || c_mode == 1, "gemm(lowp): bf16 operands give fp32 / bf16 C");
+    g.a_bf16 = true; g.c_bf16 = c_mode == 1;
+    return gemm_bf16_stored(g, W, (hipStream_t)stream);
+  }
+  if (dtype == 2) {
+    WN_CHECK(c_mode == 0 || c_mode == 2, "gemm(lowp): MXFP8 operands give fp32 / MXFP8 C");
+    g.fp8 = true; g.c_mx = c_mode == 2;
+    g.a_scale = reinterpret_cast<const unsigned*>(a_scale); g.a_scale_pitch = M;
+    g.w_scale = reinterpret_cast<const unsigned*>(w_scale); g.w_scale_pitch = N;
+    g.c_scale = reinterpret_cast<unsigned*>(c_scale); g.c_scale_pitch = M;
+    return gemm_mxfp8(g, W, (hipStream_t)stream);
+  }
   set_error("gemm(lowp): unknown dtype");
   return -1;
+}
+
+int wn_op_mx_quantize(const float* x, int32_t rows, int32_t K, void* q, void* scale,
+                      void* stream) {
+  WN_CHECK(x && q && scale && rows > 0 && K > 0 && K % 128 == 0,
+           "mx_quantize: null / empty / K % 128");
+  return mx_quantize(x, K, rows, K, q, reinterpret_cast<unsigned*>(scale), rows,
+                     (hipStream_t)stream);
 }
 
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,

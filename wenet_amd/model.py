@@ -255,23 +255,26 @@ class ASRModel:
 
     # ---- compute dtype (recognize.py --dtype, recognize.py:52-56,250-255) ----
     _DTYPES = {'fp32': 0, 'float32': 0, torch.float32: 0,
-               'bf16': 1, 'bfloat16': 1, torch.bfloat16: 1}
+               'bf16': 1, 'bfloat16': 1, torch.bfloat16: 1,
+               'fp8': 2, 'mxfp8': 2}
 
     def set_compute_dtype(self, dtype) -> 'ASRModel':
         """'fp32' (default, the parity mode) or 'bf16': every Linear / pointwise
         conv / subsampling conv rounds its operands to bf16 and accumulates in
         fp32 on the bf16 matrix cores (wn_model_set_precision).  The reference
         gets the same effect from torch autocast around model.decode; 'fp16' is
-        not offered (no fp16 kernels)."""
+        not offered (no fp16 kernels).  'fp8': the bf16 mode with the encoder's
+        feed-forward GEMMs on OCP MXFP8 operands (WN_PREC_FP8, BASELINE.json
+        configs[4])."""
         if dtype not in self._DTYPES:
-            raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {dtype!r}")
+            raise ValueError(f"compute dtype must be 'fp32', 'bf16' or 'fp8', got {dtype!r}")
         _lib.check(self._L.wn_model_set_precision(self._h, self._DTYPES[dtype]),
                    'wn_model_set_precision')
         return self
 
     @property
     def compute_dtype(self) -> str:
-        return 'bf16' if self._L.wn_model_get_precision(self._h) == 1 else 'fp32'
+        return {1: 'bf16', 2: 'fp8'}.get(self._L.wn_model_get_precision(self._h), 'fp32')
 
     # torch.nn.Module-flavoured no-ops so reference driver code keeps working
     def eval(self):
