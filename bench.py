@@ -306,6 +306,7 @@ def main():
         # every rank sees the same max-reduced times, so they stop together
         if sum(round_s) >= args.min_seconds or len(round_s) >= MAX_ROUNDS:
             break
+    prof_name = L.wn_profile_kernel_name(pipe.models[0]._h).decode()
     n_launch, ms, flops = ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
     tot_launch, tot_ms, tot_flops = 0, 0.0, 0.0
     for mdl in pipe.models:
@@ -374,7 +375,10 @@ def main():
             },
             'roofline': {
                 'bound': 'mfma',
-                'kernel': f'{kern} (FFN w_1, M={enc_rows} N={ffn} K={d_model})',
+                'kernel': (f'{prof_name}, M={enc_rows} F={ffn} D={d_model}: '
+                           f'{4 * enc_rows * ffn * d_model / 1e9:.2f} GFLOP per launch'
+                           if 'fused' in prof_name else
+                           f'{kern} (FFN w_1, M={enc_rows} N={ffn} K={d_model})'),
                 'achieved': round(achieved, 2),
                 'peak': peak,
                 'unit': 'TFLOP/s',

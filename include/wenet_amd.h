@@ -332,6 +332,16 @@ int wn_op_gemm_lowp(const void* A_dev, const void* W_dev, const void* a_scale_de
  * (block rule: the smallest power of two 2^e with amax <= 448 * 2^e; csrc/mxfp8.h). */
 int wn_op_mx_quantize(const float* x_dev, int32_t rows, int32_t K, void* q_dev,
                       void* scale_dev, void* stream);
+/* The fused fp32 feed-forward module the encoder runs (csrc/ffn_fused.hip;
+ * positionwise_feed_forward.py:50-58 inside encoder_layer.py:220-228): x_inout (M, D) +=
+ * alpha * (act(X W1^T + b1) W2^T + b2) with X (M, D) the already normalised input, then
+ * y_out = LayerNorm(x_inout; ln_w, ln_b, eps).  D in {256, 512}, F % 64 == 0, act 1 SiLU /
+ * 2 ReLU / 3 GELU.  Operator tests and micro-benchmarks call this. */
+int wn_op_ffn_fused(const float* X_dev, const float* W1_dev, const float* b1_dev,
+                    const float* W2_dev, const float* b2_dev, float* x_inout_dev,
+                    const float* ln_w_dev, const float* ln_b_dev, float* y_out_dev,
+                    int32_t M, int32_t D, int32_t F, int32_t act, float alpha, float eps,
+                    void* stream);
 /* out[i] = log_add(a[i], b[i]) (wenet/utils/common.py:302-310) in fp64 with the
  * routine the prefix beam search uses. */
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,
@@ -347,6 +357,9 @@ int wn_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev,
 int wn_profile_enable(wn_model* m, int32_t on);
 int wn_profile_collect(wn_model* m, int32_t* n_launches, double* total_ms,
                        double* total_flops);
+/* What the bracketed launches were (static string): the FFN w_1 GEMM, or the fused
+ * feed-forward kernel (w_1 + activation + w_2) when the fp32 path runs it. */
+const char* wn_profile_kernel_name(const wn_model* m);
 
 /* Test hook: "n_layers" = run only the first n encoder layers (-1: all),
  * "skip_after_norm" = 1 leaves out encoder.after_norm; lets the parity tests

@@ -1,0 +1,84 @@
+"""The fused fp32 feed-forward module (csrc/ffn_fused.hip) through the C ABI against an
+fp64 torch evaluation of PositionwiseFeedForward + residual + LayerNorm
+(positionwise_feed_forward.py:50-58, encoder_layer.py:220-228), and through the model
+against the two-GEMM path it replaces."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import cached_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(X, W1, b1, W2, b2, x, lw, lb, act, alpha, ring=4):
+    from wenet_amd import _lib
+    L = _lib.lib()
+    M, D = X.shape
+    F = W1.shape[0]
+    xo = x.clone().cuda()
+    y = torch.empty((M, D), device='cuda')
+    t = [t.cuda().contiguous() for t in (X, W1, b1, W2, b2, lw, lb)]
+    _lib.check(L.wn_tune_set(b'ffn_ring', ring), 'tune')
+    try:
+        _lib.check(L.wn_op_ffn_fused(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                     t[3].data_ptr(), t[4].data_ptr(), xo.data_ptr(),
+                                     t[5].data_ptr(), t[6].data_ptr(), y.data_ptr(), M, D, F,
+                                     act, alpha, 1e-5,
+                                     torch.cuda.current_stream().cuda_stream), 'ffn_fused')
+        torch.cuda.synchronize()
+    finally:
+        L.wn_tune_set(b'ffn_ring', 4)
+    return xo.cpu(), y.cpu()
+
+
+@pytest.mark.parametrize('M,D,F,act,ring', [
+    (128, 256, 128, 1, 4),       # one block, two chunks
+    (700, 256, 2048, 1, 4),      # ragged M, S = 16
+    (7932, 256, 2048, 1, 4),     # BASELINE config 2: 62 x 4 blocks
+    (1000, 512, 2048, 2, 4),     # d = 512 (two W2 stages per k tile), ReLU
+    (333, 512, 1024, 3, 4),      # GELU
+    (16231, 512, 2048, 1, 4),    # BASELINE config 3: 127 x 2 blocks, 16 chunks per block
+])
+def test_ffn_fused_vs_fp64(M, D, F, act, ring):
+    g = torch.Generator().manual_seed(M + D + F + act)
+    X = torch.randn(M, D, generator=g)
+    W1 = torch.randn(F, D, generator=g) / D ** 0.5
+    b1 = torch.randn(F, generator=g) * 0.3
+    W2 = torch.randn(D, F, generator=g) / F ** 0.5
+    b2 = torch.randn(D, generator=g) * 0.3
+    x = torch.randn(M, D, generator=g)
+    lw = 1.0 + 0.2 * torch.randn(D, generator=g)
+    lb = 0.1 * torch.randn(D, generator=g)
+    h = X.double() @ W1.double().T + b1.double()
+    h = {1: torch.nn.functional.silu, 2: torch.relu, 3: torch.nn.functional.gelu}[act](h)
+    xr = x.double() + 0.5 * (h @ W2.double().T + b2.double())
+    yr = torch.nn.functional.layer_norm(xr, (D, ), lw.double(), lb.double(), 1e-5)
+    xo, y = _run(X, W1, b1, W2, b2, x, lw, lb, act, 0.5, ring)
+    assert (xo.double() - xr).abs().max().item() < 2e-5
+    assert (y.double() - yr).abs().max().item() < 2e-5
+    xo2, y2 = _run(X, W1, b1, W2, b2, x, lw, lb, act, 0.5, ring)   # race screen
+    assert torch.equal(xo, xo2) and torch.equal(y, y2)
+
+
+@pytest.mark.parametrize('config,B,frames,chunk', [('aishell_u2pp', 4, (400, 700), -1),
+                                                   ('wenetspeech_u2pp', 3, (300, 500), 16)])
+def test_encoder_with_fused_ffn_matches_the_gemm_pair(config, B, frames, chunk):
+    """Whole encoder, fused FFN forced on a small batch (S = 16) against the two-GEMM
+    path: same arithmetic up to the split of the hidden sum."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=71)
+    try:
+        _lib.check(L.wn_tune_set(b'ffn_fused', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        ref = ref.cpu()
+        _lib.check(L.wn_tune_set(b'ffn_fused', 2), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got = got.cpu()
+    finally:
+        L.wn_tune_set(b'ffn_fused', 1)
+    err = (got - ref).abs().max().item()
+    print(f'\n[{config}] fused vs GEMM pair: max |d enc| {err:.2e}')
+    assert 0 < err < 2e-4 or err == 0.0

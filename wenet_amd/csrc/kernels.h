@@ -79,6 +79,27 @@ int attention_bf16(const AttnArgs& a, hipStream_t s);
 extern int g_attn_bf16;      // 1 (default): bf16 mode uses the bf16 attention kernel
 extern int g_attn_bf16_nw;   // 0 auto, else waves (32-query groups) per block
 
+// Fused feed-forward module, fp32 (ffn_fused.hip): P[s] (S, M, D) = partial
+// act(X W1^T + b1) W2^T over hidden slice s; ffn_reduce_ln then forms
+// x += alpha (sum_s P[s] + b2) and the following LayerNorm(s).
+struct FfnArgs {
+  const float* X;     // [M][D] = LayerNorm(x)
+  const float* W1;    // [F][D]
+  const float* b1;    // [F]
+  const float* W2;    // [D][F]
+  float* P;           // [S][M][D]
+  int M, D, F, S, act;
+};
+extern int g_ffn_fused, g_ffn_ring;
+int ffn_fused_split(int M, int F);
+bool ffn_fused_supported(int M, int D, int F, int act);
+int ffn_fused(const FfnArgs& a, hipStream_t s);
+// mode 0: x <- x_new, y <- LN(x_new; w, b); mode 1: x <- LN(x_new; w, b),
+// y <- LN(x; w2, b2); mode 2: x <- LN(x_new; w, b)
+int ffn_reduce_ln(float* x, const float* P, int S, const float* b2, float alpha,
+                  const float* w, const float* b, const float* w2, const float* bb2, float* y,
+                  int M, int D, float eps, int mode, hipStream_t s);
+
 // CTC head tail: per row log-softmax statistics + top-k (descending, lower
 // index first on ties) (+ optionally the full log-prob row).
 struct CtcRowArgs {

@@ -262,6 +262,7 @@ struct wn_model {
   std::vector<int> off, len;            // per utterance (rows layout)
   DevBuf d_off, d_len, d_row_utt, d_off1, d_len1, d_a_row_off;
   DevBuf c1, c2, x, t1, t2, hbuf, qkv, enc;
+  DevBuf ffn_part;                      // hidden-slice partials of the fused FFN
   DevBuf xpad, pos_rows, d_row_t, d_zero_rows;
   DevBuf ck_kv, ck_xext, ck_glu, ck_desc, ck_rowutt;  // forward_chunk scratch
   // Whisper log-mel: DFT / window tables (shared), mel matrix per bin count
@@ -293,6 +294,7 @@ struct wn_model {
   bool prof_on = false;
   unsigned prof_seq = 0;
   double prof_flops = 0.0;
+  const char* prof_kernel = "gemm (FFN w_1)";  // what the bracketed launches were
   int prec = PREC_F32;       // GEMM operand precision (wn_model_set_precision)
   // one host thread per handle: the workspace, the descriptor staging and the
   // current batch are per-handle state.  Entry points take this flag and fail
@@ -481,6 +483,40 @@ int ffn_module(wn_model* m, const Norm& nrm, const Linear& w1, const Linear& w2,
   return gemm_mxfp8(h, q2->q, s);
 }
 
+// fp32 fused feed-forward module (ffn_fused.hip): t1 = LN(x) is in place; leaves the
+// hidden-slice partials in m->ffn_part and returns S (0: shape not taken, caller runs
+// the two-GEMM path).  Every 6th launch is bracketed for the roofline (wn_profile_*).
+int ffn_fused_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStream_t s) {
+  const wn_config& c = m->cfg;
+  const int d = c.d_model, M = m->rows;
+  if (t_gemm_prec != PREC_F32 || g_ffn_fused == 0 || w1.out != w2.in ||
+      !ffn_fused_supported(M, d, w1.out, act))
+    return 0;
+  FfnArgs a;
+  a.X = m->t1.as<float>(); a.W1 = w1.w; a.b1 = w1.b; a.W2 = w2.w;
+  a.M = M; a.D = d; a.F = w1.out; a.S = ffn_fused_split(M, w1.out); a.act = act;
+  if (m->ffn_part.ensure((size_t)a.S * M * d * sizeof(float)) != 0) return -1;
+  a.P = m->ffn_part.as<float>();
+  const bool bracket = m->prof_on && (m->prof_seq++ % 6) == 0;
+  if (bracket) {
+    if (m->prof_used + 2 > m->prof_ev.size())
+      for (int i = 0; i < 64; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        m->prof_ev.push_back(e);
+      }
+    (void)hipEventRecord(m->prof_ev[m->prof_used], s);
+  }
+  if (ffn_fused(a, s) != 0) return -1;
+  if (bracket) {
+    (void)hipEventRecord(m->prof_ev[m->prof_used + 1], s);
+    m->prof_used += 2;
+    m->prof_flops += 4.0 * M * (double)w1.out * d;    // both contractions
+    m->prof_kernel = "ffn_fused_kernel (FFN w_1 + act + w_2)";
+  }
+  return a.S;
+}
+
 // ---- set the per-utterance row layout of the current batch -----------------
 int set_layout(wn_model* m, int B, int Tp, const std::vector<int>& off,
                const std::vector<int>& len, int rows, hipStream_t s) {
@@ -589,9 +625,23 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     const EncLayer& L = m->layers[li];
     // x += 0.5 * FFN_macaron(LN(x))                 encoder_layer.py:220-228
     // (for li > 0 the previous layer's tail already left LN(x) in t1)
-    WN_TRY(ffn_module(m, L.norm_ff_mac, L.ffm1, L.ffm2, ACT_SILU, 0.5f, li > 0, h16, s));
-    // x += MHA(LN(x))                               encoder_layer.py:230-238
-    WN_TRY(ln(L.norm_mha, x, t1, M, d, eps, s, h16));
+    // fp32: fused FFN (hidden tensor stays on chip), its partial reduction carries the
+    // residual add and the NEXT LayerNorm (norm_mha)
+    int fS = 0;
+    if (!h16 && t_gemm_prec == PREC_F32) {
+      if (li == 0) WN_TRY(ln(L.norm_ff_mac, x, t1, M, d, eps, s));
+      fS = ffn_fused_try(m, L.ffm1, L.ffm2, ACT_SILU, s);
+      if (fS < 0) return -2;
+    }
+    if (fS > 0) {
+      WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ffm2.b, 0.5f, L.norm_mha.w,
+                           L.norm_mha.b, nullptr, nullptr, t1, M, d, eps, 0, s));
+    } else {
+      WN_TRY(ffn_module(m, L.norm_ff_mac, L.ffm1, L.ffm2, ACT_SILU, 0.5f,
+                        li > 0 || (!h16 && t_gemm_prec == PREC_F32), h16, s));
+      // x += MHA(LN(x))                               encoder_layer.py:230-238
+      WN_TRY(ln(L.norm_mha, x, t1, M, d, eps, s, h16));
+    }
     WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s, ACT_NONE, nullptr, 0, 1.0f, false,
                   h16));
     AttnArgs a;
@@ -620,7 +670,27 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     WN_TRY(dwconv_ln_silu(dw, s));
     WN_TRY(linear(L.pw2, t1, d, x, d, M, s, ACT_NONE, x, d));
     // x += 0.5 * FFN(LN(x)); x = LN(x)              encoder_layer.py:253-263
-    WN_TRY(ffn_module(m, L.norm_ff, L.ff1, L.ff2, ACT_SILU, 0.5f, false, h16, s));
+    fS = 0;
+    if (!h16 && t_gemm_prec == PREC_F32) {
+      WN_TRY(ln(L.norm_ff, x, t1, M, d, eps, s));
+      fS = ffn_fused_try(m, L.ff1, L.ff2, ACT_SILU, s);
+      if (fS < 0) return -2;
+    }
+    if (fS > 0) {
+      // partial reduction + residual + norm_final (+ the next layer's norm_ff_macaron)
+      if (li + 1 < n_run) {
+        const EncLayer& Ln = m->layers[li + 1];
+        WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ff2.b, 0.5f, L.norm_final.w,
+                             L.norm_final.b, Ln.norm_ff_mac.w, Ln.norm_ff_mac.b, t1, M, d, eps,
+                             1, s));
+      } else {
+        WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ff2.b, 0.5f, L.norm_final.w,
+                             L.norm_final.b, nullptr, nullptr, nullptr, M, d, eps, 2, s));
+      }
+      continue;
+    }
+    WN_TRY(ffn_module(m, L.norm_ff, L.ff1, L.ff2, ACT_SILU, 0.5f,
+                      !h16 && t_gemm_prec == PREC_F32, h16, s));
     if (li + 1 < n_run) {
       const EncLayer& Ln = m->layers[li + 1];
       WN_TRY(layernorm2(x, L.norm_final.w, L.norm_final.b, Ln.norm_ff_mac.w,
@@ -1454,6 +1524,10 @@ int wn_profile_enable(wn_model* m, int32_t on) {
   return 0;
 }
 
+const char* wn_profile_kernel_name(const wn_model* m) {
+  return m ? m->prof_kernel : "";
+}
+
 int wn_profile_collect(wn_model* m, int32_t* n_launches, double* total_ms,
                        double* total_flops) {
   WN_CHECK(m && n_launches && total_ms && total_flops, "wn_profile_collect: null");
@@ -1495,6 +1569,8 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "bf16_store") g_bf16_store = value;
   else if (k == "attn_bf16_nw") g_attn_bf16_nw = value;
   else if (k == "fp8_min_tiles") g_fp8_min_tiles = value;
+  else if (k == "ffn_fused") g_ffn_fused = value;
+  else if (k == "ffn_ring") g_ffn_ring = value;
   else { set_error("wn_tune_set: unknown key " + k); return -1; }
   return 0;
 }
@@ -2274,6 +2350,24 @@ int wn_op_mx_quantize(const float* x, int32_t rows, int32_t K, void* q, void* sc
            "mx_quantize: null / empty / K % 128");
   return mx_quantize(x, K, rows, K, q, reinterpret_cast<unsigned*>(scale), rows,
                      (hipStream_t)stream);
+}
+
+int wn_op_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2,
+                    const float* b2, float* x, const float* ln_w, const float* ln_b,
+                    float* y, int32_t M, int32_t D, int32_t F, int32_t act, float alpha,
+                    float eps, void* stream) {
+  WN_CHECK(X && W1 && b1 && W2 && b2 && x && ln_w && ln_b && y, "ffn_fused: null argument");
+  WN_CHECK(M > 0 && (D == 256 || D == 512) && F > 0 && F % 64 == 0, "ffn_fused: shape");
+  const int S = ffn_fused_split(M, F);
+  WN_CHECK(S > 0, "ffn_fused: hidden size cannot be split for this M");
+  static thread_local DevBuf part;
+  WN_TRY(part.ensure((size_t)S * M * D * sizeof(float)));
+  FfnArgs a;
+  a.X = X; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.P = part.as<float>();
+  a.M = M; a.D = D; a.F = F; a.S = S; a.act = act;
+  WN_TRY(ffn_fused(a, (hipStream_t)stream));
+  return ffn_reduce_ln(x, part.as<float>(), S, b2, alpha, ln_w, ln_b, nullptr, nullptr, y, M,
+                       D, eps, 0, (hipStream_t)stream);
 }
 
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,
