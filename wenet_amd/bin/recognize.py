@@ -366,7 +366,13 @@ def main(argv=None):
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        # WN_BENCH_SHARE_GPU=1: every rank on one GPU (self-test of the N > 1 path on a
+        # 1-GPU box; RCCL refuses two ranks on one device, so the barriers run on gloo)
+        if os.environ.get('WN_BENCH_SHARE_GPU') == '1':
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
 
     with open(args.config, 'r') as fin:
         configs = yaml.load(fin, Loader=yaml.FullLoader)

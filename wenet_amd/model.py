@@ -75,10 +75,54 @@ def config_from_yaml(configs: dict) -> _lib.WnConfig:
             raise NotImplementedError(
                 f'encoder_conf.{k}={got!r} is outside the accelerated path '
                 f'(needs {v!r})')
+    # Keys that change the architecture and have no kernel here: any value other
+    # than the reference default (encoder.py:44-63,383-400,464-483, decoder.py:59-84)
+    # is refused instead of being decoded with the wrong network.
+    enc_only_default = dict(layer_norm_type='layer_norm', mlp_type='position_wise_feed_forward',
+                            final_norm=True, query_bias=True, value_bias=True, mlp_bias=True,
+                            n_kv_head=None, head_dim=None, n_expert=8,
+                            n_expert_activated=2, gradient_checkpointing=False,
+                            use_sdpa=False, positionwise_conv_kernel_size=1)
+    if enc_type == 'conformer':
+        enc_only_default.update(conv_bias=True, conv_inner_factor=2, key_bias=True,
+                                conv_norm_eps=ec.get('norm_eps', 1e-5))
+    for k, v in enc_only_default.items():
+        if k in ec and ec[k] != v and not (k in ('use_sdpa', 'gradient_checkpointing')):
+            raise NotImplementedError(
+                f'encoder_conf.{k}={ec[k]!r} is outside the accelerated path '
+                f'(only the reference default {v!r} has kernels)')
+    dec_default = dict(normalize_before=True, src_attention=True, query_bias=True,
+                       key_bias=True, value_bias=True, mlp_bias=True, n_kv_head=None,
+                       head_dim=None, layer_norm_type='layer_norm',
+                       mlp_type='position_wise_feed_forward', tie_word_embedding=False,
+                       use_output_layer=True)
+    if enc_type == 'conformer':
+        dec_default.update(activation_type='relu', input_layer='embed')
+    dec_off = False   # Whisper-style decoders: the encoder (+ CTC head) runs, not the decoder
+    for k, v in dec_default.items():
+        if k in dc and dc[k] != v:
+            if enc_type == 'transformer':
+                dec_off = True
+                continue
+            raise NotImplementedError(
+                f'decoder_conf.{k}={dc[k]!r} is outside the accelerated path '
+                f'(only the reference default {v!r} has kernels)')
+    # asr_model.py:46,321-323: the encoder output is filtered to the non-blank frames
+    # before attention_rescoring -- not built here
+    if (configs.get('model_conf') or {}).get('apply_non_blank_embedding', False):
+        raise NotImplementedError(
+            'model_conf.apply_non_blank_embedding=True is outside the accelerated path '
+            '(filter_blank_embedding, asr_model.py:240-252, is not built)')
     vocab = configs['output_dim']
     st = (configs.get('tokenizer_conf') or {}).get('special_tokens')
-    sos = vocab - 1 if st is None else st.get('<sos>', vocab - 1)
-    eos = vocab - 1 if st is None else st.get('<eos>', vocab - 1)
+    if model_type == 'whisper':
+        # Whisper.__init__ (models/whisper/whisper.py:45-52): sos / eos are the
+        # tokenizer's 'sot' / 'eot'
+        sos = vocab - 1 if st is None else st.get('sot', vocab - 1)
+        eos = vocab - 1 if st is None else st.get('eot', vocab - 1)
+    else:
+        sos = vocab - 1 if st is None else st.get('<sos>', vocab - 1)
+        eos = vocab - 1 if st is None else st.get('<eos>', vocab - 1)
     dec_type = configs.get('decoder', 'bitransformer')
     bidir = dec_type == 'bitransformer'
     c = _lib.WnConfig()
@@ -114,7 +158,7 @@ def config_from_yaml(configs: dict) -> _lib.WnConfig:
         c.cnn_kernel, c.causal = 1, 0
         # the Whisper decoder (learnable positions, tied embedding) is not on
         # the accelerated path: encoder (+ CTC head) only
-        if dc.get('input_layer', 'embed') != 'embed' or \
+        if dec_off or dc.get('input_layer', 'embed') != 'embed' or \
                 dc.get('activation_type', 'relu') != 'relu':
             c.dec_layers = c.dec_r_layers = 0
             c.bidirectional = 0
@@ -363,12 +407,13 @@ class ASRModel:
         time = xs.size(1)
         chunk = ((time - 1) // 2 - 1) // 2
         L, H, d = cfg.n_layers, cfg.n_heads, cfg.d_model
+        dk2 = 2 * d // H       # att_cache holds K | V per head (attention.py:226-234)
         lorder = cfg.cnn_kernel - 1 if cfg.causal else 0
         t1 = 0
         att_ptr = None
         if att_cache is not None and att_cache.numel() > 0:
             _require_cuda(att_cache, 'forward_encoder_chunk(att_cache)')
-            assert tuple(att_cache.shape[:2]) == (L, H) and att_cache.size(3) == 128
+            assert tuple(att_cache.shape[:2]) == (L, H) and att_cache.size(3) == dk2
             att_cache = att_cache.detach().to(torch.float32).contiguous()
             t1 = att_cache.size(2)
             att_ptr = att_cache.data_ptr()
@@ -386,7 +431,7 @@ class ASRModel:
         else:
             start = max(key - required_cache_size, 0)
         ys = torch.empty((1, chunk, d), dtype=torch.float32, device=self.device)
-        new_att = torch.empty((L, H, key - start, 128), dtype=torch.float32,
+        new_att = torch.empty((L, H, key - start, dk2), dtype=torch.float32,
                               device=self.device)
         if lorder > 0:
             new_cnn = torch.empty((L, 1, d, lorder), dtype=torch.float32,
