@@ -38,6 +38,15 @@ def ref_fbank(waveform: np.ndarray, num_bins: int = 80, sample_rate: int = 16000
     return out[:got]
 
 
+def has_whisper_frontend() -> bool:
+    if not available():
+        return False
+    try:
+        return hasattr(ctypes.CDLL(LIB_PATH), 'ref_whisper_fbank')
+    except OSError:
+        return False
+
+
 def has_wav_reader() -> bool:
     """The built library exports ref_wav_read (a library built before that entry
     point existed does not: rebuild with `make -C oracle`)."""
@@ -64,3 +73,33 @@ def ref_wav_read(path: str):
                          ctypes.byref(sr), ctypes.byref(bits))
     assert n >= 0, f'ref_wav_read failed ({n})'
     return out[:n], ch.value, sr.value, bits.value
+
+
+def ref_whisper_fbank(waveform: np.ndarray, num_bins: int = 80) -> np.ndarray:
+    """The reference C++ frontend in its Whisper configuration (feature_pipeline.h:64-72)
+    on a float waveform in [-1, 1] -> (T, num_bins)."""
+    lib = ctypes.CDLL(LIB_PATH)
+    x = np.ascontiguousarray(np.asarray(waveform, dtype=np.float32) * 32768.0)
+    max_frames = max(1, 1 + (len(x) - 400) // 160) if len(x) >= 400 else 1
+    out = np.zeros((max_frames, num_bins), dtype=np.float32)
+    lib.ref_whisper_fbank.restype = ctypes.c_int
+    lib.ref_whisper_fbank.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_int]
+    n = lib.ref_whisper_fbank(x.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(x),
+                              num_bins, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                              max_frames)
+    assert n >= 0
+    return out[:n]
+
+
+def ref_slaney_filters(num_bins: int = 80):
+    """(weights (num_bins, 256) on the 512-point FFT grid, periodic Hanning window (400,))
+    of the reference C++ frontend's Whisper configuration."""
+    lib = ctypes.CDLL(LIB_PATH)
+    w = np.zeros((num_bins, 256), dtype=np.float32)
+    win = np.zeros((400, ), dtype=np.float32)
+    lib.ref_slaney_filters.restype = None
+    lib.ref_slaney_filters.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ref_slaney_filters(num_bins, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                           win.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return w, win

@@ -269,9 +269,10 @@ def slaney_mel_filters(sr: int = 16000, n_fft: int = 400, n_mels: int = 80) -> n
     Slaney's Auditory-Toolbox scale, linear below 1 kHz, log above, area
     normalisation 2 / (f[i+2] - f[i])).  The reference's in-tree C++ frontend
     builds the same triangles (runtime/core/frontend/fbank.h:113-134,179-210),
-    but for a 512-point FFT, so it cannot pin this 400-point matrix: the
-    filter matrix itself is parity-UNPINNED (tests check its defining
-    properties only)."""
+    on a 512-point FFT grid: tests/test_oracle.py pins THIS function evaluated at
+    n_fft = 512 against the reference C++ filter bank (oracle/_ref), i.e. the scale,
+    the triangle construction and the area normalisation; only the evaluation grid
+    of the 400-point matrix (201 bins at 40 Hz) is not covered by reference code."""
     f_sp = 200.0 / 3
     min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
     min_log_mel = min_log_hz / f_sp
@@ -318,10 +319,35 @@ def log_mel_spectrogram(waveform: np.ndarray, num_mel_bins: int = 80,
     magnitudes = stft[..., :-1].abs()**2
     filters = torch.from_numpy(slaney_mel_filters(sample_rate, n_fft, num_mel_bins))
     mel_spec = filters @ magnitudes
+    return whisper_log_norm(mel_spec).transpose(0, 1).contiguous().numpy()
+
+
+def whisper_log_norm(mel_spec: torch.Tensor) -> torch.Tensor:
+    """processor.py:364-367: log10 with floor 1e-10, clamp to (max - 8), (x + 4) / 4 --
+    the reference C++ frontend's log + WhisperNorm (frontend/fbank.h:236-247,303-312),
+    against which tests/test_oracle.py pins it."""
     log_spec = torch.clamp(mel_spec, min=1e-10).log10()
     log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
-    log_spec = (log_spec + 4.0) / 4.0
-    return log_spec.transpose(0, 1).contiguous().numpy()
+    return (log_spec + 4.0) / 4.0
+
+
+def whisper_frontend_512(waveform: np.ndarray, num_mel_bins: int = 80) -> np.ndarray:
+    """The log-mel chain of log_mel_spectrogram assembled the way the reference's C++
+    frontend runs it in its Whisper configuration (frontend/feature_pipeline.h:64-72,
+    fbank.h:250-327): snip-edges frames of 400 samples, per-frame DC removal (the C++
+    default), periodic Hann window, zero-padded 512-point FFT, power of bins 0..255,
+    Slaney filters on that grid, then whisper_log_norm.  Built from the SAME pieces
+    (torch.hann_window, slaney_mel_filters, whisper_log_norm) so that the reference C++
+    output pins them; the 400-point STFT framing of the Python path is not pinnable."""
+    x = torch.as_tensor(np.asarray(waveform, dtype=np.float32))
+    n = 1 + (x.numel() - 400) // 160
+    frames = x.unfold(0, 400, 160)[:n].clone()
+    frames = frames - frames.mean(1, keepdim=True)
+    frames = frames * torch.hann_window(400)
+    spec = torch.fft.rfft(F.pad(frames, (0, 112)), dim=1)
+    power = (spec.real ** 2 + spec.imag ** 2)[:, :256]
+    filt = torch.from_numpy(slaney_mel_filters(16000, 512, num_mel_bins))[:, :256]
+    return whisper_log_norm(filt @ power.t()).t().contiguous().numpy()
 
 
 def resample(waveform: np.ndarray, orig_freq: int, new_freq: int = 16000) -> np.ndarray:

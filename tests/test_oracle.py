@@ -6,6 +6,7 @@
   * and, when /root/reference is present, against the live reference.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -669,3 +670,43 @@ def test_mx_quantize_rule_known_answers():
     r = O.mx_round(y)
     assert torch.equal(O.mx_round(r), r)
     assert ((r - y).abs() <= 0.0625 * y.abs() + 2.0 ** -9 * y.abs().amax()).all()
+
+
+def test_slaney_filters_window_and_whisper_norm_pinned_by_the_reference_cpp_frontend():
+    """SURVEY 8a3 / VERDICT item 9: the pieces of compute_log_mel_spectrogram the
+    reference tree CAN pin.  tests/golden/whisperfb_*.npz hold the output of the
+    reference's own C++ frontend in its Whisper configuration
+    (frontend/feature_pipeline.h:64-72, fbank.h:100-134,157-162,236-247), built by
+    oracle/Makefile, and its Slaney filter bank / periodic Hanning window.  The
+    oracle's slaney_mel_filters (evaluated on that 512-point grid), its window and
+    its log10 / floor / max-8 / (x+4)/4 normalisation reproduce them; what stays
+    unpinned is only the 400-point STFT framing of the Python path."""
+    from golden_util import GOLDEN_DIR
+    from wenet_amd import synthetic as S
+    z = np.load(os.path.join(GOLDEN_DIR, 'whisperfb_filters.npz'))
+    for bins, key in ((80, 'w80'), (128, 'w128')):
+        mine = O.slaney_mel_filters(16000, 512, bins)[:, :256]
+        assert np.abs(mine - z[key]).max() < 1e-6 * z[key].max() * 10
+        assert (np.abs(z[key]).sum(1) > 0).all()
+    assert np.abs(torch.hann_window(400).numpy() - z['window']).max() < 1e-6
+    for name in ('a', 'b'):
+        g = np.load(os.path.join(GOLDEN_DIR, f'whisperfb_{name}.npz'))
+        wave = np.asarray(S.make_audio(int(g['n']), seed=int(g['seed'])), dtype=np.float32)
+        mine = O.whisper_frontend_512(wave, int(g['bins']))
+        assert mine.shape == g['feat'].shape
+        assert np.abs(mine - g['feat']).max() < 2e-4, name
+    # the Python-path function is built from the same pieces
+    x = torch.rand(80, 50) * 3
+    assert torch.equal(O.whisper_log_norm(x),
+                       (torch.maximum(x.clamp(min=1e-10).log10(),
+                                      x.clamp(min=1e-10).log10().max() - 8.0) + 4.0) / 4.0)
+
+
+def test_whisper_frontend_pins_live_against_oracle_ref():
+    from oracle import ref_fbank
+    if not ref_fbank.has_whisper_frontend():
+        pytest.skip('oracle/_ref not built with the Whisper frontend (make -C oracle)')
+    from wenet_amd import synthetic as S
+    wave = np.asarray(S.make_audio(16000 * 2 + 123, seed=9), dtype=np.float32)
+    ref = ref_fbank.ref_whisper_fbank(wave, 80)
+    assert np.abs(O.whisper_frontend_512(wave, 80) - ref).max() < 2e-4
