@@ -284,6 +284,18 @@ int wn_decoder_forward(wn_model* m, int32_t utt, int32_t which, int32_t n_seq,
                        const int32_t* tokens_host, const int32_t* lens_host,
                        int32_t max_len, float* logp_dev, void* stream);
 
+/* attention_beam_search (search.py:252-371, the non-Whisper branch) over the CURRENT batch
+ * (its encoder output is on the device after wn_encode / wn_set_encoder_out): B x beam
+ * running hypotheses, one decoder row per hypothesis and step
+ * (TransformerDecoder.forward_one_step, decoder.py:226-281, with a self-attention K/V
+ * cache and the cross-attention K/V projected once), mask_finished_scores / _preds, the
+ * N x N -> N re-ranking, the end flags and the final length-penalised arg-max all run on
+ * the device; scores are fp32 like the reference's.  maxlen = the reference's
+ * encoder_out.size(1).  tokens_host is (B, maxlen) int32 (the winner without <sos> /
+ * <eos>), lens_host (B,).  beam <= 16. */
+int wn_attention_beam_search(wn_model* m, int32_t beam, int32_t maxlen, float length_penalty,
+                             int32_t* tokens_host, int32_t* lens_host, void* stream);
+
 /* One step of attention_beam_search (search.py:252-371): for every running
  * hypothesis (its utterance index in the current batch, its tokens so far
  * starting with <sos>), log_softmax(output_layer(after_norm(decoder(...)[:, -1])))

@@ -13,7 +13,7 @@ def case_names(prefix=''):
     return sorted(
         os.path.basename(p)[:-4]
         for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + '*.npz'))
-        if not os.path.basename(p).startswith(('fbank', 'whisperenc', 'stream_', 'attn_', 'ctx', 'chunk_',
+        if not os.path.basename(p).startswith(('fbank', 'whisper', 'stream_', 'attn_', 'ctx', 'chunk_',
                                                  'cmvn_', 'bench_')))
 
 

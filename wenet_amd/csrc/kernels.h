@@ -197,6 +197,21 @@ int logmel_power(const float* spec, float* pw, int rows, hipStream_t s);
 int logmel_finish(float* mel, int n_mels, const int* frame_off, const int* n_frames,
                   float* umax, int B, int max_frames, float* feats, hipStream_t s);
 
+// `attention` decode mode, device side (attn_search.hip)
+int attn_step_embed(const int* last_tok, int pos, const float* emb, const float* pe,
+                    float scale, int d, int n, float* x, hipStream_t s);
+int attn_self_step(const float* qkv, int d, int heads, int n, float* cache, int step,
+                   const int* path, int max_len, float* out, hipStream_t s);
+int attn_beam_init(int BN, int N, int max_len, int sos, float* score, int* end, int* tok,
+                   int* path, int* last_tok, hipStream_t s);
+int attn_beam_update(int B, int N, int step, int max_len, int eos, const float* topv,
+                     const int* topi, const float* score_in, const int* end_in,
+                     const int* tok_in, const int* path_in, float* score_out, int* end_out,
+                     int* tok_out, int* path_out, int* last_tok, int* n_done, hipStream_t s);
+int attn_beam_finish(int B, int N, int len, int max_len, int eos, float length_penalty,
+                     const float* score, const int* tok, int* out_tok, int* out_len,
+                     hipStream_t s);
+
 // rows scatter/gather helpers
 // forward_chunk cache plumbing (see encoder_kernels.hip)
 int chunk_kv_assemble(const float* cache, int t1, const float* qkv, int R, int H,

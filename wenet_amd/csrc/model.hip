@@ -284,6 +284,7 @@ struct wn_model {
   DevBuf r_tok, r_rtok, r_pos, r_tgt, r_rtgt, r_qoff, r_qlen, r_kvoff, r_kvlen;
   DevBuf r_x, r_t1, r_t2, r_qkv, r_h, r_mem, r_logits, r_out;
   DevBuf r_mem_all;            // per-layer cross-attention K/V of the current batch
+  DevBuf ab_cache, ab_state;   // `attention` mode: self-attention K|V cache, beam state
   bool mem_cache_valid = false;
 
   Stager stage;
@@ -2115,6 +2116,134 @@ int wn_decoder_next_topk(wn_model* m, int32_t n_seq, const int32_t* seq_utt_host
   WN_HIP(hipMemcpyAsync(idx_host, ti, (size_t)n_seq * topk * sizeof(int),
                         hipMemcpyDeviceToHost, s));
   WN_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// attention_beam_search (search.py:252-371) for the current batch, entirely on the
+// device: one decoder row per running hypothesis and step (self-attention K/V cache
+// addressed through per-hypothesis ancestor paths, cross-attention K/V projected once),
+// beam bookkeeping in beam_update_kernel; the host only reads the "all ended" counter.
+int wn_attention_beam_search(wn_model* m, int32_t beam, int32_t maxlen, float length_penalty,
+                             int32_t* tokens_host, int32_t* lens_host, void* stream) {
+  WN_CHECK(m && m->B > 0 && m->enc.p, "attention beam search: no current batch");
+  WN_ENTER(m);
+  PrecisionScope prec_scope(m);
+  WN_CHECK(!m->left.layers.empty(), "attention beam search: the model has no attention decoder");
+  WN_CHECK(beam >= 1 && beam <= 16 && maxlen >= 1 && tokens_host && lens_host,
+           "attention beam search: beam_size in [1, 16], maxlen >= 1");
+  hipStream_t s = (hipStream_t)stream;
+  WN_HIP(hipSetDevice(m->device));
+  const wn_config& c = m->cfg;
+  const Decoder& D = m->left;
+  const int d = c.d_model, V = c.vocab, B = m->B, N = beam, BN = B * N, Menc = m->rows;
+  WN_CHECK(beam <= V, "attention beam search: beam larger than the vocabulary");
+  WN_CHECK(maxlen + 1 <= c.max_pos, "attention beam search: longer than the positional table");
+  const int W = maxlen + 2;                       // columns of the token / path rows
+  const int nl = (int)D.layers.size();
+  for (int b = 0; b < B; ++b)
+    WN_CHECK(m->len[b] > 0, "attention beam search: utterance without encoder frames");
+  // ---- descriptors of the cross attention: one query row per hypothesis -------------
+  std::vector<int> qoff(BN), qlen(BN, 1), kvoff(BN), kvlen(BN);
+  for (int r = 0; r < BN; ++r) { qoff[r] = r; kvoff[r] = m->off[r / N]; kvlen[r] = m->len[r / N]; }
+  WN_TRY(m->stage.begin((size_t)(4 * BN + 64) * sizeof(int) + 4096));
+  WN_TRY(upload_desc(m, m->r_qoff, qoff, s));
+  WN_TRY(upload_desc(m, m->r_qlen, qlen, s));
+  WN_TRY(upload_desc(m, m->r_kvoff, kvoff, s));
+  WN_TRY(upload_desc(m, m->r_kvlen, kvlen, s));
+  WN_TRY(m->stage.end(s));
+  WN_TRY(m->r_x.ensure((size_t)BN * d * sizeof(float)));
+  WN_TRY(m->r_t1.ensure((size_t)BN * d * sizeof(float)));
+  WN_TRY(m->r_t2.ensure((size_t)BN * d * sizeof(float)));
+  WN_TRY(m->r_qkv.ensure((size_t)BN * 3 * d * sizeof(float)));
+  WN_TRY(m->r_h.ensure((size_t)BN * c.dec_ffn_dim * sizeof(float)));
+  WN_TRY(m->r_logits.ensure((size_t)BN * V * sizeof(float)));
+  WN_TRY(m->r_out.ensure((size_t)2 * BN * N * sizeof(float)));
+  const size_t cache_layer = (size_t)maxlen * BN * 2 * d;
+  WN_TRY(m->ab_cache.ensure(nl * cache_layer * sizeof(float)));
+  const size_t mem_layer = (size_t)Menc * 2 * d;
+  WN_TRY(m->r_mem_all.ensure(nl * mem_layer * sizeof(float)));
+  // state: 2 x {score, end, tok, path} + last_tok + n_done + out_tok + out_len
+  const size_t n_int = (size_t)2 * (BN + BN + (size_t)BN * W * 2) + BN + 16 + (size_t)B * W + B;
+  WN_TRY(m->ab_state.ensure(n_int * sizeof(int)));
+  int* base = m->ab_state.as<int>();
+  float* score[2]; int* endf[2]; int* tok[2]; int* path[2];
+  for (int k = 0; k < 2; ++k) {
+    score[k] = reinterpret_cast<float*>(base); base += BN;
+    endf[k] = base; base += BN;
+    tok[k] = base; base += (size_t)BN * W;
+    path[k] = base; base += (size_t)BN * W;
+  }
+  int* last_tok = base; base += BN;
+  int* n_done = base; base += 16;
+  int* out_tok = base; base += (size_t)B * W;
+  int* out_len = base;
+  WN_TRY(attn_beam_init(BN, N, W, c.sos, score[0], endf[0], tok[0], path[0], last_tok, s));
+  WN_HIP(hipMemsetAsync(n_done, 0, sizeof(int), s));
+  float* x = m->r_x.as<float>();
+  float* t1 = m->r_t1.as<float>();
+  float* t2 = m->r_t2.as<float>();
+  float* qkv = m->r_qkv.as<float>();
+  float* hb = m->r_h.as<float>();
+  float* tv = m->r_out.as<float>();
+  int* ti = reinterpret_cast<int*>(tv + (size_t)BN * N);
+  const float eps = c.norm_eps;
+  int cur = 0, len = 1, done_host = 0;
+  for (int i = 1; i <= maxlen; ++i) {
+    if (done_host == BN) break;
+    const int step = i - 1;                       // position of the newest token
+    WN_TRY(attn_step_embed(last_tok, step, D.embed, D.pe, sqrtf((float)d), d, BN, x, s));
+    for (int li = 0; li < nl; ++li) {
+      const DecLayer& L = D.layers[li];
+      WN_TRY(ln(L.n1, x, t1, BN, d, eps, s));
+      WN_TRY(linear(L.self_qkv, t1, d, qkv, 3 * d, BN, s));
+      WN_TRY(attn_self_step(qkv, d, c.dec_heads, BN, m->ab_cache.as<float>() + li * cache_layer,
+                            step, path[cur], W, t2, s));
+      WN_TRY(linear(L.self_out, t2, d, x, d, BN, s, ACT_NONE, x, d));
+      WN_TRY(ln(L.n2, x, t1, BN, d, eps, s));
+      WN_TRY(linear(L.src_q, t1, d, t2, d, BN, s));
+      float* mem = m->r_mem_all.as<float>() + (size_t)li * mem_layer;
+      if (!m->mem_cache_valid) WN_TRY(linear(L.src_kv, m->enc.as<float>(), d, mem, 2 * d, Menc, s));
+      AttnArgs cx;
+      cx.Q = t2; cx.ldq = d; cx.K = mem; cx.V = mem + d; cx.ldk = cx.ldv = 2 * d;
+      cx.O = t1; cx.ldo = d;
+      cx.q_off = m->r_qoff.as<int>(); cx.q_len = m->r_qlen.as<int>();
+      cx.kv_off = m->r_kvoff.as<int>(); cx.kv_len = m->r_kvlen.as<int>();
+      cx.n_seq = BN; cx.n_heads = c.dec_heads; cx.max_q_len = 1;
+      cx.mask_mode = 0; cx.scale = 0.125f;
+      WN_TRY(attention(cx, s));
+      WN_TRY(linear(L.src_out, t1, d, x, d, BN, s, ACT_NONE, x, d));
+      WN_TRY(ln(L.n3, x, t1, BN, d, eps, s));
+      WN_TRY(linear(L.ff1, t1, d, hb, c.dec_ffn_dim, BN, s, ACT_RELU));
+      WN_TRY(linear(L.ff2, hb, c.dec_ffn_dim, x, d, BN, s, ACT_NONE, x, d));
+    }
+    m->mem_cache_valid = true;
+    // log_softmax(output_layer(after_norm(x))) -> the N best (log-prob, token) per row
+    WN_TRY(ln(D.after, x, t1, BN, d, eps, s));
+    WN_TRY(linear(D.out, t1, d, m->r_logits.as<float>(), V, BN, s));
+    CtcRowArgs r;
+    r.logits = m->r_logits.as<float>(); r.ld = V; r.M = BN; r.V = V; r.k = N;
+    r.blank = -1; r.blank_penalty = 0.f;
+    r.topk_val = tv; r.topk_idx = ti; r.logp = nullptr; r.ld_out = V;
+    WN_TRY(ctc_logsoftmax_topk(r, s));
+    WN_HIP(hipMemsetAsync(n_done, 0, sizeof(int), s));
+    WN_TRY(attn_beam_update(B, N, i, W, c.eos, tv, ti, score[cur], endf[cur], tok[cur],
+                            path[cur], score[cur ^ 1], endf[cur ^ 1], tok[cur ^ 1],
+                            path[cur ^ 1], last_tok, n_done, s));
+    cur ^= 1;
+    len = i + 1;
+    WN_HIP(hipMemcpyAsync(&done_host, n_done, sizeof(int), hipMemcpyDeviceToHost, s));
+    WN_HIP(hipStreamSynchronize(s));
+  }
+  WN_TRY(attn_beam_finish(B, N, len, W, c.eos, length_penalty, score[cur], tok[cur], out_tok,
+                          out_len, s));
+  std::vector<int> ot((size_t)B * W), ol(B);
+  WN_HIP(hipMemcpyAsync(ot.data(), out_tok, ot.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  WN_HIP(hipMemcpyAsync(ol.data(), out_len, ol.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  WN_HIP(hipStreamSynchronize(s));
+  for (int b = 0; b < B; ++b) {
+    lens_host[b] = std::min(ol[b], maxlen);
+    for (int j = 0; j < lens_host[b]; ++j) tokens_host[(size_t)b * maxlen + j] = ot[(size_t)b * W + j];
+  }
   return 0;
 }
 

@@ -207,68 +207,20 @@ def rescore_from_logps(hyps_per_utt, ctc_scores_per_utt, times_per_utt,
 def attention_beam_search(model, batch_size: int, maxlen: int, beam_size: int = 10,
                           length_penalty: float = 0.0) -> List[DecodeResult]:
     """attention_beam_search (wenet/models/transformer/search.py:252-371, the
-    non-Whisper branch) over the model's CURRENT batch (the encoder output of
-    the last `_decode_begin` / `_forward_encoder` stays on the device).  Every
-    step asks the library for the `beam_size` best next tokens of all B*N
-    running hypotheses (wn_decoder_next_topk); the beam bookkeeping below is the
-    reference's, on fp32 torch CPU tensors like the reference's own scores."""
-    import ctypes
-    L = _lib.lib()
-    device = model.device
-    running = batch_size * beam_size
-    sos, eos = model.sos, model.eos
-    hyps = torch.ones([running, 1], dtype=torch.long).fill_(sos)
-    scores = torch.tensor([0.0] + [-float('inf')] * (beam_size - 1),
-                          dtype=torch.float).repeat([batch_size]).unsqueeze(1)
-    end_flag = torch.zeros_like(scores, dtype=torch.bool)
-    seq_utt = np.repeat(np.arange(batch_size, dtype=np.int32), beam_size)
-    logp = np.zeros((running, beam_size), dtype=np.float32)
-    idx = np.zeros((running, beam_size), dtype=np.int32)
-    for i in range(1, maxlen + 1):
-        if end_flag.sum() == running:
-            break
-        toks = np.ascontiguousarray(hyps.numpy().astype(np.int32))
-        lens = np.full((running, ), i, dtype=np.int32)
-        _lib.check(
-            L.wn_decoder_next_topk(model._h, running, _lib.i32p(seq_utt),
-                                   _lib.i32p(lens), _lib.i32p(toks), i, beam_size,
-                                   _lib.f32p(logp), _lib.i32p(idx),
-                                   _stream_ptr(device)), 'wn_decoder_next_topk')
-        top_k_logp = torch.from_numpy(logp.copy())
-        top_k_index = torch.from_numpy(idx.astype(np.int64))
-        # mask_finished_scores / mask_finished_preds (utils/mask.py:258-304)
-        if beam_size > 1:
-            zero = torch.zeros_like(end_flag)
-            unfinished = torch.cat((zero, end_flag.repeat([1, beam_size - 1])), dim=1)
-            finished = torch.cat((end_flag, zero.repeat([1, beam_size - 1])), dim=1)
-        else:
-            unfinished, finished = torch.zeros_like(end_flag), end_flag
-        top_k_logp.masked_fill_(unfinished, -float('inf'))
-        top_k_logp.masked_fill_(finished, 0)
-        top_k_index.masked_fill_(end_flag.repeat([1, beam_size]), eos)
-        scores = (scores + top_k_logp).view(batch_size, beam_size * beam_size)
-        scores, offset_k_index = scores.topk(k=beam_size)
-        scores = scores.view(-1, 1)
-        base_k_index = torch.arange(batch_size).view(-1, 1).repeat(
-            [1, beam_size]) * beam_size * beam_size
-        best_k_index = base_k_index.view(-1) + offset_k_index.view(-1)
-        best_k_pred = torch.index_select(top_k_index.view(-1), dim=-1,
-                                         index=best_k_index)
-        best_hyps_index = best_k_index // beam_size
-        hyps = torch.cat((torch.index_select(hyps, dim=0, index=best_hyps_index),
-                          best_k_pred.view(-1, 1)), dim=1)
-        end_flag = torch.eq(hyps[:, -1], eos).view(-1, 1)
-    scores = scores.view(batch_size, beam_size)
-    lengths = hyps.ne(eos).sum(dim=1).view(batch_size, beam_size).float()
-    scores = scores / lengths.pow(length_penalty)
-    _, best_index = scores.max(dim=-1)
-    best_hyps_index = best_index + torch.arange(batch_size, dtype=torch.long) * beam_size
-    best_hyps = torch.index_select(hyps, dim=0, index=best_hyps_index)[:, 1:]
-    results = []
-    for b in range(batch_size):
-        hyp = best_hyps[b]
-        results.append(DecodeResult(hyp[hyp != eos].tolist()))
-    return results
+    non-Whisper branch) over the model's CURRENT batch (the encoder output of the last
+    `_decode_begin` / `_forward_encoder` stays on the device).  The whole search --
+    one decoder step per token with a self-attention cache, the finished-hypothesis
+    masks, the beam x beam re-ranking and the length-penalised arg-max -- runs on the
+    device (wn_attention_beam_search); this function only shapes the result."""
+    assert maxlen >= 1
+    tokens = np.zeros((batch_size, maxlen), dtype=np.int32)
+    lens = np.zeros((batch_size, ), dtype=np.int32)
+    _lib.check(
+        _lib.lib().wn_attention_beam_search(model._h, beam_size, maxlen,
+                                            float(length_penalty), _lib.i32p(tokens),
+                                            _lib.i32p(lens), _stream_ptr(model.device)),
+        'wn_attention_beam_search')
+    return [DecodeResult(tokens[b, :lens[b]].tolist()) for b in range(batch_size)]
 
 
 def attention_rescoring(model,
