@@ -201,6 +201,22 @@ int wn_encode_chunk(wn_model* m, const float* feats_dev, int32_t time, int32_t o
                     float* new_att_cache_dev, float* new_cnn_cache_dev,
                     int32_t* chunk_out, int32_t* new_cache_t1_out, void* stream);
 
+/* The same for n_sess streaming sessions in ONE call (the reference's
+ * batched formulation is wenet/bin/export_onnx_gpu.py:83-232): feats_dev (n_sess, time,
+ * feat_dim) -- every session contributes a window of the same length --, offsets_host /
+ * cache_t1_host [n_sess] (sessions may be at different positions and hold caches of
+ * different lengths), att_cache_dev / cnn_cache_dev / new_*_dev: host arrays of n_sess
+ * device pointers, each tensor in the per-session layout above (entry NULL where that
+ * session has none).  out_dev (n_sess, chunk, d_model); new_cache_t1_out [n_sess].
+ * Every GEMM / LayerNorm runs on the n_sess * chunk rows at once; session b's attention
+ * reads only its own [cache | chunk] keys at positions offset_b - cache_t1_b ... */
+int wn_encode_chunk_batch(wn_model* m, int32_t n_sess, const float* feats_dev, int32_t time,
+                          const int32_t* offsets_host, int32_t required_cache_size,
+                          const float* const* att_cache_dev, const int32_t* cache_t1_host,
+                          const float* const* cnn_cache_dev, float* out_dev,
+                          float* const* new_att_cache_dev, float* const* new_cnn_cache_dev,
+                          int32_t* chunk_out, int32_t* new_cache_t1_out, void* stream);
+
 /* Use caller-provided padded encoder output (B, Tp, d_model) + lengths as the
  * current batch (for the reference's free functions that take encoder_out). */
 int wn_set_encoder_out(wn_model* m, const float* enc_out_dev,

@@ -1129,3 +1129,78 @@ def test_busy_handle_is_refused_not_corrupted():
                 want['ctc_prefix_beam_search'][b].tokens
             assert g['ctc_prefix_beam_search'][b].nbest_scores == \
                 want['ctc_prefix_beam_search'][b].nbest_scores
+
+
+def test_forward_encoder_chunk_batch_equals_single_sessions():
+    """B streaming sessions per forward_chunk call.  Sessions at
+    DIFFERENT positions with caches of DIFFERENT lengths (one of them on its first
+    chunk) go through wn_encode_chunk_batch together; every session's output and new
+    caches equal the single-session call (same kernels per row, so to fp32 GEMM-tile
+    reordering) and the oracle's forward_chunk."""
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('tiny_causal', 1)
+    B, step_frames, required = 4, 19, 6
+    feats = [S.make_features(1, (400, 400), seed=300 + b)[0] for b in range(B)]
+    # bring the sessions to different states: session b has already consumed b chunks
+    att = [None] * B
+    cnn = [None] * B
+    o_att = [None] * B
+    o_cnn = [None] * B
+    offset = [0] * B
+    cur = [0] * B
+    for b in range(B):
+        for _ in range(b):
+            win = feats[b][:, cur[b]:cur[b] + step_frames]
+            y, att[b], cnn[b] = model.forward_encoder_chunk(win.cuda(), offset[b], required,
+                                                            att[b], cnn[b])
+            _, o_att[b], o_cnn[b] = O.forward_chunk(configs, sd, win, offset[b], required,
+                                                    o_att[b], o_cnn[b])
+            offset[b] += y.size(1)
+            cur[b] += 4 * y.size(1)
+    assert len({(a.size(2) if a is not None else 0) for a in att}) > 2   # ragged caches
+    for _ in range(3):                               # three batched steps
+        wins = torch.cat([feats[b][:, cur[b]:cur[b] + step_frames] for b in range(B)])
+        ys, natt, ncnn = model.forward_encoder_chunk_batch(wins.cuda(), offset, required, att,
+                                                           cnn)
+        for b in range(B):
+            y1, a1, c1 = model.forward_encoder_chunk(wins[b:b + 1].cuda(), offset[b], required,
+                                                     att[b], cnn[b])
+            assert (ys[b] - y1[0]).abs().max().item() < 1e-4
+            assert tuple(natt[b].shape) == tuple(a1.shape)
+            assert (natt[b] - a1).abs().max().item() < 1e-4
+            assert (ncnn[b] - c1).abs().max().item() < 1e-4
+            oy, o_att[b], o_cnn[b] = O.forward_chunk(configs, sd, wins[b:b + 1], offset[b],
+                                                     required, o_att[b], o_cnn[b])
+            assert (ys[b].cpu() - oy[0]).abs().max().item() < 2e-3
+            assert (natt[b].cpu() - o_att[b]).abs().max().item() < 2e-3
+            assert (ncnn[b].cpu() - o_cnn[b]).abs().max().item() < 2e-3
+        att, cnn = natt, ncnn
+        for b in range(B):
+            offset[b] += ys.size(1)
+            cur[b] += 4 * ys.size(1)
+
+
+def test_forward_encoder_chunk_batch_aishell_16_sessions():
+    """The AIShell 12-layer model, 16 sessions, chunk 16 (67-frame windows), caches
+    limited to 32 frames: batched == single session per row."""
+    from wenet_amd import synthetic as S
+    configs, sd, model = cached_model('aishell_u2pp', 0)
+    B, win_frames, required = 16, 67, 32
+    feats, _ = S.make_features(B, (300, 300), seed=77)
+    att = [None] * B
+    cnn = [None] * B
+    offset = [0] * B
+    cur = 0
+    for step in range(3):
+        wins = feats[:, cur:cur + win_frames].cuda()
+        ys, natt, ncnn = model.forward_encoder_chunk_batch(wins, offset, required, att, cnn)
+        for b in (0, 7, 15):
+            y1, a1, c1 = model.forward_encoder_chunk(wins[b:b + 1], offset[b], required, att[b],
+                                                     cnn[b])
+            assert (ys[b] - y1[0]).abs().max().item() < 2e-4, (step, b)
+            assert (natt[b] - a1).abs().max().item() < 2e-4
+            assert (ncnn[b] - c1).abs().max().item() < 2e-4
+        att, cnn = natt, ncnn
+        offset = [o + ys.size(1) for o in offset]
+        cur += 4 * ys.size(1)

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
   if (q0 >= qlen) return;
   const int kvlen = a.kv_len[s];
   const int qoff = a.q_off[s], kvoff = a.kv_off[s];
+  const int p_off = a.p_off ? a.p_off[s] : 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
         rK[i] = *reinterpret_cast<const f32x4*>(a.K + (int64_t)(kvoff + j) * a.ldk +
                                                 h * 64 + c4 * 4);
         if (RELPOS)
-          rP[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)j * a.ldp + h * 64 +
+          rP[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)(j + p_off) * a.ldp + h * 64 +
                                                   c4 * 4);
       }
     }

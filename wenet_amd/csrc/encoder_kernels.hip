@@ -330,6 +330,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
   if (q0 >= qlen) return;
   const int kvlen = a.kv_len[s];
   const int qoff = a.q_off[s], kvoff = a.kv_off[s];
+  const int p_off = a.p_off ? a.p_off[s] : 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform
   const int wave = wave_all % NW;   // query group
@@ -412,8 +413,8 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
       rK[i] = *reinterpret_cast<const f32x4*>(a.K + grow * a.ldk + h * 64 + c4 * 4);
       rV[i] = *reinterpret_cast<const f32x4*>(a.V + grow * a.ldv + h * 64 + c4 * 4);
       if (RELPOS)
-        rP[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)j * a.ldp + h * 64 +
-                                                c4 * 4);
+        rP[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)(j + p_off) * a.ldp +
+                                                h * 64 + c4 * 4);
     }
   };
   auto lstore = [&](int buf) {  // KS == 1: buffer index; KS == 2: ignored
@@ -762,9 +763,11 @@ namespace {
 // (K | V) floats.  Writes the contiguous [Tk][2d] K|V rows the attention
 // kernel reads and, for frames >= next_start, the new cache slice
 // (heads, new_t1, 128) of this layer (attention.py:207-215, encoder.py:271-279).
-__global__ void chunk_kv_kernel(const float* cache, int t1, const float* qkv, int R,
-                                int H, float* kv, float* new_cache, int next_start) {
-  const int d = H * 64, Tk = t1 + R;
+__global__ void chunk_kv_kernel(const ChunkSess* __restrict__ sess, int layer,
+                                const float* __restrict__ qkv, int R, int H,
+                                float* __restrict__ kv) {
+  const ChunkSess ss = sess[blockIdx.y];
+  const int t1 = ss.t1, d = H * 64, Tk = t1 + R;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Tk * H * 32) return;
   const int e = i & 31, h = (i >> 5) % H, j = i / (32 * H);
@@ -772,50 +775,56 @@ __global__ void chunk_kv_kernel(const float* cache, int t1, const float* qkv, in
   const int c = h * 64 + (e & 15) * 4;
   f32x4 v;
   if (j < t1)
-    v = *reinterpret_cast<const f32x4*>(cache + ((int64_t)h * t1 + j) * 128 + e * 4);
+    v = *reinterpret_cast<const f32x4*>(ss.att_cache + ((int64_t)layer * H * t1 +
+                                                         (int64_t)h * t1 + j) * 128 + e * 4);
   else
-    v = *reinterpret_cast<const f32x4*>(qkv + (int64_t)(j - t1) * 3 * d +
+    v = *reinterpret_cast<const f32x4*>(qkv + ((int64_t)blockIdx.y * R + (j - t1)) * 3 * d +
                                         (is_v ? 2 * d : d) + c);
-  *reinterpret_cast<f32x4*>(kv + (int64_t)j * 2 * d + (is_v ? d : 0) + c) = v;
-  if (j >= next_start) {
-    const int nt = Tk - next_start;
-    *reinterpret_cast<f32x4*>(new_cache + ((int64_t)h * nt + (j - next_start)) * 128 +
-                              e * 4) = v;
+  *reinterpret_cast<f32x4*>(kv + ((int64_t)ss.kv_off + j) * 2 * d + (is_v ? d : 0) + c) = v;
+  if (j >= ss.next_start) {
+    const int nt = ss.nt;
+    *reinterpret_cast<f32x4*>(ss.new_att + ((int64_t)layer * H * nt + (int64_t)h * nt +
+                                            (j - ss.next_start)) * 128 + e * 4) = v;
   }
 }
 
 // Causal convolution input with its left context (convolution.py:121-130):
 // rows [0, lorder) come from the cache ((d, lorder) channel-major; zeros for
 // the first chunk), rows lorder.. are the chunk; the last lorder rows are the
-// new cache.
-__global__ void chunk_conv_in_kernel(const float* cache, const float* x, int R, int d,
-                                     int lorder, float* xext, float* new_cache) {
+// new cache.  Session b owns rows b * (lorder + R) .. of xext.
+__global__ void chunk_conv_in_kernel(const ChunkSess* __restrict__ sess, int layer,
+                                     const float* __restrict__ x, int R, int d, int lorder,
+                                     float* __restrict__ xext) {
+  const ChunkSess ss = sess[blockIdx.y];
+  const int LR = lorder + R;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (lorder + R) * d) return;
+  if (i >= LR * d) return;
   const int row = i / d, c = i - row * d;
+  const float* cache = ss.cnn_cache ? ss.cnn_cache + (int64_t)layer * d * lorder : nullptr;
   const float v = row < lorder ? (cache ? cache[(int64_t)c * lorder + row] : 0.f)
-                               : x[(int64_t)(row - lorder) * d + c];
-  xext[i] = v;
-  if (row >= R) new_cache[(int64_t)c * lorder + (row - R)] = v;
+                               : x[((int64_t)blockIdx.y * R + (row - lorder)) * d + c];
+  xext[(int64_t)blockIdx.y * LR * d + i] = v;
+  if (row >= R)
+    ss.new_cnn[(int64_t)layer * d * lorder + (int64_t)c * lorder + (row - R)] = v;
 }
 }  // namespace
 
-int chunk_kv_assemble(const float* cache, int t1, const float* qkv, int R, int H,
-                      float* kv, float* new_cache, int next_start, hipStream_t s) {
-  const int n = (t1 + R) * H * 32;
-  WN_CHECK(R > 0 && H > 0 && t1 >= 0 && (t1 == 0 || cache), "chunk kv: bad argument");
-  hipLaunchKernelGGL(chunk_kv_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, cache, t1,
-                     qkv, R, H, kv, new_cache, next_start);
+int chunk_kv_assemble(const ChunkSess* sess, int n_sess, int layer, int max_tk,
+                      const float* qkv, int R, int H, float* kv, hipStream_t s) {
+  WN_CHECK(R > 0 && H > 0 && n_sess > 0 && max_tk >= R, "chunk kv: bad argument");
+  const int n = max_tk * H * 32;
+  hipLaunchKernelGGL(chunk_kv_kernel, dim3(cdiv(n, 256), n_sess), dim3(256), 0, s, sess, layer,
+                     qkv, R, H, kv);
   WN_HIP(hipGetLastError());
   return 0;
 }
 
-int chunk_conv_input(const float* cache, const float* x, int R, int d, int lorder,
-                     float* xext, float* new_cache, hipStream_t s) {
-  WN_CHECK(R > 0 && lorder > 0, "chunk conv: bad argument");
+int chunk_conv_input(const ChunkSess* sess, int n_sess, int layer, const float* x, int R,
+                     int d, int lorder, float* xext, hipStream_t s) {
+  WN_CHECK(R > 0 && lorder > 0 && n_sess > 0, "chunk conv: bad argument");
   const int n = (lorder + R) * d;
-  hipLaunchKernelGGL(chunk_conv_in_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, cache,
-                     x, R, d, lorder, xext, new_cache);
+  hipLaunchKernelGGL(chunk_conv_in_kernel, dim3(cdiv(n, 256), n_sess), dim3(256), 0, s, sess,
+                     layer, x, R, d, lorder, xext);
   WN_HIP(hipGetLastError());
   return 0;
 }

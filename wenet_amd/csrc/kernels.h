@@ -62,6 +62,7 @@ struct AttnArgs {
   const float* Q; const float* K; const float* V;
   int ldq, ldk, ldv;
   const float* P = nullptr; int ldp = 0;      // [T][h*64] projected pos table
+  const int* p_off = nullptr;  // [n_seq] or null: key j of sequence s uses row p_off[s] + j
   const float* bias_u = nullptr; const float* bias_v = nullptr;  // [h][64]
   float* O; int ldo;
   const int* q_off; const int* q_len;   // [n_seq]
@@ -213,11 +214,20 @@ int attn_beam_finish(int B, int N, int len, int max_len, int eos, float length_p
                      hipStream_t s);
 
 // rows scatter/gather helpers
-// forward_chunk cache plumbing (see encoder_kernels.hip)
-int chunk_kv_assemble(const float* cache, int t1, const float* qkv, int R, int H,
-                      float* kv, float* new_cache, int next_start, hipStream_t s);
-int chunk_conv_input(const float* cache, const float* x, int R, int d, int lorder,
-                     float* xext, float* new_cache, hipStream_t s);
+// forward_chunk cache plumbing (see encoder_kernels.hip), one descriptor per streaming
+// session of the call.  The cache tensors keep the reference's per-session layouts:
+// att (n_layers, heads, t1, 128), cnn (n_layers, 1, d, lorder).
+struct ChunkSess {
+  const float* att_cache;   // null iff t1 == 0
+  float* new_att;           // (n_layers, heads, nt, 128)
+  const float* cnn_cache;   // null: zeros (first chunk)
+  float* new_cnn;
+  int t1, next_start, nt, kv_off;   // kv_off: first row of this session in the K|V buffer
+};
+int chunk_kv_assemble(const ChunkSess* sess, int n_sess, int layer, int max_tk,
+                      const float* qkv, int R, int H, float* kv, hipStream_t s);
+int chunk_conv_input(const ChunkSess* sess, int n_sess, int layer, const float* x, int R,
+                     int d, int lorder, float* xext, hipStream_t s);
 int copy_rows(const float* src, int lds, const int* src_rows, float* dst,
               int ldd, const int* dst_rows, int n_rows, int D, hipStream_t s);
 int fill_zero(void* p, size_t bytes, hipStream_t s);

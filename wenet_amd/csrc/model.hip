@@ -264,7 +264,7 @@ struct wn_model {
   DevBuf c1, c2, x, t1, t2, hbuf, qkv, enc;
   DevBuf ffn_part;                      // hidden-slice partials of the fused FFN
   DevBuf xpad, pos_rows, d_row_t, d_zero_rows;
-  DevBuf ck_kv, ck_xext, ck_glu, ck_desc, ck_rowutt;  // forward_chunk scratch
+  DevBuf ck_kv, ck_xext, ck_glu, ck_desc, ck_rowutt, ck_sess;  // forward_chunk scratch
   // Whisper log-mel: DFT / window tables (shared), mel matrix per bin count
   std::shared_ptr<DevBuf> lm_dft = std::make_shared<DevBuf>();
   // resampler taps per (orig, new) rate pair (wn_resample)
@@ -710,36 +710,59 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
   return 0;
 }
 
-// The Conformer layers over ONE chunk of R frames with the streaming caches
-// (ConformerEncoderLayer.forward with att_cache / cnn_cache, encoder_layer.py:
-// 188-265, driven by BaseEncoder.forward_chunk, encoder.py:246-285).  Same
-// kernels as encoder_layers; attention sees [cache | chunk] keys with the
-// position rows offset - t1 ..., the causal convolution sees its cached left
+// The Conformer layers over ONE chunk of R frames of n_sess streaming sessions with their
+// caches (ConformerEncoderLayer.forward with att_cache / cnn_cache, encoder_layer.py:
+// 188-265, driven by BaseEncoder.forward_chunk, encoder.py:246-285; batched formulation:
+// wenet/bin/export_onnx_gpu.py:83-232).  Same kernels as encoder_layers on n_sess * R rows;
+// session b's attention sees its [cache | chunk] keys (ragged: cache lengths differ) with
+// the position rows offset_b - t1_b ..., its causal convolution sees its cached left
 // context.  All masks are the all-ones fakes of forward_chunk.
-int encoder_layers_chunk(wn_model* m, int R, int offset, int t1c, int next_start,
-                         const float* att_cache, const float* cnn_cache,
-                         float* new_att, float* new_cnn, float* out, hipStream_t s) {
+int encoder_layers_chunk(wn_model* m, int n_sess, int R, const int* offsets,
+                         std::vector<ChunkSess>& sess, float* out, hipStream_t s) {
   const wn_config& c = m->cfg;
-  const int d = c.d_model, H = c.n_heads, M = R;
+  const int d = c.d_model, H = c.n_heads, M = n_sess * R;
   const int lorder = c.causal ? c.cnn_kernel - 1 : 0;
-  const int Tk = t1c + R, nt = Tk - next_start, LR = lorder + R;
+  const int LR = lorder + R;
   float* x = m->x.as<float>();
   float* t1 = m->t1.as<float>();
   float* t2 = m->t2.as<float>();
   float* hb = m->hbuf.as<float>();
   float* qkv = m->qkv.as<float>();
   const float eps = c.norm_eps;
-  WN_TRY(m->ck_kv.ensure((size_t)Tk * 2 * d * sizeof(float)));
-  WN_TRY(m->ck_xext.ensure((size_t)LR * d * sizeof(float)));
-  WN_TRY(m->ck_glu.ensure((size_t)LR * d * sizeof(float)));
-  // descriptors: [0] = 0 (row offset), [1] = R, [2] = Tk, [3] = LR; row->utt = 0
-  const std::vector<int> desc = {0, R, Tk, LR};
-  const std::vector<int> rowutt(LR, 0);
-  WN_TRY(m->stage.begin((size_t)(LR + 64) * sizeof(int) + 1024));
-  WN_TRY(upload_desc(m, m->ck_desc, desc, s));
+  // descriptors: attention (queries R per session, ragged keys), conv (LR rows per session)
+  std::vector<int> qoff(n_sess), qlen(n_sess, R), kvoff(n_sess), kvlen(n_sess), poff(n_sess),
+      coff(n_sess), clen(n_sess, LR), rowutt((size_t)n_sess * LR);
+  std::vector<int64_t> pw2_rows((size_t)M);
+  int total_kv = 0, max_tk = 0;
+  for (int b = 0; b < n_sess; ++b) {
+    const int tk = sess[b].t1 + R;
+    qoff[b] = b * R;
+    kvoff[b] = total_kv; kvlen[b] = tk;
+    sess[b].kv_off = total_kv;
+    total_kv += tk; max_tk = std::max(max_tk, tk);
+    // key j of this call sits at position offset - t1 + j   encoder.py:256-257
+    poff[b] = offsets[b] - sess[b].t1;
+    coff[b] = b * LR;
+    for (int r = 0; r < LR; ++r) rowutt[(size_t)b * LR + r] = b;
+    for (int r = 0; r < R; ++r) pw2_rows[(size_t)b * R + r] = ((int64_t)b * LR + lorder + r) * d;
+  }
+  WN_TRY(m->ck_kv.ensure((size_t)total_kv * 2 * d * sizeof(float)));
+  WN_TRY(m->ck_xext.ensure((size_t)n_sess * LR * d * sizeof(float)));
+  WN_TRY(m->ck_glu.ensure((size_t)n_sess * LR * d * sizeof(float)));
+  WN_TRY(m->stage.begin((size_t)(n_sess * (LR + 8) + 64) * sizeof(int) +
+                        (size_t)M * sizeof(int64_t) + n_sess * sizeof(ChunkSess) + 4096));
+  WN_TRY(upload_desc(m, m->ck_desc, qoff, s));
+  WN_TRY(upload_desc(m, m->r_qlen, qlen, s));
+  WN_TRY(upload_desc(m, m->r_kvoff, kvoff, s));
+  WN_TRY(upload_desc(m, m->r_kvlen, kvlen, s));
+  WN_TRY(upload_desc(m, m->r_pos, poff, s));
+  WN_TRY(upload_desc(m, m->r_qoff, coff, s));
+  WN_TRY(upload_desc(m, m->r_tgt, clen, s));
   WN_TRY(upload_desc(m, m->ck_rowutt, rowutt, s));
+  WN_TRY(m->stage.put(m->d_a_row_off, pw2_rows.data(), pw2_rows.size() * sizeof(int64_t), s));
+  WN_TRY(m->stage.put(m->ck_sess, sess.data(), sess.size() * sizeof(ChunkSess), s));
   WN_TRY(m->stage.end(s));
-  const int* dd = m->ck_desc.as<int>();
+  const ChunkSess* dsess = m->ck_sess.as<ChunkSess>();
   float* kv = m->ck_kv.as<float>();
   float* xext = m->ck_xext.as<float>();
   float* glu = m->ck_glu.as<float>();
@@ -751,40 +774,45 @@ int encoder_layers_chunk(wn_model* m, int R, int offset, int t1c, int next_start
     // attention over [cached | new] keys             attention.py:180-245,364-438
     WN_TRY(ln(L.norm_mha, x, t1, M, d, eps, s));
     WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s));
-    WN_TRY(chunk_kv_assemble(att_cache ? att_cache + (size_t)li * H * t1c * 128 : nullptr,
-                             t1c, qkv, R, H, kv, new_att + (size_t)li * H * nt * 128,
-                             next_start, s));
+    WN_TRY(chunk_kv_assemble(dsess, n_sess, li, max_tk, qkv, R, H, kv, s));
     AttnArgs a;
     a.Q = qkv; a.ldq = 3 * d;
     a.K = kv; a.V = kv + d; a.ldk = a.ldv = 2 * d;
-    // key j of this call sits at position offset - t1 + j   encoder.py:256-257
-    a.P = L.pos_tab + (size_t)(offset - t1c) * d; a.ldp = d;
+    a.P = L.pos_tab; a.ldp = d; a.p_off = m->r_pos.as<int>();
     a.bias_u = L.bias_u; a.bias_v = L.bias_v;
     a.O = t2; a.ldo = d;
-    a.q_off = dd; a.q_len = dd + 1; a.kv_off = dd; a.kv_len = dd + 2;
-    a.n_seq = 1; a.n_heads = H; a.max_q_len = R;
+    a.q_off = m->ck_desc.as<int>(); a.q_len = m->r_qlen.as<int>();
+    a.kv_off = m->r_kvoff.as<int>(); a.kv_len = m->r_kvlen.as<int>();
+    a.n_seq = n_sess; a.n_heads = H; a.max_q_len = R;
     a.mask_mode = 0;
     a.scale = 1.0f / sqrtf(64.0f);
     WN_TRY(attention(a, s));
     WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d));
     // convolution module with its left-context cache  convolution.py:98-153
     WN_TRY(ln(L.norm_conv, x, t1, M, d, eps, s));
-    const float* conv_in = t1;
     if (lorder > 0) {
-      WN_TRY(chunk_conv_input(cnn_cache ? cnn_cache + (size_t)li * d * lorder : nullptr,
-                              t1, R, d, lorder, xext, new_cnn + (size_t)li * d * lorder, s));
-      conv_in = xext;
+      WN_TRY(chunk_conv_input(dsess, n_sess, li, t1, R, d, lorder, xext, s));
+      WN_TRY(linear(L.pw1, xext, d, glu, d, n_sess * LR, s, ACT_NONE, nullptr, 0, 1.0f, true));
+    } else {
+      WN_TRY(linear(L.pw1, t1, d, glu, d, M, s, ACT_NONE, nullptr, 0, 1.0f, true));
     }
-    WN_TRY(linear(L.pw1, conv_in, d, glu, d, LR, s, ACT_NONE, nullptr, 0, 1.0f, true));
     DwConvArgs dw;
     dw.x = glu; dw.ldx = d; dw.wt = L.dw_wt; dw.bias = L.dw_b; dw.cpad = L.cpad;
     dw.ln_w = L.conv_norm.w; dw.ln_b = L.conv_norm.b; dw.norm_mode = c.cnn_norm;
     dw.y = xext; dw.ldy = d;
-    dw.row_utt = m->ck_rowutt.as<int>(); dw.off = dd; dw.len = dd + 3;
-    dw.M = LR; dw.D = d; dw.K = c.cnn_kernel; dw.causal = c.causal;
+    dw.row_utt = m->ck_rowutt.as<int>(); dw.off = m->r_qoff.as<int>();
+    dw.len = m->r_tgt.as<int>();
+    dw.M = n_sess * LR; dw.D = d; dw.K = c.cnn_kernel; dw.causal = c.causal;
     dw.t_max = LR; dw.eps = 1e-5f;
     WN_TRY(dwconv_ln_silu(dw, s));
-    WN_TRY(linear(L.pw2, xext + (size_t)lorder * d, d, x, d, M, s, ACT_NONE, x, d));
+    {
+      // pointwise_conv2 on the chunk rows of every session (rows lorder.. of its segment)
+      GemmArgs g;
+      g.A = xext; g.W = L.pw2.w; g.bias = L.pw2.b; g.C = x; g.resid = x;
+      g.M = M; g.N = d; g.K = d; g.lda = d; g.ldc = d; g.ldr = d;
+      g.a_row_off = m->d_a_row_off.as<int64_t>(); g.conv_C = d;
+      WN_TRY(gemm_f32(g, s));
+    }
     WN_TRY(ln(L.norm_ff, x, t1, M, d, eps, s));
     WN_TRY(linear(L.ff1, t1, d, hb, c.ffn_dim, M, s, ACT_SILU));
     WN_TRY(linear(L.ff2, hb, c.ffn_dim, x, d, M, s, ACT_NONE, x, d, 0.5f));
@@ -1629,45 +1657,69 @@ int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host
   return 0;
 }
 
-int wn_encode_chunk(wn_model* m, const float* feats_dev, int32_t time, int32_t offset,
-                    int32_t required_cache_size, const float* att_cache_dev,
-                    int32_t cache_t1, const float* cnn_cache_dev, float* out_dev,
-                    float* new_att_cache_dev, float* new_cnn_cache_dev,
-                    int32_t* chunk_out, int32_t* new_cache_t1_out, void* stream) {
-  WN_CHECK(m && feats_dev && out_dev, "wn_encode_chunk: null argument");
+int wn_encode_chunk_batch(wn_model* m, int32_t n_sess, const float* feats_dev, int32_t time,
+                          const int32_t* offsets_host, int32_t required_cache_size,
+                          const float* const* att_cache_dev, const int32_t* cache_t1_host,
+                          const float* const* cnn_cache_dev, float* out_dev,
+                          float* const* new_att_cache_dev, float* const* new_cnn_cache_dev,
+                          int32_t* chunk_out, int32_t* new_cache_t1_out, void* stream) {
+  WN_CHECK(m && feats_dev && out_dev && offsets_host && cache_t1_host && n_sess >= 1,
+           "wn_encode_chunk: null argument");
   WN_ENTER(m);
   PrecisionScope prec_scope(m);
   WN_CHECK(!m->layers.empty() && m->cfg.encoder_type == 0,
            "wn_encode_chunk: needs a Conformer encoder");
   WN_CHECK(time >= 7, "wn_encode_chunk: at least 7 frames are needed by Conv2dSubsampling4");
-  WN_CHECK(offset >= 0 && cache_t1 >= 0 && cache_t1 <= offset,
-           "wn_encode_chunk: need 0 <= cache_t1 <= offset");
-  WN_CHECK(cache_t1 == 0 || att_cache_dev, "wn_encode_chunk: att_cache is null");
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));
   const wn_config& c = m->cfg;
   const int R = ((time - 1) / 2 - 1) / 2;
-  const int key = cache_t1 + R;
-  // encoder.py:258-263
-  const int next_start = required_cache_size < 0 ? 0
-                         : required_cache_size == 0 ? key
-                         : std::max(key - required_cache_size, 0);
-  const int nt = key - next_start;
   const int lorder = c.causal ? c.cnn_kernel - 1 : 0;
-  WN_CHECK(nt == 0 || new_att_cache_dev, "wn_encode_chunk: new_att_cache is null");
-  WN_CHECK(lorder == 0 || new_cnn_cache_dev, "wn_encode_chunk: new_cnn_cache is null");
-  WN_CHECK(offset + R <= c.max_pos, "wn_encode_chunk: offset beyond the positional table");
-  const int32_t len = time;
-  WN_TRY(subsample_conv2d4(m, feats_dev, &len, 1, time, nullptr, offset, s));
-  WN_CHECK(m->rows == R, "wn_encode_chunk: internal row count");
-  // nt == 0: the kernel writes no cache rows, any non-null pointer will do
-  float* natt = new_att_cache_dev ? new_att_cache_dev : out_dev;
-  WN_TRY(encoder_layers_chunk(m, R, offset, cache_t1, next_start, att_cache_dev,
-                              cnn_cache_dev, natt, new_cnn_cache_dev, out_dev, s));
+  std::vector<ChunkSess> sess(n_sess);
+  std::vector<int32_t> lens(n_sess, time);
+  for (int b = 0; b < n_sess; ++b) {
+    const int offset = offsets_host[b], t1c = cache_t1_host[b];
+    WN_CHECK(offset >= 0 && t1c >= 0 && t1c <= offset,
+             "wn_encode_chunk: need 0 <= cache_t1 <= offset");
+    WN_CHECK(t1c == 0 || (att_cache_dev && att_cache_dev[b]), "wn_encode_chunk: att_cache is null");
+    WN_CHECK(offset + R <= c.max_pos, "wn_encode_chunk: offset beyond the positional table");
+    const int key = t1c + R;
+    // encoder.py:258-263
+    const int next_start = required_cache_size < 0 ? 0
+                           : required_cache_size == 0 ? key
+                           : std::max(key - required_cache_size, 0);
+    const int nt = key - next_start;
+    WN_CHECK(nt == 0 || (new_att_cache_dev && new_att_cache_dev[b]),
+             "wn_encode_chunk: new_att_cache is null");
+    WN_CHECK(lorder == 0 || (new_cnn_cache_dev && new_cnn_cache_dev[b]),
+             "wn_encode_chunk: new_cnn_cache is null");
+    ChunkSess& ss = sess[b];
+    ss.att_cache = t1c > 0 ? att_cache_dev[b] : nullptr;
+    // nt == 0: the kernel writes no cache rows, any non-null pointer will do
+    ss.new_att = nt > 0 ? new_att_cache_dev[b] : out_dev;
+    ss.cnn_cache = (cnn_cache_dev && lorder > 0) ? cnn_cache_dev[b] : nullptr;
+    ss.new_cnn = lorder > 0 ? new_cnn_cache_dev[b] : nullptr;
+    ss.t1 = t1c; ss.next_start = next_start; ss.nt = nt; ss.kv_off = 0;
+    if (new_cache_t1_out) new_cache_t1_out[b] = nt;
+  }
+  WN_TRY(subsample_conv2d4(m, feats_dev, lens.data(), n_sess, time, nullptr,
+                           offsets_host[0], s));
+  WN_CHECK(m->rows == n_sess * R, "wn_encode_chunk: internal row count");
+  WN_TRY(encoder_layers_chunk(m, n_sess, R, offsets_host, sess, out_dev, s));
   m->rows = 0; m->B = 0;  // the handle holds no decodable batch after a chunk call
   if (chunk_out) *chunk_out = R;
-  if (new_cache_t1_out) *new_cache_t1_out = nt;
   return 0;
+}
+
+int wn_encode_chunk(wn_model* m, const float* feats_dev, int32_t time, int32_t offset,
+                    int32_t required_cache_size, const float* att_cache_dev,
+                    int32_t cache_t1, const float* cnn_cache_dev, float* out_dev,
+                    float* new_att_cache_dev, float* new_cnn_cache_dev,
+                    int32_t* chunk_out, int32_t* new_cache_t1_out, void* stream) {
+  return wn_encode_chunk_batch(m, 1, feats_dev, time, &offset, required_cache_size,
+                               &att_cache_dev, &cache_t1, &cnn_cache_dev, out_dev,
+                               &new_att_cache_dev, &new_cnn_cache_dev, chunk_out,
+                               new_cache_t1_out, stream);
 }
 
 int wn_set_encoder_out(wn_model* m, const float* enc_out_dev,

@@ -448,6 +448,79 @@ class ASRModel:
             'wn_encode_chunk')
         return ys, new_att, new_cnn
 
+    def forward_encoder_chunk_batch(self, xs: torch.Tensor, offsets, required_cache_size: int,
+                                    att_caches=None, cnn_caches=None):
+        """B streaming sessions in ONE forward_chunk (the reference's
+        batched formulation is wenet/bin/export_onnx_gpu.py:83-232).  xs (B, time, mel):
+        every session's window of this step (same length); offsets[b]: encoder frames
+        session b has emitted; att_caches[b] / cnn_caches[b]: that session's caches in
+        the reference's single-session layouts ((elayers, head, cache_t1_b, d_k * 2) --
+        lengths may differ between sessions -- and (elayers, 1, hidden, lorder)), None /
+        empty for a first chunk.  Returns (ys (B, chunk, hidden), [new_att_cache_b],
+        [new_cnn_cache_b]); row b equals forward_encoder_chunk on session b alone."""
+        import ctypes
+        cfg = self._cfg
+        if cfg.encoder_type != 0:
+            raise NotImplementedError('forward_encoder_chunk: Conformer encoders only')
+        _require_cuda(xs, 'forward_encoder_chunk_batch')
+        assert xs.dim() == 3 and xs.size(0) == len(offsets)
+        B = xs.size(0)
+        xs = xs.detach().to(torch.float32).contiguous()
+        time = xs.size(1)
+        chunk = ((time - 1) // 2 - 1) // 2
+        L, H, d = cfg.n_layers, cfg.n_heads, cfg.d_model
+        dk2 = 2 * d // H
+        lorder = cfg.cnn_kernel - 1 if cfg.causal else 0
+        att_caches = list(att_caches) if att_caches is not None else [None] * B
+        cnn_caches = list(cnn_caches) if cnn_caches is not None else [None] * B
+        keep, t1s, att_ptrs, cnn_ptrs = [], [], [], []
+        for b in range(B):
+            a, cc = att_caches[b], cnn_caches[b]
+            if a is not None and a.numel() > 0:
+                _require_cuda(a, 'forward_encoder_chunk_batch(att_cache)')
+                assert tuple(a.shape[:2]) == (L, H) and a.size(3) == dk2
+                a = a.detach().to(torch.float32).contiguous()
+                keep.append(a)
+                t1s.append(a.size(2)); att_ptrs.append(a.data_ptr())
+            else:
+                t1s.append(0); att_ptrs.append(None)
+            if cc is not None and cc.numel() > 0:
+                _require_cuda(cc, 'forward_encoder_chunk_batch(cnn_cache)')
+                assert tuple(cc.shape) == (L, 1, d, lorder)
+                cc = cc.detach().to(torch.float32).contiguous()
+                keep.append(cc)
+                cnn_ptrs.append(cc.data_ptr())
+            else:
+                cnn_ptrs.append(None)
+        new_att, new_cnn = [], []
+        for b in range(B):
+            key = t1s[b] + chunk
+            if required_cache_size < 0:
+                start = 0
+            elif required_cache_size == 0:
+                start = key
+            else:
+                start = max(key - required_cache_size, 0)
+            new_att.append(torch.empty((L, H, key - start, dk2), dtype=torch.float32,
+                                       device=self.device))
+            new_cnn.append(torch.empty((L, 1, d, lorder), dtype=torch.float32,
+                                       device=self.device) if lorder > 0 else
+                           torch.zeros((L, 0, 0, 0), dtype=torch.float32, device=self.device))
+        ys = torch.empty((B, chunk, d), dtype=torch.float32, device=self.device)
+        vp = ctypes.c_void_p
+        arr = lambda ptrs: (vp * B)(*[vp(p) if p else vp(None) for p in ptrs])  # noqa: E731
+        offs = np.asarray(list(offsets), dtype=np.int32)
+        t1a = np.asarray(t1s, dtype=np.int32)
+        _lib.check(
+            self._L.wn_encode_chunk_batch(
+                self._h, B, xs.data_ptr(), time, _lib.i32p(offs), int(required_cache_size),
+                arr(att_ptrs), _lib.i32p(t1a), arr(cnn_ptrs), ys.data_ptr(),
+                arr([t.data_ptr() if t.numel() else None for t in new_att]),
+                arr([t.data_ptr() if lorder > 0 else None for t in new_cnn]),
+                None, None, _stream_ptr(self.device)), 'wn_encode_chunk_batch')
+        del keep
+        return ys, new_att, new_cnn
+
     def forward_encoder_chunk_by_chunk(self, xs: torch.Tensor, decoding_chunk_size: int,
                                        num_decoding_left_chunks: int = -1
                                        ) -> Tuple[torch.Tensor, torch.Tensor]:
