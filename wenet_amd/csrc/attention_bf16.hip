@@ -22,9 +22,13 @@
 // With 16x the MFMA rate the softmax VALU work (16 scores per lane and tile)
 // bounds the kernel; NW grows with the sequence length so that the fp32 K / V
 // stream from L2 is shared by more queries (64 B/clk/CU budget).
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace wn {
+
+extern int g_attn_bf16_sub;
 
 namespace {
 
@@ -43,8 +47,14 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   return r;
 }
 
-template <int NW, bool RELPOS>
+// SUB: 32-key sub-tiles staged per barrier (2 doubles the MFMA work and the prefetch lead
+// per __syncthreads for long sequences); IN16: Q / K / V are bf16 matrices in HBM (written
+// by the QKV GEMM of the bf16-storage form; ld* in bf16 elements) -- half the K / V
+// stream, no conversion on the way into LDS.  Same arithmetic: the kernel rounds Q, K, V
+// to bf16 first thing anyway.
+template <int NW, bool RELPOS, int SUB = 1, bool IN16 = false>
 __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attention_bf16_kernel(AttnArgs a) {
+  static_assert(!(IN16 && RELPOS), "bf16 Q/K/V: plain attention only (q + bias_u is rounded once)");
   const int s = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (NW * 32);
   const int qlen = a.q_len[s];
@@ -61,13 +71,21 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
   constexpr int KMAT = KT * KSTR;        // bf16 elements
   constexpr int VMAT = 64 * VSTR;
   constexpr int BUF = KMAT + VMAT + (RELPOS ? KMAT : 0);
-  __shared__ __attribute__((aligned(16))) __bf16 stile[2 * BUF];
+  __shared__ __attribute__((aligned(16))) __bf16 stile[2 * SUB * BUF];
+  typedef typename std::conditional<IN16, bf16x4, f32x4>::type ld4_t;
+  const __bf16* Qh = reinterpret_cast<const __bf16*>(a.Q);
+  const __bf16* Kh = reinterpret_cast<const __bf16*>(a.K);
+  const __bf16* Vh = reinterpret_cast<const __bf16*>(a.V);
 
   // ---- this lane's query row: dims kk*16 + hi*8 .. +7, kk = 0..3 ------------
   const int qi = q0 + wave * 32 + li;
   const int qc = qi < qlen ? qi : qlen - 1;
   bf16x8 qu[4], qv[RELPOS ? 4 : 1];
-  {
+  if constexpr (IN16) {
+    const __bf16* qp = Qh + (int64_t)(qoff + qc) * a.ldq + h * 64 + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qu[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 16);
+  } else {
     const float* qp = a.Q + (int64_t)(qoff + qc) * a.ldq + h * 64 + hi * 8;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -107,7 +125,7 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
     }
   }
   const int t_lo = blo / KT, t_hi = (bhi + KT - 1) / KT;
-  const int n_it = t_hi - t_lo;
+  const int n_it = (t_hi - t_lo + SUB - 1) / SUB;     // stages of SUB sub-tiles
 
   f32x16 o0, o1;
 #pragma unroll
@@ -120,73 +138,91 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
   // 2m, 2m+1 (adjacent slots of Vt) and writes 4 packed bf16 pairs.
   constexpr int NCK = (KT * 16 + NTHR - 1) / NTHR;   // K chunks per thread
   constexpr int NCV = (KT * 8 + NTHR - 1) / NTHR;    // V items per thread
-  f32x4 rK[NCK], rP[RELPOS ? NCK : 1], rV0[NCV], rV1[NCV];
+  ld4_t rK[SUB][NCK], rV0[SUB][NCV], rV1[SUB][NCV];
+  f32x4 rP[RELPOS ? NCK : 1];
   auto gload = [&](int it) {
-    const int jt = (t_lo + it) * KT;
 #pragma unroll
-    for (int i = 0; i < NCK; ++i) {
-      const int c = tid + i * NTHR;
-      if (KT * 16 % NTHR == 0 || c < KT * 16) {
-        const int r = c >> 4, c4 = c & 15;
-        int j = jt + r;
-        if (j > kvlen - 1) j = kvlen - 1;
-        rK[i] = *reinterpret_cast<const f32x4*>(a.K + (int64_t)(kvoff + j) * a.ldk +
-                                                h * 64 + c4 * 4);
-        if (RELPOS)
-          rP[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)(j + p_off) * a.ldp + h * 64 +
-                                                  c4 * 4);
+    for (int sb = 0; sb < SUB; ++sb) {
+      const int jt = (t_lo + it * SUB + sb) * KT;
+#pragma unroll
+      for (int i = 0; i < NCK; ++i) {
+        const int c = tid + i * NTHR;
+        if (KT * 16 % NTHR == 0 || c < KT * 16) {
+          const int r = c >> 4, c4 = c & 15;
+          int j = jt + r;
+          if (j > kvlen - 1) j = kvlen - 1;
+          if constexpr (IN16)
+            rK[sb][i] = *reinterpret_cast<const bf16x4*>(Kh + (int64_t)(kvoff + j) * a.ldk +
+                                                         h * 64 + c4 * 4);
+          else
+            rK[sb][i] = *reinterpret_cast<const f32x4*>(a.K + (int64_t)(kvoff + j) * a.ldk +
+                                                        h * 64 + c4 * 4);
+          if (RELPOS)
+            rP[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)(j + p_off) * a.ldp +
+                                                    h * 64 + c4 * 4);
+        }
       }
-    }
 #pragma unroll
-    for (int i = 0; i < NCV; ++i) {
-      const int c = tid + i * NTHR;
-      if (KT * 8 % NTHR == 0 || c < KT * 8) {
-        const int m = c & 15, c4 = c >> 4;
-        int j0 = jt + 2 * m, j1 = j0 + 1;
-        if (j0 > kvlen - 1) j0 = kvlen - 1;
-        if (j1 > kvlen - 1) j1 = kvlen - 1;
-        rV0[i] = *reinterpret_cast<const f32x4*>(a.V + (int64_t)(kvoff + j0) * a.ldv +
-                                                 h * 64 + c4 * 4);
-        rV1[i] = *reinterpret_cast<const f32x4*>(a.V + (int64_t)(kvoff + j1) * a.ldv +
-                                                 h * 64 + c4 * 4);
+      for (int i = 0; i < NCV; ++i) {
+        const int c = tid + i * NTHR;
+        if (KT * 8 % NTHR == 0 || c < KT * 8) {
+          const int m = c & 15, c4 = c >> 4;
+          int j0 = jt + 2 * m, j1 = j0 + 1;
+          if (j0 > kvlen - 1) j0 = kvlen - 1;
+          if (j1 > kvlen - 1) j1 = kvlen - 1;
+          if constexpr (IN16) {
+            rV0[sb][i] = *reinterpret_cast<const bf16x4*>(Vh + (int64_t)(kvoff + j0) * a.ldv +
+                                                          h * 64 + c4 * 4);
+            rV1[sb][i] = *reinterpret_cast<const bf16x4*>(Vh + (int64_t)(kvoff + j1) * a.ldv +
+                                                          h * 64 + c4 * 4);
+          } else {
+            rV0[sb][i] = *reinterpret_cast<const f32x4*>(a.V + (int64_t)(kvoff + j0) * a.ldv +
+                                                         h * 64 + c4 * 4);
+            rV1[sb][i] = *reinterpret_cast<const f32x4*>(a.V + (int64_t)(kvoff + j1) * a.ldv +
+                                                         h * 64 + c4 * 4);
+          }
+        }
       }
     }
   };
   auto lstore = [&](int buf) {
-    __bf16* base = stile + buf * BUF;
 #pragma unroll
-    for (int i = 0; i < NCK; ++i) {
-      const int c = tid + i * NTHR;
-      if (KT * 16 % NTHR == 0 || c < KT * 16) {
-        const int r = c >> 4, c4 = c & 15;
-        bf16x4 k4;
-        k4[0] = (__bf16)rK[i][0]; k4[1] = (__bf16)rK[i][1];
-        k4[2] = (__bf16)rK[i][2]; k4[3] = (__bf16)rK[i][3];
-        *reinterpret_cast<bf16x4*>(base + r * KSTR + c4 * 4) = k4;
-        if (RELPOS) {
-          bf16x4 p4;
-          p4[0] = (__bf16)rP[i][0]; p4[1] = (__bf16)rP[i][1];
-          p4[2] = (__bf16)rP[i][2]; p4[3] = (__bf16)rP[i][3];
-          *reinterpret_cast<bf16x4*>(base + KMAT + VMAT + r * KSTR + c4 * 4) = p4;
+    for (int sb = 0; sb < SUB; ++sb) {
+      __bf16* base = stile + (buf * SUB + sb) * BUF;
+#pragma unroll
+      for (int i = 0; i < NCK; ++i) {
+        const int c = tid + i * NTHR;
+        if (KT * 16 % NTHR == 0 || c < KT * 16) {
+          const int r = c >> 4, c4 = c & 15;
+          bf16x4 k4;
+          k4[0] = (__bf16)rK[sb][i][0]; k4[1] = (__bf16)rK[sb][i][1];
+          k4[2] = (__bf16)rK[sb][i][2]; k4[3] = (__bf16)rK[sb][i][3];
+          *reinterpret_cast<bf16x4*>(base + r * KSTR + c4 * 4) = k4;
+          if (RELPOS) {
+            bf16x4 p4;
+            p4[0] = (__bf16)rP[i][0]; p4[1] = (__bf16)rP[i][1];
+            p4[2] = (__bf16)rP[i][2]; p4[3] = (__bf16)rP[i][3];
+            *reinterpret_cast<bf16x4*>(base + KMAT + VMAT + r * KSTR + c4 * 4) = p4;
+          }
         }
       }
-    }
 #pragma unroll
-    for (int i = 0; i < NCV; ++i) {
-      const int c = tid + i * NTHR;
-      if (KT * 8 % NTHR == 0 || c < KT * 8) {
-        const int m = c & 15, c4 = c >> 4;
-        const int k = 2 * m;                       // tile-local key of rV0
-        const int k16 = k & 15;
-        const int slot = (k >> 4) * 16 + ((k16 >> 2) & 1) * 8 + (k16 & 3) +
-                         4 * (k16 >> 3);          // even; key k+1 is slot+1
-        __bf16* vt = base + KMAT + (c4 * 4) * VSTR + slot;
+      for (int i = 0; i < NCV; ++i) {
+        const int c = tid + i * NTHR;
+        if (KT * 8 % NTHR == 0 || c < KT * 8) {
+          const int m = c & 15, c4 = c >> 4;
+          const int k = 2 * m;                       // tile-local key of rV0
+          const int k16 = k & 15;
+          const int slot = (k >> 4) * 16 + ((k16 >> 2) & 1) * 8 + (k16 & 3) +
+                           4 * (k16 >> 3);          // even; key k+1 is slot+1
+          __bf16* vt = base + KMAT + (c4 * 4) * VSTR + slot;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          bf16x2 pr;
-          pr[0] = (__bf16)rV0[i][d];
-          pr[1] = (__bf16)rV1[i][d];
-          *reinterpret_cast<bf16x2*>(vt + d * VSTR) = pr;
+          for (int d = 0; d < 4; ++d) {
+            bf16x2 pr;
+            pr[0] = (__bf16)rV0[sb][i][d];
+            pr[1] = (__bf16)rV1[sb][i][d];
+            *reinterpret_cast<bf16x2*>(vt + d * VSTR) = pr;
+          }
         }
       }
     }
@@ -197,79 +233,87 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
   }
   __syncthreads();
 
+  // scores are kept in the log2 domain: one multiply by scale * log2(e), v_exp_f32 directly
+  const float cs = a.scale * 1.4426950408889634f;
   for (int it = 0; it < n_it; ++it) {
-    const int j0 = (t_lo + it) * KT;
     const int cur = it & 1;
-    const __bf16* sK = stile + cur * BUF;
-    const __bf16* sV = sK + KMAT;
-    const __bf16* sP = sK + KMAT + VMAT;
     if (it + 1 < n_it) gload(it + 1);
+#pragma unroll
+    for (int sb = 0; sb < SUB; ++sb) {
+      if (SUB > 1 && t_lo + it * SUB + sb >= t_hi) break;   // uniform
+      const int j0 = (t_lo + it * SUB + sb) * KT;
+      const __bf16* sK = stile + (cur * SUB + sb) * BUF;
+      const __bf16* sV = sK + KMAT;
+      const __bf16* sP = sK + KMAT + VMAT;
 
-    // ---- S^T tile -----------------------------------------------------------
-    f32x16 sc;
+      // ---- S^T tile -----------------------------------------------------------
+      f32x16 sc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-    {
-      const __bf16* kf = sK + li * KSTR + hi * 8;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const bf16x8 fk = *reinterpret_cast<const bf16x8*>(kf + kk * 16);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, qu[kk], sc, 0, 0, 0);
-      }
-      if (RELPOS) {
-        const __bf16* pf = sP + li * KSTR + hi * 8;
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+      {
+        const __bf16* kf = sK + li * KSTR + hi * 8;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          const bf16x8 fp = *reinterpret_cast<const bf16x8*>(pf + kk * 16);
-          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp, qv[kk], sc, 0, 0, 0);
+          const bf16x8 fk = *reinterpret_cast<const bf16x8*>(kf + kk * 16);
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, qu[kk], sc, 0, 0, 0);
+        }
+        if (RELPOS) {
+          const __bf16* pf = sP + li * KSTR + hi * 8;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 fp = *reinterpret_cast<const bf16x8*>(pf + kk * 16);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp, qv[kk], sc, 0, 0, 0);
+          }
         }
       }
-    }
-    // ---- online softmax on this lane's query ----------------------------------
-    float tmax = -1e30f;
-    bool ok[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      ok[r] = (j >= jmin) && (j < jmax);
-      sc[r] *= a.scale;
-      if (ok[r]) tmax = fmaxf(tmax, sc[r]);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __expf(m_run - m_new);
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = ok[r] ? __expf(sc[r] - m_new) : 0.f;
-      sc[r] = p;
-      psum += p;
-    }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-    // rescale the running output: its rows are queries (r&3)+8(r>>2)+4hi
-    if (!__all(alpha == 1.0f)) {
+      // ---- online softmax on this lane's query ----------------------------------
+      // interior tiles of an unmasked sequence need no per-key window test (uniform)
+      const bool full = a.mask_mode == 0 && j0 + KT <= kvlen;
+      float tmax = -1e30f;
+      bool ok[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * hi, 64);
-        o0[r] *= ar;
-        o1[r] *= ar;
+        const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        ok[r] = full || ((j >= jmin) && (j < jmax));
+        sc[r] *= cs;
+        if (ok[r]) tmax = fmaxf(tmax, sc[r]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = ok[r] ? __builtin_amdgcn_exp2f(sc[r] - m_new) : 0.f;
+        sc[r] = p;
+        psum += p;
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      // rescale the running output: its rows are queries (r&3)+8(r>>2)+4hi
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * hi, 64);
+          o0[r] *= ar;
+          o1[r] *= ar;
+        }
+      }
+      // ---- O += P V ---------------------------------------------------------------
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bf16x8 pa;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pa[e] = (__bf16)sc[8 * j + e];
+        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(sV + li * VSTR + j * 16 + hi * 8);
+        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(sV + (32 + li) * VSTR + j * 16 +
+                                                           hi * 8);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, v0, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, v1, o1, 0, 0, 0);
       }
     }
-    // ---- O += P V ---------------------------------------------------------------
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bf16x8 pa;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pa[e] = (__bf16)sc[8 * j + e];
-      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(sV + li * VSTR + j * 16 + hi * 8);
-      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(sV + (32 + li) * VSTR + j * 16 +
-                                                         hi * 8);
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, v0, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, v1, o1, 0, 0, 0);
-    }
     if (it + 1 < n_it) lstore(cur ^ 1);
-    __syncthreads();  // next tile visible, this buffer free
+    __syncthreads();  // next stage visible, this buffer free
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   // ---- normalise and store ---------------------------------------------------
@@ -297,8 +341,15 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
 template <int NW>
 int launch(const AttnArgs& a, hipStream_t s) {
   dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 64);
-  if (a.P)
+  if (a.qkv_bf16) {
+    if (NW == 8)
+      hipLaunchKernelGGL((attention_bf16_kernel<NW, false, 2, true>), g, t, 0, s, a);
+    else
+      hipLaunchKernelGGL((attention_bf16_kernel<NW, false, 1, true>), g, t, 0, s, a);
+  } else if (a.P)
     hipLaunchKernelGGL((attention_bf16_kernel<NW, true>), g, t, 0, s, a);
+  else if (NW == 8 && g_attn_bf16_sub == 2)
+    hipLaunchKernelGGL((attention_bf16_kernel<NW, false, 2, false>), g, t, 0, s, a);
   else
     hipLaunchKernelGGL((attention_bf16_kernel<NW, false>), g, t, 0, s, a);
   WN_HIP(hipGetLastError());
@@ -308,11 +359,13 @@ int launch(const AttnArgs& a, hipStream_t s) {
 }  // namespace
 
 int g_attn_bf16_nw = 0;  // wn_tune_set("attn_bf16_nw"): 0 auto, else 2 / 4 / 8
+int g_attn_bf16_sub = 2; // 8-wave blocks: 32-key sub-tiles per barrier (1 or 2)
 
 int attention_bf16(const AttnArgs& a, hipStream_t s) {
   // argument checks are attention()'s (the only caller)
   WN_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldp % 4 == 0,
-           "attention(bf16): strides must be multiples of 4 floats");
+           "attention(bf16): strides must be multiples of 4 elements");
+  WN_CHECK(!(a.qkv_bf16 && a.P), "attention(bf16): bf16 Q/K/V only without the rel-pos term");
   int nw = g_attn_bf16_nw;
   if (nw != 2 && nw != 4 && nw != 8)
     nw = a.max_q_len >= 1024 ? 8 : a.max_q_len >= 384 ? 4 : 2;

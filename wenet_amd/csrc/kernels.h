@@ -69,6 +69,7 @@ struct AttnArgs {
   const int* kv_off; const int* kv_len; // [n_seq]
   int n_seq, n_heads, max_q_len;
   bool o_bf16 = false; // bf16 kernel only: O is a bf16 matrix (ldo in elements)
+  bool qkv_bf16 = false;  // bf16 kernel only, no rel-pos: Q / K / V are bf16 (ld* in elements)
   int mask_mode = 0;   // 0: keys < kv_len; 1: causal; 2: chunk window
   int chunk_size = 0, left_chunks = -1;
   float scale = 0.125f;
@@ -79,6 +80,7 @@ int attention(const AttnArgs& a, hipStream_t s);
 int attention_bf16(const AttnArgs& a, hipStream_t s);
 extern int g_attn_bf16;      // 1 (default): bf16 mode uses the bf16 attention kernel
 extern int g_attn_bf16_nw;   // 0 auto, else waves (32-query groups) per block
+extern int g_attn_bf16_sub;  // 8-wave blocks: 32-key sub-tiles per barrier
 
 // Fused feed-forward module, fp32 (ffn_fused.hip): P[s] (S, M, D) = partial
 // act(X W1^T + b1) W2^T over hidden slice s; ffn_reduce_ln then forms
@@ -92,6 +94,8 @@ struct FfnArgs {
   int M, D, F, S, act;
 };
 extern int g_ffn_fused, g_ffn_ring;
+extern int g_beam_prio;   // wn_tune_set("beam_prio")
+extern int g_ctc_wave;    // wn_tune_set("ctc_wave")
 int ffn_fused_split(int M, int F);
 bool ffn_fused_supported(int M, int D, int F, int act);
 int ffn_fused(const FfnArgs& a, hipStream_t s);
@@ -156,6 +160,7 @@ struct PrefixBeamArgs {
   // frames): [0] eval, [1] rank, [2] select/write, [3] frames, [4] emit
   long long* dbg_cycles = nullptr;
   CtxGraph cg;  // keys == nullptr: no context biasing
+  int prio = 0; // > 0: the search waves raise their issue priority (s_setprio; experiment)
 };
 int64_t prefix_beam_pool_ints(int max_len, int beam);
 // out[i] = log_add(a[i], b[i]) with the search's own fp64 routine (parity test)

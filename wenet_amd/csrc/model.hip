@@ -342,6 +342,9 @@ thread_local const std::map<const float*, wn_model::MxW>* t_mx = nullptr;
 // fp8 mode: smallest number of 256 x 256 tiles of an FFN GEMM pair for which the MXFP8
 // kernels are used (below it the bf16 kernels fill the chip better); tests set 0
 int g_fp8_min_tiles = 192;
+// bf16-storage form, encoders without the rel-pos term: the QKV GEMM writes bf16 and the
+// attention kernel reads it (1, default); 0 keeps fp32 Q / K / V (A/B, tests)
+int g_qkv_bf16 = 1;
 
 struct PrecisionScope {
   int saved;
@@ -842,10 +845,21 @@ int transformer_layers(wn_model* m, hipStream_t s) {
   for (int li = 0; li < n_run; ++li) {
     const TfLayer& L = m->tf_layers[li];
     WN_TRY(ln(L.n1, x, t1, M, d, eps, s, h16));
+    // bf16-storage form: Q | K | V leave the GEMM as bf16 (the attention kernel rounds
+    // them to bf16 first thing anyway): half the GEMM's store and the attention's stream
+    const bool q16 = h16 && g_qkv_bf16 != 0;
     WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s, ACT_NONE, nullptr, 0, 1.0f, false,
-                  h16));
+                  h16, q16));
     AttnArgs a;
-    a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d;
+    if (q16) {
+      const __bf16* qh = reinterpret_cast<const __bf16*>(qkv);
+      a.Q = reinterpret_cast<const float*>(qh);
+      a.K = reinterpret_cast<const float*>(qh + d);
+      a.V = reinterpret_cast<const float*>(qh + 2 * d);
+      a.qkv_bf16 = true;
+    } else {
+      a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d;
+    }
     a.ldq = a.ldk = a.ldv = 3 * d;
     a.O = t2; a.ldo = d; a.o_bf16 = h16;
     a.q_off = a.kv_off = m->d_off.as<int>();
@@ -1597,8 +1611,12 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "attn_bf16") g_attn_bf16 = value;
   else if (k == "bf16_store") g_bf16_store = value;
   else if (k == "attn_bf16_nw") g_attn_bf16_nw = value;
+  else if (k == "attn_bf16_sub") g_attn_bf16_sub = value;
+  else if (k == "qkv_bf16") g_qkv_bf16 = value;
   else if (k == "fp8_min_tiles") g_fp8_min_tiles = value;
   else if (k == "ffn_fused") g_ffn_fused = value;
+  else if (k == "beam_prio") g_beam_prio = value;
+  else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "ffn_ring") g_ffn_ring = value;
   else { set_error("wn_tune_set: unknown key " + k); return -1; }
   return 0;
