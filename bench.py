@@ -400,12 +400,24 @@ def main():
         if args.workload == 'config2' and not reduced and os.path.exists(pmc):
             with open(pmc) as f:
                 rec = json.load(f)
+            if ('ffn_fused' in rec.get('kernel', '')) != ('fused' in prof_name):
+                rec = None     # the committed counters describe another kernel
+        else:
+            rec = None
+        if rec is not None:
             line['roofline']['traffic'] = rec['hbm_bytes_per_launch']
             line['roofline']['traffic_unit'] = 'bytes/launch (HBM read + write, PMC)'
             line['roofline']['traffic_source'] = ('profiles/pmc_roofline_kernel.json, '
                                                   'visit ' + str(rec.get('visit', 'r01d')))
-            line['roofline']['algorithmic_bytes'] = int(
-                4 * (enc_rows * d_model + ffn * d_model + enc_rows * ffn))
+            # fused FFN: X in, S hidden-slice partials out, W_1 + W_2 once (they are
+            # re-read by every row tile from L2 / Infinity Cache, not from HBM)
+            if 'ffn_fused' in rec.get('kernel', ''):
+                S_split = 4 if enc_rows <= 128 * 64 else 2
+                line['roofline']['algorithmic_bytes'] = int(
+                    4 * (enc_rows * d_model * (1 + S_split) + 2 * ffn * d_model))
+            else:
+                line['roofline']['algorithmic_bytes'] = int(
+                    4 * (enc_rows * d_model + ffn * d_model + enc_rows * ffn))
         # what the timed steps produced vs the real reference's answer
         ver = verify.verify_bench_output(args.workload, world, out, method)
         line['verified'] = ver.pop('verified')

@@ -82,3 +82,30 @@ def test_encoder_with_fused_ffn_matches_the_gemm_pair(config, B, frames, chunk):
     err = (got - ref).abs().max().item()
     print(f'\n[{config}] fused vs GEMM pair: max |d enc| {err:.2e}')
     assert 0 < err < 2e-4 or err == 0.0
+
+
+@pytest.mark.parametrize('B,frames,chunk', [(4, (400, 700), -1), (32, (800, 1200), -1),
+                                            (3, (7, 90), 16)])
+def test_encoder_with_rowln_gemm_matches_gemm_plus_layernorm(B, frames, chunk):
+    """csrc/gemm_rowln.hip (out-projection / pointwise_conv2 + residual + the following
+    LayerNorm in one launch, blocks own complete rows) against the GEMM + LayerNorm
+    launches it replaces: whole AIShell encoder, ragged batches incl. the bench shape and
+    utterances of one or two frames."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model('aishell_u2pp', 0)
+    feats, lens = S.make_features(B, frames, seed=73)
+    try:
+        _lib.check(L.wn_tune_set(b'gemm_rowln', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        ref = ref.cpu()
+        _lib.check(L.wn_tune_set(b'gemm_rowln', 1), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got = got.cpu()
+    finally:
+        L.wn_tune_set(b'gemm_rowln', 1)
+    assert torch.equal(got, got2.cpu())            # race screen
+    err = (got - ref).abs().max().item()
+    print(f'\n[B={B}] row-LN GEMM vs GEMM + LayerNorm: max |d enc| {err:.2e}')
+    assert err < 2e-4

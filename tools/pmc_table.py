@@ -14,8 +14,9 @@ import os
 import sqlite3
 import sys
 
-# the roofline kernel of bench.py: FFN w_1 GEMM (128x128 tile, 2x4 waves, SiLU)
-ROOFLINE_KERNEL = 'gemm_f32_kernel<128, 128, 2, 4, 1, false, false, false, 32, 1>'
+# the roofline kernel of bench.py: the fused feed-forward kernel (round 2; round 1: the
+# FFN w_1 GEMM 'gemm_f32_kernel<128, 128, 2, 4, 1, false, false, false, 32, 1>')
+ROOFLINE_KERNEL = 'ffn_fused_kernel<1, 1, 4>'
 
 
 def load(dirname):
@@ -64,6 +65,7 @@ def main():
                        mfma_busy=round(util, 4), hbm_read_bytes_per_launch=int(rd),
                        hbm_write_bytes_per_launch=int(wr),
                        hbm_bytes_per_launch=int(rd + wr),
+                       visit=os.path.basename(os.path.normpath(out)),
                        method='rocprofv3 --pmc, separate passes for FETCH_SIZE and '
                               'WRITE_SIZE (KiB; FETCH_SIZE x2 on gfx950), --streams 1')
             with open(os.path.join(out, 'pmc_roofline_kernel.json'), 'w') as f:

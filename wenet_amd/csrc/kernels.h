@@ -105,6 +105,23 @@ int ffn_reduce_ln(float* x, const float* P, int S, const float* b2, float alpha,
                   const float* w, const float* b, const float* w2, const float* bb2, float* y,
                   int M, int D, float eps, int mode, hipStream_t s);
 
+// x_out = resid + alpha (A W^T + bias), y = LayerNorm(x_out): GEMM with N = 256 whose
+// block owns complete rows (gemm_rowln.hip)
+struct RowLnArgs {
+  const float* A; int lda;
+  const float* W;         // [256][K]
+  const float* bias;      // [256] or null
+  const float* resid; int ldr;   // may alias x_out
+  float alpha;
+  float* x_out; int ldx;
+  const float* ln_w; const float* ln_b; float eps;
+  float* y; int ldy;      // may alias A (a block reads only the rows it writes)
+  int M, N, K;
+};
+extern int g_gemm_rowln;
+bool gemm_rowln_supported(int M, int N, int K);
+int gemm_rowln(const RowLnArgs& a, hipStream_t s);
+
 // CTC head tail: per row log-softmax statistics + top-k (descending, lower
 // index first on ties) (+ optionally the full log-prob row).
 struct CtcRowArgs {

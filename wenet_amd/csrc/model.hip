@@ -659,9 +659,19 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     a.mask_mode = mask_mode; a.chunk_size = cs; a.left_chunks = lc;
     a.scale = 1.0f / sqrtf(64.0f);
     WN_TRY(attention(a, s));
-    WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d, 1.0f, false, h16));
-    // x += Conv(LN(x))                              encoder_layer.py:240-251
-    WN_TRY(ln(L.norm_conv, x, t1, M, d, eps, s, h16));
+    // x += out_proj(context); t1 = LN_conv(x)       encoder_layer.py:236-240
+    const bool rowln = !h16 && t_gemm_prec == PREC_F32 && gemm_rowln_supported(M, d, d);
+    if (rowln) {
+      RowLnArgs g;
+      g.A = t2; g.lda = d; g.W = L.out.w; g.bias = L.out.b; g.resid = x; g.ldr = d;
+      g.alpha = 1.0f; g.x_out = x; g.ldx = d; g.ln_w = L.norm_conv.w; g.ln_b = L.norm_conv.b;
+      g.eps = eps; g.y = t1; g.ldy = d; g.M = M; g.N = d; g.K = d;
+      WN_TRY(gemm_rowln(g, s));
+    } else {
+      WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d, 1.0f, false, h16));
+      // x += Conv(LN(x))                              encoder_layer.py:240-251
+      WN_TRY(ln(L.norm_conv, x, t1, M, d, eps, s, h16));
+    }
     WN_TRY(linear(L.pw1, t1, d, t2, d, M, s, ACT_NONE, nullptr, 0, 1.0f, true, h16));
     DwConvArgs dw;
     dw.x = t2; dw.ldx = d; dw.wt = L.dw_wt; dw.bias = L.dw_b; dw.cpad = L.cpad;
@@ -672,11 +682,20 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     dw.M = M; dw.D = d; dw.K = c.cnn_kernel; dw.causal = c.causal;
     dw.t_max = m->Tp; dw.eps = 1e-5f;
     WN_TRY(dwconv_ln_silu(dw, s));
-    WN_TRY(linear(L.pw2, t1, d, x, d, M, s, ACT_NONE, x, d));
+    // x += pointwise_conv2(.); t1 = LN_ff(x)        encoder_layer.py:251-255
+    if (rowln) {
+      RowLnArgs g;
+      g.A = t1; g.lda = d; g.W = L.pw2.w; g.bias = L.pw2.b; g.resid = x; g.ldr = d;
+      g.alpha = 1.0f; g.x_out = x; g.ldx = d; g.ln_w = L.norm_ff.w; g.ln_b = L.norm_ff.b;
+      g.eps = eps; g.y = t1; g.ldy = d; g.M = M; g.N = d; g.K = d;
+      WN_TRY(gemm_rowln(g, s));
+    } else {
+      WN_TRY(linear(L.pw2, t1, d, x, d, M, s, ACT_NONE, x, d));
+    }
     // x += 0.5 * FFN(LN(x)); x = LN(x)              encoder_layer.py:253-263
     fS = 0;
     if (!h16 && t_gemm_prec == PREC_F32) {
-      WN_TRY(ln(L.norm_ff, x, t1, M, d, eps, s));
+      if (!rowln) WN_TRY(ln(L.norm_ff, x, t1, M, d, eps, s));
       fS = ffn_fused_try(m, L.ff1, L.ff2, ACT_SILU, s);
       if (fS < 0) return -2;
     }
@@ -1617,6 +1636,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "ffn_fused") g_ffn_fused = value;
   else if (k == "beam_prio") g_beam_prio = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
+  else if (k == "gemm_rowln") g_gemm_rowln = value;
   else if (k == "ffn_ring") g_ffn_ring = value;
   else { set_error("wn_tune_set: unknown key " + k); return -1; }
   return 0;
