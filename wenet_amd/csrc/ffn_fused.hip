@@ -23,8 +23,9 @@
 // row) brought global -> LDS by DMA (buffer_load_dwordx4 ... lds), bank-swizzled on the
 // source side like gemm_bf16p.hip; phase-A stages hold {X rows 0-127, W1 chunk rows
 // 128-191}, phase-B stages 256 rows of W2.  A ring of 4 stages, ONE s_barrier per stage
-// placed in the MIDDLE of the stage's MFMAs (see the loop), counted s_waitcnt vmcnt with
-// two stages in flight behind it; with 2048 .. 8192 MFMA cycles per stage the DMA latency
+// placed in the MIDDLE of the stage's MFMAs (see the loop), the DMA of a stage issued by
+// one wave of each SIMD (alternating per stage) while the other keeps the matrix pipe fed,
+// two stages in flight behind the stage being read; with 2048 .. 8192 MFMA cycles per stage the DMA latency
 // is covered many times over.  No global loads
 // other than the DMA inside the loop (the bias of the block's hidden slice is read into
 // registers up front): hipcc would drain the DMA queue for them.
@@ -71,42 +72,54 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       const_cast<float*>(p.W1), 0, (int)min((int64_t)p.F * D * 4, (int64_t)0x7fffffff), 0x00020000);
   const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.W2), 0, (int)min((int64_t)D * p.F * 4, (int64_t)0x7fffffff), 0x00020000);
-  // piece j of a wave covers stage rows (j*8 + wave)*8 .. +8; lane -> row + (lane >> 3),
-  // LDS slot lane & 7, source slot = slot ^ ((row >> 1) & 7)
-  unsigned vx[2], vw1, vw2[4];
+  // DMA issue is the job of ONE wave group per stage (waves 0-3 for even stages, 4-7 for
+  // odd ones): a buffer_load ... lds costs the issuing wave 60-200 cycles, and with all 8
+  // waves issuing right after the barrier both waves of every SIMD were busy with DMAs
+  // instead of MFMAs.  Now the other wave of the SIMD can keep the pipe fed meanwhile
+  // (measured neutral, 142 us either way at config 2, r02r: the issue time was not what
+  // the matrix pipe waits for).  A wave of the issuing group moves 8 of the stage's
+  // 32 one-KB pieces: piece pj = q*4 + (wave & 3) covers stage rows pj*8 .. +8; lane ->
+  // row + (lane >> 3), LDS slot lane & 7, source slot = slot ^ ((row >> 1) & 7).
+  const int w4 = wave & 3, grp = wave >> 2;
+  unsigned vx[4], vw1[2], vw2[8];
   {
     const int rr = lane >> 3;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = (j * 8 + wave) * 8 + rr;            // stage row 0..255
+    for (int q = 0; q < 8; ++q) {
+      const int r = (q * 4 + w4) * 8 + rr;              // stage row 0..255
       const unsigned swz = (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
-      if (j < 2) vx[j] = (unsigned)min(m0 + r, p.M - 1) * (unsigned)(D * 4) + swz;
-      if (j == 2) vw1 = (unsigned)(r - 128) * (unsigned)(D * 4) + swz;
-      vw2[j] = (unsigned)r * (unsigned)p.F * 4u + swz;
+      if (q < 4) vx[q] = (unsigned)min(m0 + r, p.M - 1) * (unsigned)(D * 4) + swz;
+      else if (q < 6) vw1[q - 4] = (unsigned)(r - 128) * (unsigned)(D * 4) + swz;
+      vw2[q] = (unsigned)r * (unsigned)p.F * 4u + swz;
     }
   }
   // stage g (clamped to the last one past the end: harmless re-load into a free buffer)
   auto issue = [&](int g) {
+    if (grp != (g & 1)) return;
     g = min(g, total - 1);
     const int c = g / SPC, i = g - c * SPC;
     const int h0 = h_base + c * FHC;
-    char* dst = smem_f + (g % RING) * STG + wave * 1024;
+    char* dst = smem_f + (g % RING) * STG + w4 * 1024;
     if (i < NA) {
       const int koff = i * 128;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)dst, 16, vx[0], koff, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(dst + 8192), 16, vx[1], koff, 0, 0);
       const int w1off = h0 * (D * 4) + koff;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(dst + 16384), 16, vw1, w1off, 0, 0);
-      // rows 192-255 are not used in phase A; the same piece again keeps the DMA count
-      // per stage uniform for the counted waits
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(dst + 24576), 16, vw1, w1off, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(dst + q * 4096), 16, vx[q], koff,
+                                                 0, 0);
+      // rows 192-255 are not used in phase A; the W1 pieces again keep the DMA count per
+      // stage uniform for the counted waits
+#pragma unroll
+      for (int q = 4; q < 8; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(dst + q * 4096), 16,
+                                                 vw1[q & 1], w1off, 0, 0);
     } else {
       const int j = i - NA;
       const int kt = j / ND, nd = j - kt * ND;
       const int off = nd * 256 * p.F * 4 + (h0 + kt * 32) * 4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr)(dst + q * 8192), 16, vw2[q], off,
+      for (int q = 0; q < 8; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr)(dst + q * 4096), 16, vw2[q], off,
                                                  0, 0);
     }
   };
@@ -180,13 +193,15 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
     return f;
   };
   auto mid_barrier = [&](int gg) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // own pieces of stage gg+1 landed
+    // the group that issued stage gg+1 (two stages ago) waits for it; it has nothing else
+    // in flight, and it is the group that issues stage gg+3 next
+    if (grp == ((gg + 1) & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue(gg + 3);
   };
 
   issue(0); issue(1); issue(2);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if (grp == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage 0 (2 in flight)
   __builtin_amdgcn_s_barrier();
   FragA xa0 = loadA(0, 0), xa1 = loadA(0, 1);
 
