@@ -11,7 +11,7 @@ from gpu_util import cached_model
 pytestmark = pytest.mark.gpu
 
 
-def _run(X, W1, b1, W2, b2, x, lw, lb, act, alpha, ring=4):
+def _run(X, W1, b1, W2, b2, x, lw, lb, act, alpha, bm64=0):
     from wenet_amd import _lib
     L = _lib.lib()
     M, D = X.shape
@@ -19,7 +19,7 @@ def _run(X, W1, b1, W2, b2, x, lw, lb, act, alpha, ring=4):
     xo = x.clone().cuda()
     y = torch.empty((M, D), device='cuda')
     t = [t.cuda().contiguous() for t in (X, W1, b1, W2, b2, lw, lb)]
-    _lib.check(L.wn_tune_set(b'ffn_ring', ring), 'tune')
+    _lib.check(L.wn_tune_set(b'ffn_bm64', bm64), 'tune')
     try:
         _lib.check(L.wn_op_ffn_fused(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
                                      t[3].data_ptr(), t[4].data_ptr(), xo.data_ptr(),
@@ -28,19 +28,24 @@ def _run(X, W1, b1, W2, b2, x, lw, lb, act, alpha, ring=4):
                                      torch.cuda.current_stream().cuda_stream), 'ffn_fused')
         torch.cuda.synchronize()
     finally:
-        L.wn_tune_set(b'ffn_ring', 4)
+        L.wn_tune_set(b'ffn_bm64', 0)
     return xo.cpu(), y.cpu()
 
 
-@pytest.mark.parametrize('M,D,F,act,ring', [
-    (128, 256, 128, 1, 4),       # one block, two chunks
-    (700, 256, 2048, 1, 4),      # ragged M, S = 16
-    (7932, 256, 2048, 1, 4),     # BASELINE config 2: 62 x 4 blocks
-    (1000, 512, 2048, 2, 4),     # d = 512 (two W2 stages per k tile), ReLU
-    (333, 512, 1024, 3, 4),      # GELU
-    (16231, 512, 2048, 1, 4),    # BASELINE config 3: 127 x 2 blocks, 16 chunks per block
+@pytest.mark.parametrize('M,D,F,act,bm64', [
+    (128, 256, 128, 1, 0),       # 128-row blocks: one block, two chunks
+    (700, 256, 2048, 1, 0),      # ragged M, S = 16
+    (7932, 256, 2048, 1, 0),     # BASELINE config 2: 62 x 4 blocks
+    (128, 256, 128, 1, 1),       # 64-row blocks (two per CU): two blocks, two chunks
+    (64, 256, 64, 2, 1),         # one block, one chunk, ReLU
+    (700, 256, 2048, 3, 1),      # ragged M, S = 16, GELU
+    (7932, 256, 2048, 1, 1),     # BASELINE config 2: 124 x 4 blocks
+    (33000, 256, 2048, 1, 1),    # more blocks than fit at once; S = 2 -> 16 chunks per block
+    (1000, 512, 2048, 2, 1),     # d = 512 (two W2 stages per k tile), ReLU
+    (333, 512, 1024, 3, 1),      # GELU
+    (16231, 512, 2048, 1, 1),    # BASELINE config 3: 127 x 2 blocks, 16 chunks per block
 ])
-def test_ffn_fused_vs_fp64(M, D, F, act, ring):
+def test_ffn_fused_vs_fp64(M, D, F, act, bm64):
     g = torch.Generator().manual_seed(M + D + F + act)
     X = torch.randn(M, D, generator=g)
     W1 = torch.randn(F, D, generator=g) / D ** 0.5
@@ -54,10 +59,10 @@ def test_ffn_fused_vs_fp64(M, D, F, act, ring):
     h = {1: torch.nn.functional.silu, 2: torch.relu, 3: torch.nn.functional.gelu}[act](h)
     xr = x.double() + 0.5 * (h @ W2.double().T + b2.double())
     yr = torch.nn.functional.layer_norm(xr, (D, ), lw.double(), lb.double(), 1e-5)
-    xo, y = _run(X, W1, b1, W2, b2, x, lw, lb, act, 0.5, ring)
+    xo, y = _run(X, W1, b1, W2, b2, x, lw, lb, act, 0.5, bm64)
     assert (xo.double() - xr).abs().max().item() < 2e-5
     assert (y.double() - yr).abs().max().item() < 2e-5
-    xo2, y2 = _run(X, W1, b1, W2, b2, x, lw, lb, act, 0.5, ring)   # race screen
+    xo2, y2 = _run(X, W1, b1, W2, b2, x, lw, lb, act, 0.5, bm64)   # race screen
     assert torch.equal(xo, xo2) and torch.equal(y, y2)
 
 

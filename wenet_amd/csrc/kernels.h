@@ -93,10 +93,10 @@ struct FfnArgs {
   float* P;           // [S][M][D]
   int M, D, F, S, act;
 };
-extern int g_ffn_fused, g_ffn_ring;
+extern int g_ffn_fused, g_ffn_ring, g_ffn_bm64;
 extern int g_beam_prio;   // wn_tune_set("beam_prio")
 extern int g_ctc_wave;    // wn_tune_set("ctc_wave")
-int ffn_fused_split(int M, int F);
+int ffn_fused_split(int M, int D, int F);
 bool ffn_fused_supported(int M, int D, int F, int act);
 int ffn_fused(const FfnArgs& a, hipStream_t s);
 // mode 0: x <- x_new, y <- LN(x_new; w, b); mode 1: x <- LN(x_new; w, b),

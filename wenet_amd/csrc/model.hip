@@ -498,7 +498,7 @@ int ffn_fused_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipS
     return 0;
   FfnArgs a;
   a.X = m->t1.as<float>(); a.W1 = w1.w; a.b1 = w1.b; a.W2 = w2.w;
-  a.M = M; a.D = d; a.F = w1.out; a.S = ffn_fused_split(M, w1.out); a.act = act;
+  a.M = M; a.D = d; a.F = w1.out; a.S = ffn_fused_split(M, d, w1.out); a.act = act;
   if (m->ffn_part.ensure((size_t)a.S * M * d * sizeof(float)) != 0) return -1;
   a.P = m->ffn_part.as<float>();
   const bool bracket = m->prof_on && (m->prof_seq++ % 6) == 0;
@@ -1634,6 +1634,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "qkv_bf16") g_qkv_bf16 = value;
   else if (k == "fp8_min_tiles") g_fp8_min_tiles = value;
   else if (k == "ffn_fused") g_ffn_fused = value;
+  else if (k == "ffn_bm64") g_ffn_bm64 = value;
   else if (k == "beam_prio") g_beam_prio = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "gemm_rowln") g_gemm_rowln = value;
@@ -2577,7 +2578,7 @@ int wn_op_ffn_fused(const float* X, const float* W1, const float* b1, const floa
                     float eps, void* stream) {
   WN_CHECK(X && W1 && b1 && W2 && b2 && x && ln_w && ln_b && y, "ffn_fused: null argument");
   WN_CHECK(M > 0 && (D == 256 || D == 512) && F > 0 && F % 64 == 0, "ffn_fused: shape");
-  const int S = ffn_fused_split(M, F);
+  const int S = ffn_fused_split(M, D, F);
   WN_CHECK(S > 0, "ffn_fused: hidden size cannot be split for this M");
   static thread_local DevBuf part;
   WN_TRY(part.ensure((size_t)S * M * D * sizeof(float)));
