@@ -205,6 +205,8 @@ def main():
                          'bf16 operands / fp32 accumulate (recognize.py --dtype bf16); '
                          'fp8 = bf16 mode with e4m3 FFN GEMMs (BASELINE.json '
                          'configs[4]) -- extra data points, never the headline line')
+    ap.add_argument('--no-f32-mfma-leg', action='store_true',
+                    help='skip the extra round that runs every GEMM on v_mfma_f32')
     ap.add_argument('--tune', default='',
                     help='experiments: comma list of key=value for wn_tune_set')
     args = ap.parse_args()
@@ -317,6 +319,20 @@ def main():
         tot_launch += n_launch.value
         tot_ms += ms.value
         tot_flops += flops.value
+    # transparency leg: the same decode with every GEMM on v_mfma_f32 (gemm_x6 = 0), one
+    # round of --steps steps; reported beside the headline, never as `value`
+    f32_only = None
+    if args.dtype == 'fp32' and 'x6' in prof_name and not args.no_f32_mfma_leg:
+        _lib.check(L.wn_tune_set(b'gemm_x6', 0), 'tune')
+        try:
+            run_steps(max(2, args.warmup // 2))
+            barrier()
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            barrier()
+            f32_only = max_over_ranks(time.perf_counter() - t0)
+        finally:
+            _lib.check(L.wn_tune_set(b'gemm_x6', 1), 'tune')
     pipe.close()
     assert len(out) == batch_per_gpu * world, 'result gather lost utterances'
 
@@ -330,11 +346,21 @@ def main():
                     else int(sum(max(0, (int(t) - 7) // 4 + 1) for t in lens.tolist())))
         ffn = configs['encoder_conf']['linear_units']
         peak = PEAK_TFLOPS[args.dtype]
+        x6 = 'x6' in prof_name
+        if x6:
+            # six bf16 plane products per fp32 multiply-add: the matrix-pipe ceiling of
+            # this algorithm is the dense bf16 peak / 6 (in algorithmic fp32 FLOP/s)
+            peak = round(PEAK_TFLOPS['bf16'] / 6.0, 1)
         whole_flops = contraction_flops(configs, glens.tolist())
         # the FFN GEMMs run in e4m3 in the fp8 mode, everything else in bf16: the
         # whole-decode fraction is priced against the bf16 peak there
-        whole_peak = PEAK_TFLOPS['bf16'] if args.dtype == 'fp8' else peak
-        dtype_txt = {'fp32': 'f32',
+        whole_peak = (PEAK_TFLOPS['bf16'] if args.dtype == 'fp8'
+                      else PEAK_TFLOPS[args.dtype])
+        dtype_txt = {'fp32': ('f32 (feed-forward GEMMs: fp32 operands as three exact bf16 '
+                              'planes, six plane products on the bf16 matrix cores, f32 '
+                              'accumulate -- error <= the v_mfma_f32 kernel\'s, '
+                              'tests/test_gpu_x6.py; everything else v_mfma_f32)'
+                              if x6 else 'f32'),
                      'bf16': 'bf16 operands, f32 accumulate / activations',
                      'fp8': 'e4m3 FFN GEMM operands (per-row / per-channel scales), '
                             'bf16 elsewhere, f32 accumulate'}[args.dtype]
@@ -375,7 +401,11 @@ def main():
             },
             'roofline': {
                 'bound': 'mfma',
-                'kernel': (f'{prof_name}, M={enc_rows} F={ffn} D={d_model}: '
+                'kernel': (f'{prof_name}, M={enc_rows} N={ffn} K={d_model}: '
+                           f'{2 * enc_rows * ffn * d_model / 1e9:.2f} algorithmic GFLOP per '
+                           f'launch, x 6 executed as v_mfma_f32_32x32x16_bf16; peak = dense '
+                           f'bf16 peak 2500 / 6' if x6 else
+                           f'{prof_name}, M={enc_rows} F={ffn} D={d_model}: '
                            f'{4 * enc_rows * ffn * d_model / 1e9:.2f} GFLOP per launch'
                            if 'fused' in prof_name else
                            f'{kern} (FFN w_1, M={enc_rows} N={ffn} K={d_model})'),
@@ -400,7 +430,8 @@ def main():
         if args.workload == 'config2' and not reduced and os.path.exists(pmc):
             with open(pmc) as f:
                 rec = json.load(f)
-            if ('ffn_fused' in rec.get('kernel', '')) != ('fused' in prof_name):
+            if (('ffn_fused' in rec.get('kernel', '')) != ('fused' in prof_name) or
+                    ('x6' in rec.get('kernel', '')) != x6):
                 rec = None     # the committed counters describe another kernel
         else:
             rec = None
@@ -411,13 +442,28 @@ def main():
                                                   'visit ' + str(rec.get('visit', 'r01d')))
             # fused FFN: X in, S hidden-slice partials out, W_1 + W_2 once (they are
             # re-read by every row tile from L2 / Infinity Cache, not from HBM)
-            if 'ffn_fused' in rec.get('kernel', ''):
+            if x6:
+                # A planes in (6 B / element), W planes (L2-resident across row tiles),
+                # hidden-tensor planes out
+                line['roofline']['algorithmic_bytes'] = int(
+                    6 * (enc_rows * d_model + ffn * d_model + enc_rows * ffn))
+            elif 'ffn_fused' in rec.get('kernel', ''):
                 S_split = 4 if enc_rows <= 128 * 64 else 2
                 line['roofline']['algorithmic_bytes'] = int(
                     4 * (enc_rows * d_model * (1 + S_split) + 2 * ffn * d_model))
             else:
                 line['roofline']['algorithmic_bytes'] = int(
                     4 * (enc_rows * d_model + ffn * d_model + enc_rows * ffn))
+        if x6:
+            line['roofline']['executed_mfma_tflops'] = round(6 * achieved, 1)
+            line['roofline']['fp32_mfma_peak'] = PEAK_TFLOPS['fp32']
+        if f32_only is not None:
+            line['f32_mfma_only'] = {
+                'value': round(total_audio * args.steps / f32_only, 1),
+                'ms_per_step': round(f32_only / args.steps * 1e3, 3),
+                'note': 'same decode, every GEMM on v_mfma_f32_32x32x2_f32 (gemm_x6 = 0), '
+                        'one round of --steps steps',
+            }
         # what the timed steps produced vs the real reference's answer
         ver = verify.verify_bench_output(args.workload, world, out, method)
         line['verified'] = ver.pop('verified')

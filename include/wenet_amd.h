@@ -370,6 +370,23 @@ int wn_op_ffn_fused(const float* X_dev, const float* W1_dev, const float* b1_dev
                     const float* ln_w_dev, const float* ln_b_dev, float* y_out_dev,
                     int32_t M, int32_t D, int32_t F, int32_t act, float alpha, float eps,
                     void* stream);
+/* fp32 GEMM on the bf16 matrix cores (csrc/gemm_x6.hip): every fp32 operand is split
+ * exactly into three bf16 planes and six of the nine plane products are accumulated in
+ * fp32 (the dropped ones are below 2^-26 of a product).  C (M, N) = resid + alpha *
+ * act(A W^T + bias); A (M, K), W (N, K) fp32 row-major, K % 16 == 0, N % 4 == 0.  `bm`:
+ * block rows 128 / 256 (0 = auto); `reps` > 1 repeats the GEMM launch (micro-benchmarks).
+ * Replaces torch.nn.functional.linear as the reference's layers call it
+ * (positionwise_feed_forward.py:50-58, attention.py:100-176, convolution.py:120-148). */
+int wn_op_gemm_x6(const float* A_dev, const float* W_dev, const float* bias_dev,
+                  const float* resid_dev, float* C_dev, int32_t M, int32_t N, int32_t K,
+                  float alpha, int32_t act, int32_t bm, int32_t reps, void* stream);
+/* wn_op_ffn_fused's contract with both contractions run by the six-product GEMM: the
+ * hidden tensor goes from the first GEMM's epilogue to the second as a plane image. */
+int wn_op_ffn_x6(const float* X_dev, const float* W1_dev, const float* b1_dev,
+                 const float* W2_dev, const float* b2_dev, float* x_inout_dev,
+                 const float* ln_w_dev, const float* ln_b_dev, float* y_out_dev, int32_t M,
+                 int32_t D, int32_t F, int32_t act, float alpha, float eps, int32_t reps,
+                 void* stream);
 /* out[i] = log_add(a[i], b[i]) (wenet/utils/common.py:302-310) in fp64 with the
  * routine the prefix beam search uses. */
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,

@@ -1,0 +1,159 @@
+"""The six-product fp32 GEMM (csrc/gemm_x6.hip: fp32 operands as three exact bf16 planes,
+six bf16 MFMA products, fp32 accumulate) through the C ABI against fp64, next to the
+v_mfma_f32 kernel on the same inputs: the claim under test is that it is an fp32 GEMM --
+its error against fp64 is not larger than the fp32 matrix-core kernel's."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _x6(A, W, b, r, act, alpha, bm=0):
+    from wenet_amd import _lib
+    L = _lib.lib()
+    M, K = A.shape
+    N = W.shape[0]
+    C = torch.empty((M, N), device='cuda')
+    _lib.check(L.wn_op_gemm_x6(A.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None,
+                               r.data_ptr() if r is not None else None, C.data_ptr(), M, N, K,
+                               alpha, act, bm, 1, torch.cuda.current_stream().cuda_stream),
+               'gemm_x6')
+    torch.cuda.synchronize()
+    return C
+
+
+def _f32(A, W, b, r, act, alpha):
+    from wenet_amd import _lib
+    L = _lib.lib()
+    M, K = A.shape
+    N = W.shape[0]
+    C = torch.empty((M, N), device='cuda')
+    _lib.check(L.wn_op_gemm(A.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None,
+                            r.data_ptr() if r is not None else None, C.data_ptr(), M, N, K,
+                            alpha, act, torch.cuda.current_stream().cuda_stream), 'gemm')
+    torch.cuda.synchronize()
+    return C
+
+
+def _ref(A, W, b, r, act, alpha):
+    h = A.double() @ W.double().T
+    if b is not None:
+        h = h + b.double()
+    h = {0: lambda t: t, 1: torch.nn.functional.silu, 2: torch.relu,
+         3: torch.nn.functional.gelu}[act](h)
+    h = alpha * h
+    if r is not None:
+        h = h + r.double()
+    return h
+
+
+@pytest.mark.parametrize('M,N,K,act,resid,bm', [
+    (7932, 2048, 256, 1, False, 0),     # FFN w_1 of BASELINE config 2
+    (7932, 256, 2048, 0, True, 0),      # FFN w_2 (one N tile: 128-row blocks)
+    (7932, 768, 256, 0, False, 256),
+    (1000, 4236, 256, 0, False, 128),   # ragged N (CTC-sized)
+    (33, 20, 16, 2, True, 0),           # one k block, ragged everything
+    (257, 516, 48, 3, False, 256),      # GELU, partial tiles on both sides
+    (4096, 1024, 4864, 0, False, 0),    # long K (the subsampling output layer)
+])
+def test_gemm_x6_is_an_fp32_gemm(M, N, K, act, resid, bm):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = (torch.randn(N, generator=g) * 0.3).cuda()
+    r = torch.randn(M, N, generator=g).cuda() if resid else None
+    ref = _ref(A, W, b, r, act, 0.5)
+    c6 = _x6(A, W, b, r, act, 0.5, bm)
+    e6 = (c6.double() - ref).abs().max().item()
+    r6 = ((c6.double() - ref) ** 2).mean().sqrt().item()
+    assert torch.equal(c6, _x6(A, W, b, r, act, 0.5, bm))      # race screen
+    if K % 32 != 0:          # the v_mfma_f32 kernel wants K % 32 == 0: torch fp32 instead
+        assert e6 < 2e-6
+        return
+    c32 = _f32(A, W, b, r, act, 0.5)
+    e32 = (c32.double() - ref).abs().max().item()
+    r32 = ((c32.double() - ref) ** 2).mean().sqrt().item()
+    print(f'\n[{M}x{N}x{K}] max |err| x6 {e6:.2e} / f32 mfma {e32:.2e}; rms {r6:.2e} / {r32:.2e}')
+    assert e6 < 2e-5
+    # an fp32 GEMM: not worse than the fp32 matrix-core kernel (noise margin 1.5x on the
+    # maximum, 1.2x on the rms)
+    assert e6 <= 1.5 * e32 + 1e-7
+    assert r6 <= 1.2 * r32 + 1e-8
+
+
+def test_x6_planes_are_exact():
+    """The operand split is exact (x0 + x1 + x2 == x for every fp32 input), so with W = I
+    the GEMM must return A bit for bit up to the six-product rule: x * 1 keeps x0, x1, x2
+    times the single plane of 1.0 -- all three survive (a0 b0, a1 b0, a2 b0)."""
+    g = torch.Generator().manual_seed(5)
+    A = (torch.randn(512, 256, generator=g) * torch.logspace(-20, 20, 256)).cuda()
+    W = torch.eye(256).cuda()
+    C = _x6(A, W, None, None, 0, 1.0)
+    assert torch.equal(C, A)
+
+
+@pytest.mark.parametrize('M,D,F,act', [
+    (128, 256, 128, 1), (700, 256, 2048, 3), (7932, 256, 2048, 1), (1000, 512, 2048, 2),
+    (16231, 512, 2048, 1),
+])
+def test_ffn_x6_vs_fp64(M, D, F, act):
+    from wenet_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + D + F + act)
+    X = torch.randn(M, D, generator=g)
+    W1 = torch.randn(F, D, generator=g) / D ** 0.5
+    b1 = torch.randn(F, generator=g) * 0.3
+    W2 = torch.randn(D, F, generator=g) / F ** 0.5
+    b2 = torch.randn(D, generator=g) * 0.3
+    x = torch.randn(M, D, generator=g)
+    lw = 1.0 + 0.2 * torch.randn(D, generator=g)
+    lb = 0.1 * torch.randn(D, generator=g)
+    h = X.double() @ W1.double().T + b1.double()
+    h = {1: torch.nn.functional.silu, 2: torch.relu, 3: torch.nn.functional.gelu}[act](h)
+    xr = x.double() + 0.5 * (h @ W2.double().T + b2.double())
+    yr = torch.nn.functional.layer_norm(xr, (D, ), lw.double(), lb.double(), 1e-5)
+    t = [t.cuda().contiguous() for t in (X, W1, b1, W2, b2, lw, lb)]
+    outs = []
+    for _ in range(2):
+        xo = x.clone().cuda()
+        y = torch.empty((M, D), device='cuda')
+        _lib.check(L.wn_op_ffn_x6(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                  t[3].data_ptr(), t[4].data_ptr(), xo.data_ptr(),
+                                  t[5].data_ptr(), t[6].data_ptr(), y.data_ptr(), M, D, F, act,
+                                  0.5, 1e-5, 1, torch.cuda.current_stream().cuda_stream),
+                   'ffn_x6')
+        torch.cuda.synchronize()
+        outs.append((xo.cpu(), y.cpu()))
+    (xo, y), (xo2, y2) = outs
+    ex, ey = (xo.double() - xr).abs().max().item(), (y.double() - yr).abs().max().item()
+    print(f'\n[{M} {D} {F}] max |err| x {ex:.2e} y {ey:.2e}')
+    assert ex < 2e-5 and ey < 2e-5
+    assert torch.equal(xo, xo2) and torch.equal(y, y2)
+
+
+@pytest.mark.parametrize('config,B,frames,chunk', [('aishell_u2pp', 4, (400, 700), -1),
+                                                   ('aishell_u2pp', 32, (800, 1200), -1),
+                                                   ('wenetspeech_u2pp', 3, (300, 500), 16)])
+def test_encoder_with_x6_ffn_matches_the_f32_mfma_path(config, B, frames, chunk):
+    """Whole encoder with the feed-forward GEMMs on the six-product kernel (forced on small
+    batches too) against every GEMM on v_mfma_f32: fp32 reordering noise only."""
+    from gpu_util import cached_model
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=79)
+    try:
+        _lib.check(L.wn_tune_set(b'gemm_x6', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        ref = ref.cpu()
+        _lib.check(L.wn_tune_set(b'gemm_x6', 2), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got = got.cpu()
+    finally:
+        L.wn_tune_set(b'gemm_x6', 1)
+    assert torch.equal(got, got2.cpu())
+    err = (got - ref).abs().max().item()
+    print(f'\n[{config} B={B}] x6 FFN vs f32 MFMA: max |d enc| {err:.2e}')
+    assert 0 < err < 1e-4

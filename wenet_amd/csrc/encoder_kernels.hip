@@ -2,6 +2,7 @@
 // conv, the depthwise-conv core of the Conformer conv module, and the
 // relative-position multi-head attention (online softmax, fp32 MFMA).
 #include "kernels.h"
+#include "x6.h"
 #include "mxfp8.h"
 
 namespace wn {
@@ -239,6 +240,60 @@ __global__ __launch_bounds__(256) void cmvn_conv1_kernel(Conv1Args a) {
         for (int kx = 0; kx < 3; ++kx)
           acc = fmaf(w[ky * 3 + kx], xin[ky][2 * f1 + kx], acc);
       dst[f1 * a.C + c] = fmaxf(acc, 0.f);
+    }
+  }
+}
+
+// The same convolution written as the plane image of its output (gemm_x6.hip) for the
+// six-product conv2: one image row per conv1 pixel, pixel index = frame * F1 + pos with the
+// even f1 first (pos = f1 / 2) and the odd ones behind them (pos = (F1 + 1) / 2 + f1 / 2),
+// so that the stride-2 taps of conv2 read CONSECUTIVE pixels.  Lane = pixel of the frame,
+// wave = group of 8 channels (looped): a plane store covers consecutive 16-B pieces, the
+// weights of a channel group are wave-uniform.  Same accumulation order as above, the
+// fp32 result is split exactly -- conv2 sees the same operand values.
+__global__ __launch_bounds__(256) void cmvn_conv1_x3_kernel(Conv1Args a) {
+  const int b = blockIdx.y;
+  const int t1 = blockIdx.x;
+  if (t1 >= a.t1_len[b]) return;
+  __shared__ float xin[3][128];
+  const float* src = a.feats + ((int64_t)b * a.T + 2 * t1) * a.F;
+  for (int i = threadIdx.x; i < 3 * a.F; i += 256) {
+    const int r = i / a.F, f = i % a.F;
+    float v = src[r * a.F + f];
+    if (a.mean) v = (v - a.mean[f]) * a.istd[f];
+    xin[r][f] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ne = (a.F1 + 1) / 2;
+  const int pos = min(lane, a.F1 - 1);
+  const int f1 = pos < ne ? 2 * pos : 2 * (pos - ne) + 1;
+  float x[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) x[ky * 3 + kx] = xin[ky][2 * f1 + kx];
+  const int P = (a.t1_off[b] + t1) * a.F1 + pos;
+  for (int cg = wave; cg < a.C / 8; cg += 4) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = a.bias[cg * 8 + e];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(a.w[k * a.C + cg * 8 + e], x[k], acc[e]);
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const Split3 sp = split3(fmaxf(acc[e], 0.f));
+      p0[e] = sp.h0; p1[e] = sp.h1; p2[e] = sp.h2;
+    }
+    if (lane < a.F1) {
+      char* o = a.out3 + x3_piece(cg >> 1, a.tiles, P, cg & 1);
+      *reinterpret_cast<bf16x8*>(o) = p0;
+      *reinterpret_cast<bf16x8*>(o + X3_REC) = p1;
+      *reinterpret_cast<bf16x8*>(o + 2 * X3_REC) = p2;
     }
   }
 }
@@ -695,6 +750,12 @@ int layernorm2(const float* x, const float* w1, const float* b1, const float* w2
 int cmvn_conv1_relu(const Conv1Args& a, hipStream_t s) {
   WN_CHECK(a.F <= 128, "conv1: feature dim > 128");
   WN_CHECK(a.max_t1 > 0 && a.B > 0, "conv1: empty");
+  if (a.out3) {
+    WN_CHECK(a.F1 <= 64 && a.C % 16 == 0 && a.tiles > 0, "conv1: plane image shape");
+    hipLaunchKernelGGL(cmvn_conv1_x3_kernel, dim3(a.max_t1, a.B), dim3(256), 0, s, a);
+    WN_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(cmvn_conv1_kernel, dim3(a.max_t1, a.B), dim3(256), 0, s,
                      a);
   WN_HIP(hipGetLastError());

@@ -1,0 +1,409 @@
+// fp32 GEMM on the bf16 matrix cores: C = act(A W^T + bias) with every fp32 operand
+// carried as THREE bf16 planes whose sum is the fp32 value exactly,
+//     x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = x - x0 - x1
+// (8 + 8 + 8 significand bits; both subtractions and the last conversion are exact), and
+// the product formed from six of the nine plane products, accumulated in fp32:
+//     a b ~ a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0,
+// each of them EXACT in fp32 (8 x 8 bits).  Dropped: a1 b2 + a2 b1 + a2 b2 <= 2^-26 |a b|,
+// a quarter of the half-ulp an fp32 multiply-add rounds away itself -- the result is an
+// fp32 GEMM with a different (and not larger) rounding error, not a reduced-precision
+// one; tests/test_gpu_x6.py holds it against fp64 next to the v_mfma_f32 kernel.
+//
+// Why: gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of v_mfma_f32_32x32x2_f32
+// (2.5 PFLOP/s against 157 TFLOP/s dense), so six bf16 products cost 6/16 of the one fp32
+// product -- and they share their fragments: 3 + 3 plane fragments feed 6 MFMAs where a
+// plain bf16 GEMM reads 1 + 1 for one, which halves the LDS and DMA bytes per MFMA.
+//
+// Operand image ("X3", x6_split_kernel or a producer's epilogue): for a matrix of R rows
+// and K columns, records of 1 KB indexed [K/16][ceil(R/32)][plane] holding 32 rows x 16 k
+// of one plane as [k half h][row][8 bf16] -- byte h*512 + row*16 -- which is exactly the
+// order in which the 64 lanes of a wave read a 32x32x16 MFMA operand (lane = 32 h + row):
+// the DMA global -> LDS is linear (64 lanes x 16 B = one record), the ds_read_b128 of a
+// fragment is linear (no bank conflicts, no swizzle), and a whole stage of a block tile
+// (all row tiles x planes of one k block) is ONE contiguous piece of the image.
+//
+// Kernel: BM (128 | 256) x 256 block tile, 8 waves as 2 (M) x 4 (N), wave tile BM/2 x 64,
+// one k block (16) per stage: BM/32*3 + 24 records = 36 / 48 KB, ring of 3 stages.  Per
+// stage ONE barrier in the middle of the stage's MFMAs (see the loop).  MFMA operands are
+// swapped (the W fragment is the "A" of the instruction): a lane then owns one ROW of C
+// and 4 consecutive columns per register quad, so fp32 C is stored in 16-B pieces and an
+// X3 image of C (EPI 2: the next GEMM's operand, e.g. the FFN hidden tensor) in whole
+// 16-B plane pieces after one half-wave exchange (v_permlane32_swap).
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "kernels.h"
+#include "x6.h"
+
+namespace wn {
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int REC = X3_REC;        // one (k block, 32-row tile, plane) record
+constexpr int TILE3 = X3_TILE;     // the three planes of a tile and k block
+constexpr int XBN = 256;
+
+// fp32 [R][ld] (K columns) -> X3 image.  One thread per 16-B piece and plane triple:
+// 32 consecutive threads = the 32 rows of a tile (512 contiguous bytes per plane).
+__global__ __launch_bounds__(256) void x6_split_kernel(const float* __restrict__ src, int R,
+                                                       int K, int ld, char* __restrict__ dst) {
+  const int tiles = (R + 31) >> 5, nkb = K >> 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int row_l = (int)(idx & 31), h = (int)((idx >> 5) & 1);
+  const int64_t rest = idx >> 6;
+  const int kb = (int)(rest % nkb), tile = (int)(rest / nkb);
+  if (tile >= tiles) return;
+  const int row = tile * 32 + row_l;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+  if (row < R) {
+    const float* s = src + (int64_t)row * ld + kb * 16 + h * 8;
+    a = *reinterpret_cast<const f32x4*>(s);
+    b = *reinterpret_cast<const f32x4*>(s + 4);
+  }
+  bf16x8 p0, p1, p2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const Split3 sa = split3(a[e]), sb = split3(b[e]);
+    p0[e] = sa.h0; p1[e] = sa.h1; p2[e] = sa.h2;
+    p0[4 + e] = sb.h0; p1[4 + e] = sb.h1; p2[4 + e] = sb.h2;
+  }
+  char* o = dst + ((int64_t)kb * tiles + tile) * TILE3 + h * 512 + row_l * 16;
+  *reinterpret_cast<bf16x8*>(o) = p0;
+  *reinterpret_cast<bf16x8*>(o + REC) = p1;
+  *reinterpret_cast<bf16x8*>(o + 2 * REC) = p2;
+}
+
+// EPI 0: C = resid + alpha act(acc + bias) (fp32, [M][ldc]); EPI 1: K-slice partial
+// P[slice][M][N] = acc; EPI 2: X3 image of act(acc + bias) (rows M, columns N)
+// CONV: the A operand is gathered (implicit GEMM of a strided convolution over a
+// channels-last tensor whose X3 image has one row per input pixel): GEMM row r reads pixel
+// a_pix[r] + tap_delta[tap] for the k blocks of tap = kb / conv_kbc -- the DMA addresses
+// are per lane instead of linear, the LDS side is unchanged.
+template <int BM, int EPI, int ACT, bool CONV = false>
+__global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem_x[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  constexpr int TA = BM / 64;                  // A tiles (32 rows) per wave
+  constexpr int A_BYTES = (BM / 32) * TILE3;
+  constexpr int STAGE = A_BYTES + 8 * TILE3;   // 36 / 48 KB
+  constexpr int NP = STAGE / REC;              // DMA pieces per stage
+  constexpr int BAR = TA / 2 - 1;              // the A tile after which the barrier sits
+
+  const int nblk = tiles_m * tiles_n;
+  const int bid = xcd_block_order(blockIdx.x, nblk * p.ksplit);
+  const int slice = bid / nblk, tb = bid - slice * nblk;
+  // M fastest inside groups of 4 M panels (gemm_bf16p.hip): the blocks an XCD runs at a
+  // time share few A and W panels
+  constexpr int GM = 4;
+  const int per_group = GM * tiles_n;
+  const int grp = tb / per_group, in_grp = tb - grp * per_group;
+  const int gm = min(GM, tiles_m - grp * GM);
+  const int tm = grp * GM + in_grp % gm, tn = in_grp / gm;
+  const int m0 = tm * BM, n0 = tn * XBN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int hi = lane >> 5, li = lane & 31;
+
+  const int Ta = CONV ? p.a_tiles : (p.M + 31) >> 5, Tb = (p.N + 31) >> 5;
+  const int nkb_all = p.K >> 4;
+  const int nkb = nkb_all / p.ksplit, kb0 = slice * nkb;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.A3), 0, (int)min((int64_t)(CONV ? p.conv_kbc : nkb_all) * Ta * TILE3, (int64_t)0x7fffffff),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.B3), 0, (int)min((int64_t)nkb_all * Tb * TILE3, (int64_t)0x7fffffff),
+      0x00020000);
+  // Stage g = k block kb0 + g: A records of the block's BM/32 row tiles (contiguous in the
+  // image), then the 8 W tiles.  Piece j of the stage goes to wave j % 8.  Tiles past the
+  // last one read the next k block's records or (buffer bounds) zeros: they only reach
+  // rows / columns of C that are never stored.
+  const unsigned vlane = (unsigned)lane * 16u;
+  // CONV: base pixel of this lane's row in each A piece the wave issues (piece j -> row
+  // tile j / 3)
+  constexpr int NPA = (A_BYTES / REC + 7) / 8;
+  int pix[NPA];
+  if (CONV) {
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) {
+      const int j = q * 8 + wave;
+      pix[q] = p.a_pix[min(m0 + (j / 3) * 32 + li, p.M - 1)];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // before the DMA ring starts
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) asm volatile("" : "+v"(pix[q]));
+  }
+  auto issue = [&](int g) {
+    const int kb = kb0 + g;
+    char* dst = smem_x + (g % 3) * STAGE;
+    int sa = (kb * Ta + (m0 >> 5)) * TILE3, delta = 0;
+    if (CONV) {
+      const int tap = kb / p.conv_kbc;
+      sa = (kb - tap * p.conv_kbc) * Ta * TILE3;
+      delta = p.tap_delta[tap];
+    }
+    const int sb = (kb * Tb + (n0 >> 5)) * TILE3;
+#pragma unroll
+    for (int j0 = 0; j0 < NP; j0 += 8) {
+      const int j = j0 + wave;
+      if (j < A_BYTES / REC) {
+        if (CONV) {
+          const int P = pix[j0 / 8] + delta;
+          const unsigned vo = (unsigned)(((P >> 5) * 3 + j % 3) * REC + hi * 512 + (P & 31) * 16);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + j * REC), 16, vo, sa, 0,
+                                                   0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + j * REC), 16, vlane,
+                                                   sa + j * REC, 0, 0);
+        }
+      } else if (j < NP)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(dst + j * REC), 16, vlane,
+                                                 sb + (j - A_BYTES / REC) * REC, 0, 0);
+    }
+  };
+
+  struct FA { bf16x8 p[3]; };
+  struct FB { bf16x8 p[2][3]; };
+  auto loadA = [&](int g, int i) {
+    const char* st = smem_x + (g % 3) * STAGE + (wm * TA + i) * TILE3 + lane * 16;
+    FA f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) f.p[q] = *reinterpret_cast<const bf16x8*>(st + q * REC);
+    return f;
+  };
+  auto loadB = [&](int g) {
+    const char* st = smem_x + (g % 3) * STAGE + A_BYTES + (wn * 2) * TILE3 + lane * 16;
+    FB f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        f.p[j][q] = *reinterpret_cast<const bf16x8*>(st + j * TILE3 + q * REC);
+    return f;
+  };
+
+  f32x16 acc[TA][2];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // six plane products, the small ones first; W fragment = MFMA "A" (rows of the
+  // instruction's result = columns of C)
+  auto mma = [&](const FA& a, const FB& b, int i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x16 c = acc[i][j];
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][2], a.p[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][0], a.p[2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][1], a.p[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][1], a.p[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][0], a.p[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][0], a.p[0], c, 0, 0, 0);
+      acc[i][j] = c;
+    }
+  };
+
+  // ---- pipeline ----------------------------------------------------------------------------
+  // Top of stage g: stages <= g landed and visible, stage g+1 in flight, the W fragments
+  // and the first A tile of stage g in registers.  After A tile BAR each wave waits for
+  // its own pieces of stage g+1 (nothing else is in flight), the barrier makes stage g+1
+  // visible and proves every wave has left stage g-1, whose buffer the DMA of stage g+2
+  // then overwrites.  The fragments of stage g+1 are read during the last A tile.
+  issue(0);
+  if (nkb > 1) issue(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  FB fb = loadB(0);
+  FA fa = loadA(0, 0);
+  for (int g = 0; g < nkb; ++g) {
+#pragma unroll
+    for (int i = 0; i < TA; ++i) {
+      FA na; FB nb;
+      if (i + 1 < TA) na = loadA(g, i + 1);
+      else if (g + 1 < nkb) { nb = loadB(g + 1); na = loadA(g + 1, 0); }
+      mma(fa, fb, i);
+      if (i == BAR) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g + 2 < nkb) issue(g + 2);
+      }
+      if (i + 1 < TA) fa = na;
+      else if (g + 1 < nkb) { fa = na; fb = nb; }
+    }
+  }
+
+  // ---- epilogue: lane = row of C, registers = columns 8 g + 4 hi + e ------------------------
+  const int Tm = Ta;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int cb = n0 + (wn * 2 + j) * 32;               // first column of the 32-col tile
+    f32x4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = cb + 8 * g + 4 * hi;
+      bias4[g] = (EPI != 1 && p.bias && c < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + c)
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < TA; ++i) {
+      const int row = m0 + (wm * TA + i) * 32 + li;
+      f32x4 v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[i][j][4 * g + e] + bias4[g][e];
+          if (EPI != 1) {
+            if (ACT == ACT_SILU) x = silu_fast(x);
+            if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
+            if (ACT == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+          }
+          v[g][e] = x;
+        }
+      if constexpr (EPI == 2) {
+        // planes of the lane's 16 values; after the half-wave exchange the low lane holds
+        // columns 0-15 (k block 2 t), the high lane 16-31 (k block 2 t + 1) of its row
+        i32x2 q[3][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 h0, h1, h2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const Split3 sp = split3(v[g][e]);
+            h0[e] = sp.h0; h1[e] = sp.h1; h2[e] = sp.h2;
+          }
+          q[0][g] = __builtin_bit_cast(i32x2, h0);
+          q[1][g] = __builtin_bit_cast(i32x2, h1);
+          q[2][g] = __builtin_bit_cast(i32x2, h2);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            auto s0 = __builtin_amdgcn_permlane32_swap(q[pl][0][d], q[pl][2][d], false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(q[pl][1][d], q[pl][3][d], false, false);
+            q[pl][0][d] = s0[0]; q[pl][2][d] = s0[1];
+            q[pl][1][d] = s1[0]; q[pl][3][d] = s1[1];
+          }
+        const int tile_m = (m0 >> 5) + wm * TA + i;
+        const int kbn = (cb >> 4) + hi;
+        if (tile_m < Tm && cb + 16 * hi < p.N) {
+          char* o = reinterpret_cast<char*>(p.C3) + ((int64_t)kbn * Tm + tile_m) * TILE3 + li * 16;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            // half 0: columns 0-7 of the k block = (own g0 | partner's g0), half 1: g1
+            *reinterpret_cast<i32x4*>(o + pl * REC) =
+                i32x4{q[pl][0][0], q[pl][0][1], q[pl][2][0], q[pl][2][1]};
+            *reinterpret_cast<i32x4*>(o + pl * REC + 512) =
+                i32x4{q[pl][1][0], q[pl][1][1], q[pl][3][0], q[pl][3][1]};
+          }
+        }
+      } else {
+        if (row >= p.M) continue;
+        float* crow = EPI == 1 ? p.C + ((int64_t)slice * p.M + row) * p.N
+                               : p.C + (int64_t)row * p.ldc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = cb + 8 * g + 4 * hi;
+          if (c >= p.N) continue;
+          f32x4 o = v[g];
+          if constexpr (EPI == 0) {
+            o *= p.alpha;
+            if (p.resid) o += *reinterpret_cast<const f32x4*>(p.resid + (int64_t)row * p.ldr + c);
+          }
+          *reinterpret_cast<f32x4*>(crow + c) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int EPI, int ACT, bool CONV = false>
+int launch_x6(const X6Args& a, hipStream_t s) {
+  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, XBN);
+  const size_t lds = 3 * ((BM / 32) * TILE3 + 8 * TILE3);
+  auto kern = gemm_x6_kernel<BM, EPI, ACT, CONV>;
+  static bool done = false;
+  if (!done) {
+    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * a.ksplit), dim3(512), lds, s, a, tiles_m,
+                     tiles_n);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int BM, int EPI>
+int launch_x6_act(const X6Args& a, hipStream_t s) {
+  if (EPI == 1) return launch_x6<BM, EPI, ACT_NONE>(a, s);
+  switch (a.act) {
+    case ACT_NONE: return launch_x6<BM, EPI, ACT_NONE>(a, s);
+    case ACT_SILU: return launch_x6<BM, EPI, ACT_SILU>(a, s);
+    case ACT_RELU: return launch_x6<BM, EPI, ACT_RELU>(a, s);
+    case ACT_GELU: return launch_x6<BM, EPI, ACT_GELU>(a, s);
+    default: break;
+  }
+  set_error("gemm_x6: unsupported activation");
+  return -1;
+}
+
+}  // namespace
+
+int g_gemm_x6 = 1;
+int g_x6_conv_bm = 0;
+
+size_t x6_bytes(int R, int K) { return (size_t)(K / 16) * cdiv(R, 32) * TILE3; }
+
+int x6_split(const float* src, int R, int K, int ld, void* dst, hipStream_t s) {
+  WN_CHECK(src && dst && R > 0 && K > 0 && K % 16 == 0 && ld % 4 == 0, "x6_split: shape");
+  const int64_t n = (int64_t)cdiv(R, 32) * (K / 16) * 64;
+  hipLaunchKernelGGL(x6_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, R,
+                     K, ld, reinterpret_cast<char*>(dst));
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+// block rows: 256 when that still gives the 256 CUs a block each, else 128
+int gemm_x6_bm(int M, int N, int ksplit) {
+  return cdiv(M, 256) * cdiv(N, XBN) * ksplit >= 200 ? 256 : 128;
+}
+
+int gemm_x6(const X6Args& a, hipStream_t s) {
+  WN_CHECK(a.A3 && a.B3 && a.M > 0 && a.N > 0 && a.K > 0 && a.K % 16 == 0, "gemm_x6: shape");
+  WN_CHECK(a.ksplit >= 1 && (a.K / 16) % a.ksplit == 0, "gemm_x6: K split");
+  WN_CHECK(a.N % 4 == 0 && (a.epi != 2 || a.N % 16 == 0), "gemm_x6: N");
+  WN_CHECK((a.a_pix || x6_bytes(a.M, a.K) < ((size_t)1 << 31)) &&
+               x6_bytes(a.N, a.K) < ((size_t)1 << 31), "gemm_x6: operand image over 2 GB");
+  WN_CHECK(a.epi == 2 ? a.C3 != nullptr : a.C != nullptr, "gemm_x6: no output");
+  WN_CHECK(a.epi == 1 || a.ksplit == 1, "gemm_x6: K slices need the partial epilogue");
+  const int bm = a.bm ? a.bm : gemm_x6_bm(a.M, a.N, a.ksplit);
+  if (a.a_pix) {
+    // implicit GEMM of the subsampling conv2: fp32 C with bias + ReLU
+    WN_CHECK(a.epi == 0 && a.act == ACT_RELU && a.conv_kbc > 0 && a.a_tiles > 0 &&
+                 (a.K / 16) % a.conv_kbc == 0 && a.K / 16 / a.conv_kbc <= 9,
+             "gemm_x6: gathered A operand");
+    return bm == 256 ? launch_x6<256, 0, ACT_RELU, true>(a, s)
+                     : launch_x6<128, 0, ACT_RELU, true>(a, s);
+  }
+#define WN_X6(BM)                                              \
+  switch (a.epi) {                                             \
+    case 0: return launch_x6_act<BM, 0>(a, s);                 \
+    case 1: return launch_x6_act<BM, 1>(a, s);                 \
+    case 2: return launch_x6_act<BM, 2>(a, s);                 \
+    default: break;                                            \
+  }
+  if (bm == 256) { WN_X6(256) } else { WN_X6(128) }
+#undef WN_X6
+  set_error("gemm_x6: unknown epilogue");
+  return -1;
+}
+
+}  // namespace wn

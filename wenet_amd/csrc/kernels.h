@@ -31,6 +31,10 @@ struct Conv1Args {
   const float* w;        // [9][C]  (tap-major, reordered from (C,1,3,3))
   const float* bias;     // [C]
   float* out;            // [sum T1_b][F1][C]
+  // instead of `out`: plane image (gemm_x6.hip) with one row per pixel, `tiles` 32-pixel
+  // tiles; pixel = frame * F1 + pos, even f1 first (pos = f1 / 2), odd ones behind them
+  char* out3 = nullptr;
+  int tiles = 0;
   const int* t1_off;     // [B] packed row offset (in T1 frames)
   const int* t1_len;     // [B] number of T1 frames to produce
   int B, T, F, F1, C, max_t1;
@@ -104,6 +108,35 @@ int ffn_fused(const FfnArgs& a, hipStream_t s);
 int ffn_reduce_ln(float* x, const float* P, int S, const float* b2, float alpha,
                   const float* w, const float* b, const float* w2, const float* bb2, float* y,
                   int M, int D, float eps, int mode, hipStream_t s);
+
+// fp32 GEMM as six bf16 plane products (gemm_x6.hip).  Operands are "X3" images:
+// x6_bytes(R, K) bytes for an R x K matrix, made by x6_split or by a GEMM's EPI 2.
+struct X6Args {
+  const void* A3 = nullptr;   // image of A (M x K)
+  const void* B3 = nullptr;   // image of W (N x K)
+  int M = 0, N = 0, K = 0;
+  int ksplit = 1;             // K slices (epi 1 only)
+  int bm = 0;                 // block rows 128 / 256, 0 = auto
+  int epi = 0;                // 0: C = resid + alpha act(acc + bias); 1: P[slice][M][N] = acc;
+                              // 2: C3 = X3 image of act(acc + bias)
+  const float* bias = nullptr;
+  const float* resid = nullptr; int ldr = 0;
+  float alpha = 1.0f; int act = 0;
+  float* C = nullptr; int ldc = 0;
+  void* C3 = nullptr;
+  // gathered A (implicit GEMM of a convolution): A3 is the image of the channels-last input
+  // with one row per pixel (a_tiles 32-pixel tiles, conv_kbc = C / 16 k blocks per tap);
+  // GEMM row r reads pixel a_pix[r] + tap_delta[tap]
+  const int* a_pix = nullptr;
+  int a_tiles = 0, conv_kbc = 0;
+  int tap_delta[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+extern int g_x6_conv_bm;   // wn_tune_set("x6_conv_bm"): block rows of the conv2 GEMM (0 auto)
+extern int g_gemm_x6;     // wn_tune_set("gemm_x6"): 0 = the v_mfma_f32 kernels (A/B, tests)
+size_t x6_bytes(int R, int K);
+int x6_split(const float* src, int R, int K, int ld, void* dst, hipStream_t s);
+int gemm_x6_bm(int M, int N, int ksplit);
+int gemm_x6(const X6Args& a, hipStream_t s);
 
 // x_out = resid + alpha (A W^T + bias), y = LayerNorm(x_out): GEMM with N = 256 whose
 // block owns complete rows (gemm_rowln.hip)

@@ -118,6 +118,17 @@ struct Decoder {
   std::vector<DecLayer> layers;
 };
 
+// x6 conv2: base pixel (plane image row of conv1's output, even-first order inside a
+// frame) of GEMM row (g, f2): frame off1[u] + 2 t2, position f2 (= f1 2 f2)
+__global__ void build_conv2_pix_kernel(const int* row_utt2, const int* off2, const int* off1,
+                                       int M, int F1, int F2, int* a_pix) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * F2) return;
+  const int g = i / F2, f2 = i % F2;
+  const int u = row_utt2[g];
+  a_pix[i] = (off1[u] + 2 * (g - off2[u])) * F1 + f2;
+}
+
 __global__ void build_conv2_rows_kernel(const int* row_utt2, const int* off2,
                                         const int* off1, int M, int F1, int F2,
                                         int C, int64_t* a_row_off) {
@@ -241,6 +252,11 @@ struct wn_model {
   std::shared_ptr<DevBuf> weights_mx;
   std::shared_ptr<std::map<const float*, MxW>> mx_at;
   bool fp8_ffn = false;                  // WN_PREC_FP8: prec == PREC_BF16 + MXFP8 FFN GEMMs
+  // plane images of the weights the six-product fp32 GEMM runs (gemm_x6.hip): fp32 weight
+  // pointer -> X3 image; built at create, shared by clones
+  std::shared_ptr<DevBuf> weights_x6;
+  std::shared_ptr<std::map<const float*, const void*>> x6_at;
+  DevBuf x6_a, x6_h;                     // images of the GEMM input rows / the FFN hidden tensor
   DevBuf mx_sa, mx_sh;                   // block scales of the LN output / FFN hidden
   std::map<std::string, const float*> w; // name -> device pointer
   // re-laid-out subsampling weights
@@ -487,12 +503,92 @@ int ffn_module(wn_model* m, const Norm& nrm, const Linear& w1, const Linear& w2,
   return gemm_mxfp8(h, q2->q, s);
 }
 
+// Plane images (gemm_x6.hip) of the encoder's feed-forward weights, once per model.
+int build_x6_images(wn_model* m) {
+  std::vector<const Linear*> ws;
+  for (const auto& L : m->layers) { ws.push_back(&L.ffm1); ws.push_back(&L.ffm2);
+                                    ws.push_back(&L.ff1); ws.push_back(&L.ff2); }
+  for (const auto& L : m->tf_layers) { ws.push_back(&L.ff1); ws.push_back(&L.ff2); }
+  ws.push_back(&m->conv2);          // [d][(ky*3+kx)*d + c]: k blocks of 16 channels per tap
+  size_t bytes = 0;
+  for (const Linear* l : ws)
+    if (l->w && l->in % 16 == 0) bytes += x6_bytes(l->out, l->in);
+  auto buf = std::make_shared<DevBuf>();
+  auto at = std::make_shared<std::map<const float*, const void*>>();
+  if (bytes > 0) {
+    WN_TRY(buf->ensure(bytes));
+    char* p = buf->as<char>();
+    for (const Linear* l : ws) {
+      if (!l->w || l->in % 16 != 0 || at->count(l->w)) continue;
+      WN_TRY(x6_split(l->w, l->out, l->in, l->in, p, nullptr));
+      (*at)[l->w] = p;
+      p += x6_bytes(l->out, l->in);
+    }
+  }
+  m->weights_x6 = buf;
+  m->x6_at = at;
+  return 0;
+}
+
+// hidden split of the x6 FFN's second GEMM: K slices so that 128-row tiles x slices fill
+// the CUs once
+int ffn_x6_split(int M, int F) {
+  int S = 1;
+  while (S < 16 && cdiv(M, 128) * (S * 2) <= 256 && (F / 16) % (S * 2) == 0) S *= 2;
+  return S;
+}
+
+// fp32 feed-forward module on the bf16 matrix cores (gemm_x6.hip): t1 = LN(x) is in place;
+// split it into planes, w_1 + activation straight into the plane image of the hidden
+// tensor, w_2 as K-slice partials in m->ffn_part.  Returns the slice count (0: not taken).
+int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStream_t s) {
+  const int d = m->cfg.d_model, M = m->rows, F = w1.out;
+  if (t_gemm_prec != PREC_F32 || g_gemm_x6 == 0 || !m->x6_at || w1.out != w2.in ||
+      d % 16 != 0 || F % 16 != 0 || (M < 512 && g_gemm_x6 != 2))
+    return 0;
+  auto i1 = m->x6_at->find(w1.w), i2 = m->x6_at->find(w2.w);
+  if (i1 == m->x6_at->end() || i2 == m->x6_at->end()) return 0;
+  if (x6_bytes(M, F) >= ((size_t)1 << 31)) return 0;
+  const int S = ffn_x6_split(M, F);
+  if (m->x6_a.ensure(x6_bytes(M, d)) != 0 || m->x6_h.ensure(x6_bytes(M, F)) != 0 ||
+      m->ffn_part.ensure((size_t)S * M * d * sizeof(float)) != 0)
+    return -1;
+  if (x6_split(m->t1.as<float>(), M, d, d, m->x6_a.as<char>(), s) != 0) return -1;
+  X6Args g1;
+  g1.A3 = m->x6_a.as<char>(); g1.B3 = i1->second; g1.M = M; g1.N = F; g1.K = d;
+  g1.epi = 2; g1.bias = w1.b; g1.act = act; g1.C3 = m->x6_h.as<char>();
+  static thread_local int tick = 0;
+  const bool bracket = m->prof_on && (tick++ % 6) == 0;
+  if (bracket) {
+    if (m->prof_used + 2 > m->prof_ev.size())
+      for (int i = 0; i < 64; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        m->prof_ev.push_back(e);
+      }
+    (void)hipEventRecord(m->prof_ev[m->prof_used], s);
+  }
+  if (gemm_x6(g1, s) != 0) return -1;
+  if (bracket) {
+    (void)hipEventRecord(m->prof_ev[m->prof_used + 1], s);
+    m->prof_used += 2;
+    m->prof_flops += 2.0 * M * (double)F * d;       // the contraction (x 6 MFMA products)
+    m->prof_kernel = "gemm_x6_kernel (FFN w_1 + act, six bf16 plane products)";
+  }
+  X6Args g2;
+  g2.A3 = m->x6_h.as<char>(); g2.B3 = i2->second; g2.M = M; g2.N = d; g2.K = F;
+  g2.epi = 1; g2.ksplit = S; g2.C = m->ffn_part.as<float>();
+  if (gemm_x6(g2, s) != 0) return -1;
+  return S;
+}
+
 // fp32 fused feed-forward module (ffn_fused.hip): t1 = LN(x) is in place; leaves the
 // hidden-slice partials in m->ffn_part and returns S (0: shape not taken, caller runs
 // the two-GEMM path).  Every 6th launch is bracketed for the roofline (wn_profile_*).
 int ffn_fused_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStream_t s) {
   const wn_config& c = m->cfg;
   const int d = c.d_model, M = m->rows;
+  if (const int s6 = ffn_x6_try(m, w1, w2, act, s)) return s6;
   if (t_gemm_prec != PREC_F32 || g_ffn_fused == 0 || w1.out != w2.in ||
       !ffn_fused_supported(M, d, w1.out, act))
     return 0;
@@ -575,6 +671,45 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
     WN_TRY(m->hbuf.ensure((size_t)M * c.ffn_dim * sizeof(float)));
     WN_TRY(m->qkv.ensure((size_t)M * 3 * d * sizeof(float)));
     WN_TRY(m->d_a_row_off.ensure((size_t)M * F2 * sizeof(int64_t)));
+    // fp32 on the bf16 matrix cores (gemm_x6.hip): conv1 writes the plane image of its
+    // output, conv2 gathers its rows from it
+    const void* w6 = nullptr;
+    if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && m->x6_at && d % 16 == 0 && F1 <= 64 &&
+        (M * F2 >= 4096 || g_gemm_x6 == 2)) {
+      auto it = m->x6_at->find(m->conv2.w);
+      if (it != m->x6_at->end() &&
+          x6_bytes(M1 * F1, d) < ((size_t)1 << 31)) w6 = it->second;
+    }
+    if (w6) {
+      const int tiles = cdiv(M1 * F1, 32);
+      WN_TRY(m->c1.ensure(x6_bytes(M1 * F1, d)));
+      Conv1Args c1;
+      c1.feats = feats_dev; c1.mean = m->cmvn_mean; c1.istd = m->cmvn_istd;
+      c1.w = m->conv1_w; c1.bias = m->conv1_b; c1.out = nullptr;
+      c1.out3 = m->c1.as<char>(); c1.tiles = tiles;
+      c1.t1_off = m->d_off1.as<int>(); c1.t1_len = m->d_len1.as<int>();
+      c1.B = B; c1.T = T; c1.F = c.feat_dim; c1.F1 = F1; c1.C = d; c1.max_t1 = max_t1;
+      WN_TRY(cmvn_conv1_relu(c1, s));
+      int* pix = reinterpret_cast<int*>(m->d_a_row_off.as<int64_t>());
+      hipLaunchKernelGGL(build_conv2_pix_kernel, dim3(cdiv(M * F2, 256)), dim3(256), 0, s,
+                         m->d_row_utt.as<int>(), m->d_off.as<int>(), m->d_off1.as<int>(), M,
+                         F1, F2, pix);
+      WN_HIP(hipGetLastError());
+      X6Args g;
+      g.A3 = m->c1.as<char>(); g.B3 = w6; g.M = M * F2; g.N = d; g.K = 9 * d;
+      g.epi = 0; g.bias = m->conv2.b; g.act = ACT_RELU; g.C = m->c2.as<float>(); g.ldc = d;
+      g.a_pix = pix; g.a_tiles = tiles; g.conv_kbc = d / 16; g.bm = g_x6_conv_bm;
+      const int ne = (F1 + 1) / 2;
+      for (int ky = 0; ky < 3; ++ky) {
+        g.tap_delta[ky * 3 + 0] = ky * F1;            // f1 = 2 f2     (even, position f2)
+        g.tap_delta[ky * 3 + 1] = ky * F1 + ne;       // f1 = 2 f2 + 1 (odd, position ne + f2)
+        g.tap_delta[ky * 3 + 2] = ky * F1 + 1;        // f1 = 2 f2 + 2 (even, position f2 + 1)
+      }
+      WN_TRY(gemm_x6(g, s));
+      WN_TRY(linear(m->sub_out, m->c2.as<float>(), F2 * d, m->x.as<float>(), d, M,
+                    s, ACT_NONE, nullptr, 0, sqrtf((float)d)));
+      return 0;
+    }
     // GlobalCMVN + conv1 + ReLU                        encoder.py:155, subsampling.py:188
     Conv1Args c1;
     c1.feats = feats_dev; c1.mean = m->cmvn_mean; c1.istd = m->cmvn_istd;
@@ -1480,6 +1615,7 @@ int wn_model_create(const wn_config* cfg, const wn_tensor* weights,
       DEC(m->left, "decoder", c.dec_layers);
     }
   }
+  WN_TRY(build_x6_images(m.get()));
   WN_HIP(hipDeviceSynchronize());
   *out = m.release();
   return 0;
@@ -1499,6 +1635,7 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->n_weight_elems = src->n_weight_elems;
   m->weights_bf16 = src->weights_bf16;
   m->weights_mx = src->weights_mx; m->mx_at = src->mx_at; m->fp8_ffn = src->fp8_ffn;
+  m->weights_x6 = src->weights_x6; m->x6_at = src->x6_at;
   m->pos_tabs = src->pos_tabs;
   m->fb_tab_i = src->fb_tab_i;
   m->w = src->w;
@@ -1635,6 +1772,8 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "fp8_min_tiles") g_fp8_min_tiles = value;
   else if (k == "ffn_fused") g_ffn_fused = value;
   else if (k == "ffn_bm64") g_ffn_bm64 = value;
+  else if (k == "gemm_x6") g_gemm_x6 = value;
+  else if (k == "x6_conv_bm") g_x6_conv_bm = value;
   else if (k == "beam_prio") g_beam_prio = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "gemm_rowln") g_gemm_rowln = value;
@@ -2588,6 +2727,57 @@ int wn_op_ffn_fused(const float* X, const float* W1, const float* b1, const floa
   WN_TRY(ffn_fused(a, (hipStream_t)stream));
   return ffn_reduce_ln(x, part.as<float>(), S, b2, alpha, ln_w, ln_b, nullptr, nullptr, y, M,
                        D, eps, 0, (hipStream_t)stream);
+}
+
+int wn_op_gemm_x6(const float* A, const float* W, const float* bias, const float* resid,
+                  float* C, int32_t M, int32_t N, int32_t K, float alpha, int32_t act,
+                  int32_t bm, int32_t reps, void* stream) {
+  WN_CHECK(A && W && C && M > 0 && N > 0 && K > 0 && K % 16 == 0 && N % 4 == 0,
+           "gemm_x6: shape");
+  hipStream_t s = (hipStream_t)stream;
+  static thread_local DevBuf a3, w3;
+  WN_TRY(a3.ensure(x6_bytes(M, K)));
+  WN_TRY(w3.ensure(x6_bytes(N, K)));
+  WN_TRY(x6_split(A, M, K, K, a3.as<char>(), s));
+  WN_TRY(x6_split(W, N, K, K, w3.as<char>(), s));
+  X6Args a;
+  a.A3 = a3.as<char>(); a.B3 = w3.as<char>(); a.M = M; a.N = N; a.K = K; a.bm = bm;
+  a.bias = bias; a.resid = resid; a.ldr = N; a.alpha = alpha; a.act = act; a.C = C; a.ldc = N;
+  for (int r = 0; r < (reps > 0 ? reps : 1); ++r) WN_TRY(gemm_x6(a, s));
+  return 0;
+}
+
+int wn_op_ffn_x6(const float* X, const float* W1, const float* b1, const float* W2,
+                 const float* b2, float* x, const float* ln_w, const float* ln_b, float* y,
+                 int32_t M, int32_t D, int32_t F, int32_t act, float alpha, float eps,
+                 int32_t reps, void* stream) {
+  WN_CHECK(X && W1 && b1 && W2 && b2 && x && ln_w && ln_b && y, "ffn_x6: null argument");
+  WN_CHECK(M > 0 && (D == 256 || D == 512) && F > 0 && F % 64 == 0, "ffn_x6: shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int S = ffn_x6_split(M, F);
+  static thread_local DevBuf x3, w13, w23, h3, part;
+  WN_TRY(x3.ensure(x6_bytes(M, D)));
+  WN_TRY(w13.ensure(x6_bytes(F, D)));
+  WN_TRY(w23.ensure(x6_bytes(D, F)));
+  WN_TRY(h3.ensure(x6_bytes(M, F)));
+  WN_TRY(part.ensure((size_t)S * M * D * sizeof(float)));
+  WN_TRY(x6_split(W1, F, D, D, w13.as<char>(), s));
+  WN_TRY(x6_split(W2, D, F, F, w23.as<char>(), s));
+  for (int r = 0; r < (reps > 0 ? reps : 1); ++r) {
+    WN_TRY(x6_split(X, M, D, D, x3.as<char>(), s));
+    X6Args g1;
+    g1.A3 = x3.as<char>(); g1.B3 = w13.as<char>(); g1.M = M; g1.N = F; g1.K = D;
+    g1.epi = 2; g1.bias = b1; g1.act = act; g1.C3 = h3.as<char>();
+    WN_TRY(gemm_x6(g1, s));
+    X6Args g2;
+    g2.A3 = h3.as<char>(); g2.B3 = w23.as<char>(); g2.M = M; g2.N = D; g2.K = F;
+    g2.epi = 1; g2.ksplit = S; g2.C = part.as<float>();
+    WN_TRY(gemm_x6(g2, s));
+    if (r + 1 < reps) continue;      // timing loops: the residual update only once
+    WN_TRY(ffn_reduce_ln(x, part.as<float>(), S, b2, alpha, ln_w, ln_b, nullptr, nullptr, y,
+                         M, D, eps, 0, s));
+  }
+  return 0;
 }
 
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,
