@@ -23,8 +23,8 @@
 // (all row tiles x planes of one k block) is ONE contiguous piece of the image.
 //
 // Kernel: BM (128 | 256) x 256 block tile, 8 waves as 2 (M) x 4 (N), wave tile BM/2 x 64,
-// one k block (16) per stage: BM/32*3 + 24 records = 36 / 48 KB, ring of 3 stages.  Per
-// stage ONE barrier in the middle of the stage's MFMAs (see the loop).  MFMA operands are
+// one k block (16) per stage: BM/32*3 + 24 records = 36 / 48 KB, ring of 3 stages, two in
+// flight.  Per stage ONE barrier, late in the stage's MFMAs (see the loop).  MFMA operands are
 // swapped (the W fragment is the "A" of the instruction): a lane then owns one ROW of C
 // and 4 consecutive columns per register quad, so fp32 C is stored in 16-B pieces and an
 // X3 image of C (EPI 2: the next GEMM's operand, e.g. the FFN hidden tensor) in whole
@@ -89,7 +89,6 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   constexpr int A_BYTES = (BM / 32) * TILE3;
   constexpr int STAGE = A_BYTES + 8 * TILE3;   // 36 / 48 KB
   constexpr int NP = STAGE / REC;              // DMA pieces per stage
-  constexpr int BAR = TA / 2 - 1;              // the A tile after which the barrier sits
 
   const int nblk = tiles_m * tiles_n;
   const int bid = xcd_block_order(blockIdx.x, nblk * p.ksplit);
@@ -105,6 +104,7 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 8);
   const int wm = wave >> 2, wn = wave & 3;
   const int hi = lane >> 5, li = lane & 31;
 
@@ -193,31 +193,45 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // six plane products, the small ones first; W fragment = MFMA "A" (rows of the
-  // instruction's result = columns of C)
+  // six plane products, the small ones first, the two accumulators of the A tile
+  // alternating (no MFMA waits for its predecessor's result); W fragment = MFMA "A" (rows
+  // of the instruction's result = columns of C)
   auto mma = [&](const FA& a, const FB& b, int i) {
+    constexpr int PB[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      f32x16 c = acc[i][j];
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][2], a.p[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][0], a.p[2], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][1], a.p[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][1], a.p[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][0], a.p[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][0], a.p[0], c, 0, 0, 0);
-      acc[i][j] = c;
-    }
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][PB[q]], a.p[PA[q]],
+                                                            acc[i][j], 0, 0, 0);
   };
 
   // ---- pipeline ----------------------------------------------------------------------------
-  // Top of stage g: stages <= g landed and visible, stage g+1 in flight, the W fragments
-  // and the first A tile of stage g in registers.  After A tile BAR each wave waits for
-  // its own pieces of stage g+1 (nothing else is in flight), the barrier makes stage g+1
-  // visible and proves every wave has left stage g-1, whose buffer the DMA of stage g+2
-  // then overwrites.  The fragments of stage g+1 are read during the last A tile.
+  // Ring of 3 stages, TWO of them in flight behind the one being read.  Top of stage g:
+  // stages <= g landed and visible, g+1 and g+2 in flight, the W fragments and the first
+  // A tile of stage g in registers.  The last A tile's fragments are read while tile
+  // TA-2 is multiplied, so after those MFMAs the wave is done with stage g's buffer: it
+  // waits (counted: stage g+2's pieces may stay in flight) for its own pieces of stage
+  // g+1, the ONE barrier of the stage makes g+1 visible and proves everyone has left
+  // stage g -- whose buffer the DMA of stage g+3 then overwrites.  A stage is needed two
+  // barriers after it was issued (~2 x 3000 MFMA cycles: the DMA latency is covered
+  // twice).  The fragments of stage g+1 are read during the last A tile.
+  constexpr int BAR = TA - 2;
+  const int npw = (NP - wave + 7) / 8;            // DMA pieces this wave issues per stage
+  auto wait_pieces = [&](int stages_in_flight) {  // of the stages younger than the awaited one
+    const int n = stages_in_flight * npw;
+    if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  };
   issue(0);
   if (nkb > 1) issue(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nkb > 2) issue(2);
+  wait_pieces(min(nkb, 3) - 1);
   __builtin_amdgcn_s_barrier();
   FB fb = loadB(0);
   FA fa = loadA(0, 0);
@@ -229,9 +243,10 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
       else if (g + 1 < nkb) { nb = loadB(g + 1); na = loadA(g + 1, 0); }
       mma(fa, fb, i);
       if (i == BAR) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stage g fully read
+        wait_pieces(g + 2 < nkb ? 1 : 0);
         __builtin_amdgcn_s_barrier();
-        if (g + 2 < nkb) issue(g + 2);
+        if (g + 3 < nkb) issue(g + 3);
       }
       if (i + 1 < TA) fa = na;
       else if (g + 1 < nkb) { fa = na; fb = nb; }
