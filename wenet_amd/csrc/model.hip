@@ -543,8 +543,9 @@ int ffn_x6_split(int M, int F) {
 // tensor, w_2 as K-slice partials in m->ffn_part.  Returns the slice count (0: not taken).
 int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStream_t s) {
   const int d = m->cfg.d_model, M = m->rows, F = w1.out;
+  // (d: the widths ffn_reduce_ln takes)
   if (t_gemm_prec != PREC_F32 || g_gemm_x6 == 0 || !m->x6_at || w1.out != w2.in ||
-      d % 16 != 0 || F % 16 != 0 || (M < 512 && g_gemm_x6 != 2))
+      !(d == 256 || d == 512) || F % 16 != 0 || (M < 512 && g_gemm_x6 != 2))
     return 0;
   auto i1 = m->x6_at->find(w1.w), i2 = m->x6_at->find(w2.w);
   if (i1 == m->x6_at->end() || i2 == m->x6_at->end()) return 0;
