@@ -247,54 +247,65 @@ __global__ __launch_bounds__(256) void cmvn_conv1_kernel(Conv1Args a) {
 // The same convolution written as the plane image of its output (gemm_x6.hip) for the
 // six-product conv2: one image row per conv1 pixel, pixel index = frame * F1 + pos with the
 // even f1 first (pos = f1 / 2) and the odd ones behind them (pos = (F1 + 1) / 2 + f1 / 2),
-// so that the stride-2 taps of conv2 read CONSECUTIVE pixels.  Lane = pixel of the frame,
-// wave = group of 8 channels (looped): a plane store covers consecutive 16-B pieces, the
-// weights of a channel group are wave-uniform.  Same accumulation order as above, the
-// fp32 result is split exactly -- conv2 sees the same operand values.
+// so that the stride-2 taps of conv2 read CONSECUTIVE pixels.  A wave owns ONE group of 8
+// channels (its 72 weights + 8 biases are loaded once, wave-uniform) and walks the pixels
+// of CF1 consecutive frames, 64 per pass (lane = pixel): a plane store covers consecutive
+// 16-B pieces.  Same accumulation order as above and an exact split -- conv2 sees the same
+// operand values.  (First version: one frame per block, the channel groups looped inside:
+// 375 us at config 2, waiting for the scalar weight loads of every iteration and with 39
+// of 64 lanes busy; the 976-MB image alone is ~200 us of HBM writes.)
+constexpr int CF1 = 16;    // frames per block
 __global__ __launch_bounds__(256) void cmvn_conv1_x3_kernel(Conv1Args a) {
   const int b = blockIdx.y;
-  const int t1 = blockIdx.x;
-  if (t1 >= a.t1_len[b]) return;
-  __shared__ float xin[3][128];
-  const float* src = a.feats + ((int64_t)b * a.T + 2 * t1) * a.F;
-  for (int i = threadIdx.x; i < 3 * a.F; i += 256) {
-    const int r = i / a.F, f = i % a.F;
-    float v = src[r * a.F + f];
+  const int f0 = blockIdx.x * CF1;
+  const int nf = min(CF1, a.t1_len[b] - f0);
+  if (nf <= 0) return;
+  __shared__ float xin[2 * CF1 + 1][128];
+  const float* src = a.feats + ((int64_t)b * a.T + 2 * f0) * a.F;
+  for (int i = threadIdx.x; i < (2 * nf + 1) * a.F; i += 256) {
+    const int r = i / a.F, f = i - r * a.F;
+    float v = src[i];
     if (a.mean) v = (v - a.mean[f]) * a.istd[f];
     xin[r][f] = v;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = blockIdx.z * 4 + wave;            // channels cg*8 .. +8
+  float w[9][8], bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = a.bias[cg * 8 + e];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[k][e] = a.w[k * a.C + cg * 8 + e];
   const int ne = (a.F1 + 1) / 2;
-  const int pos = min(lane, a.F1 - 1);
-  const int f1 = pos < ne ? 2 * pos : 2 * (pos - ne) + 1;
-  float x[9];
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) x[ky * 3 + kx] = xin[ky][2 * f1 + kx];
-  const int P = (a.t1_off[b] + t1) * a.F1 + pos;
-  for (int cg = wave; cg < a.C / 8; cg += 4) {
+  const int total = nf * a.F1;
+  const int64_t P0 = (int64_t)(a.t1_off[b] + f0) * a.F1;
+  for (int px = lane; px < total; px += 64) {
+    const int fr = px / a.F1, pos = px - fr * a.F1;
+    const int f1 = pos < ne ? 2 * pos : 2 * (pos - ne) + 1;
     float acc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = a.bias[cg * 8 + e];
+    for (int e = 0; e < 8; ++e) acc[e] = bias[e];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(a.w[k * a.C + cg * 8 + e], x[k], acc[e]);
+      for (int kx = 0; kx < 3; ++kx) {
+        const float x = xin[2 * fr + ky][2 * f1 + kx];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(w[ky * 3 + kx][e], x, acc[e]);
+      }
     bf16x8 p0, p1, p2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const Split3 sp = split3(fmaxf(acc[e], 0.f));
       p0[e] = sp.h0; p1[e] = sp.h1; p2[e] = sp.h2;
     }
-    if (lane < a.F1) {
-      char* o = a.out3 + x3_piece(cg >> 1, a.tiles, P, cg & 1);
-      *reinterpret_cast<bf16x8*>(o) = p0;
-      *reinterpret_cast<bf16x8*>(o + X3_REC) = p1;
-      *reinterpret_cast<bf16x8*>(o + 2 * X3_REC) = p2;
-    }
+    char* o = a.out3 + x3_piece(cg >> 1, a.tiles, (int)(P0 + px), cg & 1);
+    *reinterpret_cast<bf16x8*>(o) = p0;
+    *reinterpret_cast<bf16x8*>(o + X3_REC) = p1;
+    *reinterpret_cast<bf16x8*>(o + 2 * X3_REC) = p2;
   }
 }
 
@@ -751,8 +762,9 @@ int cmvn_conv1_relu(const Conv1Args& a, hipStream_t s) {
   WN_CHECK(a.F <= 128, "conv1: feature dim > 128");
   WN_CHECK(a.max_t1 > 0 && a.B > 0, "conv1: empty");
   if (a.out3) {
-    WN_CHECK(a.F1 <= 64 && a.C % 16 == 0 && a.tiles > 0, "conv1: plane image shape");
-    hipLaunchKernelGGL(cmvn_conv1_x3_kernel, dim3(a.max_t1, a.B), dim3(256), 0, s, a);
+    WN_CHECK(a.F1 <= 64 && a.C % 32 == 0 && a.tiles > 0, "conv1: plane image shape");
+    hipLaunchKernelGGL(cmvn_conv1_x3_kernel, dim3(cdiv(a.max_t1, CF1), a.B, a.C / 32), dim3(256),
+                       0, s, a);
     WN_HIP(hipGetLastError());
     return 0;
   }

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   const int grp = tb / per_group, in_grp = tb - grp * per_group;
   const int gm = min(GM, tiles_m - grp * GM);
   const int tm = grp * GM + in_grp % gm, tn = in_grp / gm;
-  const int m0 = tm * BM, n0 = tn * XBN;
+  const int m0 = p.row0 + tm * BM, n0 = tn * XBN;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
 
 template <int BM, int EPI, int ACT, bool CONV = false>
 int launch_x6(const X6Args& a, hipStream_t s) {
-  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, XBN);
+  const int tiles_m = cdiv(a.M - a.row0, BM), tiles_n = cdiv(a.N, XBN);
   const size_t lds = 3 * ((BM / 32) * TILE3 + 8 * TILE3);
   auto kern = gemm_x6_kernel<BM, EPI, ACT, CONV>;
   static bool done = false;
@@ -374,6 +374,7 @@ int launch_x6_act(const X6Args& a, hipStream_t s) {
 
 int g_gemm_x6 = 1;
 int g_x6_conv_bm = 0;
+int g_x6_ffn_s = 0;
 
 size_t x6_bytes(int R, int K) { return (size_t)(K / 16) * cdiv(R, 32) * TILE3; }
 
@@ -405,6 +406,17 @@ int gemm_x6(const X6Args& a, hipStream_t s) {
     WN_CHECK(a.epi == 0 && a.act == ACT_RELU && a.conv_kbc > 0 && a.a_tiles > 0 &&
                  (a.K / 16) % a.conv_kbc == 0 && a.K / 16 / a.conv_kbc <= 9,
              "gemm_x6: gathered A operand");
+    // One 256-row tile per CU and round: when the last round would be less than half
+    // full, its rows go to a second launch of 128-row tiles (half as long) instead --
+    // 589 tiles at config 2 = 2.3 rounds become 2 rounds + 154 half tiles.
+    const int t256 = cdiv(a.M, 256), full = t256 / 256 * 256;
+    if (a.bm == 0 && a.N <= XBN && full > 0 && t256 - full > 0 && t256 - full <= 128) {
+      X6Args main = a, rest = a;
+      main.M = full * 256;
+      rest.row0 = full * 256;
+      if (launch_x6<256, 0, ACT_RELU, true>(main, s) != 0) return -1;
+      return launch_x6<128, 0, ACT_RELU, true>(rest, s);
+    }
     return bm == 256 ? launch_x6<256, 0, ACT_RELU, true>(a, s)
                      : launch_x6<128, 0, ACT_RELU, true>(a, s);
   }

@@ -115,6 +115,7 @@ struct X6Args {
   const void* A3 = nullptr;   // image of A (M x K)
   const void* B3 = nullptr;   // image of W (N x K)
   int M = 0, N = 0, K = 0;
+  int row0 = 0;               // first row of C this launch computes (multiple of 256)
   int ksplit = 1;             // K slices (epi 1 only)
   int bm = 0;                 // block rows 128 / 256, 0 = auto
   int epi = 0;                // 0: C = resid + alpha act(acc + bias); 1: P[slice][M][N] = acc;
@@ -131,6 +132,7 @@ struct X6Args {
   int a_tiles = 0, conv_kbc = 0;
   int tap_delta[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
+extern int g_x6_ffn_s;     // wn_tune_set("x6_ffn_s"): K slices of the FFN w_2 GEMM (0 auto)
 extern int g_x6_conv_bm;   // wn_tune_set("x6_conv_bm"): block rows of the conv2 GEMM (0 auto)
 extern int g_gemm_x6;     // wn_tune_set("gemm_x6"): 0 = the v_mfma_f32 kernels (A/B, tests)
 size_t x6_bytes(int R, int K);

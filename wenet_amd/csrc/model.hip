@@ -533,6 +533,7 @@ int build_x6_images(wn_model* m) {
 // hidden split of the x6 FFN's second GEMM: K slices so that 128-row tiles x slices fill
 // the CUs once
 int ffn_x6_split(int M, int F) {
+  if (g_x6_ffn_s > 0 && (F / 16) % g_x6_ffn_s == 0) return g_x6_ffn_s;   // A/B knob
   int S = 1;
   while (S < 16 && cdiv(M, 128) * (S * 2) <= 256 && (F / 16) % (S * 2) == 0) S *= 2;
   return S;
@@ -675,7 +676,7 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
     // fp32 on the bf16 matrix cores (gemm_x6.hip): conv1 writes the plane image of its
     // output, conv2 gathers its rows from it
     const void* w6 = nullptr;
-    if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && m->x6_at && d % 16 == 0 && F1 <= 64 &&
+    if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && m->x6_at && d % 32 == 0 && F1 <= 64 &&
         (M * F2 >= 4096 || g_gemm_x6 == 2)) {
       auto it = m->x6_at->find(m->conv2.w);
       if (it != m->x6_at->end() &&
@@ -1775,6 +1776,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "ffn_bm64") g_ffn_bm64 = value;
   else if (k == "gemm_x6") g_gemm_x6 = value;
   else if (k == "x6_conv_bm") g_x6_conv_bm = value;
+  else if (k == "x6_ffn_s") g_x6_ffn_s = value;
   else if (k == "beam_prio") g_beam_prio = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "gemm_rowln") g_gemm_rowln = value;
