@@ -128,6 +128,32 @@ def mx_round(x: torch.Tensor) -> torch.Tensor:
     return mx_dequantize(*mx_quantize(x))
 
 
+def x6_planes(x: torch.Tensor):
+    """The product's exact three-way bf16 split of an fp32 tensor (csrc/x6.h split3,
+    restated): x0 = bf16(x) (round to nearest even), x1 = bf16(x - x0), x2 = x - x0 - x1.
+    Both subtractions are exact in fp32 and x2 has at most 8 significant bits, so
+    x0 + x1 + x2 == x bit for bit (returned as three fp32 tensors holding bf16 values)."""
+    x = x.to(torch.float32)
+    x0 = x.to(torch.bfloat16).to(torch.float32)
+    r1 = x - x0
+    x1 = r1.to(torch.bfloat16).to(torch.float32)
+    x2 = (r1 - x1).to(torch.bfloat16).to(torch.float32)
+    return x0, x1, x2
+
+
+def x6_matmul(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """a @ w.T as the product's six-product fp32 GEMM forms it (csrc/gemm_x6.hip): of the
+    nine plane products the six with i + j <= 2 (a0b0, a0b1, a1b0, a1b1, a0b2, a2b0); every
+    plane product is exact in fp32 (8 x 8 significand bits).  Evaluated here in fp64 --
+    what is restated is WHICH terms are kept, not the accumulation order."""
+    ap = [t.double() for t in x6_planes(a)]
+    wp = [t.double() for t in x6_planes(w)]
+    out = torch.zeros(a.shape[0], w.shape[0], dtype=torch.float64)
+    for i, j in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)):
+        out += ap[i] @ wp[j].T
+    return out
+
+
 @contextlib.contextmanager
 def bf16_operands(sd=None, attention=True, fp8_ffn=False):
     """Run the oracle with the product's bf16-operand arithmetic (see

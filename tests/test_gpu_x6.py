@@ -82,6 +82,18 @@ def test_gemm_x6_is_an_fp32_gemm(M, N, K, act, resid, bm):
     assert r6 <= 1.2 * r32 + 1e-8
 
 
+def test_gemm_x6_vs_the_oracle_restatement():
+    """The HIP kernel against oracle.x6_matmul (the same six plane products, summed in
+    fp64): what separates them is only the fp32 accumulation order."""
+    from oracle import wenet_oracle as O
+    g = torch.Generator().manual_seed(17)
+    A = torch.randn(777, 384, generator=g)
+    W = torch.randn(300, 384, generator=g) / 384 ** 0.5
+    ref = O.x6_matmul(A, W)
+    c6 = _x6(A.cuda(), W.cuda(), None, None, 0, 1.0).cpu().double()
+    assert (c6 - ref).abs().max().item() < 2e-6
+
+
 def test_x6_planes_are_exact():
     """The operand split is exact (x0 + x1 + x2 == x for every fp32 input), so with W = I
     the GEMM must return A bit for bit up to the six-product rule: x * 1 keeps x0, x1, x2

@@ -710,3 +710,38 @@ def test_whisper_frontend_pins_live_against_oracle_ref():
     wave = np.asarray(S.make_audio(16000 * 2 + 123, seed=9), dtype=np.float32)
     ref = ref_fbank.ref_whisper_fbank(wave, 80)
     assert np.abs(O.whisper_frontend_512(wave, 80) - ref).max() < 2e-4
+
+
+def test_x6_plane_split_is_exact_and_the_dropped_products_are_below_fp32_rounding():
+    """The arithmetic claim of csrc/gemm_x6.hip (restated in the oracle): the three bf16
+    planes of an fp32 value sum to it exactly, and the three plane products the GEMM drops
+    (a1b2 + a2b1 + a2b2) are below 2^-26 of |a b| -- a quarter of the half-ulp one fp32
+    multiply-add rounds away -- so against fp64 the six-product GEMM is not worse than an
+    fp32 GEMM."""
+    g = torch.Generator().manual_seed(11)
+    # (exact while the third plane stays a NORMAL bf16 number, |x| >= ~2^-108; below that
+    # the split is off by less than 2^-133 absolute, the fp32 subnormal grid itself)
+    x = torch.randn(50000, generator=g) * torch.logspace(-28, 30, 50000)
+    x = x[x.abs() > 2.0 ** -100]
+    x = torch.cat([x, torch.tensor([0.0, 1.0, -1.0, 3.0e38, 1.0 + 2.0 ** -23])])
+    t0, t1, t2 = O.x6_planes(torch.tensor([1.0e-37, -3.0e-36]))
+    assert ((t0.double() + t1.double() + t2.double()) -
+            torch.tensor([1.0e-37, -3.0e-36]).double()).abs().max() < 2.0 ** -133
+    x0, x1, x2 = O.x6_planes(x)
+    for p in (x0, x1, x2):                       # every plane is a bf16 value
+        assert torch.equal(p.to(torch.bfloat16).to(torch.float32), p)
+    assert torch.equal((x0.double() + x1.double() + x2.double()).float(), x)
+    assert torch.equal(x0.double() + x1.double() + x2.double(), x.double())   # exactly
+    assert (x1.abs() <= 2.0 ** -8 * x.abs()).all() and (x2.abs() <= 2.0 ** -16 * x.abs()).all()
+    a = torch.randn(64, 512, generator=g)
+    w = torch.randn(48, 512, generator=g)
+    ap, wp = O.x6_planes(a), O.x6_planes(w)
+    dropped = (ap[1].double().abs() @ wp[2].double().abs().T +
+               ap[2].double().abs() @ wp[1].double().abs().T +
+               ap[2].double().abs() @ wp[2].double().abs().T)
+    bound = 2.0 ** -26 * (a.double().abs() @ w.double().abs().T)
+    assert (dropped <= bound).all()
+    ref = a.double() @ w.double().T
+    e6 = (O.x6_matmul(a, w) - ref).abs().max().item()
+    e32 = ((a @ w.T).double() - ref).abs().max().item()
+    assert e6 <= 2.0 ** -26 * float((a.abs() @ w.abs().T).max()) and e6 < e32

@@ -23,8 +23,8 @@
 // (all row tiles x planes of one k block) is ONE contiguous piece of the image.
 //
 // Kernel: BM (128 | 256) x 256 block tile, 8 waves as 2 (M) x 4 (N), wave tile BM/2 x 64,
-// one k block (16) per stage: BM/32*3 + 24 records = 36 / 48 KB, ring of 3 stages, two in
-// flight.  Per stage ONE barrier, late in the stage's MFMAs (see the loop).  MFMA operands are
+// one k block (16) per stage: BM/32*3 + 24 records = 36 / 48 KB, ring of 4 / 3 stages, all
+// but the one being read in flight.  Per stage ONE barrier, late in the stage's MFMAs (see the loop).  MFMA operands are
 // swapped (the W fragment is the "A" of the instruction): a lane then owns one ROW of C
 // and 4 consecutive columns per register quad, so fp32 C is stored in 16-B pieces and an
 // X3 image of C (EPI 2: the next GEMM's operand, e.g. the FFN hidden tensor) in whole
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   constexpr int A_BYTES = (BM / 32) * TILE3;
   constexpr int STAGE = A_BYTES + 8 * TILE3;   // 36 / 48 KB
   constexpr int NP = STAGE / REC;              // DMA pieces per stage
+  constexpr int RING = BM == 128 ? 4 : 3;      // stages in LDS (144 KB either way)
 
   const int nblk = tiles_m * tiles_n;
   const int bid = xcd_block_order(blockIdx.x, nblk * p.ksplit);
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   }
   auto issue = [&](int g) {
     const int kb = kb0 + g;
-    char* dst = smem_x + (g % 3) * STAGE;
+    char* dst = smem_x + (g % RING) * STAGE;
     int sa = (kb * Ta + (m0 >> 5)) * TILE3, delta = 0;
     if (CONV) {
       const int tap = kb / p.conv_kbc;
@@ -168,14 +169,14 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   struct FA { bf16x8 p[3]; };
   struct FB { bf16x8 p[2][3]; };
   auto loadA = [&](int g, int i) {
-    const char* st = smem_x + (g % 3) * STAGE + (wm * TA + i) * TILE3 + lane * 16;
+    const char* st = smem_x + (g % RING) * STAGE + (wm * TA + i) * TILE3 + lane * 16;
     FA f;
 #pragma unroll
     for (int q = 0; q < 3; ++q) f.p[q] = *reinterpret_cast<const bf16x8*>(st + q * REC);
     return f;
   };
   auto loadB = [&](int g) {
-    const char* st = smem_x + (g % 3) * STAGE + A_BYTES + (wn * 2) * TILE3 + lane * 16;
+    const char* st = smem_x + (g % RING) * STAGE + A_BYTES + (wn * 2) * TILE3 + lane * 16;
     FB f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -207,31 +208,34 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   };
 
   // ---- pipeline ----------------------------------------------------------------------------
-  // Ring of 3 stages, TWO of them in flight behind the one being read.  Top of stage g:
-  // stages <= g landed and visible, g+1 and g+2 in flight, the W fragments and the first
-  // A tile of stage g in registers.  The last A tile's fragments are read while tile
-  // TA-2 is multiplied, so after those MFMAs the wave is done with stage g's buffer: it
-  // waits (counted: stage g+2's pieces may stay in flight) for its own pieces of stage
-  // g+1, the ONE barrier of the stage makes g+1 visible and proves everyone has left
-  // stage g -- whose buffer the DMA of stage g+3 then overwrites.  A stage is needed two
-  // barriers after it was issued (~2 x 3000 MFMA cycles: the DMA latency is covered
-  // twice).  The fragments of stage g+1 are read during the last A tile.
+  // Ring of RING stages, RING-1 of them in flight behind the one being read (3 stages of 48
+  // KB for 256-row tiles, 4 of 36 KB for 128-row tiles: the K-slice GEMMs that use those
+  // stream their A operand from HBM, not from L2).  Top of stage g: stages <= g landed and
+  // visible, g+1 .. g+RING-1 in flight, the W fragments and the first A tile of stage g in
+  // registers.  The last A tile's fragments are read while tile TA-2 is multiplied, so
+  // after those MFMAs the wave is done with stage g's buffer: it waits (counted: the
+  // younger stages may stay in flight) for its own pieces of stage g+1, the ONE barrier of
+  // the stage makes g+1 visible and proves everyone has left stage g -- whose buffer the
+  // DMA of stage g+RING then overwrites.  The fragments of stage g+1 are read during the
+  // last A tile.
   constexpr int BAR = TA - 2;
   const int npw = (NP - wave + 7) / 8;            // DMA pieces this wave issues per stage
   auto wait_pieces = [&](int stages_in_flight) {  // of the stages younger than the awaited one
-    const int n = stages_in_flight * npw;
-    if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    switch (stages_in_flight * npw) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;   // 3 x 5
+    }
   };
-  issue(0);
-  if (nkb > 1) issue(1);
-  if (nkb > 2) issue(2);
-  wait_pieces(min(nkb, 3) - 1);
+#pragma unroll
+  for (int g = 0; g < RING; ++g)
+    if (g < nkb) issue(g);
+  wait_pieces(min(nkb, RING) - 1);
   __builtin_amdgcn_s_barrier();
   FB fb = loadB(0);
   FA fa = loadA(0, 0);
@@ -244,9 +248,9 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
       mma(fa, fb, i);
       if (i == BAR) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stage g fully read
-        wait_pieces(g + 2 < nkb ? 1 : 0);
+        wait_pieces(max(0, min(nkb - 2 - g, RING - 2)));
         __builtin_amdgcn_s_barrier();
-        if (g + 3 < nkb) issue(g + 3);
+        if (g + RING < nkb) issue(g + RING);
       }
       if (i + 1 < TA) fa = na;
       else if (g + 1 < nkb) { fa = na; fb = nb; }
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
 template <int BM, int EPI, int ACT, bool CONV = false>
 int launch_x6(const X6Args& a, hipStream_t s) {
   const int tiles_m = cdiv(a.M - a.row0, BM), tiles_n = cdiv(a.N, XBN);
-  const size_t lds = 3 * ((BM / 32) * TILE3 + 8 * TILE3);
+  const size_t lds = (size_t)(BM == 128 ? 4 : 3) * ((BM / 32) * TILE3 + 8 * TILE3);
   auto kern = gemm_x6_kernel<BM, EPI, ACT, CONV>;
   static bool done = false;
   if (!done) {

@@ -12,7 +12,8 @@ constexpr int X3_REC = 1024;            // one (k block, 32-row tile, plane) rec
 constexpr int X3_TILE = 3 * X3_REC;     // the three planes of a tile and k block
 
 // x = h0 + h1 + h2 exactly: h0 = bf16(x) (round to nearest even), h1 = bf16(x - h0),
-// h2 = x - h0 - h1 (<= 8 significant bits left, so the last conversion is exact)
+// h2 = x - h0 - h1 (<= 8 significant bits left, so the last conversion is exact; only
+// below |x| ~ 2^-108, where h2 would be a subnormal bf16, is the sum off -- by < 2^-133)
 struct Split3 { __bf16 h0, h1, h2; };
 __device__ __forceinline__ Split3 split3(float x) {
   Split3 s;
