@@ -9,6 +9,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[1, 0], ids=['a_fp32', 'a_planes'], autouse=True)
+def a_operand_form(request):
+    """Both forms of the A operand: a plane image made by x6_split / a GEMM epilogue (the
+    default) and plain fp32 rows split in registers."""
+    from wenet_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.wn_tune_set(b'x6_af32', request.param), 'tune')
+    yield
+    L.wn_tune_set(b'x6_af32', 0)
+
+
 def _x6(A, W, b, r, act, alpha, bm=0):
     from wenet_amd import _lib
     L = _lib.lib()
@@ -91,7 +102,8 @@ def test_gemm_x6_vs_the_oracle_restatement():
     W = torch.randn(300, 384, generator=g) / 384 ** 0.5
     ref = O.x6_matmul(A, W)
     c6 = _x6(A.cuda(), W.cuda(), None, None, 0, 1.0).cpu().double()
-    assert (c6 - ref).abs().max().item() < 2e-6
+    # fp32 accumulation of 384 terms of magnitude ~1: a few ulp of the result
+    assert (c6 - ref).abs().max().item() < 1e-5
 
 
 def test_x6_planes_are_exact():

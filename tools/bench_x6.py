@@ -39,8 +39,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', default='')
+    ap.add_argument('--af32', type=int, default=0,
+                    help='1: A as plain fp32 rows split in registers, 0: plane image')
+    ap.add_argument('--probe', type=int, default=0,
+                    help='ablation: 1 = no MFMAs (DMA + fragment reads), 2 = no DMA')
     args = ap.parse_args()
     L = _lib.lib()
+    _lib.check(L.wn_tune_set(b'x6_probe', args.probe), 'tune')
+    _lib.check(L.wn_tune_set(b'x6_af32', args.af32), 'tune')
     st = torch.cuda.current_stream().cuda_stream
     only = [s for s in args.only.split(',') if s]
     for name, (m, n, k, act) in SHAPES.items():

@@ -81,13 +81,22 @@ __global__ __launch_bounds__(256) void x6_split_kernel(const float* __restrict__
 // channels-last tensor whose X3 image has one row per input pixel): GEMM row r reads pixel
 // a_pix[r] + tap_delta[tap] for the k blocks of tap = kb / conv_kbc -- the DMA addresses
 // are per lane instead of linear, the LDS side is unchanged.
-template <int BM, int EPI, int ACT, bool CONV = false>
+// AF32: the A operand is a plain row-major fp32 matrix (p.A, p.lda) -- or, with CONV, the
+// channels-last fp32 tensor itself -- and is split into its three planes IN REGISTERS after
+// the fragment read: no plane image of an activation ever exists (none is written by a
+// producer, none is read back), at the price of ~50 VALU operations per A fragment.  The A
+// part of a stage is then 32 rows x 64 B per tile, fetched by 4 lanes per row (16 cache
+// lines per DMA instruction instead of 8) into row-major LDS rows whose four 16-B slots are
+// XOR-swizzled with (row >> 2) & 3 on the source side, so that the two ds_read_b128 of a
+// lane's 8 k values are conflict-free.
+template <int BM, int EPI, int ACT, bool CONV = false, bool AF32 = false>
 __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   constexpr int TA = BM / 64;                  // A tiles (32 rows) per wave
-  constexpr int A_BYTES = (BM / 32) * TILE3;
-  constexpr int STAGE = A_BYTES + 8 * TILE3;   // 36 / 48 KB
+  constexpr int A_TILE = AF32 ? 2048 : TILE3;  // bytes of a 32-row A tile and k block
+  constexpr int A_BYTES = (BM / 32) * A_TILE;
+  constexpr int STAGE = A_BYTES + 8 * TILE3;   // 36 / 48 KB (AF32: 32 / 40 KB)
   constexpr int NP = STAGE / REC;              // DMA pieces per stage
   constexpr int RING = BM == 128 ? 4 : 3;      // stages in LDS (144 KB either way)
 
@@ -113,7 +122,9 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   const int nkb_all = p.K >> 4;
   const int nkb = nkb_all / p.ksplit, kb0 = slice * nkb;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.A3), 0, (int)min((int64_t)(CONV ? p.conv_kbc : nkb_all) * Ta * TILE3, (int64_t)0x7fffffff),
+      const_cast<void*>(AF32 ? (const void*)p.A : p.A3), 0,
+      (int)min(AF32 ? p.a_bytes : (int64_t)(CONV ? p.conv_kbc : nkb_all) * Ta * TILE3,
+               (int64_t)0x7fffffff),
       0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.B3), 0, (int)min((int64_t)nkb_all * Tb * TILE3, (int64_t)0x7fffffff),
@@ -123,35 +134,51 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   // last one read the next k block's records or (buffer bounds) zeros: they only reach
   // rows / columns of C that are never stored.
   const unsigned vlane = (unsigned)lane * 16u;
-  // CONV: base pixel of this lane's row in each A piece the wave issues (piece j -> row
-  // tile j / 3)
+  // CONV: base pixel of this lane's row in each A piece the wave issues (planes: piece j
+  // -> row tile j / 3, lane -> row lane & 31; AF32: piece j -> rows (j / 2) * 32 + (j & 1) *
+  // 16 + lane / 4).  AF32 without CONV: the lane's byte offset into A instead.
   constexpr int NPA = (A_BYTES / REC + 7) / 8;
   int pix[NPA];
-  if (CONV) {
+  if (CONV || AF32) {
 #pragma unroll
     for (int q = 0; q < NPA; ++q) {
       const int j = q * 8 + wave;
-      pix[q] = p.a_pix[min(m0 + (j / 3) * 32 + li, p.M - 1)];
+      const int rl = AF32 ? (j >> 1) * 32 + (j & 1) * 16 + (lane >> 2) : (j / 3) * 32 + li;
+      const int row = min(m0 + rl, p.M - 1);
+      if (CONV) pix[q] = p.a_pix[row];
+      else pix[q] = row * p.lda * 4 + (((lane & 3) ^ ((rl >> 2) & 3)) << 4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // before the DMA ring starts
 #pragma unroll
     for (int q = 0; q < NPA; ++q) asm volatile("" : "+v"(pix[q]));
   }
   auto issue = [&](int g) {
+    if (p.probe & 2) return;                       // ablation: no DMA (tools/bench_x6.py)
     const int kb = kb0 + g;
     char* dst = smem_x + (g % RING) * STAGE;
     int sa = (kb * Ta + (m0 >> 5)) * TILE3, delta = 0;
     if (CONV) {
       const int tap = kb / p.conv_kbc;
-      sa = (kb - tap * p.conv_kbc) * Ta * TILE3;
+      sa = AF32 ? (kb - tap * p.conv_kbc) * 64 : (kb - tap * p.conv_kbc) * Ta * TILE3;
       delta = p.tap_delta[tap];
+    } else if (AF32) {
+      sa = kb * 64;
     }
     const int sb = (kb * Tb + (n0 >> 5)) * TILE3;
 #pragma unroll
     for (int j0 = 0; j0 < NP; j0 += 8) {
       const int j = j0 + wave;
       if (j < A_BYTES / REC) {
-        if (CONV) {
+        if (AF32) {
+          unsigned vo = (unsigned)pix[j0 / 8];
+          if (CONV) {
+            const int rl = (j & 1) * 16 + (lane >> 2);
+            vo = (unsigned)((pix[j0 / 8] + delta) * p.conv_kbc * 64 +
+                            (((lane & 3) ^ ((rl >> 2) & 3)) << 4));
+          }
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + j * REC), 16, vo, sa, 0,
+                                                   0);
+        } else if (CONV) {
           const int P = pix[j0 / 8] + delta;
           const unsigned vo = (unsigned)(((P >> 5) * 3 + j % 3) * REC + hi * 512 + (P & 31) * 16);
           __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + j * REC), 16, vo, sa, 0,
@@ -169,10 +196,24 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   struct FA { bf16x8 p[3]; };
   struct FB { bf16x8 p[2][3]; };
   auto loadA = [&](int g, int i) {
-    const char* st = smem_x + (g % RING) * STAGE + (wm * TA + i) * TILE3 + lane * 16;
     FA f;
+    if constexpr (AF32) {
+      // row li of the tile: 64 B, slots swizzled; this lane's k half = slots 2 hi, 2 hi + 1
+      const char* st = smem_x + (g % RING) * STAGE + (wm * TA + i) * A_TILE + li * 64;
+      const int fz = (li >> 2) & 3;
+      const f32x4 u = *reinterpret_cast<const f32x4*>(st + (((2 * hi) ^ fz) << 4));
+      const f32x4 v = *reinterpret_cast<const f32x4*>(st + (((2 * hi + 1) ^ fz) << 4));
 #pragma unroll
-    for (int q = 0; q < 3; ++q) f.p[q] = *reinterpret_cast<const bf16x8*>(st + q * REC);
+      for (int e = 0; e < 4; ++e) {
+        const Split3 su = split3(u[e]), sv = split3(v[e]);
+        f.p[0][e] = su.h0; f.p[1][e] = su.h1; f.p[2][e] = su.h2;
+        f.p[0][4 + e] = sv.h0; f.p[1][4 + e] = sv.h1; f.p[2][4 + e] = sv.h2;
+      }
+    } else {
+      const char* st = smem_x + (g % RING) * STAGE + (wm * TA + i) * TILE3 + lane * 16;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) f.p[q] = *reinterpret_cast<const bf16x8*>(st + q * REC);
+    }
     return f;
   };
   auto loadB = [&](int g) {
@@ -199,6 +240,12 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   // of the instruction's result = columns of C)
   auto mma = [&](const FA& a, const FB& b, int i) {
     constexpr int PB[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
+    if (p.probe & 1) {                             // ablation: no MFMAs, keep the reads alive
+      asm volatile("" :: "v"(a.p[0]), "v"(a.p[1]), "v"(a.p[2]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(b.p[j][0]), "v"(b.p[j][1]), "v"(b.p[j][2]));
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 6; ++q)
 #pragma unroll
@@ -343,11 +390,12 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   }
 }
 
-template <int BM, int EPI, int ACT, bool CONV = false>
+template <int BM, int EPI, int ACT, bool CONV = false, bool AF32 = false>
 int launch_x6(const X6Args& a, hipStream_t s) {
   const int tiles_m = cdiv(a.M - a.row0, BM), tiles_n = cdiv(a.N, XBN);
-  const size_t lds = (size_t)(BM == 128 ? 4 : 3) * ((BM / 32) * TILE3 + 8 * TILE3);
-  auto kern = gemm_x6_kernel<BM, EPI, ACT, CONV>;
+  const size_t lds =
+      (size_t)(BM == 128 ? 4 : 3) * ((BM / 32) * (AF32 ? 2048 : TILE3) + 8 * TILE3);
+  auto kern = gemm_x6_kernel<BM, EPI, ACT, CONV, AF32>;
   static bool done = false;
   if (!done) {
     WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -360,14 +408,14 @@ int launch_x6(const X6Args& a, hipStream_t s) {
   return 0;
 }
 
-template <int BM, int EPI>
+template <int BM, int EPI, bool AF32 = false>
 int launch_x6_act(const X6Args& a, hipStream_t s) {
-  if (EPI == 1) return launch_x6<BM, EPI, ACT_NONE>(a, s);
+  if (EPI == 1) return launch_x6<BM, EPI, ACT_NONE, false, AF32>(a, s);
   switch (a.act) {
-    case ACT_NONE: return launch_x6<BM, EPI, ACT_NONE>(a, s);
-    case ACT_SILU: return launch_x6<BM, EPI, ACT_SILU>(a, s);
-    case ACT_RELU: return launch_x6<BM, EPI, ACT_RELU>(a, s);
-    case ACT_GELU: return launch_x6<BM, EPI, ACT_GELU>(a, s);
+    case ACT_NONE: return launch_x6<BM, EPI, ACT_NONE, false, AF32>(a, s);
+    case ACT_SILU: return launch_x6<BM, EPI, ACT_SILU, false, AF32>(a, s);
+    case ACT_RELU: return launch_x6<BM, EPI, ACT_RELU, false, AF32>(a, s);
+    case ACT_GELU: return launch_x6<BM, EPI, ACT_GELU, false, AF32>(a, s);
     default: break;
   }
   set_error("gemm_x6: unsupported activation");
@@ -379,6 +427,12 @@ int launch_x6_act(const X6Args& a, hipStream_t s) {
 int g_gemm_x6 = 1;
 int g_x6_conv_bm = 0;
 int g_x6_ffn_s = 0;
+// 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in
+// registers.  Measured (r02ag): the split costs more than the plane bytes it saves -- FFN w_1
+// 53.8 -> 63.7 us, w_2 54.6 -> 60.7, conv2 921 -> 1055 (+ conv1 185 -> 125), 8192 x 4096 x
+// 4096 1124 -> 1312 us, decode step 7.28 -> 7.4-7.7 ms.
+int g_x6_af32 = 0;
+int g_x6_probe = 0;     // wn_tune_set("x6_probe"): 1 no MFMAs, 2 no DMA (ablation)
 
 size_t x6_bytes(int R, int K) { return (size_t)(K / 16) * cdiv(R, 32) * TILE3; }
 
@@ -397,41 +451,55 @@ int gemm_x6_bm(int M, int N, int ksplit) {
 }
 
 int gemm_x6(const X6Args& a, hipStream_t s) {
-  WN_CHECK(a.A3 && a.B3 && a.M > 0 && a.N > 0 && a.K > 0 && a.K % 16 == 0, "gemm_x6: shape");
+  const bool af32 = a.A != nullptr;
+  WN_CHECK((a.A3 || af32) && a.B3 && a.M > 0 && a.N > 0 && a.K > 0 && a.K % 16 == 0,
+           "gemm_x6: shape");
   WN_CHECK(a.ksplit >= 1 && (a.K / 16) % a.ksplit == 0, "gemm_x6: K split");
   WN_CHECK(a.N % 4 == 0 && (a.epi != 2 || a.N % 16 == 0), "gemm_x6: N");
-  WN_CHECK((a.a_pix || x6_bytes(a.M, a.K) < ((size_t)1 << 31)) &&
+  WN_CHECK((a.a_pix || af32 || x6_bytes(a.M, a.K) < ((size_t)1 << 31)) &&
                x6_bytes(a.N, a.K) < ((size_t)1 << 31), "gemm_x6: operand image over 2 GB");
+  WN_CHECK(!af32 || (a.a_bytes > 0 && a.a_bytes < ((int64_t)1 << 31) &&
+                     (a.a_pix || a.lda % 4 == 0)), "gemm_x6: fp32 A operand");
   WN_CHECK(a.epi == 2 ? a.C3 != nullptr : a.C != nullptr, "gemm_x6: no output");
   WN_CHECK(a.epi == 1 || a.ksplit == 1, "gemm_x6: K slices need the partial epilogue");
   const int bm = a.bm ? a.bm : gemm_x6_bm(a.M, a.N, a.ksplit);
+  if (g_x6_probe) const_cast<X6Args&>(a).probe = g_x6_probe;
   if (a.a_pix) {
     // implicit GEMM of the subsampling conv2: fp32 C with bias + ReLU
-    WN_CHECK(a.epi == 0 && a.act == ACT_RELU && a.conv_kbc > 0 && a.a_tiles > 0 &&
+    WN_CHECK(a.epi == 0 && a.act == ACT_RELU && a.conv_kbc > 0 && (af32 || a.a_tiles > 0) &&
                  (a.K / 16) % a.conv_kbc == 0 && a.K / 16 / a.conv_kbc <= 9,
              "gemm_x6: gathered A operand");
     // One 256-row tile per CU and round: when the last round would be less than half
     // full, its rows go to a second launch of 128-row tiles (half as long) instead --
     // 589 tiles at config 2 = 2.3 rounds become 2 rounds + 154 half tiles.
     const int t256 = cdiv(a.M, 256), full = t256 / 256 * 256;
+    auto run = [&](const X6Args& x, int rows) {
+      if (af32) return rows == 256 ? launch_x6<256, 0, ACT_RELU, true, true>(x, s)
+                                   : launch_x6<128, 0, ACT_RELU, true, true>(x, s);
+      return rows == 256 ? launch_x6<256, 0, ACT_RELU, true>(x, s)
+                         : launch_x6<128, 0, ACT_RELU, true>(x, s);
+    };
     if (a.bm == 0 && a.N <= XBN && full > 0 && t256 - full > 0 && t256 - full <= 128) {
       X6Args main = a, rest = a;
       main.M = full * 256;
       rest.row0 = full * 256;
-      if (launch_x6<256, 0, ACT_RELU, true>(main, s) != 0) return -1;
-      return launch_x6<128, 0, ACT_RELU, true>(rest, s);
+      if (run(main, 256) != 0) return -1;
+      return run(rest, 128);
     }
-    return bm == 256 ? launch_x6<256, 0, ACT_RELU, true>(a, s)
-                     : launch_x6<128, 0, ACT_RELU, true>(a, s);
+    return run(a, bm);
   }
-#define WN_X6(BM)                                              \
+#define WN_X6(BM, AF)                                          \
   switch (a.epi) {                                             \
-    case 0: return launch_x6_act<BM, 0>(a, s);                 \
-    case 1: return launch_x6_act<BM, 1>(a, s);                 \
-    case 2: return launch_x6_act<BM, 2>(a, s);                 \
+    case 0: return launch_x6_act<BM, 0, AF>(a, s);             \
+    case 1: return launch_x6_act<BM, 1, AF>(a, s);             \
+    case 2: return launch_x6_act<BM, 2, AF>(a, s);             \
     default: break;                                            \
   }
-  if (bm == 256) { WN_X6(256) } else { WN_X6(128) }
+  if (af32) {
+    if (bm == 256) { WN_X6(256, true) } else { WN_X6(128, true) }
+  } else {
+    if (bm == 256) { WN_X6(256, false) } else { WN_X6(128, false) }
+  }
 #undef WN_X6
   set_error("gemm_x6: unknown epilogue");
   return -1;

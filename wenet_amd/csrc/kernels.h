@@ -113,6 +113,9 @@ int ffn_reduce_ln(float* x, const float* P, int S, const float* b2, float alpha,
 // x6_bytes(R, K) bytes for an R x K matrix, made by x6_split or by a GEMM's EPI 2.
 struct X6Args {
   const void* A3 = nullptr;   // image of A (M x K)
+  // instead of A3: A as plain row-major fp32 (lda floats per row, a_bytes = extent of the
+  // buffer), split into planes in registers; with a_pix: the channels-last fp32 tensor
+  const float* A = nullptr; int lda = 0; int64_t a_bytes = 0;
   const void* B3 = nullptr;   // image of W (N x K)
   int M = 0, N = 0, K = 0;
   int row0 = 0;               // first row of C this launch computes (multiple of 256)
@@ -131,7 +134,10 @@ struct X6Args {
   const int* a_pix = nullptr;
   int a_tiles = 0, conv_kbc = 0;
   int tap_delta[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int probe = 0;              // ablation bits (g_x6_probe)
 };
+extern int g_x6_probe;
+extern int g_x6_af32;      // wn_tune_set("x6_af32"): 0 plane images (default), 1 fp32 A rows split in registers
 extern int g_x6_ffn_s;     // wn_tune_set("x6_ffn_s"): K slices of the FFN w_2 GEMM (0 auto)
 extern int g_x6_conv_bm;   // wn_tune_set("x6_conv_bm"): block rows of the conv2 GEMM (0 auto)
 extern int g_gemm_x6;     // wn_tune_set("gemm_x6"): 0 = the v_mfma_f32 kernels (A/B, tests)

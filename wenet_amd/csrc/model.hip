@@ -120,13 +120,14 @@ struct Decoder {
 
 // x6 conv2: base pixel (plane image row of conv1's output, even-first order inside a
 // frame) of GEMM row (g, f2): frame off1[u] + 2 t2, position f2 (= f1 2 f2)
+// (fstep 1: plane image with the even f1 first; 2: the plain channels-last tensor)
 __global__ void build_conv2_pix_kernel(const int* row_utt2, const int* off2, const int* off1,
-                                       int M, int F1, int F2, int* a_pix) {
+                                       int M, int F1, int F2, int fstep, int* a_pix) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * F2) return;
   const int g = i / F2, f2 = i % F2;
   const int u = row_utt2[g];
-  a_pix[i] = (off1[u] + 2 * (g - off2[u])) * F1 + f2;
+  a_pix[i] = (off1[u] + 2 * (g - off2[u])) * F1 + fstep * f2;
 }
 
 __global__ void build_conv2_rows_kernel(const int* row_utt2, const int* off2,
@@ -552,13 +553,21 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
   if (i1 == m->x6_at->end() || i2 == m->x6_at->end()) return 0;
   if (x6_bytes(M, F) >= ((size_t)1 << 31)) return 0;
   const int S = ffn_x6_split(M, F);
-  if (m->x6_a.ensure(x6_bytes(M, d)) != 0 || m->x6_h.ensure(x6_bytes(M, F)) != 0 ||
-      m->ffn_part.ensure((size_t)S * M * d * sizeof(float)) != 0)
-    return -1;
-  if (x6_split(m->t1.as<float>(), M, d, d, m->x6_a.as<char>(), s) != 0) return -1;
+  if (m->ffn_part.ensure((size_t)S * M * d * sizeof(float)) != 0) return -1;
+  // plane images (x6_split of t1, w_1 writes the hidden planes); g_x6_af32 (A/B knob): the A
+  // operands stay plain fp32 (t1, the hidden tensor in hbuf) and are split in registers
+  const bool af32 = g_x6_af32 != 0 && (int64_t)M * F * 4 < ((int64_t)1 << 31);
   X6Args g1;
-  g1.A3 = m->x6_a.as<char>(); g1.B3 = i1->second; g1.M = M; g1.N = F; g1.K = d;
-  g1.epi = 2; g1.bias = w1.b; g1.act = act; g1.C3 = m->x6_h.as<char>();
+  g1.B3 = i1->second; g1.M = M; g1.N = F; g1.K = d; g1.bias = w1.b; g1.act = act;
+  if (af32) {
+    if (m->hbuf.ensure((size_t)M * F * sizeof(float)) != 0) return -1;
+    g1.A = m->t1.as<float>(); g1.lda = d; g1.a_bytes = (int64_t)M * d * 4;
+    g1.epi = 0; g1.C = m->hbuf.as<float>(); g1.ldc = F;
+  } else {
+    if (m->x6_a.ensure(x6_bytes(M, d)) != 0 || m->x6_h.ensure(x6_bytes(M, F)) != 0) return -1;
+    if (x6_split(m->t1.as<float>(), M, d, d, m->x6_a.as<char>(), s) != 0) return -1;
+    g1.A3 = m->x6_a.as<char>(); g1.epi = 2; g1.C3 = m->x6_h.as<char>();
+  }
   static thread_local int tick = 0;
   const bool bracket = m->prof_on && (tick++ % 6) == 0;
   if (bracket) {
@@ -578,8 +587,10 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
     m->prof_kernel = "gemm_x6_kernel (FFN w_1 + act, six bf16 plane products)";
   }
   X6Args g2;
-  g2.A3 = m->x6_h.as<char>(); g2.B3 = i2->second; g2.M = M; g2.N = d; g2.K = F;
+  g2.B3 = i2->second; g2.M = M; g2.N = d; g2.K = F;
   g2.epi = 1; g2.ksplit = S; g2.C = m->ffn_part.as<float>();
+  if (af32) { g2.A = m->hbuf.as<float>(); g2.lda = F; g2.a_bytes = (int64_t)M * F * 4; }
+  else g2.A3 = m->x6_h.as<char>();
   if (gemm_x6(g2, s) != 0) return -1;
   return S;
 }
@@ -682,6 +693,33 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
       if (it != m->x6_at->end() &&
           x6_bytes(M1 * F1, d) < ((size_t)1 << 31)) w6 = it->second;
     }
+    if (w6 && g_x6_af32 != 0 && (int64_t)M1 * F1 * d * 4 < ((int64_t)1 << 31)) {
+      // conv1 as always (fp32, channels last); conv2 gathers its A rows from it, 64 B per
+      // pixel and k block, and splits them in registers
+      WN_TRY(m->c1.ensure((size_t)M1 * F1 * d * sizeof(float)));
+      Conv1Args c1;
+      c1.feats = feats_dev; c1.mean = m->cmvn_mean; c1.istd = m->cmvn_istd;
+      c1.w = m->conv1_w; c1.bias = m->conv1_b; c1.out = m->c1.as<float>();
+      c1.t1_off = m->d_off1.as<int>(); c1.t1_len = m->d_len1.as<int>();
+      c1.B = B; c1.T = T; c1.F = c.feat_dim; c1.F1 = F1; c1.C = d; c1.max_t1 = max_t1;
+      WN_TRY(cmvn_conv1_relu(c1, s));
+      int* pix = reinterpret_cast<int*>(m->d_a_row_off.as<int64_t>());
+      hipLaunchKernelGGL(build_conv2_pix_kernel, dim3(cdiv(M * F2, 256)), dim3(256), 0, s,
+                         m->d_row_utt.as<int>(), m->d_off.as<int>(), m->d_off1.as<int>(), M,
+                         F1, F2, 2, pix);
+      WN_HIP(hipGetLastError());
+      X6Args g;
+      g.A = m->c1.as<float>(); g.a_bytes = (int64_t)M1 * F1 * d * 4;
+      g.B3 = w6; g.M = M * F2; g.N = d; g.K = 9 * d;
+      g.epi = 0; g.bias = m->conv2.b; g.act = ACT_RELU; g.C = m->c2.as<float>(); g.ldc = d;
+      g.a_pix = pix; g.conv_kbc = d / 16; g.bm = g_x6_conv_bm;
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) g.tap_delta[ky * 3 + kx] = ky * F1 + kx;
+      WN_TRY(gemm_x6(g, s));
+      WN_TRY(linear(m->sub_out, m->c2.as<float>(), F2 * d, m->x.as<float>(), d, M,
+                    s, ACT_NONE, nullptr, 0, sqrtf((float)d)));
+      return 0;
+    }
     if (w6) {
       const int tiles = cdiv(M1 * F1, 32);
       WN_TRY(m->c1.ensure(x6_bytes(M1 * F1, d)));
@@ -695,7 +733,7 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
       int* pix = reinterpret_cast<int*>(m->d_a_row_off.as<int64_t>());
       hipLaunchKernelGGL(build_conv2_pix_kernel, dim3(cdiv(M * F2, 256)), dim3(256), 0, s,
                          m->d_row_utt.as<int>(), m->d_off.as<int>(), m->d_off1.as<int>(), M,
-                         F1, F2, pix);
+                         F1, F2, 1, pix);
       WN_HIP(hipGetLastError());
       X6Args g;
       g.A3 = m->c1.as<char>(); g.B3 = w6; g.M = M * F2; g.N = d; g.K = 9 * d;
@@ -1777,6 +1815,8 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "gemm_x6") g_gemm_x6 = value;
   else if (k == "x6_conv_bm") g_x6_conv_bm = value;
   else if (k == "x6_ffn_s") g_x6_ffn_s = value;
+  else if (k == "x6_probe") g_x6_probe = value;
+  else if (k == "x6_af32") g_x6_af32 = value;
   else if (k == "beam_prio") g_beam_prio = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "gemm_rowln") g_gemm_rowln = value;
@@ -2739,12 +2779,17 @@ int wn_op_gemm_x6(const float* A, const float* W, const float* bias, const float
            "gemm_x6: shape");
   hipStream_t s = (hipStream_t)stream;
   static thread_local DevBuf a3, w3;
-  WN_TRY(a3.ensure(x6_bytes(M, K)));
   WN_TRY(w3.ensure(x6_bytes(N, K)));
-  WN_TRY(x6_split(A, M, K, K, a3.as<char>(), s));
   WN_TRY(x6_split(W, N, K, K, w3.as<char>(), s));
   X6Args a;
-  a.A3 = a3.as<char>(); a.B3 = w3.as<char>(); a.M = M; a.N = N; a.K = K; a.bm = bm;
+  if (g_x6_af32 != 0 && (int64_t)M * K * 4 < ((int64_t)1 << 31)) {
+    a.A = A; a.lda = K; a.a_bytes = (int64_t)M * K * 4;      // split in registers
+  } else {
+    WN_TRY(a3.ensure(x6_bytes(M, K)));
+    WN_TRY(x6_split(A, M, K, K, a3.as<char>(), s));
+    a.A3 = a3.as<char>();
+  }
+  a.B3 = w3.as<char>(); a.M = M; a.N = N; a.K = K; a.bm = bm;
   a.bias = bias; a.resid = resid; a.ldr = N; a.alpha = alpha; a.act = act; a.C = C; a.ldc = N;
   for (int r = 0; r < (reps > 0 ? reps : 1); ++r) WN_TRY(gemm_x6(a, s));
   return 0;
@@ -2766,15 +2811,24 @@ int wn_op_ffn_x6(const float* X, const float* W1, const float* b1, const float* 
   WN_TRY(part.ensure((size_t)S * M * D * sizeof(float)));
   WN_TRY(x6_split(W1, F, D, D, w13.as<char>(), s));
   WN_TRY(x6_split(W2, D, F, F, w23.as<char>(), s));
+  const bool af32 = g_x6_af32 != 0 && (int64_t)M * F * 4 < ((int64_t)1 << 31);
+  static thread_local DevBuf hf;
+  if (af32) WN_TRY(hf.ensure((size_t)M * F * sizeof(float)));
   for (int r = 0; r < (reps > 0 ? reps : 1); ++r) {
-    WN_TRY(x6_split(X, M, D, D, x3.as<char>(), s));
-    X6Args g1;
-    g1.A3 = x3.as<char>(); g1.B3 = w13.as<char>(); g1.M = M; g1.N = F; g1.K = D;
-    g1.epi = 2; g1.bias = b1; g1.act = act; g1.C3 = h3.as<char>();
-    WN_TRY(gemm_x6(g1, s));
-    X6Args g2;
-    g2.A3 = h3.as<char>(); g2.B3 = w23.as<char>(); g2.M = M; g2.N = D; g2.K = F;
+    X6Args g1, g2;
+    g1.B3 = w13.as<char>(); g1.M = M; g1.N = F; g1.K = D; g1.bias = b1; g1.act = act;
+    g2.B3 = w23.as<char>(); g2.M = M; g2.N = D; g2.K = F;
     g2.epi = 1; g2.ksplit = S; g2.C = part.as<float>();
+    if (af32) {
+      g1.A = X; g1.lda = D; g1.a_bytes = (int64_t)M * D * 4;
+      g1.epi = 0; g1.C = hf.as<float>(); g1.ldc = F;
+      g2.A = hf.as<float>(); g2.lda = F; g2.a_bytes = (int64_t)M * F * 4;
+    } else {
+      WN_TRY(x6_split(X, M, D, D, x3.as<char>(), s));
+      g1.A3 = x3.as<char>(); g1.epi = 2; g1.C3 = h3.as<char>();
+      g2.A3 = h3.as<char>();
+    }
+    WN_TRY(gemm_x6(g1, s));
     WN_TRY(gemm_x6(g2, s));
     if (r + 1 < reps) continue;      // timing loops: the residual update only once
     WN_TRY(ffn_reduce_ln(x, part.as<float>(), S, b2, alpha, ln_w, ln_b, nullptr, nullptr, y,
