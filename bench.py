@@ -356,7 +356,7 @@ def main():
         # whole-decode fraction is priced against the bf16 peak there
         whole_peak = (PEAK_TFLOPS['bf16'] if args.dtype == 'fp8'
                       else PEAK_TFLOPS[args.dtype])
-        dtype_txt = {'fp32': ('f32 (feed-forward GEMMs: fp32 operands as three exact bf16 '
+        dtype_txt = {'fp32': ('f32 (feed-forward and subsampling-conv2 GEMMs: fp32 operands as three exact bf16 '
                               'planes, six plane products on the bf16 matrix cores, f32 '
                               'accumulate -- error <= the v_mfma_f32 kernel\'s, '
                               'tests/test_gpu_x6.py; everything else v_mfma_f32)'
