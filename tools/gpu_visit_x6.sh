@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU visit: six-product fp32 GEMM -- tests + micro-benchmark
-TAG=${1:-r02t}
+TAG=${1:-x6}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

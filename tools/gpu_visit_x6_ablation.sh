@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU visit: x6 GEMM ablation (DMA ceiling / MFMA ceiling)
-TAG=${1:-r02af}
+TAG=${1:-x6abl}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU visit: PMC counters of the x6 GEMM micro-benchmark (MFMA busy, effective clock)
-TAG=${1:-r02x}
+TAG=${1:-x6pmc}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -11,7 +11,7 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INST_CYCLES_VMEM SQ_
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o prof -- $CMD > $OUT/kt.log 2>&1; echo "kt $?"
 python - <<'PY'
 import csv, glob, collections, sqlite3, os
-out = os.environ.get('OUT', 'gpurun_out/r02x')
+out = os.environ.get('OUT', 'gpurun_out/x6pmc')
 def load(d):
     f = glob.glob(os.path.join(out, d, '**', '*counter_collection.csv'), recursive=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))

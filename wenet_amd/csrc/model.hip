@@ -509,8 +509,9 @@ int build_x6_images(wn_model* m) {
   std::vector<const Linear*> ws;
   for (const auto& L : m->layers) { ws.push_back(&L.ffm1); ws.push_back(&L.ffm2);
                                     ws.push_back(&L.ff1); ws.push_back(&L.ff2); }
-  for (const auto& L : m->tf_layers) { ws.push_back(&L.ff1); ws.push_back(&L.ff2); }
-  ws.push_back(&m->conv2);          // [d][(ky*3+kx)*d + c]: k blocks of 16 channels per tap
+  // (the Transformer encoder of the Whisper configuration runs its GEMMs on v_mfma_f32 or,
+  // in the bf16 / fp8 modes, on the low-precision kernels: no images for tf_layers)
+  if (m->conv2.w) ws.push_back(&m->conv2);   // [d][(ky*3+kx)*d + c]: 16-channel k blocks per tap
   size_t bytes = 0;
   for (const Linear* l : ws)
     if (l->w && l->in % 16 == 0) bytes += x6_bytes(l->out, l->in);
