@@ -1,0 +1,72 @@
+"""CPU tests of the measurement helpers bench.py relies on: the output check against the
+committed real-reference goldens (wenet_amd/verify.py) and the algorithmic FLOP count
+(bench.contraction_flops)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from wenet_amd import synthetic as S, verify  # noqa: E402
+
+
+def _meta(name):
+    z = np.load(os.path.join(verify.GOLDEN_DIR, name + '.npz'))
+    return json.loads(bytes(z['meta']).decode('utf8'))
+
+
+@pytest.mark.parametrize('workload', ['config2', 'config3', 'config4'])
+def test_verify_accepts_the_reference_answer_and_rejects_anything_else(workload):
+    meta = _meta(f'bench_{workload}')
+    method = S.BENCH_WORKLOADS[workload]['method']
+    exp = verify._expected(meta, method, 1)
+    res = [(i, list(e[0]), 0.0) for i, e in enumerate(exp)]
+    v = verify.verify_bench_output(workload, 1, res, method)
+    assert v['verified'] is True and v['identical'] == len(exp) and v['mismatched'] == []
+    # one token changed in one utterance: not verified, and the utterance is named
+    bad = [list(r) for r in res]
+    k = next(i for i, r in enumerate(bad) if len(r[1]) > 0)
+    bad[k][1] = list(bad[k][1])
+    bad[k][1][0] = int(bad[k][1][0]) + 1
+    v = verify.verify_bench_output(workload, 1, [tuple(r) for r in bad], method)
+    assert v['verified'] is False and k in [m if isinstance(m, int) else m[0]
+                                            for m in v['mismatched']]
+    # a missing utterance is a failure, not a pass over fewer items
+    v = verify.verify_bench_output(workload, 1, res[:-1], method)
+    assert v['verified'] is False
+
+
+def test_verify_runner_up_only_inside_the_tie_window():
+    meta = _meta('bench_config2')
+    exp = verify._expected(meta, 'ctc_prefix_beam_search', 1)
+    res = [(i, list(e[0]), 0.0) for i, e in enumerate(exp)]
+    # the runner-up of an utterance whose top-2 gap is far outside the window is a mismatch
+    k = max(range(len(exp)), key=lambda i: exp[i][2] if exp[i][1] is not None else -1)
+    assert exp[k][1] is not None and exp[k][2] > verify.NBEST_TIE
+    res[k] = (k, list(exp[k][1]), 0.0)
+    v = verify.verify_bench_output('config2', 1, res, 'ctc_prefix_beam_search')
+    assert v['verified'] is False
+
+
+def test_world_8_golden_covers_eight_groups_and_unknown_workloads_report_none():
+    v = verify.verify_bench_output('config5', 1, [], 'ctc_greedy_search')
+    assert v['verified'] is None
+    meta = _meta('bench_config2_w8')
+    assert len(meta['groups']) == 8
+    exp = verify._expected(meta, 'ctc_prefix_beam_search', 8)
+    assert len(exp) == 8 * S.BENCH_WORKLOADS['config2']['batch']
+
+
+def test_contraction_flops_matches_the_survey_figure():
+    """11.776 GMAC for one 998-frame AIShell utterance (T' = 248)."""
+    import bench
+    configs = S.make_configs('aishell_u2pp')
+    gmac = bench.contraction_flops(configs, [998]) / 2 / 1e9
+    assert abs(gmac - 11.776) < 0.01
+    # additive over utterances, quadratic only in the attention term
+    a = bench.contraction_flops(configs, [998, 998])
+    assert abs(a - 2 * bench.contraction_flops(configs, [998])) < 1.0

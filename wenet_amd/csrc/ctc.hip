@@ -198,7 +198,11 @@ constexpr double NEG_INF = -HUGE_VAL;
 // can be re-created later as a new node while its old children are still
 // alive.  Every prefix therefore carries a 64-bit hash of its token sequence
 // (chained splitmix64), and all "is this the same prefix / is this its parent"
-// tests compare hashes.
+// tests compare hashes.  This is the one place where "identical to the reference" is
+// probabilistic: two DIFFERENT prefixes alive in the same frame's candidate set (<= beam +
+// beam^2 = 272 entries) with equal 64-bit hashes would be merged; there is no fallback
+// token-by-token compare.  Per frame that is < 272^2 / 2^65 ~ 2e-15, i.e. ~2e-4 over a
+// million hours of audio at 25 frames per second.
 typedef unsigned long long u64;
 __device__ __forceinline__ u64 prefix_hash(u64 h, int tok) {
   u64 z = h ^ ((u64)(tok + 1) * 0x9E3779B97F4A7C15ull);
