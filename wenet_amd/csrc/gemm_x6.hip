@@ -1,7 +1,8 @@
 // fp32 GEMM on the bf16 matrix cores: C = act(A W^T + bias) with every fp32 operand
 // carried as THREE bf16 planes whose sum is the fp32 value exactly,
 //     x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = x - x0 - x1
-// (8 + 8 + 8 significand bits; both subtractions and the last conversion are exact), and
+// (8 + 8 + 8 significand bits; both subtractions and the last conversion are exact for
+// |x| >= 2^-108, below that the sum is off by less than 2^-133: csrc/x6.h), and
 // the product formed from six of the nine plane products, accumulated in fp32:
 //     a b ~ a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0,
 // each of them EXACT in fp32 (8 x 8 bits).  Dropped: a1 b2 + a2 b1 + a2 b2 <= 2^-26 |a b|,
@@ -24,7 +25,8 @@
 //
 // Kernel: BM (128 | 256) x 256 block tile, 8 waves as 2 (M) x 4 (N), wave tile BM/2 x 64,
 // one k block (16) per stage: BM/32*3 + 24 records = 36 / 48 KB, ring of 4 / 3 stages, all
-// but the one being read in flight.  Per stage ONE barrier, late in the stage's MFMAs (see the loop).  MFMA operands are
+// but the one being read in flight.  Per stage ONE barrier, late in the stage's MFMAs (see
+// the loop).  MFMA operands are
 // swapped (the W fragment is the "A" of the instruction): a lane then owns one ROW of C
 // and 4 consecutive columns per register quad, so fp32 C is stored in 16-B pieces and an
 // X3 image of C (EPI 2: the next GEMM's operand, e.g. the FFN hidden tensor) in whole
@@ -81,7 +83,8 @@ __global__ __launch_bounds__(256) void x6_split_kernel(const float* __restrict__
 // channels-last tensor whose X3 image has one row per input pixel): GEMM row r reads pixel
 // a_pix[r] + tap_delta[tap] for the k blocks of tap = kb / conv_kbc -- the DMA addresses
 // are per lane instead of linear, the LDS side is unchanged.
-// AF32: the A operand is a plain row-major fp32 matrix (p.A, p.lda) -- or, with CONV, the
+// AF32 (opt-in, g_x6_af32: measured slower than plane images, see below): the A operand is
+// a plain row-major fp32 matrix (p.A, p.lda) -- or, with CONV, the
 // channels-last fp32 tensor itself -- and is split into its three planes IN REGISTERS after
 // the fragment read: no plane image of an activation ever exists (none is written by a
 // producer, none is read back), at the price of ~50 VALU operations per A fragment.  The A
