@@ -1064,9 +1064,17 @@ class PrefixScore:
 
 def ctc_prefix_beam_search(ctc_probs, ctc_lens, beam_size: int,
                            blank_id: int = 0,
-                           context_graph: Optional[ContextGraph] = None
+                           context_graph: Optional[ContextGraph] = None,
+                           edge_gaps: Optional[list] = None
                            ) -> List[DecodeResult]:
     """wenet/models/transformer/search.py:127-249.
+
+    `edge_gaps` (test instrumentation, not in the reference): a list that receives, per
+    utterance, the smallest margin by which any pruning decision of the search was taken --
+    min over frames of (score of the last hypothesis kept - score of the first one dropped)
+    and of (log-prob of the last token inside topk - first one outside).  A search whose
+    margin is below the log-prob tolerance cannot be expected to prune the same way from
+    log-probs that differ within that tolerance.
 
     With a context graph every dict entry takes its (state, bonus) from the
     FIRST contribution that reaches it (`has_context`), the second prune ranks
@@ -1086,10 +1094,14 @@ def ctc_prefix_beam_search(ctc_probs, ctc_lens, beam_size: int,
                                           v_ns=0.0,
                                           context_state=None if cg is None else 0,
                                           context_score=0.0))]
+        min_gap = float('inf')
         for t in range(0, num_t):
             logp = ctc_prob[t]
             next_hyps = defaultdict(lambda: PrefixScore())
             _, top_k_index = logp.topk(beam_size)
+            if edge_gaps is not None and logp.numel() > beam_size:
+                tv = logp.topk(beam_size + 1)[0]
+                min_gap = min(min_gap, float(tv[beam_size - 1] - tv[beam_size]))
             for u in top_k_index:
                 u = u.item()
                 prob = logp[u].item()
@@ -1138,7 +1150,12 @@ def ctc_prefix_beam_search(ctc_probs, ctc_lens, beam_size: int,
                             nx.has_context = True
             next_hyps = sorted(next_hyps.items(), key=lambda x: x[1].total_score(),
                                reverse=True)
+            if edge_gaps is not None and len(next_hyps) > beam_size:
+                min_gap = min(min_gap, next_hyps[beam_size - 1][1].total_score() -
+                              next_hyps[beam_size][1].total_score())
             cur_hyps = next_hyps[:beam_size]
+        if edge_gaps is not None:
+            edge_gaps.append(min_gap)
         if cg is not None:
             for _, ps in cur_hyps:
                 ps.context_score, ps.context_state = cg.finalize(ps.context_state)

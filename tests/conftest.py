@@ -38,3 +38,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _tune_from_env():
+    """WN_TUNE="key=value,key=value": wn_tune_set knobs for a whole test session (A/B of a
+    kernel variant under the parity tests); unset = the defaults."""
+    spec = os.environ.get('WN_TUNE', '')
+    if spec:
+        from wenet_amd import _lib
+        for kv in filter(None, spec.split(',')):
+            k, v = kv.split('=')
+            _lib.check(_lib.lib().wn_tune_set(k.encode(), int(v)), 'tune')
+    yield

@@ -160,3 +160,49 @@ def rescoring_check(got, got_pre, ref, ref_pre_nbest, what='', tol=RESCORE_TOL):
         assert list(got.tokens) == list(ref['tokens']), f'{what}: rescoring winner differs'
         assert abs(got.score - ref['score']) < tol, (what, got.score, ref['score'])
     return len(errs), max(errs)
+
+
+def pruning_tie_check(got, logp_b, beam, what='', tol=NBEST_TOL):
+    """Fallback for an utterance whose n-best list differs from the reference's beyond the
+    direct rules: the reference's search and the GPU's start from log-probs that differ by
+    up to LOGP_TOL, so a pruning decision taken by a smaller margin may legitimately go the
+    other way -- and everything downstream of it (which alignments a prefix's score sums)
+    then differs by far more than the tolerance.  Accepted only if BOTH hold:
+      * the GPU search is EXACT on its own inputs: the oracle's prefix beam search
+        (search.py:127-249 restated) on the GPU's own log-probs reproduces the GPU n-best
+        list -- tokens, order, time stamps, scores;
+      * that search really passes through a near-tie: its smallest pruning margin is below
+        2 x tol.
+    Returns the margin."""
+    from oracle import wenet_oracle as O
+    import torch
+    gaps = []
+    lp = torch.as_tensor(logp_b, dtype=torch.float32).unsqueeze(0)
+    ref = O.ctc_prefix_beam_search(lp, torch.tensor([lp.shape[1]]), beam, edge_gaps=gaps)[0]
+    assert [list(x) for x in got.nbest] == [list(x) for x in ref.nbest], \
+        f'{what}: GPU n-best differs from the oracle search on the GPU\'s own log-probs'
+    for a, b in zip(got.nbest_scores, ref.nbest_scores):
+        assert abs(a - b) < 1e-6 * max(1.0, abs(b)), (what, a, b)
+    assert [list(x) for x in got.nbest_times] == [list(x) for x in ref.nbest_times], what
+    assert gaps[0] < 2 * tol, (f'{what}: n-best differs from the reference although no '
+                               f'pruning decision was closer than {gaps[0]:.2e}')
+    return gaps[0]
+
+
+def rescoring_attention_part_check(got, got_pre, ref, ref_pre_nbest, ref_pre_scores,
+                                   ctc_weight, what='', tol=RESCORE_TOL):
+    """rescoring_check for an utterance whose CTC prefix scores took the other side of a
+    pruning tie (pruning_tie_check): the attention-decoder part of every common hypothesis'
+    score -- score - ctc_weight * ctc_score -- within `tol` of the reference's."""
+    g_nbest = [list(x) for x in got_pre.nbest]
+    r_nbest = [list(x) for x in ref_pre_nbest]
+    errs = []
+    for i, h in enumerate(r_nbest):
+        if h in g_nbest:
+            j = g_nbest.index(h)
+            errs.append(abs((got.all_scores[j] - ctc_weight * got_pre.nbest_scores[j]) -
+                            (ref['all_scores'][i] - ctc_weight * ref_pre_scores[i])))
+    assert errs, f'{what}: no common hypothesis'
+    assert max(errs) < tol, (f'{what}: attention part of the rescoring score off by '
+                             f'{max(errs):.3e}', errs)
+    return len(errs), max(errs)

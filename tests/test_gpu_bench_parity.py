@@ -9,7 +9,10 @@ produced on them (tests/golden/bench_*.npz, oracle/gen_golden_bench.py).
 Rules (tests/gpu_util.py): per-FRAME greedy identity (strict above a 1e-3 margin,
 top-2 below; >= 95 % of frames strictly compared, flips counted and printed),
 n-best lists with fp64 scores within 2e-3 and identical time stamps, EVERY
-hypothesis' rescoring score within 1e-3 absolute and the reference's winner.
+hypothesis' rescoring score within 1e-3 absolute and the reference's winner.  The one
+accepted deviation is a pruning near-tie (gpu_util.pruning_tie_check): the GPU search
+reproduced exactly by the oracle search on the GPU's own log-probs AND a pruning margin
+below the tolerance in that search; at most one utterance per 32, printed.
 """
 import numpy as np
 import pytest
@@ -17,7 +20,8 @@ import torch
 
 from golden_util import load_case
 from gpu_util import (FRAME_EPS, LOGP_TOL, cached_model, greedy_frame_check,
-                      nbest_check, rescoring_check)
+                      nbest_check, pruning_tie_check, rescoring_attention_part_check,
+                      rescoring_check)
 
 pytestmark = pytest.mark.gpu
 
@@ -57,6 +61,7 @@ def test_bench_batch_vs_reference(workload):
     logp_err = 0.0
     nb_total = nb_cmp = rs_cmp = 0
     rs_err = 0.0
+    ties = []
     for b in range(B):
         o, n = int(arr['row_off'][b]), int(arr['enc_lens'][b])
         rv, ri = arr['ctc_topk_val'][o:o + n], arr['ctc_topk_idx'][o:o + n]
@@ -66,18 +71,33 @@ def test_bench_batch_vs_reference(workload):
                                       meta['greedy'][b], what=f'{workload}[{b}]')
         n_frames += f; n_strict += s; n_flips += fl
         g = meta['prefix'][b]
-        t, c = nbest_check(res['ctc_prefix_beam_search'][b], g['nbest'],
-                           g['nbest_scores'], g['nbest_times'], what=f'{workload}[{b}]')
-        nb_total += t; nb_cmp += c
-        c, e = rescoring_check(res['attention_rescoring'][b],
-                               res['ctc_prefix_beam_search'][b], meta['rescoring'][b],
-                               g['nbest'], what=f'{workload}[{b}]')
+        try:
+            t, c = nbest_check(res['ctc_prefix_beam_search'][b], g['nbest'],
+                               g['nbest_scores'], g['nbest_times'], what=f'{workload}[{b}]')
+            nb_total += t; nb_cmp += c
+            c, e = rescoring_check(res['attention_rescoring'][b],
+                                   res['ctc_prefix_beam_search'][b], meta['rescoring'][b],
+                                   g['nbest'], what=f'{workload}[{b}]')
+        except AssertionError:
+            # the one legitimate way to differ: a pruning decision closer than the log-prob
+            # tolerance went the other way (gpu_util.pruning_tie_check proves both halves)
+            gap = pruning_tie_check(res['ctc_prefix_beam_search'][b], logp[b, :n].cpu(),
+                                    meta['beam'], what=f'{workload}[{b}]')
+            ties.append((b, gap))
+            nb_total += len(g['nbest'])
+            c, e = rescoring_attention_part_check(
+                res['attention_rescoring'][b], res['ctc_prefix_beam_search'][b],
+                meta['rescoring'][b], g['nbest'], g['nbest_scores'], meta['ctc_weight'],
+                what=f'{workload}[{b}]')
         rs_cmp += c; rs_err = max(rs_err, e)
     print(f'\n[{workload}] utterances {B}, frames {n_frames}, strictly compared '
           f'{n_strict} ({100.0 * n_strict / n_frames:.2f} %), arg-max flips on '
           f'sub-{FRAME_EPS:g} frames {n_flips}; max |d logp| {logp_err:.2e}, encoder '
           f'{enc_err:.2e}; n-best hyps compared {nb_cmp}/{nb_total}; rescoring hyps '
-          f'compared {rs_cmp}, max |d score| {rs_err:.2e}')
+          f'compared {rs_cmp}, max |d score| {rs_err:.2e}; utterances on the other side of a '
+          f'pruning near-tie (search exact on its own log-probs, margin): '
+          f'{[(b, float(f"{g_:.1e}")) for b, g_ in ties]}')
+    assert len(ties) <= max(1, B // 32), ties
     assert logp_err < LOGP_TOL, logp_err
     assert n_strict >= 0.95 * n_frames
 

@@ -124,14 +124,13 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   const int Ta = CONV ? p.a_tiles : (p.M + 31) >> 5, Tb = (p.N + 31) >> 5;
   const int nkb_all = p.K >> 4;
   const int nkb = nkb_all / p.ksplit, kb0 = slice * nkb;
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(AF32 ? (const void*)p.A : p.A3), 0,
-      (int)min(AF32 ? p.a_bytes : (int64_t)(CONV ? p.conv_kbc : nkb_all) * Ta * TILE3,
-               (int64_t)0x7fffffff),
-      0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.B3), 0, (int)min((int64_t)nkb_all * Tb * TILE3, (int64_t)0x7fffffff),
-      0x00020000);
+  // Buffer descriptors address 2 GB at most.  fp32 A (AF32): the whole matrix; plane images:
+  // ONE k-block slab (all row tiles x planes of a k block: rows / 32 * 3 KB) per descriptor,
+  // rebuilt per stage from a 64-bit base -- an image may have any size (conv1's at config 3:
+  // 3.9 GB), only a slab must stay under 2 GB (22 M rows).
+  const int64_t slab_a = (int64_t)Ta * TILE3, slab_b = (int64_t)Tb * TILE3;
+  const __amdgpu_buffer_rsrc_t ra32 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.A), 0, (int)min(p.a_bytes, (int64_t)0x7fffffff), 0x00020000);
   // Stage g = k block kb0 + g: A records of the block's BM/32 row tiles (contiguous in the
   // image), then the 8 W tiles.  Piece j of the stage goes to wave j % 8.  Tiles past the
   // last one read the next k block's records or (buffer bounds) zeros: they only reach
@@ -159,15 +158,24 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
     if (p.probe & 2) return;                       // ablation: no DMA (tools/bench_x6.py)
     const int kb = kb0 + g;
     char* dst = smem_x + (g % RING) * STAGE;
-    int sa = (kb * Ta + (m0 >> 5)) * TILE3, delta = 0;
+    int sa = (m0 >> 5) * TILE3, delta = 0, ka = kb;
     if (CONV) {
       const int tap = kb / p.conv_kbc;
-      sa = AF32 ? (kb - tap * p.conv_kbc) * 64 : (kb - tap * p.conv_kbc) * Ta * TILE3;
+      ka = kb - tap * p.conv_kbc;
+      sa = AF32 ? ka * 64 : 0;
       delta = p.tap_delta[tap];
     } else if (AF32) {
       sa = kb * 64;
     }
-    const int sb = (kb * Tb + (n0 >> 5)) * TILE3;
+    const __amdgpu_buffer_rsrc_t ra =
+        AF32 ? ra32
+             : __builtin_amdgcn_make_buffer_rsrc(
+                   const_cast<char*>(reinterpret_cast<const char*>(p.A3)) + ka * slab_a, 0,
+                   (int)min(slab_a, (int64_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.B3)) + kb * slab_b, 0,
+        (int)min(slab_b, (int64_t)0x7fffffff), 0x00020000);
+    const int sb = (n0 >> 5) * TILE3;
 #pragma unroll
     for (int j0 = 0; j0 < NP; j0 += 8) {
       const int j = j0 + wave;
@@ -430,6 +438,7 @@ int launch_x6_act(const X6Args& a, hipStream_t s) {
 int g_gemm_x6 = 1;
 int g_x6_conv_bm = 0;
 int g_x6_ffn_s = 0;
+int g_x6_conv = 1;
 // 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in
 // registers.  Measured (r02ag): the split costs more than the plane bytes it saves -- FFN w_1
 // 53.8 -> 63.7 us, w_2 54.6 -> 60.7, conv2 921 -> 1055 (+ conv1 185 -> 125), 8192 x 4096 x
@@ -459,8 +468,9 @@ int gemm_x6(const X6Args& a, hipStream_t s) {
            "gemm_x6: shape");
   WN_CHECK(a.ksplit >= 1 && (a.K / 16) % a.ksplit == 0, "gemm_x6: K split");
   WN_CHECK(a.N % 4 == 0 && (a.epi != 2 || a.N % 16 == 0), "gemm_x6: N");
-  WN_CHECK((a.a_pix || af32 || x6_bytes(a.M, a.K) < ((size_t)1 << 31)) &&
-               x6_bytes(a.N, a.K) < ((size_t)1 << 31), "gemm_x6: operand image over 2 GB");
+  WN_CHECK((int64_t)cdiv(a.a_pix ? 32 * a.a_tiles : a.M, 32) * TILE3 < ((int64_t)1 << 31) &&
+               (int64_t)cdiv(a.N, 32) * TILE3 < ((int64_t)1 << 31),
+           "gemm_x6: a k-block slab of an operand image over 2 GB");
   WN_CHECK(!af32 || (a.a_bytes > 0 && a.a_bytes < ((int64_t)1 << 31) &&
                      (a.a_pix || a.lda % 4 == 0)), "gemm_x6: fp32 A operand");
   WN_CHECK(a.epi == 2 ? a.C3 != nullptr : a.C != nullptr, "gemm_x6: no output");

@@ -137,6 +137,7 @@ struct X6Args {
   int probe = 0;              // ablation bits (g_x6_probe)
 };
 extern int g_x6_probe;
+extern int g_x6_conv;      // wn_tune_set("x6_conv"): 0 = conv2 stays on v_mfma_f32
 extern int g_x6_af32;      // wn_tune_set("x6_af32"): 0 plane images (default), 1 fp32 A rows split in registers
 extern int g_x6_ffn_s;     // wn_tune_set("x6_ffn_s"): K slices of the FFN w_2 GEMM (0 auto)
 extern int g_x6_conv_bm;   // wn_tune_set("x6_conv_bm"): block rows of the conv2 GEMM (0 auto)

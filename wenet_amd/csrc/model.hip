@@ -552,7 +552,6 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
     return 0;
   auto i1 = m->x6_at->find(w1.w), i2 = m->x6_at->find(w2.w);
   if (i1 == m->x6_at->end() || i2 == m->x6_at->end()) return 0;
-  if (x6_bytes(M, F) >= ((size_t)1 << 31)) return 0;
   const int S = ffn_x6_split(M, F);
   if (m->ffn_part.ensure((size_t)S * M * d * sizeof(float)) != 0) return -1;
   // plane images (x6_split of t1, w_1 writes the hidden planes); g_x6_af32 (A/B knob): the A
@@ -688,11 +687,11 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
     // fp32 on the bf16 matrix cores (gemm_x6.hip): conv1 writes the plane image of its
     // output, conv2 gathers its rows from it
     const void* w6 = nullptr;
-    if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && m->x6_at && d % 32 == 0 && F1 <= 64 &&
+    if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_conv != 0 && m->x6_at && d % 32 == 0 &&
+        F1 <= 64 &&
         (M * F2 >= 4096 || g_gemm_x6 == 2)) {
       auto it = m->x6_at->find(m->conv2.w);
-      if (it != m->x6_at->end() &&
-          x6_bytes(M1 * F1, d) < ((size_t)1 << 31)) w6 = it->second;
+      if (it != m->x6_at->end()) w6 = it->second;
     }
     if (w6 && g_x6_af32 != 0 && (int64_t)M1 * F1 * d * 4 < ((int64_t)1 << 31)) {
       // conv1 as always (fp32, channels last); conv2 gathers its A rows from it, 64 B per
@@ -1817,6 +1816,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_conv_bm") g_x6_conv_bm = value;
   else if (k == "x6_ffn_s") g_x6_ffn_s = value;
   else if (k == "x6_probe") g_x6_probe = value;
+  else if (k == "x6_conv") g_x6_conv = value;
   else if (k == "x6_af32") g_x6_af32 = value;
   else if (k == "beam_prio") g_beam_prio = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
