@@ -93,6 +93,24 @@ def test_gemm_x6_is_an_fp32_gemm(M, N, K, act, resid, bm):
     assert r6 <= 1.2 * r32 + 1e-8
 
 
+@pytest.mark.parametrize('M,N,K,act,bm', [
+    (7932, 2048, 256, 1, 129), (7932, 2048, 256, 1, 130), (1000, 516, 48, 3, 130),
+    (333, 256, 2048, 0, 129),
+])
+def test_gemm_x6_four_wave_tiles(M, N, K, act, bm):
+    """128-row tiles on four waves, two blocks per CU (bm 129; 130: the lower half of the
+    grid at s_setprio 3): same result as the 8-wave tiles, bit for bit (same products, same
+    order per accumulator)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = (torch.randn(N, generator=g) * 0.3).cuda()
+    ref = _x6(A, W, b, None, act, 1.0, 120)      # the 8-wave form of the 128-row tile
+    got = _x6(A, W, b, None, act, 1.0, bm)
+    assert torch.equal(ref, got)
+    assert torch.equal(got, _x6(A, W, b, None, act, 1.0, bm))
+
+
 def test_gemm_x6_vs_the_oracle_restatement():
     """The HIP kernel against oracle.x6_matmul (the same six plane products, summed in
     fp64): what separates them is only the fp32 accumulation order."""
@@ -175,9 +193,13 @@ def test_encoder_with_x6_ffn_matches_the_f32_mfma_path(config, B, frames, chunk)
         got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got = got.cpu()
+        _lib.check(L.wn_tune_set(b'x6_nw4', 7), 'tune')      # the other tile forms of the FFN GEMMs
+        got4, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
     finally:
         L.wn_tune_set(b'gemm_x6', 1)
+        L.wn_tune_set(b'x6_nw4', 0)
     assert torch.equal(got, got2.cpu())
+    assert torch.equal(got, got4.cpu())
     err = (got - ref).abs().max().item()
     print(f'\n[{config} B={B}] x6 FFN vs f32 MFMA: max |d enc| {err:.2e}')
     assert 0 < err < 1e-4

@@ -68,11 +68,12 @@ def main():
                                         C.data_ptr(), m, n, k, 1.0, act, st), 'gemm')
         x6(0, 1); f32()
         row = [f'{name:8s} M={m} N={n} K={k}']
-        for bm in (256, 128):
+        for bm in (256, 128, 120):
             t1 = timed(lambda: x6(bm, 1))
             tn = timed(lambda: x6(bm, args.reps + 1))
             us = (tn - t1) / args.reps * 1e3
-            row.append(f'x6/{bm}: {us:8.1f} us {flops / us / 1e6:7.1f} TF-eq')
+            name = {256: '256x256 8w', 128: '128x256 4w', 120: '128x256 8w'}.get(bm, str(bm))
+            row.append(f'x6 {name}: {us:8.1f} us {flops / us / 1e6:7.1f} TF-eq')
         us = timed(f32) / args.reps * 1e3
         row.append(f'f32 mfma: {us:8.1f} us {flops / us / 1e6:7.1f} TF')
         print(' | '.join(row), flush=True)

@@ -92,16 +92,23 @@ __global__ __launch_bounds__(256) void x6_split_kernel(const float* __restrict__
 // lines per DMA instruction instead of 8) into row-major LDS rows whose four 16-B slots are
 // XOR-swizzled with (row >> 2) & 3 on the source side, so that the two ds_read_b128 of a
 // lane's 8 k values are conflict-free.
-template <int BM, int EPI, int ACT, bool CONV = false, bool AF32 = false>
-__global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int tiles_n) {
+// NW = 4: a 128-row tile run by FOUR waves side by side along N (each owns all four A tiles:
+// the 8-wave 256-row kernel's lower half), ring of 2 stages = 72 KB, <= 256 registers: two
+// blocks share a CU.  With p.prio_split the blocks below that index run at s_setprio 3: the
+// high-priority block of a CU takes the matrix pipe first and finishes first, and its
+// store burst drains while the other block multiplies -- two co-resident blocks that start
+// together would otherwise finish, and store, together.
+template <int BM, int EPI, int ACT, bool CONV = false, bool AF32 = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  constexpr int TA = BM / 64;                  // A tiles (32 rows) per wave
+  static_assert(NW == 8 || (NW == 4 && BM == 128), "4 waves: 128-row tiles");
+  constexpr int TA = BM / 32 / (NW / 4);       // A tiles (32 rows) per wave
   constexpr int A_TILE = AF32 ? 2048 : TILE3;  // bytes of a 32-row A tile and k block
   constexpr int A_BYTES = (BM / 32) * A_TILE;
   constexpr int STAGE = A_BYTES + 8 * TILE3;   // 36 / 48 KB (AF32: 32 / 40 KB)
   constexpr int NP = STAGE / REC;              // DMA pieces per stage
-  constexpr int RING = BM == 128 ? 4 : 3;      // stages in LDS (144 KB either way)
+  constexpr int RING = NW == 4 ? 2 : BM == 128 ? 4 : 3;   // stages in LDS (72 / 144 / 144 KB)
 
   const int nblk = tiles_m * tiles_n;
   const int bid = xcd_block_order(blockIdx.x, nblk * p.ksplit);
@@ -117,7 +124,15 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  __builtin_assume(wave >= 0 && wave < 8);
+  __builtin_assume(wave >= 0 && wave < NW);
+  if (NW == 4 && p.prio_split != 0) {
+    // > 0: blocks below the index; -1: even blocks; -2: even groups of 8 blocks (experiments)
+    const bool hi_prio = p.prio_split > 0    ? (int)blockIdx.x < p.prio_split
+                         : p.prio_split == -1 ? (blockIdx.x & 1) == 0
+                                              : ((blockIdx.x >> 3) & 1) == 0;
+    if (hi_prio) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+  }
   const int wm = wave >> 2, wn = wave & 3;
   const int hi = lane >> 5, li = lane & 31;
 
@@ -139,12 +154,12 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   // CONV: base pixel of this lane's row in each A piece the wave issues (planes: piece j
   // -> row tile j / 3, lane -> row lane & 31; AF32: piece j -> rows (j / 2) * 32 + (j & 1) *
   // 16 + lane / 4).  AF32 without CONV: the lane's byte offset into A instead.
-  constexpr int NPA = (A_BYTES / REC + 7) / 8;
+  constexpr int NPA = (A_BYTES / REC + NW - 1) / NW;
   int pix[NPA];
   if (CONV || AF32) {
 #pragma unroll
     for (int q = 0; q < NPA; ++q) {
-      const int j = q * 8 + wave;
+      const int j = q * NW + wave;
       const int rl = AF32 ? (j >> 1) * 32 + (j & 1) * 16 + (lane >> 2) : (j / 3) * 32 + li;
       const int row = min(m0 + rl, p.M - 1);
       if (CONV) pix[q] = p.a_pix[row];
@@ -177,20 +192,20 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
         (int)min(slab_b, (int64_t)0x7fffffff), 0x00020000);
     const int sb = (n0 >> 5) * TILE3;
 #pragma unroll
-    for (int j0 = 0; j0 < NP; j0 += 8) {
+    for (int j0 = 0; j0 < NP; j0 += NW) {
       const int j = j0 + wave;
       if (j < A_BYTES / REC) {
         if (AF32) {
-          unsigned vo = (unsigned)pix[j0 / 8];
+          unsigned vo = (unsigned)pix[j0 / NW];
           if (CONV) {
             const int rl = (j & 1) * 16 + (lane >> 2);
-            vo = (unsigned)((pix[j0 / 8] + delta) * p.conv_kbc * 64 +
+            vo = (unsigned)((pix[j0 / NW] + delta) * p.conv_kbc * 64 +
                             (((lane & 3) ^ ((rl >> 2) & 3)) << 4));
           }
           __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + j * REC), 16, vo, sa, 0,
                                                    0);
         } else if (CONV) {
-          const int P = pix[j0 / 8] + delta;
+          const int P = pix[j0 / NW] + delta;
           const unsigned vo = (unsigned)(((P >> 5) * 3 + j % 3) * REC + hi * 512 + (P & 31) * 16);
           __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + j * REC), 16, vo, sa, 0,
                                                    0);
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   // DMA of stage g+RING then overwrites.  The fragments of stage g+1 are read during the
   // last A tile.
   constexpr int BAR = TA - 2;
-  const int npw = (NP - wave + 7) / 8;            // DMA pieces this wave issues per stage
+  const int npw = (NP - wave + NW - 1) / NW;      // DMA pieces this wave issues per stage
   auto wait_pieces = [&](int stages_in_flight) {  // of the stages younger than the awaited one
     switch (stages_in_flight * npw) {
       case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -285,6 +300,7 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
       case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
       case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
       case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
       case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
       case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;   // 3 x 5
@@ -401,32 +417,32 @@ __global__ __launch_bounds__(512) void gemm_x6_kernel(X6Args p, int tiles_m, int
   }
 }
 
-template <int BM, int EPI, int ACT, bool CONV = false, bool AF32 = false>
+template <int BM, int EPI, int ACT, bool CONV = false, bool AF32 = false, int NW = 8>
 int launch_x6(const X6Args& a, hipStream_t s) {
   const int tiles_m = cdiv(a.M - a.row0, BM), tiles_n = cdiv(a.N, XBN);
-  const size_t lds =
-      (size_t)(BM == 128 ? 4 : 3) * ((BM / 32) * (AF32 ? 2048 : TILE3) + 8 * TILE3);
-  auto kern = gemm_x6_kernel<BM, EPI, ACT, CONV, AF32>;
+  const size_t lds = (size_t)(NW == 4 ? 2 : BM == 128 ? 4 : 3) *
+                     ((BM / 32) * (AF32 ? 2048 : TILE3) + 8 * TILE3);
+  auto kern = gemm_x6_kernel<BM, EPI, ACT, CONV, AF32, NW>;
   static bool done = false;
   if (!done) {
     WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * a.ksplit), dim3(512), lds, s, a, tiles_m,
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * a.ksplit), dim3(NW * 64), lds, s, a, tiles_m,
                      tiles_n);
   WN_HIP(hipGetLastError());
   return 0;
 }
 
-template <int BM, int EPI, bool AF32 = false>
+template <int BM, int EPI, bool AF32 = false, int NW = 8>
 int launch_x6_act(const X6Args& a, hipStream_t s) {
-  if (EPI == 1) return launch_x6<BM, EPI, ACT_NONE, false, AF32>(a, s);
+  if (EPI == 1) return launch_x6<BM, EPI, ACT_NONE, false, AF32, NW>(a, s);
   switch (a.act) {
-    case ACT_NONE: return launch_x6<BM, EPI, ACT_NONE, false, AF32>(a, s);
-    case ACT_SILU: return launch_x6<BM, EPI, ACT_SILU, false, AF32>(a, s);
-    case ACT_RELU: return launch_x6<BM, EPI, ACT_RELU, false, AF32>(a, s);
-    case ACT_GELU: return launch_x6<BM, EPI, ACT_GELU, false, AF32>(a, s);
+    case ACT_NONE: return launch_x6<BM, EPI, ACT_NONE, false, AF32, NW>(a, s);
+    case ACT_SILU: return launch_x6<BM, EPI, ACT_SILU, false, AF32, NW>(a, s);
+    case ACT_RELU: return launch_x6<BM, EPI, ACT_RELU, false, AF32, NW>(a, s);
+    case ACT_GELU: return launch_x6<BM, EPI, ACT_GELU, false, AF32, NW>(a, s);
     default: break;
   }
   set_error("gemm_x6: unsupported activation");
@@ -438,6 +454,7 @@ int launch_x6_act(const X6Args& a, hipStream_t s) {
 int g_gemm_x6 = 1;
 int g_x6_conv_bm = 0;
 int g_x6_ffn_s = 0;
+int g_x6_nw4 = 0;
 int g_x6_conv = 1;
 // 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in
 // registers.  Measured (r02ag): the split costs more than the plane bytes it saves -- FFN w_1
@@ -457,9 +474,14 @@ int x6_split(const float* src, int R, int K, int ld, void* dst, hipStream_t s) {
   return 0;
 }
 
-// block rows: 256 when that still gives the 256 CUs a block each, else 128
+// block rows: 256-row tiles (8 waves, one block per CU) from two rounds of the 256 CUs on;
+// below that 128-row tiles on four waves, two blocks per CU -- per tile as efficient as the
+// 256-row ones (8192 x 4096 x 4096: 1202 vs 1185 us) and at K = 256 faster, because the
+// co-resident blocks drift apart and overlap each other's prologue / store burst (FFN w_1:
+// 51.9 vs 57.9 us, r02ao).  (The 8-wave form of the 128-row tile -- 63.9 us, 1400 us -- is
+// kept only for the fp32-A variant.)
 int gemm_x6_bm(int M, int N, int ksplit) {
-  return cdiv(M, 256) * cdiv(N, XBN) * ksplit >= 200 ? 256 : 128;
+  return cdiv(M, 256) * cdiv(N, XBN) * ksplit >= 512 ? 256 : 128;
 }
 
 int gemm_x6(const X6Args& a, hipStream_t s) {
@@ -490,7 +512,7 @@ int gemm_x6(const X6Args& a, hipStream_t s) {
       if (af32) return rows == 256 ? launch_x6<256, 0, ACT_RELU, true, true>(x, s)
                                    : launch_x6<128, 0, ACT_RELU, true, true>(x, s);
       return rows == 256 ? launch_x6<256, 0, ACT_RELU, true>(x, s)
-                         : launch_x6<128, 0, ACT_RELU, true>(x, s);
+                         : launch_x6<128, 0, ACT_RELU, true, false, 4>(x, s);
     };
     if (a.bm == 0 && a.N <= XBN && full > 0 && t256 - full > 0 && t256 - full <= 128) {
       X6Args main = a, rest = a;
@@ -508,7 +530,15 @@ int gemm_x6(const X6Args& a, hipStream_t s) {
     case 2: return launch_x6_act<BM, 2, AF>(a, s);             \
     default: break;                                            \
   }
-  if (af32) {
+  if (bm == 128 && !af32 && a.nw != 8) {
+    // 128-row tiles on four waves, two blocks per CU
+    switch (a.epi) {
+      case 0: return launch_x6_act<128, 0, false, 4>(a, s);
+      case 1: return launch_x6_act<128, 1, false, 4>(a, s);
+      case 2: return launch_x6_act<128, 2, false, 4>(a, s);
+      default: break;
+    }
+  } else if (af32) {
     if (bm == 256) { WN_X6(256, true) } else { WN_X6(128, true) }
   } else {
     if (bm == 256) { WN_X6(256, false) } else { WN_X6(128, false) }

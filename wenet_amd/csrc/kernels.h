@@ -121,6 +121,8 @@ struct X6Args {
   int row0 = 0;               // first row of C this launch computes (multiple of 256)
   int ksplit = 1;             // K slices (epi 1 only)
   int bm = 0;                 // block rows 128 / 256, 0 = auto
+  int nw = 0;                 // 128-row tiles: four waves, two blocks per CU; 8 forces the 8-wave form
+  int prio_split = 0;         // nw 4: blocks below this index run at s_setprio 3 (0 = off)
   int epi = 0;                // 0: C = resid + alpha act(acc + bias); 1: P[slice][M][N] = acc;
                               // 2: C3 = X3 image of act(acc + bias)
   const float* bias = nullptr;
@@ -137,6 +139,7 @@ struct X6Args {
   int probe = 0;              // ablation bits (g_x6_probe)
 };
 extern int g_x6_probe;
+extern int g_x6_nw4;       // wn_tune_set("x6_nw4") A/B bits: 1 FFN w_1 on 256-row tiles, 2 FFN w_2 on the 8-wave 128-row tile, 4 priorities
 extern int g_x6_conv;      // wn_tune_set("x6_conv"): 0 = conv2 stays on v_mfma_f32
 extern int g_x6_af32;      // wn_tune_set("x6_af32"): 0 plane images (default), 1 fp32 A rows split in registers
 extern int g_x6_ffn_s;     // wn_tune_set("x6_ffn_s"): K slices of the FFN w_2 GEMM (0 auto)

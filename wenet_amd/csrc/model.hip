@@ -568,6 +568,8 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
     if (x6_split(m->t1.as<float>(), M, d, d, m->x6_a.as<char>(), s) != 0) return -1;
     g1.A3 = m->x6_a.as<char>(); g1.epi = 2; g1.C3 = m->x6_h.as<char>();
   }
+  if (g_x6_nw4 & 1) g1.bm = 256;                      // A/B: the 256-row tiles for w_1
+  if (g_x6_nw4 & 4) g1.prio_split = cdiv(M, 128) * cdiv(F, 256) / 2;
   static thread_local int tick = 0;
   const bool bracket = m->prof_on && (tick++ % 6) == 0;
   if (bracket) {
@@ -591,6 +593,7 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
   g2.epi = 1; g2.ksplit = S; g2.C = m->ffn_part.as<float>();
   if (af32) { g2.A = m->hbuf.as<float>(); g2.lda = F; g2.a_bytes = (int64_t)M * F * 4; }
   else g2.A3 = m->x6_h.as<char>();
+  if (g_x6_nw4 & 2) g2.nw = 8;                        // A/B: the 8-wave form of the 128-row tile
   if (gemm_x6(g2, s) != 0) return -1;
   return S;
 }
@@ -1816,6 +1819,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_conv_bm") g_x6_conv_bm = value;
   else if (k == "x6_ffn_s") g_x6_ffn_s = value;
   else if (k == "x6_probe") g_x6_probe = value;
+  else if (k == "x6_nw4") g_x6_nw4 = value;
   else if (k == "x6_conv") g_x6_conv = value;
   else if (k == "x6_af32") g_x6_af32 = value;
   else if (k == "beam_prio") g_beam_prio = value;
@@ -2791,6 +2795,13 @@ int wn_op_gemm_x6(const float* A, const float* W, const float* bias, const float
     a.A3 = a3.as<char>();
   }
   a.B3 = w3.as<char>(); a.M = M; a.N = N; a.K = K; a.bm = bm;
+  if (bm == 120) { a.bm = 128; a.nw = 8; }   // micro-benchmark: the 8-wave 128-row tile
+  if (bm >= 129 && bm <= 132) {      // 4-wave 128-row tiles with priorities (130+)
+    a.bm = 128; a.nw = 4;
+    if (bm == 130) a.prio_split = cdiv(M, 128) * cdiv(N, 256) / 2;
+    if (bm == 131) a.prio_split = -1;
+    if (bm == 132) a.prio_split = -2;
+  }
   a.bias = bias; a.resid = resid; a.ldr = N; a.alpha = alpha; a.act = act; a.C = C; a.ldc = N;
   for (int r = 0; r < (reps > 0 ? reps : 1); ++r) WN_TRY(gemm_x6(a, s));
   return 0;
