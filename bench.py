@@ -396,6 +396,7 @@ def main():
                 'ms_per_step_median': round(ms_per_step, 3),
                 'ms_per_step_min': round(min(round_s) / args.steps * 1e3, 3),
                 'ms_per_step_max': round(max(round_s) / args.steps * 1e3, 3),
+                'ms_per_step_each': [round(r / args.steps * 1e3, 2) for r in round_s],
                 'note': 'each round = exactly --steps steps between barrier + '
                         'synchronize brackets, max over ranks; value = median round',
             },
