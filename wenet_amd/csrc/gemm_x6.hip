@@ -456,6 +456,7 @@ int g_x6_conv_bm = 0;
 int g_x6_ffn_s = 0;
 int g_x6_nw4 = 0;
 int g_x6_conv = 1;
+int g_x6_linear = 1;
 // 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in
 // registers.  Measured (r02ag): the split costs more than the plane bytes it saves -- FFN w_1
 // 53.8 -> 63.7 us, w_2 54.6 -> 60.7, conv2 921 -> 1055 (+ conv1 185 -> 125), 8192 x 4096 x

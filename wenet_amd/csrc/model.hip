@@ -258,6 +258,7 @@ struct wn_model {
   std::shared_ptr<DevBuf> weights_x6;
   std::shared_ptr<std::map<const float*, const void*>> x6_at;
   DevBuf x6_a, x6_h;                     // images of the GEMM input rows / the FFN hidden tensor
+  DevBuf x6_lin;                         // image of linear()'s A operand (large fp32 GEMMs)
   DevBuf mx_sa, mx_sh;                   // block scales of the LN output / FFN hidden
   std::map<std::string, const float*> w; // name -> device pointer
   // re-laid-out subsampling weights
@@ -356,6 +357,10 @@ struct HandleGuard {
   }
 
 thread_local const std::map<const float*, wn_model::MxW>* t_mx = nullptr;
+// plane images of the current model's weights and its activation-image scratch: linear()
+// routes the large fp32 GEMMs to the six-product kernel through them (gemm_x6.hip)
+thread_local const std::map<const float*, const void*>* t_x6 = nullptr;
+thread_local DevBuf* t_x6_a = nullptr;
 // fp8 mode: smallest number of 256 x 256 tiles of an FFN GEMM pair for which the MXFP8
 // kernels are used (below it the bf16 kernels fill the chip better); tests set 0
 int g_fp8_min_tiles = 192;
@@ -367,10 +372,13 @@ struct PrecisionScope {
   int saved;
   const float* s_f32; const void* s_bf16; int64_t s_elems;
   const std::map<const float*, wn_model::MxW>* s_mx;
+  const std::map<const float*, const void*>* s_x6; DevBuf* s_x6_a;
   explicit PrecisionScope(const wn_model* m)
       : saved(t_gemm_prec), s_f32(t_wslab_f32), s_bf16(t_wslab_bf16),
-        s_elems(t_wslab_elems), s_mx(t_mx) {
+        s_elems(t_wslab_elems), s_mx(t_mx), s_x6(t_x6), s_x6_a(t_x6_a) {
     t_mx = (m->fp8_ffn && m->mx_at) ? m->mx_at.get() : nullptr;
+    t_x6 = m->x6_at ? m->x6_at.get() : nullptr;
+    t_x6_a = const_cast<DevBuf*>(&m->x6_lin);
     t_gemm_prec = m->prec;
     const bool img = m->prec == PREC_BF16 && m->weights_bf16 && m->weights_bf16->p;
     t_wslab_f32 = img ? m->weights->as<float>() : nullptr;
@@ -381,6 +389,7 @@ struct PrecisionScope {
     t_gemm_prec = saved;
     t_wslab_f32 = s_f32; t_wslab_bf16 = s_bf16; t_wslab_elems = s_elems;
     t_mx = s_mx;
+    t_x6 = s_x6; t_x6_a = s_x6_a;
   }
 };
 
@@ -403,6 +412,24 @@ int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M,
            hipStream_t s, int act = ACT_NONE, const float* resid = nullptr,
            int ldr = 0, float alpha = 1.0f, bool glu = false, bool a_bf16 = false,
            bool c_bf16 = false) {
+  // Large fp32 GEMMs (the d = 512 encoders' projections, the decoders' GEMMs over B x N x L
+  // rows): split A into planes (one pass, 4 B in / 6 B out) and run the six-product kernel
+  // -- worth it from ~6 GFLOP on, where the split is a few per cent of the GEMM it halves.
+  if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_linear != 0 && t_x6 && t_x6_a && !glu &&
+      !a_bf16 && !c_bf16 && l.in % 16 == 0 && l.out % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 &&
+      (resid == nullptr || ldr % 4 == 0) && M >= 512 &&
+      2.0 * M * (double)l.out * l.in >= 6e9) {
+    auto it = t_x6->find(l.w);
+    if (it != t_x6->end()) {
+      WN_TRY(t_x6_a->ensure(x6_bytes(M, l.in)));
+      WN_TRY(x6_split(A, M, l.in, lda, t_x6_a->as<char>(), s));
+      X6Args x;
+      x.A3 = t_x6_a->as<char>(); x.B3 = it->second; x.M = M; x.N = l.out; x.K = l.in;
+      x.epi = 0; x.bias = l.b; x.resid = resid; x.ldr = ldr; x.alpha = alpha; x.act = act;
+      x.C = C; x.ldc = ldc;
+      return gemm_x6(x, s);
+    }
+  }
   GemmArgs g;
   g.A = A; g.W = l.w; g.bias = l.b; g.C = C; g.resid = resid;
   g.M = M; g.N = l.out; g.K = l.in; g.lda = lda; g.ldc = ldc; g.ldr = ldr;
@@ -508,7 +535,15 @@ int ffn_module(wn_model* m, const Norm& nrm, const Linear& w1, const Linear& w2,
 int build_x6_images(wn_model* m) {
   std::vector<const Linear*> ws;
   for (const auto& L : m->layers) { ws.push_back(&L.ffm1); ws.push_back(&L.ffm2);
-                                    ws.push_back(&L.ff1); ws.push_back(&L.ff2); }
+                                    ws.push_back(&L.ff1); ws.push_back(&L.ff2);
+                                    ws.push_back(&L.qkv); ws.push_back(&L.out);
+                                    ws.push_back(&L.pw2); }
+  for (const Decoder* D : {&m->left, &m->right})
+    for (const auto& L : D->layers) {
+      ws.push_back(&L.self_qkv); ws.push_back(&L.self_out); ws.push_back(&L.src_q);
+      ws.push_back(&L.src_kv); ws.push_back(&L.src_out); ws.push_back(&L.ff1);
+      ws.push_back(&L.ff2);
+    }
   // (the Transformer encoder of the Whisper configuration runs its GEMMs on v_mfma_f32 or,
   // in the bf16 / fp8 modes, on the low-precision kernels: no images for tf_layers)
   if (m->conv2.w) ws.push_back(&m->conv2);   // [d][(ky*3+kx)*d + c]: 16-channel k blocks per tap
@@ -1821,6 +1856,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_probe") g_x6_probe = value;
   else if (k == "x6_nw4") g_x6_nw4 = value;
   else if (k == "x6_conv") g_x6_conv = value;
+  else if (k == "x6_linear") g_x6_linear = value;
   else if (k == "x6_af32") g_x6_af32 = value;
   else if (k == "beam_prio") g_beam_prio = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
