@@ -259,6 +259,7 @@ struct wn_model {
   std::shared_ptr<std::map<const float*, const void*>> x6_at;
   DevBuf x6_a, x6_h;                     // images of the GEMM input rows / the FFN hidden tensor
   DevBuf x6_lin;                         // image of linear()'s A operand (large fp32 GEMMs)
+  std::shared_ptr<DevBuf> ctc_bias4;     // CTC-head bias padded with zeros to a multiple of 4
   DevBuf mx_sa, mx_sh;                   // block scales of the LN output / FFN hidden
   std::map<std::string, const float*> w; // name -> device pointer
   // re-laid-out subsampling weights
@@ -547,6 +548,7 @@ int build_x6_images(wn_model* m) {
   // (the Transformer encoder of the Whisper configuration runs its GEMMs on v_mfma_f32 or,
   // in the bf16 / fp8 modes, on the low-precision kernels: no images for tf_layers)
   if (m->conv2.w) ws.push_back(&m->conv2);   // [d][(ky*3+kx)*d + c]: 16-channel k blocks per tap
+  if (m->ctc.w) ws.push_back(&m->ctc);       // V rows; the image pads them to a multiple of 32
   size_t bytes = 0;
   for (const Linear* l : ws)
     if (l->w && l->in % 16 == 0) bytes += x6_bytes(l->out, l->in);
@@ -564,6 +566,17 @@ int build_x6_images(wn_model* m) {
   }
   m->weights_x6 = buf;
   m->x6_at = at;
+  if (m->ctc.w && m->ctc.b && m->ctc.out % 4 != 0) {
+    // the six-product kernel stores 16-B pieces: the CTC head runs with N = V rounded up
+    // to 4 (the image rows past V are zero, their bias too), the logits rows get that pitch
+    const int V4 = (m->ctc.out + 3) / 4 * 4;
+    auto b4 = std::make_shared<DevBuf>();
+    WN_TRY(b4->ensure((size_t)V4 * sizeof(float)));
+    WN_HIP(hipMemsetAsync(b4->p, 0, (size_t)V4 * sizeof(float), nullptr));
+    WN_HIP(hipMemcpyAsync(b4->p, m->ctc.b, (size_t)m->ctc.out * sizeof(float),
+                          hipMemcpyDeviceToDevice, nullptr));
+    m->ctc_bias4 = b4;
+  }
   return 0;
 }
 
@@ -1713,7 +1726,7 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->n_weight_elems = src->n_weight_elems;
   m->weights_bf16 = src->weights_bf16;
   m->weights_mx = src->weights_mx; m->mx_at = src->mx_at; m->fp8_ffn = src->fp8_ffn;
-  m->weights_x6 = src->weights_x6; m->x6_at = src->x6_at;
+  m->weights_x6 = src->weights_x6; m->x6_at = src->x6_at; m->ctc_bias4 = src->ctc_bias4;
   m->pos_tabs = src->pos_tabs;
   m->fb_tab_i = src->fb_tab_i;
   m->w = src->w;
@@ -2021,24 +2034,45 @@ int wn_ctc_logprobs(wn_model* m, int32_t topk, int32_t blank_id,
   WN_CHECK(k <= V, "top-k larger than the vocabulary");
   WN_CHECK(!logp_dev || Tp == m->Tp, "wn_ctc_logprobs: Tp mismatch");
   m->ctc_rows = M; m->ctc_k = k;
+  int ldv = V;
   if (M > 0) {
-    WN_TRY(m->logits.ensure((size_t)M * V * sizeof(float)));
+    // logits rows at a pitch of V rounded up to 4 floats (16-B aligned rows; what the
+    // six-product GEMM needs to store them)
+    const int V4 = (V + 3) / 4 * 4;
+    ldv = V4;
+    WN_TRY(m->logits.ensure((size_t)M * V4 * sizeof(float)));
     WN_TRY(m->topk_val.ensure((size_t)M * k * sizeof(float)));
     WN_TRY(m->topk_idx.ensure((size_t)M * k * sizeof(int)));
-    WN_TRY(linear(m->ctc, m->enc.as<float>(), c.d_model, m->logits.as<float>(),
-                  V, M, s));
+    const void* w6 = nullptr;
+    if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_linear != 0 && m->x6_at &&
+        c.d_model % 16 == 0 && M >= 512 && (V == V4 || m->ctc_bias4)) {
+      auto it = m->x6_at->find(m->ctc.w);
+      if (it != m->x6_at->end()) w6 = it->second;
+    }
+    if (w6) {
+      WN_TRY(m->x6_lin.ensure(x6_bytes(M, c.d_model)));
+      WN_TRY(x6_split(m->enc.as<float>(), M, c.d_model, c.d_model, m->x6_lin.as<char>(), s));
+      X6Args x;
+      x.A3 = m->x6_lin.as<char>(); x.B3 = w6; x.M = M; x.N = V4; x.K = c.d_model;
+      x.epi = 0; x.bias = V == V4 ? m->ctc.b : m->ctc_bias4->as<float>();
+      x.C = m->logits.as<float>(); x.ldc = V4;
+      WN_TRY(gemm_x6(x, s));
+    } else {
+      WN_TRY(linear(m->ctc, m->enc.as<float>(), c.d_model, m->logits.as<float>(),
+                    V4, M, s));
+    }
     CtcRowArgs r;
-    r.logits = m->logits.as<float>(); r.ld = V; r.M = M; r.V = V; r.k = k;
+    r.logits = m->logits.as<float>(); r.ld = V4; r.M = M; r.V = V; r.k = k;
     r.blank = blank_id; r.blank_penalty = blank_penalty > 0.f ? blank_penalty : 0.f;
     r.topk_val = m->topk_val.as<float>(); r.topk_idx = m->topk_idx.as<int>();
     // normalised rows are written back in place when the caller wants them
-    r.logp = logp_dev ? m->logits.as<float>() : nullptr; r.ld_out = V;
+    r.logp = logp_dev ? m->logits.as<float>() : nullptr; r.ld_out = V4;
     WN_TRY(ctc_logsoftmax_topk(r, s));
   }
   if (logp_dev) {
     if (M > 0) {
       hipLaunchKernelGGL(scatter_padded_any_kernel, dim3(m->Tp, m->B), dim3(256),
-                         0, s, m->logits.as<float>(), V, m->d_off.as<int>(),
+                         0, s, m->logits.as<float>(), ldv, m->d_off.as<int>(),
                          m->d_len.as<int>(), m->Tp, V, logp_dev);
       WN_HIP(hipGetLastError());
     } else {
