@@ -173,10 +173,17 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
     if (p.probe & 2) return;                       // ablation: no DMA (tools/bench_x6.py)
     const int kb = kb0 + g;
     char* dst = smem_x + (g % RING) * STAGE;
-    int sa = (m0 >> 5) * TILE3, delta = 0, ka = kb;
+    int sa = (m0 >> 5) * TILE3, delta = 0, ka = kb, kw = kb;
     if (CONV) {
-      const int tap = kb / p.conv_kbc;
+      // K is walked channel block by channel block with the taps inside (p.conv_taps > 0):
+      // the 9 taps of a 16-channel block re-read the same input pixels, and the block tiles
+      // an XCD runs together then keep that working set in its L2 (28 frames x 39 pixels x
+      // 96 B per tile) instead of fetching every tap from HBM again.  The weight image
+      // stays tap-major: its k block is tap * conv_kbc + channel block.
+      int tap = kb / p.conv_kbc;
       ka = kb - tap * p.conv_kbc;
+      if (p.conv_taps > 0) { ka = kb / p.conv_taps; tap = kb - ka * p.conv_taps; }
+      kw = tap * p.conv_kbc + ka;
       sa = AF32 ? ka * 64 : 0;
       delta = p.tap_delta[tap];
     } else if (AF32) {
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
                    const_cast<char*>(reinterpret_cast<const char*>(p.A3)) + ka * slab_a, 0,
                    (int)min(slab_a, (int64_t)0x7fffffff), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.B3)) + kb * slab_b, 0,
+        const_cast<char*>(reinterpret_cast<const char*>(p.B3)) + kw * slab_b, 0,
         (int)min(slab_b, (int64_t)0x7fffffff), 0x00020000);
     const int sb = (n0 >> 5) * TILE3;
 #pragma unroll
@@ -456,6 +463,7 @@ int g_x6_conv_bm = 0;
 int g_x6_ffn_s = 0;
 int g_x6_nw4 = 0;
 int g_x6_conv = 1;
+int g_x6_conv_order = 1;   // 1: channel blocks outside, taps inside (L2 reuse); 0: tap-major
 int g_x6_linear = 1;
 // 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in
 // registers.  Measured (r02ag): the split costs more than the plane bytes it saves -- FFN w_1

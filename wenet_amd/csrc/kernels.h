@@ -135,12 +135,14 @@ struct X6Args {
   // GEMM row r reads pixel a_pix[r] + tap_delta[tap]
   const int* a_pix = nullptr;
   int a_tiles = 0, conv_kbc = 0;
+  int conv_taps = 0;          // > 0: K order (channel block, tap) instead of (tap, channel block)
   int tap_delta[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int probe = 0;              // ablation bits (g_x6_probe)
 };
 extern int g_x6_probe;
 extern int g_x6_nw4;       // wn_tune_set("x6_nw4") A/B bits: 1 FFN w_1 on 256-row tiles, 2 FFN w_2 on the 8-wave 128-row tile, 4 priorities
 extern int g_x6_linear;    // wn_tune_set("x6_linear"): 0 = linear() never routes to the six-product GEMM
+extern int g_x6_conv_order;
 extern int g_x6_conv;      // wn_tune_set("x6_conv"): 0 = conv2 stays on v_mfma_f32
 extern int g_x6_af32;      // wn_tune_set("x6_af32"): 0 plane images (default), 1 fp32 A rows split in registers
 extern int g_x6_ffn_s;     // wn_tune_set("x6_ffn_s"): K slices of the FFN w_2 GEMM (0 auto)

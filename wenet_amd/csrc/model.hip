@@ -790,6 +790,7 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
       g.A3 = m->c1.as<char>(); g.B3 = w6; g.M = M * F2; g.N = d; g.K = 9 * d;
       g.epi = 0; g.bias = m->conv2.b; g.act = ACT_RELU; g.C = m->c2.as<float>(); g.ldc = d;
       g.a_pix = pix; g.a_tiles = tiles; g.conv_kbc = d / 16; g.bm = g_x6_conv_bm;
+      g.conv_taps = g_x6_conv_order ? 9 : 0;
       const int ne = (F1 + 1) / 2;
       for (int ky = 0; ky < 3; ++ky) {
         g.tap_delta[ky * 3 + 0] = ky * F1;            // f1 = 2 f2     (even, position f2)
@@ -1869,6 +1870,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_probe") g_x6_probe = value;
   else if (k == "x6_nw4") g_x6_nw4 = value;
   else if (k == "x6_conv") g_x6_conv = value;
+  else if (k == "x6_conv_order") g_x6_conv_order = value;
   else if (k == "x6_linear") g_x6_linear = value;
   else if (k == "x6_af32") g_x6_af32 = value;
   else if (k == "beam_prio") g_beam_prio = value;
