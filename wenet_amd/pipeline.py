@@ -27,6 +27,7 @@ in flight.  The library enforces this: a second thread entering a busy handle
 gets status -4 instead of corrupting it.
 """
 import concurrent.futures
+import gc
 import queue
 import threading
 from typing import List
@@ -34,6 +35,20 @@ from typing import List
 import torch
 
 from wenet_amd.model import ASRModel
+
+
+def freeze_host_heap() -> int:
+    """Call once a serving process is up (model loaded, first batches decoded): moves every
+    object alive so far -- the modules, state dicts and tables of a loaded model are a large,
+    static heap -- to the cyclic collector's permanent generation (`gc.freeze`), so that full
+    collections stop re-walking it while the decode threads wait.  The collector stays
+    enabled for everything allocated afterwards.  Measured with two decodes in flight at
+    BASELINE configs[1]: without it about one round in seven of 20 decodes runs 25 % slower
+    and the median is 2-4 % lower.  Returns the number of frozen
+    objects; `gc.unfreeze()` undoes it."""
+    gc.collect()
+    gc.freeze()
+    return gc.get_freeze_count()
 
 
 class DecodePipeline:
