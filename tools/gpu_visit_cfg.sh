@@ -1,12 +1,14 @@
 #!/bin/bash
-# GPU visit: FFN w_2 in 8 K slices (two blocks per CU) vs 4 -- kernel stats
-TAG=${1:-r02aw}
+# GPU visit: decoder output layers on the six-product GEMM -- full suite + config 3
+TAG=${1:-r02az}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ulimit -c 0
-for t in x6_ffn_s=8 x6_ffn_s=0; do
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$t -o prof -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-mfma-leg --streams 1 --min-seconds 0.2 --tune $t > $OUT/bench_under_rocprof_$t.json 2> $OUT/prof.err
-python tools/rocpd_stats.py $OUT/prof_$t/prof_results.db $OUT/kernel_stats_$t.md > /dev/null; echo $t; head -1 $OUT/kernel_stats_$t.md; grep -E "x6_kernel<128, 1|x6_kernel<256, 1|ffn_reduce" $OUT/kernel_stats_$t.md | cut -c1-170
+timeout 1500 python -m pytest tests -m gpu -q -x > $OUT/pytest.log 2>&1
+echo "tests exit $?"; tail -3 $OUT/pytest.log | cut -c1-300
+for t in x6_linear=1 x6_linear=0; do
+timeout 400 python bench.py --workload config3 --no-cpu-baseline --no-f32-mfma-leg --tune $t > $OUT/bench_config3_$t.json 2> $OUT/b.err
+python -c "
+import json; d=json.load(open('$OUT/bench_config3_$t.json')); print('config3 $t', d['value'], d['ms_per_step'], d['verified'])"
 done
-find $OUT -size +20M -delete

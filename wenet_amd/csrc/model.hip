@@ -259,7 +259,10 @@ struct wn_model {
   std::shared_ptr<std::map<const float*, const void*>> x6_at;
   DevBuf x6_a, x6_h;                     // images of the GEMM input rows / the FFN hidden tensor
   DevBuf x6_lin;                         // image of linear()'s A operand (large fp32 GEMMs)
-  std::shared_ptr<DevBuf> ctc_bias4;     // CTC-head bias padded with zeros to a multiple of 4
+  // biases of the vocabulary-sized layers (CTC head, decoder output layers) padded with zeros
+  // to a multiple of 4 columns: weight pointer -> padded bias
+  std::shared_ptr<DevBuf> bias4_buf;
+  std::shared_ptr<std::map<const float*, const float*>> bias4;
   DevBuf mx_sa, mx_sh;                   // block scales of the LN output / FFN hidden
   std::map<std::string, const float*> w; // name -> device pointer
   // re-laid-out subsampling weights
@@ -548,7 +551,11 @@ int build_x6_images(wn_model* m) {
   // (the Transformer encoder of the Whisper configuration runs its GEMMs on v_mfma_f32 or,
   // in the bf16 / fp8 modes, on the low-precision kernels: no images for tf_layers)
   if (m->conv2.w) ws.push_back(&m->conv2);   // [d][(ky*3+kx)*d + c]: 16-channel k blocks per tap
-  if (m->ctc.w) ws.push_back(&m->ctc);       // V rows; the image pads them to a multiple of 32
+  std::vector<const Linear*> vocab;          // V rows; the image pads them to a multiple of 32
+  if (m->ctc.w) vocab.push_back(&m->ctc);
+  for (const Decoder* D : {&m->left, &m->right})
+    if (D->out.w) vocab.push_back(&D->out);
+  for (const Linear* l : vocab) ws.push_back(l);
   size_t bytes = 0;
   for (const Linear* l : ws)
     if (l->w && l->in % 16 == 0) bytes += x6_bytes(l->out, l->in);
@@ -566,18 +573,56 @@ int build_x6_images(wn_model* m) {
   }
   m->weights_x6 = buf;
   m->x6_at = at;
-  if (m->ctc.w && m->ctc.b && m->ctc.out % 4 != 0) {
-    // the six-product kernel stores 16-B pieces: the CTC head runs with N = V rounded up
-    // to 4 (the image rows past V are zero, their bias too), the logits rows get that pitch
-    const int V4 = (m->ctc.out + 3) / 4 * 4;
-    auto b4 = std::make_shared<DevBuf>();
-    WN_TRY(b4->ensure((size_t)V4 * sizeof(float)));
-    WN_HIP(hipMemsetAsync(b4->p, 0, (size_t)V4 * sizeof(float), nullptr));
-    WN_HIP(hipMemcpyAsync(b4->p, m->ctc.b, (size_t)m->ctc.out * sizeof(float),
-                          hipMemcpyDeviceToDevice, nullptr));
-    m->ctc_bias4 = b4;
+  // the six-product kernel stores 16-B pieces: the vocabulary-sized layers run with N = V
+  // rounded up to 4 (the image rows past V are zero, their bias too) and their logits rows
+  // get that pitch
+  auto b4 = std::make_shared<DevBuf>();
+  auto bmap = std::make_shared<std::map<const float*, const float*>>();
+  size_t b4_floats = 0;
+  for (const Linear* l : vocab)
+    if (l->b && l->out % 4 != 0) b4_floats += (size_t)(l->out + 3) / 4 * 4;
+  if (b4_floats > 0) {
+    WN_TRY(b4->ensure(b4_floats * sizeof(float)));
+    WN_HIP(hipMemsetAsync(b4->p, 0, b4_floats * sizeof(float), nullptr));
+    float* q = b4->as<float>();
+    for (const Linear* l : vocab) {
+      if (!l->b || l->out % 4 == 0 || bmap->count(l->w)) continue;
+      WN_HIP(hipMemcpyAsync(q, l->b, (size_t)l->out * sizeof(float), hipMemcpyDeviceToDevice,
+                            nullptr));
+      (*bmap)[l->w] = q;
+      q += (l->out + 3) / 4 * 4;
+    }
   }
+  m->bias4_buf = b4;
+  m->bias4 = bmap;
   return 0;
+}
+
+// A vocabulary-sized layer (N = V, any V) into a logits buffer whose rows have a pitch of V
+// rounded up to 4: the six-product GEMM when the layer has a plane image (and, for V % 4 !=
+// 0, a padded bias), else linear().
+int vocab_linear(wn_model* m, const Linear& l, const float* A, int lda, float* C, int M,
+                 hipStream_t s) {
+  const int V = l.out, V4 = (V + 3) / 4 * 4;
+  const void* w6 = nullptr;
+  const float* bias = l.b;
+  if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_linear != 0 && m->x6_at &&
+      l.in % 16 == 0 && lda % 4 == 0 && M >= 512) {
+    auto it = m->x6_at->find(l.w);
+    if (it != m->x6_at->end()) w6 = it->second;
+    if (w6 && V != V4) {
+      auto ib = m->bias4 ? m->bias4->find(l.w) : decltype(m->bias4->end()){};
+      if (l.b && (!m->bias4 || ib == m->bias4->end())) w6 = nullptr;
+      else if (l.b) bias = ib->second;
+    }
+  }
+  if (!w6) return linear(l, A, lda, C, V4, M, s);
+  WN_TRY(m->x6_lin.ensure(x6_bytes(M, l.in)));
+  WN_TRY(x6_split(A, M, l.in, lda, m->x6_lin.as<char>(), s));
+  X6Args x;
+  x.A3 = m->x6_lin.as<char>(); x.B3 = w6; x.M = M; x.N = V4; x.K = l.in;
+  x.epi = 0; x.bias = bias; x.C = C; x.ldc = V4;
+  return gemm_x6(x, s);
 }
 
 // hidden split of the x6 FFN's second GEMM: K slices so that 128-row tiles x slices fill
@@ -1727,7 +1772,7 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->n_weight_elems = src->n_weight_elems;
   m->weights_bf16 = src->weights_bf16;
   m->weights_mx = src->weights_mx; m->mx_at = src->mx_at; m->fp8_ffn = src->fp8_ffn;
-  m->weights_x6 = src->weights_x6; m->x6_at = src->x6_at; m->ctc_bias4 = src->ctc_bias4;
+  m->weights_x6 = src->weights_x6; m->x6_at = src->x6_at; m->bias4_buf = src->bias4_buf; m->bias4 = src->bias4;
   m->pos_tabs = src->pos_tabs;
   m->fb_tab_i = src->fb_tab_i;
   m->w = src->w;
@@ -2045,24 +2090,7 @@ int wn_ctc_logprobs(wn_model* m, int32_t topk, int32_t blank_id,
     WN_TRY(m->logits.ensure((size_t)M * V4 * sizeof(float)));
     WN_TRY(m->topk_val.ensure((size_t)M * k * sizeof(float)));
     WN_TRY(m->topk_idx.ensure((size_t)M * k * sizeof(int)));
-    const void* w6 = nullptr;
-    if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_linear != 0 && m->x6_at &&
-        c.d_model % 16 == 0 && M >= 512 && (V == V4 || m->ctc_bias4)) {
-      auto it = m->x6_at->find(m->ctc.w);
-      if (it != m->x6_at->end()) w6 = it->second;
-    }
-    if (w6) {
-      WN_TRY(m->x6_lin.ensure(x6_bytes(M, c.d_model)));
-      WN_TRY(x6_split(m->enc.as<float>(), M, c.d_model, c.d_model, m->x6_lin.as<char>(), s));
-      X6Args x;
-      x.A3 = m->x6_lin.as<char>(); x.B3 = w6; x.M = M; x.N = V4; x.K = c.d_model;
-      x.epi = 0; x.bias = V == V4 ? m->ctc.b : m->ctc_bias4->as<float>();
-      x.C = m->logits.as<float>(); x.ldc = V4;
-      WN_TRY(gemm_x6(x, s));
-    } else {
-      WN_TRY(linear(m->ctc, m->enc.as<float>(), c.d_model, m->logits.as<float>(),
-                    V4, M, s));
-    }
+    WN_TRY(vocab_linear(m, m->ctc, m->enc.as<float>(), c.d_model, m->logits.as<float>(), M, s));
     CtcRowArgs r;
     r.logits = m->logits.as<float>(); r.ld = V4; r.M = M; r.V = V; r.k = k;
     r.blank = blank_id; r.blank_penalty = blank_penalty > 0.f ? blank_penalty : 0.f;
@@ -2388,9 +2416,10 @@ int run_decoder(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
   WN_TRY(decoder_layers(m, D, R, n_seq, max_q, d_tok, false, s));
   float* t1 = m->r_t1.as<float>();
   WN_TRY(ln(D.after, m->r_x.as<float>(), t1, R, d, c.norm_eps, s));
-  WN_TRY(linear(D.out, t1, d, m->r_logits.as<float>(), V, R, s));
+  // (the caller sized r_logits for a pitch of V rounded up to 4)
+  WN_TRY(vocab_linear(m, D.out, t1, d, m->r_logits.as<float>(), R, s));
   hipLaunchKernelGGL(row_logp_at_kernel, dim3(R), dim3(256), 0, s,
-                     m->r_logits.as<float>(), V, V, d_tgt, out_dev);
+                     m->r_logits.as<float>(), (V + 3) / 4 * 4, V, d_tgt, out_dev);
   WN_HIP(hipGetLastError());
   return 0;
 }
@@ -2644,7 +2673,7 @@ int wn_decoder_forward(wn_model* m, int32_t utt, int32_t which, int32_t n_seq,
   WN_TRY(m->r_qkv.ensure((size_t)R * 3 * d * sizeof(float)));
   WN_TRY(m->r_h.ensure((size_t)R * c.dec_ffn_dim * sizeof(float)));
   WN_TRY(m->r_mem.ensure((size_t)m->rows * 2 * d * sizeof(float)));
-  WN_TRY(m->r_logits.ensure((size_t)R * V * sizeof(float)));
+  WN_TRY(m->r_logits.ensure((size_t)R * ((V + 3) / 4 * 4) * sizeof(float)));
   WN_TRY(m->r_out.ensure((size_t)2 * R * sizeof(float)));
   WN_TRY(decoder_layers(m, D, R, n_seq, max_len, m->r_tok.as<int>(), false, s,
                         m->r_tgt.as<int>()));
@@ -2731,7 +2760,7 @@ int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host
   WN_TRY(m->r_qkv.ensure((size_t)R * 3 * d * sizeof(float)));
   WN_TRY(m->r_h.ensure((size_t)R * c.dec_ffn_dim * sizeof(float)));
   WN_TRY(m->r_mem.ensure((size_t)m->rows * 2 * d * sizeof(float)));
-  WN_TRY(m->r_logits.ensure((size_t)R * V * sizeof(float)));
+  WN_TRY(m->r_logits.ensure((size_t)R * ((V + 3) / 4 * 4) * sizeof(float)));
   WN_TRY(m->r_out.ensure((size_t)2 * R * sizeof(float)));
   float* o_l = m->r_out.as<float>();
   float* o_r = o_l + R;
