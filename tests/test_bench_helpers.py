@@ -70,3 +70,14 @@ def test_contraction_flops_matches_the_survey_figure():
     # additive over utterances, quadratic only in the attention term
     a = bench.contraction_flops(configs, [998, 998])
     assert abs(a - 2 * bench.contraction_flops(configs, [998])) < 1.0
+
+
+def test_freeze_host_heap_keeps_the_collector_enabled():
+    import gc
+    from wenet_amd.pipeline import freeze_host_heap
+    try:
+        n = freeze_host_heap()
+        assert n > 0 and gc.isenabled() and gc.get_freeze_count() == n
+    finally:
+        gc.unfreeze()
+    assert gc.get_freeze_count() == 0

@@ -292,7 +292,7 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
         if isinstance(src, tuple):              # (path, start, end) segment
             return read_wav(src[0], return_rate=True, start=src[1], end=src[2])
         return read_wav(src, return_rate=True)
-    from wenet_amd.pipeline import DecodePipeline
+    from wenet_amd.pipeline import DecodePipeline, freeze_host_heap
     kw = dict(beam_size=args.beam_size,
               decoding_chunk_size=args.decoding_chunk_size,
               num_decoding_left_chunks=args.num_decoding_left_chunks,
@@ -343,6 +343,10 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
             keys = [batches[bi][i][0] for i in perm]
             inflight.append((bi, keys, pipe.submit(args.modes, feats, lens, **kw)))
             drain(args.streams)
+            if pos == 2:
+                # the process is up: stop the cyclic collector from re-walking the model's
+                # static heap on every full collection (pipeline.freeze_host_heap)
+                freeze_host_heap()
         drain(0)
     readers.shutdown(wait=True)
 
