@@ -114,3 +114,32 @@ def test_encoder_with_rowln_gemm_matches_gemm_plus_layernorm(B, frames, chunk):
     err = (got - ref).abs().max().item()
     print(f'\n[B={B}] row-LN GEMM vs GEMM + LayerNorm: max |d enc| {err:.2e}')
     assert err < 2e-4
+
+
+@pytest.mark.parametrize('config,B,frames,chunk', [('aishell_u2pp', 4, (400, 700), -1),
+                                                   ('aishell_u2pp', 32, (800, 1200), -1),
+                                                   ('wenetspeech_u2pp', 3, (300, 500), 16),
+                                                   ('aishell_u2pp', 3, (7, 90), 16)])
+def test_encoder_with_folded_relpos_attention_matches_the_two_contraction_form(config, B, frames,
+                                                                               chunk):
+    """(q + u).k + (q + v).p == q.(k + p) + (u.k + v.p): the rel-pos attention as ONE score
+    contraction with rewritten keys and a per-key scalar (relpos_fold_kernel) against the
+    two-contraction kernel, whole encoder, full-context and chunk-masked, ragged lengths."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=83)
+    try:
+        _lib.check(L.wn_tune_set(b'attn_fold', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        ref = ref.cpu()
+        _lib.check(L.wn_tune_set(b'attn_fold', 1), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got = got.cpu()
+    finally:
+        L.wn_tune_set(b'attn_fold', 1)
+    assert torch.equal(got, got2.cpu())            # race screen
+    err = (got - ref).abs().max().item()
+    print(f'\n[{config} B={B}] folded rel-pos attention vs two contractions: max |d enc| {err:.2e}')
+    assert 0 < err < 1e-4

@@ -409,6 +409,10 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
   constexpr int NMAT = RELPOS ? 3 : 2;
   constexpr int MAT = KT * KSTR;
   __shared__ __attribute__((aligned(16))) float stile[2 * NMAT * MAT];
+  // per-key additive score term of the folded rel-pos form (a.kbias): one float per key of
+  // the tile, staged with it ([buffer | half][key])
+  __shared__ float sbias[2][KT];
+  const bool kb_on = !RELPOS && a.kbias != nullptr;
 
   // ---- this lane's query row ---------------------------------------------
   const int qi = q0 + wave * 32 + li;
@@ -466,7 +470,13 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
   // staging step moves the tiles of BOTH halves.
   constexpr int NCH = KT * 16 * KS / NTHR;  // float4 chunks per thread and matrix
   f32x4 rK[NCH], rV[NCH], rP[RELPOS ? NCH : 1];
+  float rC = 0.f;
   auto gload = [&](int it) {
+    if (kb_on && tid < KT * KS) {
+      int j = (t_lo + (tid / KT) * n_it + it) * KT + (tid % KT);
+      if (j > kvlen - 1) j = kvlen - 1;
+      rC = a.kbias[(int64_t)(kvoff + j) * a.n_heads + h];
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = tid + i * NTHR;
@@ -484,6 +494,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
     }
   };
   auto lstore = [&](int buf) {  // KS == 1: buffer index; KS == 2: ignored
+    if (kb_on && tid < KT * KS) sbias[KS == 1 ? buf : tid / KT][tid % KT] = rC;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = tid + i * NTHR;
@@ -552,6 +563,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
     for (int r = 0; r < 16; ++r) {
       const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       ok[r] = (j >= jmin) && (j < jmax);
+      if (kb_on) sc[r] += sbias[cur][(r & 3) + 8 * (r >> 2) + 4 * hi];
       sc[r] *= a.scale;
       if (ok[r]) tmax = fmaxf(tmax, sc[r]);
     }
@@ -631,6 +643,43 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
       op[li] = o0[r] * ir;
       op[32 + li] = o1[r] * ir;
     }
+  }
+}
+
+// Rel-pos attention folded into plain attention.  RelPositionMultiHeadedAttention scores
+// (attention.py:410-428, this version without rel_shift: position row j for key j)
+//     (q + u) . k_j + (q + v) . p_j  =  q . (k_j + p_j)  +  (u . k_j + v . p_j)
+// -- ONE contraction with the keys k'_j = k_j + p_j and a per-key, per-head scalar instead
+// of two contractions per score (a third of the kernel's MFMA work and of its LDS traffic:
+// the P tile is gone).  This kernel rewrites K in place and writes the scalars; one wave
+// per key row, 4 columns per lane and 256-column chunk (head = column / 64).
+template <int E>
+__global__ __launch_bounds__(256) void relpos_fold_kernel(
+    float* __restrict__ K, int ldk, const float* __restrict__ P, int ldp,
+    const float* __restrict__ bias_u, const float* __restrict__ bias_v,
+    const int* __restrict__ row_utt, const int* __restrict__ off,
+    const int* __restrict__ p_off, float* __restrict__ kbias, int n_heads, int M) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int u = row_utt[row];
+  if (u < 0) return;
+  const int j = row - off[u] + (p_off ? p_off[u] : 0);
+#pragma unroll
+  for (int c = 0; c < E / 4; ++c) {
+    const int col = c * 256 + lane * 4;
+    float* kp = K + (int64_t)row * ldk + col;
+    const f32x4 k = *reinterpret_cast<const f32x4*>(kp);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(P + (int64_t)j * ldp + col);
+    const f32x4 bu = *reinterpret_cast<const f32x4*>(bias_u + col);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_v + col);
+    float d = bu[0] * k[0] + bu[1] * k[1] + bu[2] * k[2] + bu[3] * k[3] +
+              bv[0] * p[0] + bv[1] * p[1] + bv[2] * p[2] + bv[3] * p[3];
+    // a head = 64 columns = 16 lanes
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    *reinterpret_cast<f32x4*>(kp) = k + p;
+    if ((lane & 15) == 0) kbias[(int64_t)row * n_heads + c * 4 + (lane >> 4)] = d;
   }
 }
 
@@ -791,6 +840,24 @@ int dwconv_ln_silu(const DwConvArgs& a, hipStream_t s) {
   return 0;
 }
 
+int g_attn_fold = 1;   // wn_tune_set("attn_fold"): 0 = two contractions per score (A/B)
+
+int relpos_fold(float* K, int ldk, const float* P, int ldp, const float* bias_u,
+                const float* bias_v, const int* row_utt, const int* off, const int* p_off,
+                float* kbias, int n_heads, int M, int D, hipStream_t s) {
+  WN_CHECK(D == n_heads * 64 && (D == 256 || D == 512) && ldk % 4 == 0 && ldp % 4 == 0,
+           "relpos_fold: shape");
+  dim3 g(cdiv(M, 4)), t(256);
+  if (D == 256)
+    hipLaunchKernelGGL(relpos_fold_kernel<4>, g, t, 0, s, K, ldk, P, ldp, bias_u, bias_v,
+                       row_utt, off, p_off, kbias, n_heads, M);
+  else
+    hipLaunchKernelGGL(relpos_fold_kernel<8>, g, t, 0, s, K, ldk, P, ldp, bias_u, bias_v,
+                       row_utt, off, p_off, kbias, n_heads, M);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
 int g_attn_split = 0;  // wn_tune_set("attn_split")
 int g_attn_bf16 = 1;   // wn_tune_set("attn_bf16")
 
@@ -805,7 +872,8 @@ int attention(const AttnArgs& a, hipStream_t s) {
   // key split for the encoder's self attention over long sequences: twice the
   // waves for the same tiles (g_attn_split: 0 auto, 1 off, 2 on)
   const bool split = g_attn_split == 2 ||
-                     (g_attn_split == 0 && a.P != nullptr && a.max_q_len >= 128);
+                     (g_attn_split == 0 && (a.P != nullptr || a.kbias != nullptr) &&
+                      a.max_q_len >= 128);
   if (split) {
     dim3 t2(NW * 2 * 64);
     if (a.P)

@@ -68,6 +68,9 @@ struct AttnArgs {
   const float* P = nullptr; int ldp = 0;      // [T][h*64] projected pos table
   const int* p_off = nullptr;  // [n_seq] or null: key j of sequence s uses row p_off[s] + j
   const float* bias_u = nullptr; const float* bias_v = nullptr;  // [h][64]
+  // folded rel-pos form (relpos_fold): K already holds k + p, kbias [key rows][n_heads] is
+  // added to the score before the scale; P / bias_u / bias_v stay null
+  const float* kbias = nullptr;
   float* O; int ldo;
   const int* q_off; const int* q_len;   // [n_seq]
   const int* kv_off; const int* kv_len; // [n_seq]
@@ -79,6 +82,10 @@ struct AttnArgs {
   float scale = 0.125f;
 };
 int attention(const AttnArgs& a, hipStream_t s);
+extern int g_attn_fold;
+int relpos_fold(float* K, int ldk, const float* P, int ldp, const float* bias_u,
+                const float* bias_v, const int* row_utt, const int* off, const int* p_off,
+                float* kbias, int n_heads, int M, int D, hipStream_t s);
 // The same with bf16 MFMA operands (attention_bf16.hip); attention() routes here
 // when the calling thread's precision is PREC_BF16 (and g_attn_bf16 != 0).
 int attention_bf16(const AttnArgs& a, hipStream_t s);

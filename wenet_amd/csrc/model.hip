@@ -285,6 +285,7 @@ struct wn_model {
   DevBuf d_off, d_len, d_row_utt, d_off1, d_len1, d_a_row_off;
   DevBuf c1, c2, x, t1, t2, hbuf, qkv, enc;
   DevBuf ffn_part;                      // hidden-slice partials of the fused FFN
+  DevBuf attn_kbias;                    // per-key score term of the folded rel-pos attention
   DevBuf xpad, pos_rows, d_row_t, d_zero_rows;
   DevBuf ck_kv, ck_xext, ck_glu, ck_desc, ck_rowutt, ck_sess;  // forward_chunk scratch
   // Whisper log-mel: DFT / window tables (shared), mel matrix per bin count
@@ -923,7 +924,18 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     AttnArgs a;
     a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d;
     a.ldq = a.ldk = a.ldv = 3 * d;
-    a.P = L.pos_tab; a.ldp = d; a.bias_u = L.bias_u; a.bias_v = L.bias_v;
+    if (!h16 && t_gemm_prec == PREC_F32 && g_attn_fold != 0 && (d == 256 || d == 512) &&
+        d == c.n_heads * 64) {
+      // rel-pos folded: k <- k + p (in place), one scalar per key and head; the attention
+      // kernel then runs ONE score contraction (encoder_kernels.hip, relpos_fold_kernel)
+      WN_TRY(m->attn_kbias.ensure((size_t)M * c.n_heads * sizeof(float)));
+      WN_TRY(relpos_fold(qkv + d, 3 * d, L.pos_tab, d, L.bias_u, L.bias_v,
+                         m->d_row_utt.as<int>(), m->d_off.as<int>(), nullptr,
+                         m->attn_kbias.as<float>(), c.n_heads, M, d, s));
+      a.kbias = m->attn_kbias.as<float>();
+    } else {
+      a.P = L.pos_tab; a.ldp = d; a.bias_u = L.bias_u; a.bias_v = L.bias_v;
+    }
     a.O = t2; a.ldo = d; a.o_bf16 = h16;
     a.q_off = a.kv_off = m->d_off.as<int>();
     a.q_len = a.kv_len = m->d_len.as<int>();
@@ -1915,6 +1927,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_probe") g_x6_probe = value;
   else if (k == "x6_nw4") g_x6_nw4 = value;
   else if (k == "x6_conv") g_x6_conv = value;
+  else if (k == "attn_fold") g_attn_fold = value;
   else if (k == "x6_conv_order") g_x6_conv_order = value;
   else if (k == "x6_linear") g_x6_linear = value;
   else if (k == "x6_af32") g_x6_af32 = value;
