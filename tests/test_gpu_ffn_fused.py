@@ -137,9 +137,14 @@ def test_encoder_with_folded_relpos_attention_matches_the_two_contraction_form(c
         got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got = got.cpu()
+        _lib.check(L.wn_tune_set(b'attn_fold', 2), 'tune')   # the fold as a separate pass
+        sep, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        sep = sep.cpu()
     finally:
         L.wn_tune_set(b'attn_fold', 1)
     assert torch.equal(got, got2.cpu())            # race screen
     err = (got - ref).abs().max().item()
-    print(f'\n[{config} B={B}] folded rel-pos attention vs two contractions: max |d enc| {err:.2e}')
-    assert 0 < err < 1e-4
+    err2 = (sep - ref).abs().max().item()
+    print(f'\n[{config} B={B}] folded rel-pos attention vs two contractions: max |d enc| '
+          f'{err:.2e} (in the kernel), {err2:.2e} (separate pass)')
+    assert 0 < err < 1e-4 and 0 < err2 < 1e-4

@@ -388,7 +388,12 @@ constexpr int KSTR = 68;        // LDS row stride (floats): 64 + 4 pad
 // MFMA latency of the dependent chain was exposed.  The LDS budget stays 52 KB
 // per block: one buffer per half instead of two buffers (two barriers per
 // iteration; the other resident waves cover them).
-template <int NW, bool RELPOS, int KS>
+// FOLD (with RELPOS false): the rel-pos term folded into the keys while they are staged --
+// see relpos_fold_kernel below for the algebra: the thread that stages a float4 of key row j
+// adds the same float4 of position row j (k <- k + p) and forms its share of u.k + v.p; 16
+// consecutive threads hold one key row, so four shuffles complete the scalar, which goes to
+// LDS next to the tile and is added to the score before the scale.
+template <int NW, bool RELPOS, int KS, bool FOLD = false>
 __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kernel(AttnArgs a) {
   const int s = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (NW * 32);
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
   // per-key additive score term of the folded rel-pos form (a.kbias): one float per key of
   // the tile, staged with it ([buffer | half][key])
   __shared__ float sbias[2][KT];
-  const bool kb_on = !RELPOS && a.kbias != nullptr;
+  const bool kb_on = FOLD || (!RELPOS && a.kbias != nullptr);
 
   // ---- this lane's query row ---------------------------------------------
   const int qi = q0 + wave * 32 + li;
@@ -470,9 +475,14 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
   // staging step moves the tiles of BOTH halves.
   constexpr int NCH = KT * 16 * KS / NTHR;  // float4 chunks per thread and matrix
   f32x4 rK[NCH], rV[NCH], rP[RELPOS ? NCH : 1];
-  float rC = 0.f;
+  float rC = 0.f, rCf[FOLD ? NCH : 1];
+  f32x4 fu = {0.f, 0.f, 0.f, 0.f}, fv = fu;
+  if (FOLD) {   // NTHR is a multiple of 16: a thread's column quad (tid & 15) never changes
+    fu = *reinterpret_cast<const f32x4*>(a.bias_u + h * 64 + (tid & 15) * 4);
+    fv = *reinterpret_cast<const f32x4*>(a.bias_v + h * 64 + (tid & 15) * 4);
+  }
   auto gload = [&](int it) {
-    if (kb_on && tid < KT * KS) {
+    if (!FOLD && kb_on && tid < KT * KS) {
       int j = (t_lo + (tid / KT) * n_it + it) * KT + (tid % KT);
       if (j > kvlen - 1) j = kvlen - 1;
       rC = a.kbias[(int64_t)(kvoff + j) * a.n_heads + h];
@@ -491,16 +501,28 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
       if (RELPOS)
         rP[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)(j + p_off) * a.ldp +
                                                 h * 64 + c4 * 4);
+      if (FOLD) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(a.P + (int64_t)(j + p_off) * a.ldp +
+                                                        h * 64 + c4 * 4);
+        const f32x4 k = rK[i];
+        float d = fu[0] * k[0] + fu[1] * k[1] + fu[2] * k[2] + fu[3] * k[3] +
+                  fv[0] * p[0] + fv[1] * p[1] + fv[2] * p[2] + fv[3] * p[3];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        rCf[i] = d;
+        rK[i] = k + p;
+      }
     }
   };
   auto lstore = [&](int buf) {  // KS == 1: buffer index; KS == 2: ignored
-    if (kb_on && tid < KT * KS) sbias[KS == 1 ? buf : tid / KT][tid % KT] = rC;
+    if (!FOLD && kb_on && tid < KT * KS) sbias[KS == 1 ? buf : tid / KT][tid % KT] = rC;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = tid + i * NTHR;
       const int half = KS == 1 ? buf : c / (KT * 16);
       const int w = c % (KT * 16);
       const int r = w >> 4, c4 = w & 15;
+      if (FOLD && c4 == 0) sbias[half][r] = rCf[i];
       float* base = stile + half * NMAT * MAT;
       *reinterpret_cast<f32x4*>(base + r * KSTR + c4 * 4) = rK[i];
       *reinterpret_cast<f32x4*>(base + MAT + r * KSTR + c4 * 4) = rV[i];
@@ -874,13 +896,18 @@ int attention(const AttnArgs& a, hipStream_t s) {
   const bool split = g_attn_split == 2 ||
                      (g_attn_split == 0 && (a.P != nullptr || a.kbias != nullptr) &&
                       a.max_q_len >= 128);
+  const bool fold = a.P != nullptr && a.fold && a.bias_u && a.bias_v;
   if (split) {
     dim3 t2(NW * 2 * 64);
-    if (a.P)
+    if (fold)
+      hipLaunchKernelGGL((attention_kernel<NW, false, 2, true>), g, t2, 0, s, a);
+    else if (a.P)
       hipLaunchKernelGGL((attention_kernel<NW, true, 2>), g, t2, 0, s, a);
     else
       hipLaunchKernelGGL((attention_kernel<NW, false, 2>), g, t2, 0, s, a);
-  } else if (a.P)
+  } else if (fold)
+    hipLaunchKernelGGL((attention_kernel<NW, false, 1, true>), g, t, 0, s, a);
+  else if (a.P)
     hipLaunchKernelGGL((attention_kernel<NW, true, 1>), g, t, 0, s, a);
   else
     hipLaunchKernelGGL((attention_kernel<NW, false, 1>), g, t, 0, s, a);

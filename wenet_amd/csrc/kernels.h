@@ -71,6 +71,9 @@ struct AttnArgs {
   // folded rel-pos form (relpos_fold): K already holds k + p, kbias [key rows][n_heads] is
   // added to the score before the scale; P / bias_u / bias_v stay null
   const float* kbias = nullptr;
+  // fold = true with P / bias_u / bias_v set: the same folding done INSIDE the fp32 attention
+  // kernel while the keys are staged (no separate pass, K untouched)
+  bool fold = false;
   float* O; int ldo;
   const int* q_off; const int* q_len;   // [n_seq]
   const int* kv_off; const int* kv_len; // [n_seq]

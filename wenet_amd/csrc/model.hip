@@ -924,17 +924,20 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     AttnArgs a;
     a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d;
     a.ldq = a.ldk = a.ldv = 3 * d;
-    if (!h16 && t_gemm_prec == PREC_F32 && g_attn_fold != 0 && (d == 256 || d == 512) &&
+    a.P = L.pos_tab; a.ldp = d; a.bias_u = L.bias_u; a.bias_v = L.bias_v;
+    if (!h16 && t_gemm_prec == PREC_F32 && g_attn_fold == 2 && (d == 256 || d == 512) &&
         d == c.n_heads * 64) {
-      // rel-pos folded: k <- k + p (in place), one scalar per key and head; the attention
-      // kernel then runs ONE score contraction (encoder_kernels.hip, relpos_fold_kernel)
+      // A/B form: the folding as a separate pass (k <- k + p in place, scalars in HBM)
       WN_TRY(m->attn_kbias.ensure((size_t)M * c.n_heads * sizeof(float)));
       WN_TRY(relpos_fold(qkv + d, 3 * d, L.pos_tab, d, L.bias_u, L.bias_v,
                          m->d_row_utt.as<int>(), m->d_off.as<int>(), nullptr,
                          m->attn_kbias.as<float>(), c.n_heads, M, d, s));
       a.kbias = m->attn_kbias.as<float>();
-    } else {
-      a.P = L.pos_tab; a.ldp = d; a.bias_u = L.bias_u; a.bias_v = L.bias_v;
+      a.P = nullptr; a.bias_u = a.bias_v = nullptr;
+    } else if (!h16 && t_gemm_prec == PREC_F32 && g_attn_fold != 0) {
+      // rel-pos folded into the keys as the attention kernel stages them: ONE score
+      // contraction (encoder_kernels.hip, attention_kernel FOLD / relpos_fold_kernel)
+      a.fold = true;
     }
     a.O = t2; a.ldo = d; a.o_bf16 = h16;
     a.q_off = a.kv_off = m->d_off.as<int>();
