@@ -493,7 +493,9 @@ int gemm_x6_bm(int M, int N, int ksplit) {
   return cdiv(M, 256) * cdiv(N, XBN) * ksplit >= 512 ? 256 : 128;
 }
 
-int gemm_x6(const X6Args& a, hipStream_t s) {
+int gemm_x6(const X6Args& args, hipStream_t s) {
+  X6Args a = args;
+  if (g_x6_probe) a.probe = g_x6_probe;      // ablation knob (tools/bench_x6.py --probe)
   const bool af32 = a.A != nullptr;
   WN_CHECK((a.A3 || af32) && a.B3 && a.M > 0 && a.N > 0 && a.K > 0 && a.K % 16 == 0,
            "gemm_x6: shape");
@@ -507,7 +509,6 @@ int gemm_x6(const X6Args& a, hipStream_t s) {
   WN_CHECK(a.epi == 2 ? a.C3 != nullptr : a.C != nullptr, "gemm_x6: no output");
   WN_CHECK(a.epi == 1 || a.ksplit == 1, "gemm_x6: K slices need the partial epilogue");
   const int bm = a.bm ? a.bm : gemm_x6_bm(a.M, a.N, a.ksplit);
-  if (g_x6_probe) const_cast<X6Args&>(a).probe = g_x6_probe;
   if (a.a_pix) {
     // implicit GEMM of the subsampling conv2: fp32 C with bias + ReLU
     WN_CHECK(a.epi == 0 && a.act == ACT_RELU && a.conv_kbc > 0 && (af32 || a.a_tiles > 0) &&

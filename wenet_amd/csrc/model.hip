@@ -611,10 +611,13 @@ int vocab_linear(wn_model* m, const Linear& l, const float* A, int lda, float* C
       l.in % 16 == 0 && lda % 4 == 0 && M >= 512) {
     auto it = m->x6_at->find(l.w);
     if (it != m->x6_at->end()) w6 = it->second;
-    if (w6 && V != V4) {
-      auto ib = m->bias4 ? m->bias4->find(l.w) : decltype(m->bias4->end()){};
-      if (l.b && (!m->bias4 || ib == m->bias4->end())) w6 = nullptr;
-      else if (l.b) bias = ib->second;
+    if (w6 && V != V4 && l.b) {     // ragged V: the padded copy of the bias, or no x6
+      bias = nullptr;
+      if (m->bias4) {
+        auto ib = m->bias4->find(l.w);
+        if (ib != m->bias4->end()) bias = ib->second;
+      }
+      if (!bias) w6 = nullptr;
     }
   }
   if (!w6) return linear(l, A, lda, C, V4, M, s);
