@@ -402,8 +402,9 @@ int wn_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev,
 int wn_profile_enable(wn_model* m, int32_t on);
 int wn_profile_collect(wn_model* m, int32_t* n_launches, double* total_ms,
                        double* total_flops);
-/* What the bracketed launches were (static string): the FFN w_1 GEMM, or the fused
- * feed-forward kernel (w_1 + activation + w_2) when the fp32 path runs it. */
+/* What the bracketed launches were (static string): the FFN w_1 GEMM -- in the fp32 mode the
+ * six-product kernel of csrc/gemm_x6.hip -- or the fused feed-forward kernel (w_1 +
+ * activation + w_2) when wn_tune_set("gemm_x6", 0) puts the fp32 path on it. */
 const char* wn_profile_kernel_name(const wn_model* m);
 
 /* Test hook: "n_layers" = run only the first n encoder layers (-1: all),
@@ -411,9 +412,16 @@ const char* wn_profile_kernel_name(const wn_model* m);
  * compare every ConformerEncoderLayer output with the oracle. */
 int wn_debug_set(wn_model* m, const char* key, int32_t value);
 
-/* Process-wide kernel tuning knob for A/B measurements (tools/bench_gemm.py):
- * "gemm_variant" (bit mask of experimental code paths), "gemm_tile" /
- * "gemm_tile_bf16" (force a block tile).  Defaults (0) are the shipped configuration. */
+/* Process-wide kernel tuning knob for A/B measurements (tools/bench_gemm.py, tools/bench_x6.py,
+ * bench.py --tune, the WN_TUNE variable of the test session): "gemm_variant" (bit mask of
+ * experimental code paths), "gemm_tile" / "gemm_tile_bf16" (force a block tile); fp32 mode:
+ * "gemm_x6" (1 default: feed-forward, conv2, the vocabulary layers and every large linear as
+ * six bf16 plane products of exactly split fp32 operands; 0: every GEMM on
+ * v_mfma_f32_32x32x2_f32; 2: also for small batches), "x6_conv" / "x6_linear" (0: leave conv2 /
+ * the linear() route on v_mfma_f32), "x6_af32" (1: fp32 A rows split in registers), "ffn_fused",
+ * "gemm_rowln", "attn_fold" (1 default: rel-pos term folded into the keys inside the attention
+ * kernel; 0: two contractions per score; 2: folded by a separate pass), "ctc_wave", ...
+ * Unknown keys are an error.  The defaults are the shipped configuration. */
 int wn_tune_set(const char* key, int32_t value);
 
 #ifdef __cplusplus
