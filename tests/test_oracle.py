@@ -745,3 +745,28 @@ def test_x6_plane_split_is_exact_and_the_dropped_products_are_below_fp32_roundin
     e6 = (O.x6_matmul(a, w) - ref).abs().max().item()
     e32 = ((a @ w.T).double() - ref).abs().max().item()
     assert e6 <= 2.0 ** -26 * float((a.abs() @ w.abs().T).max()) and e6 < e32
+
+
+def test_relpos_fold_identity_of_the_attention_kernel():
+    """The algebra csrc/encoder_kernels.hip (attention_kernel FOLD) relies on, checked against
+    the oracle's own rel-pos scores (attention.py:410-428 restated, no rel_shift):
+    (q + u).k_j + (q + v).p_j == q.(k_j + p_j) + (u.k_j + v.p_j) for every query / key / head."""
+    g = torch.Generator().manual_seed(23)
+    B, H, T, D = 2, 4, 37, 64
+    q = torch.randn(B, H, T, D, generator=g, dtype=torch.float64)
+    k = torch.randn(B, H, T, D, generator=g, dtype=torch.float64)
+    p = torch.randn(1, H, T, D, generator=g, dtype=torch.float64)
+    u = torch.randn(H, D, generator=g, dtype=torch.float64)
+    v = torch.randn(H, D, generator=g, dtype=torch.float64)
+    # the reference's two contractions
+    ac = torch.matmul(q + u[None, :, None, :], k.transpose(-2, -1))
+    bd = torch.matmul(q + v[None, :, None, :], p.transpose(-2, -1))
+    ref = ac + bd
+    # the folded form: one contraction against k + p, plus a scalar per key and head
+    kp = k + p
+    c = (k * u[None, :, None, :]).sum(-1) + (p * v[None, :, None, :]).sum(-1)   # (B, H, T)
+    got = torch.matmul(q, kp.transpose(-2, -1)) + c[:, :, None, :]
+    assert (got - ref).abs().max().item() < 1e-12
+    # and in fp32 the two forms differ by reassociation only
+    got32 = (torch.matmul(q.float(), kp.float().transpose(-2, -1)) + c.float()[:, :, None, :])
+    assert (got32.double() - ref).abs().max().item() < 2e-4 * ref.abs().max().item()
