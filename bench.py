@@ -237,7 +237,8 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=device)
 
-    from wenet_amd import _lib, dist as wdist, verify
+    from wenet_amd import _lib, dist as wdist
+    import bench_verify as verify
     global _lib_mod
     _lib_mod = _lib
     for kv in filter(None, args.tune.split(',')):

@@ -8,7 +8,7 @@ from typing import List, Sequence, Tuple
 
 import numpy as np
 
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)),
                           'tests', 'golden')
 NBEST_TIE = 4e-3     # 2 x the fp64 prefix-score tolerance of the parity tests
 RESCORE_TIE = 2e-3   # 2 x the 1e-3 rescoring tolerance

@@ -1,5 +1,5 @@
 """CPU tests of the measurement helpers bench.py relies on: the output check against the
-committed real-reference goldens (wenet_amd/verify.py) and the algorithmic FLOP count
+committed real-reference goldens (bench_verify.py) and the algorithmic FLOP count
 (bench.contraction_flops)."""
 import json
 import os
@@ -11,7 +11,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from wenet_amd import synthetic as S, verify  # noqa: E402
+from wenet_amd import synthetic as S  # noqa: E402
+import bench_verify as verify  # noqa: E402
 
 
 def _meta(name):

@@ -103,8 +103,9 @@ def test_bench_batch_vs_reference(workload):
 
 
 def test_bench_verify_helper_matches_goldens():
-    """bench.py's own output check (wenet_amd/verify.py) on a real decode."""
-    from wenet_amd import synthetic as S, verify
+    """bench.py's own output check (bench_verify.py) on a real decode."""
+    from wenet_amd import synthetic as S
+    import bench_verify as verify
     configs, sd, model = cached_model('aishell_u2pp', 0)
     feats, lens = S.make_bench_batch('config2', 1)
     res = model.decode(['ctc_prefix_beam_search'], feats.cuda(), lens,
