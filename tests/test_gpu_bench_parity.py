@@ -71,14 +71,21 @@ def test_bench_batch_vs_reference(workload):
                                       meta['greedy'][b], what=f'{workload}[{b}]')
         n_frames += f; n_strict += s; n_flips += fl
         g = meta['prefix'][b]
+        # the two failure kinds are kept apart: ONLY an n-best list that differs from the
+        # reference's may be re-judged as a pruning near-tie; a rescoring score beyond 1e-3 on
+        # an utterance whose n-best list matched is a failure, near-tie or not
         try:
             t, c = nbest_check(res['ctc_prefix_beam_search'][b], g['nbest'],
                                g['nbest_scores'], g['nbest_times'], what=f'{workload}[{b}]')
+            nbest_ok = True
+        except AssertionError:
+            nbest_ok = False
+        if nbest_ok:
             nb_total += t; nb_cmp += c
             c, e = rescoring_check(res['attention_rescoring'][b],
                                    res['ctc_prefix_beam_search'][b], meta['rescoring'][b],
                                    g['nbest'], what=f'{workload}[{b}]')
-        except AssertionError:
+        else:
             # the one legitimate way to differ: a pruning decision closer than the log-prob
             # tolerance went the other way (gpu_util.pruning_tie_check proves both halves)
             gap = pruning_tie_check(res['ctc_prefix_beam_search'][b], logp[b, :n].cpu(),

@@ -135,11 +135,52 @@ def test_x6_planes_are_exact():
     assert torch.equal(C, A)
 
 
+@pytest.mark.parametrize('spread', ['operands', 'products'])
+def test_gemm_x6_wide_dynamic_range_inside_one_dot_product(spread):
+    """Operands whose magnitudes span 12 decades ALONG K (per-column logspace scale), so that
+    one dot product mixes plane products of very different exponents: `operands` -- A scaled
+    by s_k, W by 1 / s_k (products of comparable size from operands of wildly different
+    size); `products` -- only A scaled (the terms of the sum themselves span 12 decades).
+    Against fp64, normalised by sum_k |a_k w_k| (the natural scale of the rounding error of a
+    dot product): the six-product GEMM is not worse than the v_mfma_f32 kernel and stays in
+    the fp32 class (a few 2^-24 of the normaliser)."""
+    M, N, K = 1024, 512, 512
+    g = torch.Generator().manual_seed(31)
+    sk = torch.logspace(-6, 6, K)[torch.randperm(K, generator=g)]
+    A = torch.randn(M, K, generator=g) * sk
+    W = torch.randn(N, K, generator=g) / (sk if spread == 'operands' else 1.0)
+    ref = A.double() @ W.double().T
+    norm = A.double().abs() @ W.double().abs().T
+    c6 = _x6(A.cuda(), W.cuda(), None, None, 0, 1.0).cpu().double()
+    c32 = _f32(A.cuda(), W.cuda(), None, None, 0, 1.0).cpu().double()
+    e6 = ((c6 - ref).abs() / norm).max().item()
+    e32 = ((c32 - ref).abs() / norm).max().item()
+    r6 = (((c6 - ref) / norm) ** 2).mean().sqrt().item()
+    r32 = (((c32 - ref) / norm) ** 2).mean().sqrt().item()
+    print(f'\n[{spread}] max |err| / sum|a w|: x6 {e6:.2e} / f32 mfma {e32:.2e}; '
+          f'rms {r6:.2e} / {r32:.2e}')
+    assert e6 < 1e-6        # fp32 class: ~ sqrt(K) 2^-24 of the normaliser
+    assert e6 <= 1.5 * e32 + 1e-9 and r6 <= 1.2 * r32 + 1e-10
+
+
+@pytest.fixture(params=[0, 2], ids=['gemm_pair', 'hidden_on_chip'])
+def ffn_form(request):
+    """The feed-forward module as two six-product GEMMs (hidden tensor as a plane image in
+    HBM) and as the fused kernel of csrc/ffn_x6f.hip (hidden tensor in registers; forced on
+    every shape it supports: d_model 256, SiLU / ReLU)."""
+    from wenet_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.wn_tune_set(b'ffn_x6f', request.param), 'tune')
+    yield request.param
+    L.wn_tune_set(b'ffn_x6f', 1)
+
+
 @pytest.mark.parametrize('M,D,F,act', [
     (128, 256, 128, 1), (700, 256, 2048, 3), (7932, 256, 2048, 1), (1000, 512, 2048, 2),
-    (16231, 512, 2048, 1),
+    (16231, 512, 2048, 1), (7932, 256, 2048, 2), (33, 256, 64, 1), (3000, 256, 1024, 1),
+    (130, 256, 2048, 2),
 ])
-def test_ffn_x6_vs_fp64(M, D, F, act):
+def test_ffn_x6_vs_fp64(M, D, F, act, ffn_form):
     from wenet_amd import _lib
     L = _lib.lib()
     g = torch.Generator().manual_seed(M + D + F + act)
@@ -202,4 +243,68 @@ def test_encoder_with_x6_ffn_matches_the_f32_mfma_path(config, B, frames, chunk)
     assert torch.equal(got, got4.cpu())
     err = (got - ref).abs().max().item()
     print(f'\n[{config} B={B}] x6 FFN vs f32 MFMA: max |d enc| {err:.2e}')
+    assert 0 < err < 1e-4
+
+
+@pytest.mark.parametrize('ring', [3, 4, 5])
+def test_ffn_on_chip_equals_itself_for_every_ring_depth(ring):
+    """The DMA ring depth changes only when operands arrive, never what is multiplied: the
+    fused module must return the same bits for three stages of 48 records (ring 3, the default)
+    and four / five / six stages of 24 (a stale or early-overwritten
+    stage shows up here), on a row count that leaves a ragged last tile."""
+    from wenet_amd import _lib
+    L = _lib.lib()
+    M, D, F = 7932, 256, 2048
+    g = torch.Generator().manual_seed(99)
+    X = torch.randn(M, D, generator=g).cuda()
+    W1 = (torch.randn(F, D, generator=g) / D ** 0.5).cuda()
+    b1 = (torch.randn(F, generator=g) * 0.3).cuda()
+    W2 = (torch.randn(D, F, generator=g) / F ** 0.5).cuda()
+    b2 = (torch.randn(D, generator=g) * 0.3).cuda()
+    x0 = torch.randn(M, D, generator=g)
+    lw, lb = torch.ones(D).cuda(), torch.zeros(D).cuda()
+
+    def run():
+        xo = x0.clone().cuda()
+        y = torch.empty((M, D), device='cuda')
+        _lib.check(L.wn_op_ffn_x6(X.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(),
+                                  b2.data_ptr(), xo.data_ptr(), lw.data_ptr(), lb.data_ptr(),
+                                  y.data_ptr(), M, D, F, 1, 0.5, 1e-5, 3,
+                                  torch.cuda.current_stream().cuda_stream), 'ffn_x6')
+        torch.cuda.synchronize()
+        return xo.cpu()
+    try:
+        _lib.check(L.wn_tune_set(b'ffn_x6f', 2), 'tune')
+        _lib.check(L.wn_tune_set(b'ffn_x6f_ring', 6), 'tune')
+        ref = run()
+        _lib.check(L.wn_tune_set(b'ffn_x6f_ring', ring), 'tune')
+        for _ in range(3):
+            assert torch.equal(run(), ref)
+    finally:
+        L.wn_tune_set(b'ffn_x6f', 1)
+        L.wn_tune_set(b'ffn_x6f_ring', 3)
+
+
+def test_encoder_with_the_on_chip_ffn_matches_the_gemm_pair():
+    """BASELINE config 2 shaped batch through the encoder with the fused six-product FFN
+    (default at this size) against the two-GEMM form: same plane products, another fp32
+    summation order only."""
+    from gpu_util import cached_model
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model('aishell_u2pp', 0)
+    feats, lens = S.make_features(32, (800, 1200), seed=80)
+    try:
+        _lib.check(L.wn_tune_set(b'x6_af32', 0), 'tune')     # (plane images: the fused form's input)
+        _lib.check(L.wn_tune_set(b'ffn_x6f', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, -1, -1)
+        ref = ref.cpu()
+        _lib.check(L.wn_tune_set(b'ffn_x6f', 1), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, -1, -1)
+        got2, _ = model._forward_encoder(feats.cuda(), lens, -1, -1)
+    finally:
+        L.wn_tune_set(b'ffn_x6f', 1)
+    assert torch.equal(got, got2)
+    err = (got.cpu() - ref).abs().max().item()
+    print(f'\n[aishell B=32] on-chip FFN vs GEMM pair: max |d enc| {err:.2e}')
     assert 0 < err < 1e-4

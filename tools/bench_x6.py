@@ -99,10 +99,35 @@ def main():
                                                  W2.data_ptr(), b2.data_ptr(), x.data_ptr(),
                                                  lw.data_ptr(), lb.data_ptr(), y.data_ptr(), m,
                                                  d, f, 1, 0.5, 1e-5, st), 'ffn_fused')
+            _lib.check(L.wn_tune_set(b'ffn_x6f', 0), 'tune')
             ffn(1); fused()
             t1 = timed(lambda: ffn(1))
             tn = timed(lambda: ffn(args.reps + 1))
             us = (tn - t1) / args.reps * 1e3
+            if d == 256:
+                # hidden tensor on chip (csrc/ffn_x6f.hip); includes the split of X
+                for ring in (3, 4, 5, 6):
+                    _lib.check(L.wn_tune_set(b'ffn_x6f', 1), 'tune')
+                    _lib.check(L.wn_tune_set(b'ffn_x6f_ring', ring), 'tune')
+                    ffn(1)
+                    t1f = timed(lambda: ffn(1))
+                    tnf = timed(lambda: ffn(args.reps + 1))
+                    usf = (tnf - t1f) / args.reps * 1e3
+                    print(f'ffn M={m} D={d} F={f} | x6 ON CHIP ring {ring} (fp32 X split in registers): '
+                          f'{usf:8.1f} us {4.0 * m * d * f / usf / 1e6:7.1f} TF-eq', flush=True)
+                _lib.check(L.wn_tune_set(b'ffn_x6f_ring', 3), 'tune')
+                # measurement variants of the kernel (results wrong by design except 16)
+                for var, what in ((1, 'no MFMAs'),
+                                  (2, 'no DMA in the loop'), (4, 'no bias/act/split pieces'), (64, 'no fragment reads'), (10, 'no DMA, no waits'), (78, 'MFMAs only'), (74, 'MFMAs + pieces'), (14, 'MFMAs + fragment reads'), (76, 'MFMAs + DMA'), (70, 'MFMAs + waits/barriers'), (128, 'partials stored sc0 sc1'),
+                                  (8, 'no waits / barriers in the loop')):
+                    _lib.check(L.wn_tune_set(b'ffn_x6f_var', var), 'tune')
+                    ffn(1)
+                    t1f = timed(lambda: ffn(1))
+                    tnf = timed(lambda: ffn(args.reps + 1))
+                    usf = (tnf - t1f) / args.reps * 1e3
+                    print(f'ffn M={m} D={d} F={f} | x6 ON CHIP var {var:2d} ({what}): '
+                          f'{usf:8.1f} us', flush=True)
+                _lib.check(L.wn_tune_set(b'ffn_x6f_var', 0), 'tune')
             uf = timed(fused) / args.reps * 1e3
             fl = 4.0 * m * d * f
             print(f'ffn M={m} D={d} F={f} | x6 (split + 2 GEMMs): {us:8.1f} us '

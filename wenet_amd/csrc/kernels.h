@@ -162,6 +162,24 @@ size_t x6_bytes(int R, int K);
 int x6_split(const float* src, int R, int K, int ld, void* dst, hipStream_t s);
 int gemm_x6_bm(int M, int N, int ksplit);
 int gemm_x6(const X6Args& a, hipStream_t s);
+// Fused six-product feed-forward module (ffn_x6f.hip): hidden tensor in registers, d_model 256.
+struct FfnX6Args {
+  const float* X = nullptr;    // X = LayerNorm(x): [M][ldx] fp32 (split into planes in registers)
+  int ldx = 0;
+  const void* W13 = nullptr;   // X3 image of W1: F x 256
+  const void* W2p = nullptr;   // k-slot-permuted image of W2 (x6_split_perm): 256 x F
+  const float* b1 = nullptr;   // [F]
+  float* P = nullptr;          // [S][M][256] hidden-slice partials
+  int M = 0, D = 0, F = 0, S = 0, act = 0;
+};
+extern int g_ffn_x6f;        // wn_tune_set("ffn_x6f"): 0 = two six-product GEMMs, 2 = force (tests)
+extern int g_ffn_x6f_var;    // wn_tune_set("ffn_x6f_var"): measurement variants (ffn_x6f.hip VAR)
+extern int g_ffn_x6f_ring;   // wn_tune_set("ffn_x6f_ring"): DMA ring depth 4..6
+int x6_split_perm(const float* src, int R, int K, int ld, void* dst, hipStream_t s);
+int ffn_x6f_split(int M, int F);
+bool ffn_x6f_supported(int M, int D, int F, int act);
+int ffn_x6f(const FfnX6Args& a, hipStream_t s);
+
 
 // x_out = resid + alpha (A W^T + bias), y = LayerNorm(x_out): GEMM with N = 256 whose
 // block owns complete rows (gemm_rowln.hip)

@@ -257,6 +257,8 @@ struct wn_model {
   // pointer -> X3 image; built at create, shared by clones
   std::shared_ptr<DevBuf> weights_x6;
   std::shared_ptr<std::map<const float*, const void*>> x6_at;
+  std::shared_ptr<DevBuf> weights_x6p;      // k-slot-permuted FFN w_2 images (ffn_x6f.hip)
+  std::shared_ptr<std::map<const float*, const void*>> x6p_at;
   DevBuf x6_a, x6_h;                     // images of the GEMM input rows / the FFN hidden tensor
   DevBuf x6_lin;                         // image of linear()'s A operand (large fp32 GEMMs)
   // biases of the vocabulary-sized layers (CTC head, decoder output layers) padded with zeros
@@ -574,6 +576,29 @@ int build_x6_images(wn_model* m) {
   }
   m->weights_x6 = buf;
   m->x6_at = at;
+  // fused six-product feed-forward module (ffn_x6f.hip, d_model 256): the second layer's image
+  // with the k slots of a 16-unit block in the order a lane holds its hidden values
+  auto pbuf = std::make_shared<DevBuf>();
+  auto pat = std::make_shared<std::map<const float*, const void*>>();
+  if (m->cfg.d_model == 256) {
+    std::vector<const Linear*> w2s;
+    for (const auto& L : m->layers) { w2s.push_back(&L.ffm2); w2s.push_back(&L.ff2); }
+    size_t pbytes = 0;
+    for (const Linear* l : w2s)
+      if (l->w && l->in % 64 == 0 && l->out == 256) pbytes += x6_bytes(l->out, l->in);
+    if (pbytes > 0) {
+      WN_TRY(pbuf->ensure(pbytes));
+      char* q = pbuf->as<char>();
+      for (const Linear* l : w2s) {
+        if (!l->w || l->in % 64 != 0 || l->out != 256 || pat->count(l->w)) continue;
+        WN_TRY(x6_split_perm(l->w, l->out, l->in, l->in, q, nullptr));
+        (*pat)[l->w] = q;
+        q += x6_bytes(l->out, l->in);
+      }
+    }
+  }
+  m->weights_x6p = pbuf;
+  m->x6p_at = pat;
   // the six-product kernel stores 16-B pieces: the vocabulary-sized layers run with N = V
   // rounded up to 4 (the image rows past V are zero, their bias too) and their logits rows
   // get that pitch
@@ -649,6 +674,36 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
     return 0;
   auto i1 = m->x6_at->find(w1.w), i2 = m->x6_at->find(w2.w);
   if (i1 == m->x6_at->end() || i2 == m->x6_at->end()) return 0;
+  static thread_local int tick = 0;
+  if (g_ffn_x6f != 0 && g_x6_af32 == 0 && m->x6p_at && ffn_x6f_supported(M, d, F, act)) {
+    // hidden tensor on chip (ffn_x6f.hip)
+    auto ip = m->x6p_at->find(w2.w);
+    if (ip != m->x6p_at->end()) {
+      FfnX6Args a;
+      a.S = ffn_x6f_split(M, F);
+      if (m->ffn_part.ensure((size_t)a.S * M * d * sizeof(float)) != 0) return -1;
+      a.X = m->t1.as<float>(); a.ldx = d; a.W13 = i1->second; a.W2p = ip->second; a.b1 = w1.b;
+      a.P = m->ffn_part.as<float>(); a.M = M; a.D = d; a.F = F; a.act = act;
+      const bool br = m->prof_on && (tick++ % 6) == 0;
+      if (br) {
+        if (m->prof_used + 2 > m->prof_ev.size())
+          for (int i = 0; i < 64; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+            m->prof_ev.push_back(e);
+          }
+        (void)hipEventRecord(m->prof_ev[m->prof_used], s);
+      }
+      if (ffn_x6f(a, s) != 0) return -1;
+      if (br) {
+        (void)hipEventRecord(m->prof_ev[m->prof_used + 1], s);
+        m->prof_used += 2;
+        m->prof_flops += 4.0 * M * (double)F * d;     // both contractions (x 6 MFMA products)
+        m->prof_kernel = "ffn_x6f_kernel (FFN w_1 + act + w_2, six bf16 plane products)";
+      }
+      return a.S;
+    }
+  }
   const int S = ffn_x6_split(M, F);
   if (m->ffn_part.ensure((size_t)S * M * d * sizeof(float)) != 0) return -1;
   // plane images (x6_split of t1, w_1 writes the hidden planes); g_x6_af32 (A/B knob): the A
@@ -667,7 +722,6 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
   }
   if (g_x6_nw4 & 1) g1.bm = 256;                      // A/B: the 256-row tiles for w_1
   if (g_x6_nw4 & 4) g1.prio_split = cdiv(M, 128) * cdiv(F, 256) / 2;
-  static thread_local int tick = 0;
   const bool bracket = m->prof_on && (tick++ % 6) == 0;
   if (bracket) {
     if (m->prof_used + 2 > m->prof_ev.size())
@@ -1790,7 +1844,8 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->n_weight_elems = src->n_weight_elems;
   m->weights_bf16 = src->weights_bf16;
   m->weights_mx = src->weights_mx; m->mx_at = src->mx_at; m->fp8_ffn = src->fp8_ffn;
-  m->weights_x6 = src->weights_x6; m->x6_at = src->x6_at; m->bias4_buf = src->bias4_buf; m->bias4 = src->bias4;
+  m->weights_x6 = src->weights_x6; m->x6_at = src->x6_at;
+  m->weights_x6p = src->weights_x6p; m->x6p_at = src->x6p_at; m->bias4_buf = src->bias4_buf; m->bias4 = src->bias4;
   m->pos_tabs = src->pos_tabs;
   m->fb_tab_i = src->fb_tab_i;
   m->w = src->w;
@@ -1941,6 +1996,9 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "gemm_rowln") g_gemm_rowln = value;
   else if (k == "ffn_ring") g_ffn_ring = value;
+  else if (k == "ffn_x6f") g_ffn_x6f = value;
+  else if (k == "ffn_x6f_ring") g_ffn_x6f_ring = value;
+  else if (k == "ffn_x6f_var") g_ffn_x6f_var = value;
   else { set_error("wn_tune_set: unknown key " + k); return -1; }
   return 0;
 }
@@ -2934,8 +2992,23 @@ int wn_op_ffn_x6(const float* X, const float* W1, const float* b1, const float* 
   WN_CHECK(X && W1 && b1 && W2 && b2 && x && ln_w && ln_b && y, "ffn_x6: null argument");
   WN_CHECK(M > 0 && (D == 256 || D == 512) && F > 0 && F % 64 == 0, "ffn_x6: shape");
   hipStream_t s = (hipStream_t)stream;
-  const int S = ffn_x6_split(M, F);
   static thread_local DevBuf x3, w13, w23, h3, part;
+  if (g_ffn_x6f != 0 && g_x6_af32 == 0 && ffn_x6f_supported(M, D, F, act)) {
+    // hidden tensor on chip (ffn_x6f.hip)
+    FfnX6Args a;
+    a.S = ffn_x6f_split(M, F);
+    WN_TRY(w13.ensure(x6_bytes(F, D)));
+    WN_TRY(w23.ensure(x6_bytes(D, F)));
+    WN_TRY(part.ensure((size_t)a.S * M * D * sizeof(float)));
+    WN_TRY(x6_split(W1, F, D, D, w13.as<char>(), s));
+    WN_TRY(x6_split_perm(W2, D, F, F, w23.as<char>(), s));
+    a.X = X; a.ldx = D; a.W13 = w13.as<char>(); a.W2p = w23.as<char>(); a.b1 = b1;
+    a.P = part.as<float>(); a.M = M; a.D = D; a.F = F; a.act = act;
+    for (int r = 0; r < (reps > 0 ? reps : 1); ++r) WN_TRY(ffn_x6f(a, s));
+    return ffn_reduce_ln(x, part.as<float>(), a.S, b2, alpha, ln_w, ln_b, nullptr, nullptr, y, M,
+                         D, eps, 0, s);
+  }
+  const int S = ffn_x6_split(M, F);
   WN_TRY(x3.ensure(x6_bytes(M, D)));
   WN_TRY(w13.ensure(x6_bytes(F, D)));
   WN_TRY(w23.ensure(x6_bytes(D, F)));
