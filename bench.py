@@ -208,6 +208,8 @@ def main():
                          'configs[4]) -- extra data points, never the headline line')
     ap.add_argument('--no-f32-mfma-leg', action='store_true',
                     help='skip the extra round that runs every GEMM on v_mfma_f32')
+    ap.add_argument('--no-plain-leg', action='store_true',
+                    help='skip the extra round of plain back-to-back decode() calls')
     ap.add_argument('--tune', default='',
                     help='experiments: comma list of key=value for wn_tune_set')
     args = ap.parse_args()
@@ -228,9 +230,14 @@ def main():
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    if world > 1:
+    # WN_BENCH_FORCE_DIST=1: a process group (RCCL) even for one rank, so that the backend,
+    # the device-tensor all_gather / all_reduce / barrier of the N > 1 path execute on a
+    # 1-GPU box (tests/test_gpu_dist.py); the collectives of one rank are no-ops in time
+    dist_on = world > 1 or os.environ.get('WN_BENCH_FORCE_DIST') == '1'
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         if share_gpu:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
@@ -283,13 +290,13 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not dist_on:
             return x
         import torch.distributed as dist
         t = torch.tensor([x], dtype=torch.float64, device='cpu' if share_gpu else device)
@@ -353,6 +360,24 @@ def main():
             f32_only = max_over_ranks(time.perf_counter() - t0)
         finally:
             _lib.check(L.wn_tune_set(b'gemm_x6', 1), 'tune')
+    # transparency leg: plain back-to-back ASRModel.decode() calls -- what a caller written for
+    # the reference (wenet/bin/recognize.py:289) gets without the two-decodes-in-flight
+    # pipeline -- one round of --steps steps; reported beside the headline, never as `value`
+    plain = None
+    if args.streams != 1 and not args.no_plain_leg:
+        def plain_steps(n):
+            o = None
+            for _ in range(n):
+                o = finish(model.decode([method], feats_dev, lens, beam_size=beam,
+                                        **decode_kw)[method])
+            return o
+        plain_steps(max(2, args.warmup // 2))
+        barrier()
+        t0 = time.perf_counter()
+        plain_steps(args.steps)
+        barrier()
+        plain = max_over_ranks(time.perf_counter() - t0)
+    ffn_split = int(L.wn_profile_ffn_split(pipe.models[0]._h))
     pipe.close()
     assert len(out) == batch_per_gpu * world, 'result gather lost utterances'
 
@@ -382,10 +407,9 @@ def main():
                               'tests/test_gpu_x6.py; everything else v_mfma_f32)'
                               if x6 else 'f32'),
                      'bf16': 'bf16 operands, f32 accumulate / activations',
-                     'fp8': 'e4m3 FFN GEMM operands (per-row / per-channel scales), '
-                            'bf16 elsewhere, f32 accumulate'}[args.dtype]
-        kern = {'fp32': 'gemm_f32_kernel', 'bf16': 'gemm_bf16s_kernel',
-                'fp8': 'gemm_fp8_kernel'}[args.dtype]
+                     'fp8': 'OCP MXFP8 FFN GEMM operands (e4m3 elements, one E8M0 scale per 32 k '
+                            'of a row, activations and weights), bf16 elsewhere, f32 '
+                            'accumulate'}[args.dtype]
         line = {
             'metric': ('audio-seconds/sec (RTF^-1), Whisper-large-v3 encoder, '
                        if whisper else
@@ -407,6 +431,8 @@ def main():
                 'audio_seconds_per_step': round(total_audio, 1),
                 'encoder_frames_per_gpu': enc_rows,
                 'parallelism': f'utterance-sharded x{world}, one all_gather of results',
+                'process_group': (('gloo (ranks sharing one GPU: self-test)' if share_gpu
+                                   else 'nccl (RCCL)') if dist_on else None),
                 'decodes_in_flight_per_gpu': max(1, args.streams),
             },
             'rounds': {
@@ -422,14 +448,19 @@ def main():
             },
             'roofline': {
                 'bound': 'mfma',
-                'kernel': (f'{prof_name}, M={enc_rows} N={ffn} K={d_model}: '
+                'kernel': (f'{prof_name}, M={enc_rows} F={ffn} D={d_model}, hidden split '
+                           f'{ffn_split}: {4 * enc_rows * ffn * d_model / 1e9:.2f} algorithmic '
+                           f'GFLOP per launch (both contractions), x 6 executed as '
+                           f'v_mfma_f32_32x32x16_bf16; peak = dense bf16 peak 2500 / 6'
+                           if 'ffn_x6f' in prof_name else
+                           f'{prof_name}, M={enc_rows} N={ffn} K={d_model}: '
                            f'{2 * enc_rows * ffn * d_model / 1e9:.2f} algorithmic GFLOP per '
                            f'launch, x 6 executed as v_mfma_f32_32x32x16_bf16; peak = dense '
                            f'bf16 peak 2500 / 6' if x6 else
                            f'{prof_name}, M={enc_rows} F={ffn} D={d_model}: '
                            f'{4 * enc_rows * ffn * d_model / 1e9:.2f} GFLOP per launch'
                            if 'fused' in prof_name else
-                           f'{kern} (FFN w_1, M={enc_rows} N={ffn} K={d_model})'),
+                           f'{prof_name} (FFN w_1, M={enc_rows} N={ffn} K={d_model})'),
                 'achieved': round(achieved, 2),
                 'peak': peak,
                 'unit': 'TFLOP/s',
@@ -451,8 +482,9 @@ def main():
         if args.workload == 'config2' and not reduced and os.path.exists(pmc):
             with open(pmc) as f:
                 rec = json.load(f)
-            if (('ffn_fused' in rec.get('kernel', '')) != ('fused' in prof_name) or
-                    ('x6' in rec.get('kernel', '')) != x6):
+            kind = lambda n: ('ffn_x6f' if 'ffn_x6f' in n else 'ffn_fused' if 'ffn_fused' in n
+                              else 'x6' if 'x6' in n else 'gemm')
+            if kind(rec.get('kernel', '')) != kind(prof_name):
                 rec = None     # the committed counters describe another kernel
         else:
             rec = None
@@ -461,17 +493,21 @@ def main():
             line['roofline']['traffic_unit'] = 'bytes/launch (HBM read + write, PMC)'
             line['roofline']['traffic_source'] = ('profiles/pmc_roofline_kernel.json, '
                                                   'visit ' + str(rec.get('visit', 'r01d')))
-            # fused FFN: X in, S hidden-slice partials out, W_1 + W_2 once (they are
-            # re-read by every row tile from L2 / Infinity Cache, not from HBM)
-            if x6:
+            if 'ffn_x6f' in prof_name:
+                # fp32 X in once, W_1 + W_2 planes once (6 B / element; every row tile
+                # re-reads them from L2), the hidden-slice partials out; the hidden tensor
+                # itself never leaves the registers
+                line['roofline']['algorithmic_bytes'] = int(
+                    4 * enc_rows * d_model * (1 + ffn_split) + 6 * 2 * ffn * d_model)
+            elif x6:
                 # A planes in (6 B / element), W planes (L2-resident across row tiles),
                 # hidden-tensor planes out
                 line['roofline']['algorithmic_bytes'] = int(
                     6 * (enc_rows * d_model + ffn * d_model + enc_rows * ffn))
             elif 'ffn_fused' in rec.get('kernel', ''):
-                S_split = 4 if enc_rows <= 128 * 64 else 2
+                # fused v_mfma_f32 FFN: X in, S hidden-slice partials out, W_1 + W_2 once
                 line['roofline']['algorithmic_bytes'] = int(
-                    4 * (enc_rows * d_model * (1 + S_split) + 2 * ffn * d_model))
+                    4 * (enc_rows * d_model * (1 + ffn_split) + 2 * ffn * d_model))
             else:
                 line['roofline']['algorithmic_bytes'] = int(
                     4 * (enc_rows * d_model + ffn * d_model + enc_rows * ffn))
@@ -485,10 +521,23 @@ def main():
                 'note': 'same decode, every GEMM on v_mfma_f32_32x32x2_f32 (gemm_x6 = 0), '
                         'one round of --steps steps',
             }
+        if plain is not None:
+            line['plain_decode'] = {
+                'value': round(total_audio * args.steps / plain, 1),
+                'ms_per_step': round(plain / args.steps * 1e3, 3),
+                'note': 'same batch through back-to-back ASRModel.decode() calls (one decode '
+                        'in flight, as wenet/bin/recognize.py:289 drives the reference), one '
+                        'round of --steps steps; the headline keeps --streams decodes in '
+                        'flight (wenet_amd.pipeline.DecodePipeline)',
+            }
         # what the timed steps produced vs the real reference's answer
         ver = verify.verify_bench_output(args.workload, world, out, method)
         line['verified'] = ver.pop('verified')
         line['verify'] = ver
+        line['verify']['scope'] = ('1-best tokens of every utterance of the LAST timed step '
+                                   'against the real reference\'s (tests/golden/bench_*.npz); '
+                                   'scores, n-best lists and per-frame rules are the -m gpu '
+                                   'tests\' job (tests/test_gpu_bench_parity.py)')
         if reduced and line['verified'] is False:
             # reduced-precision modes are not bit-comparable with the fp32 reference
             line['verify']['note'] = ('reduced-precision run: token identity with the '
@@ -500,7 +549,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(configs, sd, feats, lens, method,
                                                 decode_kw, beam)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -380,8 +380,10 @@ int wn_op_ffn_fused(const float* X_dev, const float* W1_dev, const float* b1_dev
 int wn_op_gemm_x6(const float* A_dev, const float* W_dev, const float* bias_dev,
                   const float* resid_dev, float* C_dev, int32_t M, int32_t N, int32_t K,
                   float alpha, int32_t act, int32_t bm, int32_t reps, void* stream);
-/* wn_op_ffn_fused's contract with both contractions run by the six-product GEMM: the
- * hidden tensor goes from the first GEMM's epilogue to the second as a plane image. */
+/* wn_op_ffn_fused's contract with both contractions as six bf16 plane products: by default
+ * (d_model 256, SiLU / ReLU) ONE launch of csrc/ffn_x6f.hip with the hidden tensor in
+ * registers; wn_tune_set("ffn_x6f", 0) or any other shape: two launches of the six-product
+ * GEMM, the hidden tensor going from the first one's epilogue to the second as a plane image. */
 int wn_op_ffn_x6(const float* X_dev, const float* W1_dev, const float* b1_dev,
                  const float* W2_dev, const float* b2_dev, float* x_inout_dev,
                  const float* ln_w_dev, const float* ln_b_dev, float* y_out_dev, int32_t M,
@@ -403,9 +405,15 @@ int wn_profile_enable(wn_model* m, int32_t on);
 int wn_profile_collect(wn_model* m, int32_t* n_launches, double* total_ms,
                        double* total_flops);
 /* What the bracketed launches were (static string): the FFN w_1 GEMM -- in the fp32 mode the
- * six-product kernel of csrc/gemm_x6.hip -- or the fused feed-forward kernel (w_1 +
- * activation + w_2) when wn_tune_set("gemm_x6", 0) puts the fp32 path on it. */
+ * fused six-product kernel of csrc/ffn_x6f.hip (w_1 + activation + w_2, d_model 256) or the
+ * six-product w_1 GEMM of csrc/gemm_x6.hip -- or the fused v_mfma_f32 feed-forward kernel when
+ * wn_tune_set("gemm_x6", 0) puts the fp32 path on it. */
 const char* wn_profile_kernel_name(const wn_model* m);
+/* Hidden slices S (fused forms: partial sums [S][M][d] reduced by the next kernel) or K slices
+ * of the w_2 GEMM of the feed-forward module this handle ran last -- what bench.py prices the
+ * algorithmic bytes of the roofline kernel with (positionwise_feed_forward.py:50-58 has no such
+ * notion: it is a property of the launch geometry). */
+int32_t wn_profile_ffn_split(const wn_model* m);
 
 /* Test hook: "n_layers" = run only the first n encoder layers (-1: all),
  * "skip_after_norm" = 1 leaves out encoder.after_norm; lets the parity tests

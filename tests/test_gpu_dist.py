@@ -53,6 +53,24 @@ def test_bench_two_ranks_on_one_gpu_equals_the_reference_per_utterance():
     assert d['verify']['identical'] + d['verify']['near_tie'] == 64
 
 
+def test_bench_rccl_process_group_of_one_rank():
+    """The `nccl` (= RCCL) branch of the N > 1 path executed on this 1-GPU box: bench.py with a
+    process group of ONE rank -- backend initialisation on the device, the result all_gather,
+    the max-reduce of the round time and the barriers all run on device tensors through RCCL;
+    the output is the same verified line."""
+    env = dict(os.environ, WN_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0',
+               LOCAL_RANK='0', WORLD_SIZE='1',
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--steps', '2', '--warmup',
+                        '1', '--no-cpu-baseline', '--no-f32-mfma-leg', '--min-seconds', '0.1'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['config']['process_group'] == 'nccl (RCCL)'
+    assert d['verified'] is True and d['verify']['utterances'] == 32
+
+
 def test_recognize_cli_two_ranks_equal_single_process(tmp_path):
     import yaml
     from wenet_amd import synthetic as S

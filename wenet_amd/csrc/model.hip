@@ -321,6 +321,7 @@ struct wn_model {
   unsigned prof_seq = 0;
   double prof_flops = 0.0;
   const char* prof_kernel = "gemm (FFN w_1)";  // what the bracketed launches were
+  int prof_split = 1;        // hidden slices / K slices of the feed-forward module last run
   int prec = PREC_F32;       // GEMM operand precision (wn_model_set_precision)
   // one host thread per handle: the workspace, the descriptor staging and the
   // current batch are per-handle state.  Entry points take this flag and fail
@@ -701,6 +702,7 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
         m->prof_flops += 4.0 * M * (double)F * d;     // both contractions (x 6 MFMA products)
         m->prof_kernel = "ffn_x6f_kernel (FFN w_1 + act + w_2, six bf16 plane products)";
       }
+      m->prof_split = a.S;
       return a.S;
     }
   }
@@ -746,6 +748,7 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
   else g2.A3 = m->x6_h.as<char>();
   if (g_x6_nw4 & 2) g2.nw = 8;                        // A/B: the 8-wave form of the 128-row tile
   if (gemm_x6(g2, s) != 0) return -1;
+  m->prof_split = S;
   return S;
 }
 
@@ -781,6 +784,7 @@ int ffn_fused_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipS
     m->prof_flops += 4.0 * M * (double)w1.out * d;    // both contractions
     m->prof_kernel = "ffn_fused_kernel (FFN w_1 + act + w_2)";
   }
+  m->prof_split = a.S;
   return a.S;
 }
 
@@ -1936,6 +1940,8 @@ int wn_profile_enable(wn_model* m, int32_t on) {
 const char* wn_profile_kernel_name(const wn_model* m) {
   return m ? m->prof_kernel : "";
 }
+
+int32_t wn_profile_ffn_split(const wn_model* m) { return m ? m->prof_split : 0; }
 
 int wn_profile_collect(wn_model* m, int32_t* n_launches, double* total_ms,
                        double* total_flops) {

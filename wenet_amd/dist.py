@@ -50,7 +50,8 @@ def gather_results(local: torch.Tensor, world_size: int
                    ) -> List[Tuple[int, List[int], float]]:
     """One all_gather of the per-rank records -> list of
     (global index, tokens, score) sorted by global index, on every rank."""
-    if world_size > 1:
+    # (a process group of one rank still runs the collective: the world-1 RCCL self-test)
+    if world_size > 1 or (dist.is_available() and dist.is_initialized()):
         out = [torch.empty_like(local) for _ in range(world_size)]
         dist.all_gather(out, local)
         allrec = torch.cat(out, dim=0)
