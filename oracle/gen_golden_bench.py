@@ -13,6 +13,13 @@ what `bench.py --workload configN` decodes on one GPU; weights seed 0):
   bench_config4       WenetSpeech u2++ 512d, decoding_chunk_size 16, B=32 (configs[3])
   bench_config2_w8    the 8 x 32 utterances `bench.py --gpus 8` deals over the
                       ranks (groups 1..7: 1-best / 2-best only, a few KB)
+  bench_config5       Whisper-large-v3 encoder 32L / 20 heads / 1280d, 128 mel bins,
+                      B=16 x 3000 frames (configs[4] at its CONFIGURED shape:
+                      examples/aishell/whisper/conf/finetune_whisper_largev3.yaml:1-17,
+                      84-88; the real TransformerEncoder, encoder.py:122-181,365-437) +
+                      the 307-way CTC head, greedy search.  Extra arrays: layer_sample =
+                      the output of encoder blocks 8, 16, 24, 32 (before after_norm) for
+                      utterances 0 and B-1, every 16th frame (error growth per layer)
 
 Stored per case (no encoder output tensor: ~1-2 MB each):
   ctc_topk_val/idx    top-10 CTC log-probs of every valid frame (packed rows)
@@ -173,6 +180,54 @@ def run_case(workload, outdir, world=1):
     save(os.path.join(outdir, f'bench_{workload}_w{world}.npz'), {}, meta)
 
 
+def run_whisper_case(workload, outdir):
+    """configs[4]: the reference's Whisper-style TransformerEncoder at its configured
+    depth and width on the exact bench batch."""
+    from wenet.models.transformer import search as ref_search
+    from oracle.gen_golden_whisper import build_reference_encoder
+    from wenet_amd import synthetic as S
+    wl = S.BENCH_WORKLOADS[workload]
+    configs = S.make_configs(wl['config'])
+    sd = S.make_state_dict(configs, 0)
+    enc, ctc = build_reference_encoder(configs, sd)
+    feats, lens = S.make_bench_batch(workload, 1)
+    B = feats.size(0)
+    n_blocks = len(enc.encoders)
+    marks = [n_blocks * (i + 1) // 4 - 1 for i in range(4)]     # blocks 8, 16, 24, 32
+    taps = {}
+
+    def hook(i):
+        def f(mod, inp, out):
+            x = out[0] if isinstance(out, tuple) else out
+            taps[i] = torch.cat([x[b, ::16].detach().clone() for b in (0, B - 1)])
+        return f
+    hs = [enc.encoders[i].register_forward_hook(hook(i)) for i in marks]
+    with torch.no_grad():
+        out, mask = enc(feats, lens)
+        enc_lens = mask.squeeze(1).sum(1)
+        logp = ctc.log_softmax(out)
+        greedy = ref_search.ctc_greedy_search(logp, enc_lens)
+    for h in hs:
+        h.remove()
+    el = enc_lens.tolist()
+    topv, topi = logp.topk(TOPK, dim=-1)
+    arrays = dict(
+        enc_lens=enc_lens.numpy().astype(np.int32),
+        row_off=np.concatenate([[0], np.cumsum(el)[:-1]]).astype(np.int32),
+        ctc_topk_val=np.concatenate([topv[b, :el[b]].numpy() for b in range(B)]).astype(np.float32),
+        ctc_topk_idx=np.concatenate([topi[b, :el[b]].numpy() for b in range(B)]).astype(np.int16),
+        enc_sample_utts=np.asarray([0, B - 1], dtype=np.int32),
+        enc_sample=np.concatenate([out[b, :el[b]:4].numpy() for b in (0, B - 1)]).astype(np.float32),
+        layer_marks=np.asarray(marks, dtype=np.int32),
+        layer_sample=np.stack([taps[i].numpy() for i in marks]).astype(np.float32))
+    meta = dict(workload=workload, config=wl['config'], wseed=0, batch=wl['batch'],
+                beam=S.BENCH_BEAM, chunk=-1, left=-1, world=1, lens=lens.tolist(),
+                greedy=[list(map(int, r.tokens)) for r in greedy],
+                layer_sample_note='rows = frames 0, 16, 32, ... of utterance 0 then of '
+                                  'utterance B-1, after encoder blocks layer_marks + 1')
+    save(os.path.join(outdir, f'bench_{workload}.npz'), arrays, meta)
+
+
 def main():
     _ref_harness.install()
     torch.set_num_threads(max(1, os.cpu_count() or 1))
@@ -182,7 +237,10 @@ def main():
     for name in want:
         parts = name.split('_')
         world = int(parts[2][1:]) if len(parts) > 2 else 1
-        run_case(parts[1], outdir, world)
+        if parts[1] == 'config5':
+            run_whisper_case(parts[1], outdir)
+        else:
+            run_case(parts[1], outdir, world)
 
 
 if __name__ == '__main__':

@@ -382,10 +382,13 @@ def resample(waveform: np.ndarray, orig_freq: int, new_freq: int = 16000) -> np.
     defaults (resampling_method 'sinc_interp_hann', lowpass_filter_width 6,
     rolloff 0.99).
 
-    PARITY UNPINNED for this one function: torchaudio is a third-party
-    dependency that is neither vendored in /root/reference nor installed here
-    (requirements.txt: torchaudio>=2.1.2, unpinned), and the reference has no
-    test or golden vector at this call site.  The algorithm is restated from
+    Pinned (round 3) against a SECOND implementation, not against torchaudio itself:
+    torchaudio is a third-party dependency that is neither vendored in /root/reference
+    nor installed here (requirements.txt: torchaudio>=2.1.2, unpinned), and the
+    reference has no test or golden vector at this call site; tests/golden/resample_*.npz
+    (oracle/gen_golden_resample.py) is the sample-by-sample fp64 evaluation of the
+    definition the published kernel implements, sharing no table or padding arithmetic
+    with this function (agreement: 3e-8 .. 8e-8).  The algorithm is restated from
     torchaudio 2.1's published `_get_sinc_resample_kernel` /
     `_apply_sinc_resample_kernel`: reduce the rates by their gcd; per output
     phase i in [0, new) a windowed-sinc filter of 2*width + orig taps,

@@ -174,3 +174,21 @@ def test_resample_vs_oracle(orig, new, n):
     assert np.abs(got - want).max() < 2e-5, np.abs(got - want).max()
     L = model._L
     assert L.wn_resample_length(n, orig, new) == want.shape[0]
+
+
+@pytest.mark.parametrize('orig,new', [(44100, 16000), (48000, 16000), (8000, 16000),
+                                      (22050, 16000), (16000, 8000), (11025, 16000),
+                                      (32000, 16000)])
+def test_resample_vs_the_independent_fp64_definition(orig, new):
+    """wn_resample against tests/golden/resample_*.npz: the sample-by-sample fp64 evaluation of
+    the published torchaudio resampling definition (oracle/gen_golden_resample.py) -- a second
+    implementation that shares no code or intermediate table with the oracle's polyphase
+    restatement.  Bound: fp32 taps and fp32 accumulation of ~30 terms of magnitude <= 0.3."""
+    import os
+    from gpu_util import cached_model
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', f'resample_{orig}_{new}.npz'))
+    _, _, model = cached_model('tiny_sym', 0)
+    got = model.resample(z['x'], orig, new)
+    assert got.shape == z['y'].shape
+    err = np.abs(got.astype(np.float64) - z['y']).max()
+    assert err < 5e-6, err

@@ -516,6 +516,24 @@ def test_resample_properties():
     assert np.abs(lhs - rhs).max() < 1e-4
 
 
+@pytest.mark.parametrize('orig,new', [(44100, 16000), (48000, 16000), (8000, 16000),
+                                      (22050, 16000), (16000, 8000), (11025, 16000),
+                                      (32000, 16000)])
+def test_resample_vs_the_independent_fp64_definition(orig, new):
+    """The pin of O.resample while torchaudio is unavailable: tests/golden/resample_*.npz is
+    the sample-by-sample fp64 evaluation of the definition the published torchaudio kernel
+    implements (oracle/gen_golden_resample.py: no polyphase table, no padding arithmetic, no
+    fp32) -- a second implementation written from the same published source, so a slip in
+    either one (gcd reduction, the (width, width + orig) padding, window clamp, scale, the
+    ceil output length) shows up as a difference.  They agree to fp32 rounding (< 1e-6 on
+    signals of peak 0.3; measured 3e-8 .. 8e-8)."""
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', f'resample_{orig}_{new}.npz'))
+    assert int(z['orig']) == orig and int(z['new']) == new
+    y = O.resample(z['x'], orig, new)
+    assert y.shape == z['y'].shape
+    assert np.abs(y.astype(np.float64) - z['y']).max() < 1e-6
+
+
 @needs_reference
 @pytest.mark.parametrize('config,rw', [('tiny_causal', 0.0), ('tiny_causal', 0.4),
                                        ('tiny_sym', 0.0)])

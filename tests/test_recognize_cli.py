@@ -199,9 +199,13 @@ def test_override_config_and_feature_checks():
         configs = wcfg
         compute_fbank = staticmethod(lambda waves: ('fbank', waves))
         compute_log_mel_spectrogram = staticmethod(lambda waves, **kw: ('log_mel', kw))
-    assert R.feature_function(M, wcfg)(['w']) == (
+    fn, frames_of = R.feature_function(M, wcfg)
+    assert frames_of is None and fn(['w']) == (
         'log_mel', dict(num_mel_bins=128, padding=0, pad_or_trim=False, max_duration=30))
-    assert R.feature_function(M, cfg)(['w']) == ('fbank', ['w'])
+    fn, frames_of = R.feature_function(M, cfg)
+    assert fn(['w']) == ('fbank', ['w'])
+    # kaldi fbank, snip_edges: 25 ms window / 10 ms shift at 16 kHz
+    assert [frames_of(n) for n in (0, 399, 400, 559, 560, 160000)] == [0, 0, 1, 1, 2, 998]
     wcfg['dataset_conf']['log_mel_spectrogram_conf']['num_mel_bins'] = 80
     with pytest.raises(NotImplementedError):
         R.check_feature_conf(wcfg)

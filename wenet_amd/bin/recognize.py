@@ -69,6 +69,12 @@ def get_args(argv=None):
     p.add_argument('--context_graph_score', type=float, default=0.0)
     p.add_argument('--streams', type=int, default=2,
                    help='decode() calls in flight on the GPU')
+    p.add_argument('--report_rtf', default='',
+                   help='write a JSON report of the run to this file: audio seconds decoded, '
+                   'wall time of wav -> text, audio-seconds / second, and where the main '
+                   'thread waited (wav readers, resample, features, submit, results) -- the '
+                   "throughput counterpart of the reference's RTF print "
+                   '(runtime/core/bin/decoder_main.cc:52,64-70)')
     # Options of the reference's command line (recognize.py:86-190) that only its
     # transducer / HLG / LoRA modes read.  They are accepted so that existing decode
     # scripts run unchanged; the four modes on this path never look at them, exactly
@@ -238,8 +244,10 @@ def feature_function(model, configs: dict):
         kw = dict(num_mel_bins=lc.get('num_mel_bins', 80), padding=lc.get('padding', 0),
                   pad_or_trim=lc.get('pad_or_trim', False),
                   max_duration=lc.get('max_duration', 30))
-        return lambda waves: model.compute_log_mel_spectrogram(waves, **kw)
-    return model.compute_fbank
+        return lambda waves: model.compute_log_mel_spectrogram(waves, **kw), None
+    # Kaldi fbank, snip_edges: frames of a waveform are known from its length, so a batch can
+    # be put into `padding`'s order BEFORE the features are computed (no device-side reorder)
+    return model.compute_fbank, lambda n: 0 if n < 400 else 1 + (n - 400) // 160
 
 
 def format_line(key: str, text: str) -> str:
@@ -302,13 +310,18 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
               blank_id=blank_id, blank_penalty=args.blank_penalty,
               length_penalty=args.length_penalty)
     max_fmt = max(len(m) for m in args.modes)
-    compute_features = feature_function(model, model.configs)
+    compute_features, frames_of = feature_function(model, model.configs)
     depth = max(2, 2 * args.streams)  # batches of wav data read ahead
     readers = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, args.num_workers))
 
     def load(bi):
         return [readers.submit(read16k, wav) for _, wav in batches[bi]]
 
+    import time
+    clock = time.perf_counter
+    stat = dict(wav_wait=0.0, resample=0.0, features=0.0, pad_sort=0.0, submit=0.0,
+                result_wait=0.0, detokenize=0.0, audio_s=0.0, utts=0, batches=0)
+    t_begin = clock()
     pending_wavs = {}
     order = list(my_batches)
     for bi in order[:depth]:
@@ -318,30 +331,58 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
     def drain(n_keep):
         while len(inflight) > n_keep:
             bi, keys, fut = inflight.pop(0)
+            t0 = clock()
             results = fut.result()
+            stat['result_wait'] += clock() - t0
+            t0 = clock()
             for i, key in enumerate(keys):
                 for mode in args.modes:
                     text = tokenizer.detokenize(results[mode][i].tokens)[0]
                     line = format_line(key, text)
                     logging.info('%s %s', mode.ljust(max_fmt), line)
                     emit(bi, mode, line)
+            stat['detokenize'] += clock() - t0
 
     with DecodePipeline(model, n_streams=args.streams) as pipe:
         for pos, bi in enumerate(order):
-            waves = [w if sr == 16000 else model.resample(w, sr, 16000)
-                     for w, sr in (f.result() for f in pending_wavs.pop(bi))]
+            t0 = clock()
+            raw = [f.result() for f in pending_wavs.pop(bi)]
+            t1 = clock()
+            stat['wav_wait'] += t1 - t0
+            stat['audio_s'] += sum(len(w) / float(sr) for w, sr in raw)
+            stat['utts'] += len(raw)
+            stat['batches'] += 1
+            waves = [w if sr == 16000 else model.resample(w, sr, 16000) for w, sr in raw]
+            t2 = clock()
+            stat['resample'] += t2 - t1
             if pos + depth < len(order):
                 nxt = order[pos + depth]
                 pending_wavs[nxt] = load(nxt)
-            feats, n_frames = compute_features(waves)
-            perm = padding_order(n_frames.tolist())
-            idx = torch.as_tensor(perm, dtype=torch.long)
-            feats = feats.index_select(0, idx.to(feats.device))
-            lens = n_frames.index_select(0, idx)
-            tmax = int(lens.max()) if len(perm) else 0
-            feats = feats[:, :tmax].contiguous()
+            if frames_of is not None:
+                # longest first (processor.padding) on the host, then ONE feature launch
+                # straight into the padded batch tensor
+                perm = padding_order([frames_of(len(w)) for w in waves])
+                waves = [waves[i] for i in perm]
+                t3 = clock()
+                stat['pad_sort'] += t3 - t2
+                feats, lens = compute_features(waves)
+                t4 = clock()
+                stat['features'] += t4 - t3
+            else:
+                feats, n_frames = compute_features(waves)
+                t3 = clock()
+                stat['features'] += t3 - t2
+                perm = padding_order(n_frames.tolist())
+                idx = torch.as_tensor(perm, dtype=torch.long)
+                feats = feats.index_select(0, idx.to(feats.device))
+                lens = n_frames.index_select(0, idx)
+                tmax = int(lens.max()) if len(perm) else 0
+                feats = feats[:, :tmax].contiguous()
+                t4 = clock()
+                stat['pad_sort'] += t4 - t3
             keys = [batches[bi][i][0] for i in perm]
             inflight.append((bi, keys, pipe.submit(args.modes, feats, lens, **kw)))
+            stat['submit'] += clock() - t4
             drain(args.streams)
             if pos == 2:
                 # the process is up: stop the cyclic collector from re-walking the model's
@@ -349,6 +390,8 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
                 freeze_host_heap()
         drain(0)
     readers.shutdown(wait=True)
+    stat['wall_s'] = clock() - t_begin
+    return stat
 
 
 def main(argv=None):
@@ -408,9 +451,28 @@ def main(argv=None):
     def emit(bi, mode, line):
         files[mode].write(f'{bi}\t{line}\n')
 
-    recognize(model, tokenizer, batches, mine, args, blank_id, context_graph, emit)
+    stat = recognize(model, tokenizer, batches, mine, args, blank_id, context_graph, emit)
     for f in files.values():
         f.close()
+    if args.report_rtf:
+        rep = dict(rank=rank, world=world, modes=list(args.modes), batch_size=args.batch_size,
+                   num_workers=args.num_workers, streams=args.streams,
+                   data_type=args.data_type, dtype=args.dtype,
+                   audio_seconds=round(stat['audio_s'], 2), utterances=stat['utts'],
+                   batches=stat['batches'], wall_seconds=round(stat['wall_s'], 4),
+                   audio_seconds_per_second=round(stat['audio_s'] / max(stat['wall_s'], 1e-9), 1),
+                   main_thread_seconds={k: round(stat[k], 4) for k in
+                                        ('wav_wait', 'resample', 'features', 'pad_sort', 'submit',
+                                         'result_wait', 'detokenize')},
+                   note='wall = first wav read submitted .. last result line written (model '
+                        'load excluded); main_thread_seconds = where the feeding thread spent '
+                        'that time: wav_wait = blocked on the reader threads, features = '
+                        'H2D copy + fbank launch (returns device tensors), result_wait = '
+                        'blocked on the oldest decode in flight')
+        path = args.report_rtf if world == 1 else f'{args.report_rtf}.rank{rank}'
+        with open(path, 'w') as f:
+            json.dump(rep, f, indent=1)
+        logging.info('wav -> text: %.1f audio-s / s (%s)', rep['audio_seconds_per_second'], path)
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -765,6 +765,35 @@ class ASRModel:
         return self.decode(*args, **kwargs)
 
     # ---- features + single-file CLI path -----------------------------------
+    def _stage_pcm(self, waveforms, total: int) -> torch.Tensor:
+        """Concatenated waveforms -> device through a ring of PINNED host buffers and an
+        asynchronous copy on the current stream (a pageable `tensor.to(device)` stages through
+        the driver's own bounce buffer and blocks the feeding thread for the whole transfer:
+        20 MB per 32 x 10 s batch)."""
+        ring = getattr(self, '_pcm_ring', None)
+        if ring is None:
+            ring = self._pcm_ring = dict(slot=0, bufs=[None] * 4, events=[None] * 4)
+        i = ring['slot']
+        ring['slot'] = (i + 1) % len(ring['bufs'])
+        buf = ring['bufs'][i]
+        if buf is None or buf.numel() < total:
+            buf = ring['bufs'][i] = torch.empty(max(total, 1) * 5 // 4 + 1024,
+                                                 dtype=torch.float32).pin_memory()
+        elif ring['events'][i] is not None:
+            ring['events'][i].synchronize()       # the copy that last used this buffer is done
+        view = buf.numpy()
+        pos = 0
+        for w in waveforms:
+            n = len(w)
+            view[pos:pos + n] = w
+            pos += n
+        with torch.cuda.device(self.device):
+            pcm = buf[:total].to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        ring['events'][i] = ev
+        return pcm
+
     def compute_fbank(self, waveforms: List[np.ndarray]
                       ) -> Tuple[torch.Tensor, torch.Tensor]:
         """processor.compute_fbank + padding for a list of float waveforms in
@@ -773,9 +802,7 @@ class ASRModel:
         offs = np.zeros((B + 1, ), dtype=np.int64)
         for i, w in enumerate(waveforms):
             offs[i + 1] = offs[i] + len(w)
-        pcm = torch.from_numpy(
-            np.concatenate([np.asarray(w, np.float32) for w in waveforms])
-        ).to(self.device)
+        pcm = self._stage_pcm(waveforms, int(offs[B]))
         nfr = [0 if len(w) < 400 else 1 + (len(w) - 400) // 160
                for w in waveforms]
         tmax = max(max(nfr), 1)
