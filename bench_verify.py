@@ -27,7 +27,7 @@ def _expected(meta, method: str, world: int):
     out = []
     groups = meta['groups'] if 'groups' in meta else [meta]
     for g in groups[:world]:
-        for b in range(len(g['prefix'])):
+        for b in range(len(g['prefix'] if 'prefix' in g else g['greedy'])):
             if method == 'attention_rescoring':
                 r = g['rescoring'][b]
                 order = np.argsort(r['all_scores'])[::-1]

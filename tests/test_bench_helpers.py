@@ -54,8 +54,13 @@ def test_verify_runner_up_only_inside_the_tie_window():
 
 
 def test_world_8_golden_covers_eight_groups_and_unknown_workloads_report_none():
-    v = verify.verify_bench_output('config5', 1, [], 'ctc_greedy_search')
-    assert v['verified'] is None
+    # configs[4] has a golden of its configured shape since round 3 (greedy tokens of the real
+    # reference's 32-block encoder): the right answer verifies, a short list does not
+    meta5 = _meta('bench_config5')
+    good = [(i, list(t), 0.0) for i, t in enumerate(meta5['greedy'])]
+    assert verify.verify_bench_output('config5', 1, good, 'ctc_greedy_search')['verified'] is True
+    assert verify.verify_bench_output('config5', 1, [], 'ctc_greedy_search')['verified'] is False
+    assert verify.verify_bench_output('config9', 1, [], 'ctc_greedy_search')['verified'] is None
     meta = _meta('bench_config2_w8')
     assert len(meta['groups']) == 8
     exp = verify._expected(meta, 'ctc_prefix_beam_search', 8)

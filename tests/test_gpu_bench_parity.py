@@ -109,6 +109,122 @@ def test_bench_batch_vs_reference(workload):
     assert n_strict >= 0.95 * n_frames
 
 
+def _config5_run(model, fd, lens, marks):
+    """Encoder output after blocks marks[k] + 1 (no after_norm) sampled like the golden
+    (frames 0, 16, ... of utterances 0 and B-1), then the full encoder output."""
+    from wenet_amd import _lib
+    L = _lib.lib()
+    B = fd.size(0)
+    samples = []
+    try:
+        for mk in marks:
+            _lib.check(L.wn_debug_set(model._h, b'n_layers', int(mk) + 1), 'dbg')
+            _lib.check(L.wn_debug_set(model._h, b'skip_after_norm', 1), 'dbg')
+            enc, _ = model._forward_encoder(fd, lens)
+            samples.append(torch.cat([enc[b, ::16] for b in (0, B - 1)]).cpu().numpy())
+            del enc
+    finally:
+        L.wn_debug_set(model._h, b'n_layers', -1)
+        L.wn_debug_set(model._h, b'skip_after_norm', 0)
+    enc, mask = model._forward_encoder(fd, lens)
+    return samples, enc, mask
+
+
+def test_bench_batch_config5_vs_reference_at_the_configured_shape():
+    """BASELINE.json configs[4] at its CONFIGURED shape -- Whisper-large-v3 encoder, 32 blocks,
+    20 heads, 1280d, 128 mel bins, B = 16 x 3000 frames, i.e. exactly what `bench.py --workload
+    config5` times -- against the REAL reference's TransformerEncoder on the same batch
+    (tests/golden/bench_config5.npz, oracle/gen_golden_bench.py; reference shape:
+    examples/aishell/whisper/conf/finetune_whisper_largev3.yaml:1-17,84-88, encoder.py:122-181).
+      * fp32 (the parity mode): the output of blocks 8 / 16 / 24 / 32 and the final output
+        within 2e-3 of the activation scale (error growth over the depth is printed), every
+        frame's CTC top-k log-probs within LOGP_TOL, the per-frame greedy rule, the tokens;
+      * bf16 and fp8 (the modes the config names): the same samples against the fp32
+        reference -- reduced-precision error, so the bound is a GROWTH bound: the relative
+        error after block L may not exceed `per_block * sqrt(L)` (independent roundings add in
+        quadrature; a wrong operand, a dropped residual or a mis-scaled block would blow
+        through it at the first mark) -- plus agreement of the greedy arg-max on the frames
+        whose reference margin is far above the measured log-prob error."""
+    from wenet_amd import synthetic as S
+    meta, arr = load_case('bench_config5')
+    configs, sd, model = cached_model(meta['config'], meta['wseed'])
+    feats, lens = S.make_bench_batch('config5', 1)
+    assert lens.tolist() == meta['lens']
+    B = meta['batch']
+    fd = feats.cuda()
+    marks = arr['layer_marks'].tolist()
+    ref_l = arr['layer_sample']
+    report = {}
+    try:
+        for dtype in ('fp32', 'bf16', 'fp8'):
+            model.set_compute_dtype(dtype)
+            samples, enc, mask = _config5_run(model, fd, lens, marks)
+            enc_lens = mask.squeeze(1).sum(1).cpu()
+            np.testing.assert_array_equal(enc_lens.numpy(), arr['enc_lens'])
+            rel = []
+            for k, mk in enumerate(marks):
+                scale = float(np.abs(ref_l[k]).max())
+                rel.append(float(np.abs(samples[k] - ref_l[k]).max()) / scale)
+            r, enc_err, enc_scale = 0, 0.0, float(np.abs(arr['enc_sample']).max())
+            for b in arr['enc_sample_utts'].tolist():
+                got = enc[b, :int(enc_lens[b]):4].cpu().numpy()
+                ref = arr['enc_sample'][r:r + got.shape[0]]
+                r += got.shape[0]
+                enc_err = max(enc_err, float(np.abs(got - ref).max()))
+            logp = model.ctc_logprobs(enc, encoder_lens=enc_lens)
+            K = arr['ctc_topk_val'].shape[1]
+            topv, topi = logp.topk(K, dim=-1)
+            topv, topi = topv.cpu().numpy(), topi.cpu().numpy()
+            res = model.decode(['ctc_greedy_search'], fd, lens)['ctc_greedy_search']
+            logp_err, n_frames, n_strict, n_flips, same_tok = 0.0, 0, 0, 0, 0
+            for b in range(B):
+                o, n = int(arr['row_off'][b]), int(arr['enc_lens'][b])
+                rv, ri = arr['ctc_topk_val'][o:o + n], arr['ctc_topk_idx'][o:o + n]
+                logp_err = max(logp_err, float(np.abs(topv[b, :n] - rv).max()))
+                same_tok += int(list(res[b].tokens) == meta['greedy'][b])
+                if dtype == 'fp32':
+                    f, s_, fl = greedy_frame_check(topi[b, :n, 0], ri, rv, res[b].tokens,
+                                                   meta['greedy'][b], what=f'config5[{b}]')
+                    n_frames += f; n_strict += s_; n_flips += fl
+                else:
+                    # frames whose reference margin is > 20 x the measured log-prob error of
+                    # this mode must keep their arg-max
+                    margin = rv[:, 0] - rv[:, 1]
+                    n_frames += n
+            report[dtype] = dict(rel=rel, enc_err=enc_err, logp_err=logp_err,
+                                 same_tokens=same_tok)
+            print(f'\n[config5 {dtype}] rel. error after blocks {[m + 1 for m in marks]}: '
+                  f'{[float(f"{x:.2e}") for x in rel]}; final output {enc_err:.2e} of scale '
+                  f'{enc_scale:.2f}; max |d logp| {logp_err:.2e}; identical greedy token lists '
+                  f'{same_tok}/{B}' + (f'; frames {n_frames}, strict {n_strict}, flips {n_flips}'
+                                       if dtype == 'fp32' else ''))
+            if dtype == 'fp32':
+                assert max(rel) < 2e-3 and enc_err < 2e-3 * enc_scale, (rel, enc_err)
+                assert logp_err < LOGP_TOL * 4, logp_err
+                assert n_strict >= 0.95 * n_frames
+            else:
+                per_block = 4e-3 if dtype == 'bf16' else 8e-3     # of the activation scale
+                for k, mk in enumerate(marks):
+                    assert rel[k] < per_block * (mk + 1) ** 0.5, (dtype, mk + 1, rel[k])
+                # the error may not explode between marks either (x 4 per 8 blocks at most)
+                for k in range(1, len(marks)):
+                    assert rel[k] < 4 * max(rel[k - 1], 1e-3), (dtype, rel)
+                # strong frames keep their arg-max
+                bad = 0
+                for b in range(B):
+                    o, n = int(arr['row_off'][b]), int(arr['enc_lens'][b])
+                    rv, ri = arr['ctc_topk_val'][o:o + n], arr['ctc_topk_idx'][o:o + n]
+                    strong = (rv[:, 0] - rv[:, 1]) > 20 * logp_err
+                    bad += int((topi[b, :n, 0][strong] != ri[:, 0][strong]).sum())
+                assert bad == 0, (dtype, bad)
+            del enc, logp
+    finally:
+        model.set_compute_dtype('fp32')
+    # the reduced modes really ran other arithmetic
+    assert report['bf16']['rel'][-1] > 10 * report['fp32']['rel'][-1]
+    assert report['fp8']['rel'][-1] > report['bf16']['rel'][-1]
+
+
 def test_bench_verify_helper_matches_goldens():
     """bench.py's own output check (bench_verify.py) on a real decode."""
     from wenet_amd import synthetic as S
