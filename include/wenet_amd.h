@@ -308,7 +308,9 @@ int wn_decoder_forward(wn_model* m, int32_t utt, int32_t which, int32_t n_seq,
  * N x N -> N re-ranking, the end flags and the final length-penalised arg-max all run on
  * the device; scores are fp32 like the reference's.  maxlen = the reference's
  * encoder_out.size(1).  tokens_host is (B, maxlen) int32 (the winner without <sos> /
- * <eos>), lens_host (B,).  beam <= 16. */
+ * <eos>), lens_host (B,).  beam <= 64.  The cache holds the steps actually run (it starts
+ * at 32 steps and doubles), and the "all hypotheses ended" counter is read back every 4th
+ * step: steps past the end only append <eos> to finished hypotheses, which the result strips. */
 int wn_attention_beam_search(wn_model* m, int32_t beam, int32_t maxlen, float length_penalty,
                              int32_t* tokens_host, int32_t* lens_host, void* stream);
 

@@ -170,3 +170,47 @@ def test_fp8_whisper_encoder_vs_oracle_rounding_mode(B, frames):
           f'fp8 vs bf16 mode: {(enc8 - enc16).abs().max().item():.3e}')
     assert worst < 3e-2 * scale
     assert (enc8 - enc16).abs().max().item() > 1e-4 * scale
+
+
+@pytest.mark.parametrize('config,B,frames', [('aishell_u2pp', 4, (500, 700))])
+def test_fp8_conformer_encoder_every_ffn_takes_the_mx_path(config, B, frames):
+    """WN_PREC_FP8 on a CONFORMER: both feed-forward modules of every layer (macaron and
+    final) run their two GEMMs on MXFP8 operands -- in the bf16 / fp32 modes the macaron
+    module of layers 1.. gets LN(x) from the previous layer's fused tail, in the fp8 mode every
+    module normalises for itself (layernorm_mx) so that none silently stays on bf16.  Against
+    the oracle under bf16_operands(fp8_ffn=True), which rounds EVERY encoder w_1 / w_2 operand
+    pair to MXFP8; same tolerance as the Whisper-width test; and the fp8 output differs from the
+    bf16 mode's by more than one module's worth of e4m3 noise."""
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=77)
+    from wenet_amd import _lib
+    L = _lib.lib()
+    try:
+        _lib.check(L.wn_tune_set(b'fp8_min_tiles', 0), 'tune')   # small test batch
+        model.set_compute_dtype('fp8')
+        enc8, mask = model._forward_encoder(feats.cuda(), lens)
+        enc8 = enc8.cpu()
+        model.set_compute_dtype('bf16')
+        enc16, _ = model._forward_encoder(feats.cuda(), lens)
+        enc16 = enc16.cpu()
+    finally:
+        model.set_compute_dtype('fp32')
+        L.wn_tune_set(b'fp8_min_tiles', 192)
+    with torch.no_grad(), O.bf16_operands(sd, fp8_ffn=True):
+        ref8, rmask = O.encoder_forward(configs, sd, feats, lens)
+    with torch.no_grad(), O.bf16_operands(sd):
+        ref16, _ = O.encoder_forward(configs, sd, feats, lens)
+    n = rmask.squeeze(1).sum(1)
+    scale = ref8.abs().max().item()
+    e8 = max((enc8[b, :n[b]] - ref8[b, :n[b]]).abs().max().item() for b in range(B))
+    e16 = max((enc16[b, :n[b]] - ref16[b, :n[b]]).abs().max().item() for b in range(B))
+    d_ref = max((ref8[b, :n[b]] - ref16[b, :n[b]]).abs().max().item() for b in range(B))
+    d_gpu = max((enc8[b, :n[b]] - enc16[b, :n[b]]).abs().max().item() for b in range(B))
+    print(f'\n[{config}] fp8 vs oracle(fp8_ffn) {e8:.3e}, bf16 vs oracle(bf16) {e16:.3e} of scale '
+          f'{scale:.3f}; fp8 - bf16: oracle {d_ref:.3e}, GPU {d_gpu:.3e}')
+    assert e8 < 3e-2 * scale and e16 < 2e-2 * scale
+    # all 24 modules quantised: the GPU's fp8 - bf16 distance is of the oracle's size (a path
+    # that quantised only some modules would sit well below it)
+    assert d_gpu > 0.5 * d_ref

@@ -460,6 +460,38 @@ def test_attention_mode_vs_reference(name):
     assert [list(r.tokens) for r in allm['attention']] == meta['tokens']
 
 
+@pytest.mark.parametrize('beam,frames', [(20, (60, 120)), (33, (40, 90)), (3, (200, 260))])
+def test_attention_mode_wide_beams_and_long_outputs_vs_oracle(beam, frames):
+    """`--modes attention --beam_size 20` and beyond (the N x N re-ranking strided over the
+    block: beams up to 64), and outputs longer than the 32 steps the self-attention cache
+    starts with (T' ~ 50-65 steps with a random-init decoder that rarely emits <eos>: the cache
+    doubles once or twice) -- token lists identical to the oracle's attention_beam_search
+    (search.py:252-371 restated) on the GPU's own encoder output."""
+    from gpu_util import make_model
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('tiny_causal', 0)
+    if beam == 3:
+        # a decoder that (almost) never ends a hypothesis: <eos> pushed far down in every
+        # output layer, so the search runs all T' steps
+        sd = dict(sd)
+        for k in list(sd):
+            if k.endswith('output_layer.bias'):
+                b = sd[k].clone()
+                b[model.eos] = -60.0
+                sd[k] = b
+        model = make_model(configs, sd)
+    feats, lens = S.make_features(3, frames, seed=900 + beam)
+    got = model.decode(['attention'], feats.cuda(), lens, beam_size=beam,
+                       length_penalty=0.3)['attention']
+    enc, mask = model._forward_encoder(feats.cuda(), lens)
+    with torch.no_grad():
+        ref = O.attention_beam_search(configs, sd, enc.cpu(), mask.cpu(), beam, 0.3,
+                                      sos=model.sos, eos=model.eos)
+    assert [list(r.tokens) for r in got] == [list(r.tokens) for r in ref]
+    assert max(len(r.tokens) for r in got) > (32 if beam == 3 else 0)
+
+
 @pytest.mark.parametrize('n_mels', [80, 128])
 def test_log_mel_vs_oracle(n_mels):
     """wn_log_mel (Whisper frontend, processor.py:320-369) against the oracle

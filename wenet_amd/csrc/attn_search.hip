@@ -18,6 +18,8 @@
 //    path rows and end flags;
 //  * beam_finish_kernel: length penalty, arg-max, the winner without <sos> / <eos>.
 // All scores are fp32 like the reference's score tensors.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace wn {
@@ -76,9 +78,11 @@ __global__ void cache_store_kernel(const float* __restrict__ qkv, int d, int n,
   for (int i = threadIdx.x; i < 2 * d / 4; i += blockDim.x) o[i] = s[i];
 }
 
-// One block per utterance, N*N threads (N <= 16).  `step` = length of the parents'
-// token rows (the new token lands at index `step`).
-__global__ void beam_update_kernel(int N, int step, int max_len, int eos,
+// One block per utterance, the N*N candidates strided over its threads (N <= 64).  `step` =
+// length of the parents' token rows (the new token lands at index `step`).  A token index
+// outside [0, V) -- the top-k of a row of NaN / -inf logits has no valid entry -- ends the
+// hypothesis (eos) instead of indexing the embedding table with it.
+__global__ void beam_update_kernel(int N, int step, int max_len, int eos, int V,
                                    const float* __restrict__ topv, const int* __restrict__ topi,
                                    const float* __restrict__ score_in, const int* __restrict__ end_in,
                                    const int* __restrict__ tok_in, const int* __restrict__ path_in,
@@ -87,19 +91,19 @@ __global__ void beam_update_kernel(int N, int step, int max_len, int eos,
                                    int* __restrict__ last_tok, int* __restrict__ n_running_done) {
   extern __shared__ float cand[];          // [N*N] values, then N ints (winner flat index)
   int* win = reinterpret_cast<int*>(cand + N * N);
-  const int b = blockIdx.x, t = threadIdx.x;
+  const int b = blockIdx.x;
   const int nn = N * N;
-  float v = -INFINITY;
-  if (t < nn) {
+  for (int t = threadIdx.x; t < nn; t += blockDim.x) {
     const int n = t / N, k = t % N;
     const int hyp = b * N + n;
     float lp = topv[(int64_t)hyp * N + k];
     if (end_in[hyp]) lp = k == 0 ? 0.f : -INFINITY;     // mask_finished_scores
-    v = score_in[hyp] + lp;
-    cand[t] = v;
+    cand[t] = score_in[hyp] + lp;
   }
   __syncthreads();
-  if (t < nn) {
+  // rank by (value descending, flat index ascending): what scores.view(B, N*N).topk(N) returns
+  for (int t = threadIdx.x; t < nn; t += blockDim.x) {
+    const float v = cand[t];
     int rank = 0;
     for (int u = 0; u < nn; ++u) {
       const float o = cand[u];
@@ -109,11 +113,12 @@ __global__ void beam_update_kernel(int N, int step, int max_len, int eos,
   }
   __syncthreads();
   // child c of this utterance <- candidate win[c]
-  for (int c = t; c < N; c += blockDim.x) {
+  for (int c = threadIdx.x; c < N; c += blockDim.x) {
     const int f = win[c];
     const int n = f / N, k = f % N;
     const int parent = b * N + n, child = b * N + c;
-    const int tok = end_in[parent] ? eos : topi[(int64_t)parent * N + k];  // mask_finished_preds
+    int tok = end_in[parent] ? eos : topi[(int64_t)parent * N + k];  // mask_finished_preds
+    if ((unsigned)tok >= (unsigned)V) tok = eos;
     score_out[child] = cand[f];
     for (int j = 0; j < step; ++j) {
       tok_out[(int64_t)child * max_len + j] = tok_in[(int64_t)parent * max_len + j];
@@ -201,15 +206,15 @@ int attn_beam_init(int BN, int N, int max_len, int sos, float* score, int* end, 
   return 0;
 }
 
-int attn_beam_update(int B, int N, int step, int max_len, int eos, const float* topv,
+int attn_beam_update(int B, int N, int step, int max_len, int eos, int V, const float* topv,
                      const int* topi, const float* score_in, const int* end_in,
                      const int* tok_in, const int* path_in, float* score_out, int* end_out,
                      int* tok_out, int* path_out, int* last_tok, int* n_done, hipStream_t s) {
-  WN_CHECK(N >= 1 && N <= 16, "attention beam search: beam_size must be in [1, 16]");
-  const int thr = (N * N + 63) / 64 * 64;
+  WN_CHECK(N >= 1 && N <= 64, "attention beam search: beam_size must be in [1, 64]");
+  const int thr = std::min(1024, (N * N + 63) / 64 * 64);
   hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(thr), (N * N + N) * sizeof(float), s, N,
-                     step, max_len, eos, topv, topi, score_in, end_in, tok_in, path_in, score_out,
-                     end_out, tok_out, path_out, last_tok, n_done);
+                     step, max_len, eos, V, topv, topi, score_in, end_in, tok_in, path_in,
+                     score_out, end_out, tok_out, path_out, last_tok, n_done);
   WN_HIP(hipGetLastError());
   return 0;
 }

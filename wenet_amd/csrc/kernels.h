@@ -303,7 +303,7 @@ int attn_self_step(const float* qkv, int d, int heads, int n, float* cache, int 
                    const int* path, int max_len, float* out, hipStream_t s);
 int attn_beam_init(int BN, int N, int max_len, int sos, float* score, int* end, int* tok,
                    int* path, int* last_tok, hipStream_t s);
-int attn_beam_update(int B, int N, int step, int max_len, int eos, const float* topv,
+int attn_beam_update(int B, int N, int step, int max_len, int eos, int V, const float* topv,
                      const int* topi, const float* score_in, const int* end_in,
                      const int* tok_in, const int* path_in, float* score_out, int* end_out,
                      int* tok_out, int* path_out, int* last_tok, int* n_done, hipStream_t s);

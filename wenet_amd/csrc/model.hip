@@ -416,6 +416,9 @@ int upload_desc(wn_model* m, DevBuf& buf, const std::vector<int>& v,
 
 // a_bf16 / c_bf16: A / C are bf16 matrices in the same buffers (lda / ldc stay the
 // element counts) -- only under bf16_store_active().
+// linear(): GEMMs from this many 0.1 GFLOP on go to the six-product kernel through a split pass
+int g_x6_linear_min = 60;   // wn_tune_set("x6_linear_min")
+
 int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M,
            hipStream_t s, int act = ACT_NONE, const float* resid = nullptr,
            int ldr = 0, float alpha = 1.0f, bool glu = false, bool a_bf16 = false,
@@ -426,7 +429,7 @@ int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M,
   if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_linear != 0 && t_x6 && t_x6_a && !glu &&
       !a_bf16 && !c_bf16 && l.in % 16 == 0 && l.out % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 &&
       (resid == nullptr || ldr % 4 == 0) && M >= 512 &&
-      2.0 * M * (double)l.out * l.in >= 6e9) {
+      2.0 * M * (double)l.out * l.in >= 1e8 * g_x6_linear_min) {
     auto it = t_x6->find(l.w);
     if (it != t_x6->end()) {
       WN_TRY(t_x6_a->ensure(x6_bytes(M, l.in)));
@@ -494,8 +497,12 @@ int ffn_module(wn_model* m, const Norm& nrm, const Linear& w1, const Linear& w2,
   if (t_mx && h16 && !ln_done) {
     auto i1 = t_mx->find(w1.w), i2 = t_mx->find(w2.w);
     const int64_t t256 = (int64_t)cdiv(M, 256) * cdiv(std::min(w1.out, w2.out), 256);
+    GemmArgs p1, p2;      // the two launches as gemm_mxfp8 will see them: supported shapes only
+    p1.M = p2.M = M; p1.N = w1.out; p1.K = d; p1.lda = d; p1.ldc = w1.out;
+    p1.fp8 = p2.fp8 = true; p1.c_mx = true;
+    p2.N = d; p2.K = w1.out; p2.lda = w1.out; p2.ldc = d; p2.resid = x; p2.ldr = d;
     if (i1 != t_mx->end() && i2 != t_mx->end() && d % 256 == 0 && w1.out % 128 == 0 &&
-        t256 >= g_fp8_min_tiles) {
+        t256 >= g_fp8_min_tiles && gemm_bf16p_supported(p1) && gemm_bf16p_supported(p2)) {
       mx = true; q1 = &i1->second; q2 = &i2->second;
     }
   }
@@ -975,8 +982,11 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ffm2.b, 0.5f, L.norm_mha.w,
                            L.norm_mha.b, nullptr, nullptr, t1, M, d, eps, 0, s));
     } else {
+      // (fp8 mode: every feed-forward module normalises for itself -- layernorm_mx writes the
+      // MXFP8 operand -- so that ALL of them take the same path; the bf16 / fp32 modes get
+      // LN(x) from the previous layer's fused tail)
       WN_TRY(ffn_module(m, L.norm_ff_mac, L.ffm1, L.ffm2, ACT_SILU, 0.5f,
-                        li > 0 || (!h16 && t_gemm_prec == PREC_F32), h16, s));
+                        (li > 0 && !(t_mx && h16)) || (!h16 && t_gemm_prec == PREC_F32), h16, s));
       // x += MHA(LN(x))                               encoder_layer.py:230-238
       WN_TRY(ln(L.norm_mha, x, t1, M, d, eps, s, h16));
     }
@@ -1062,7 +1072,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     }
     WN_TRY(ffn_module(m, L.norm_ff, L.ff1, L.ff2, ACT_SILU, 0.5f,
                       !h16 && t_gemm_prec == PREC_F32, h16, s));
-    if (li + 1 < n_run) {
+    if (li + 1 < n_run && !(t_mx && h16)) {
       const EncLayer& Ln = m->layers[li + 1];
       WN_TRY(layernorm2(x, L.norm_final.w, L.norm_final.b, Ln.norm_ff_mac.w,
                         Ln.norm_ff_mac.b, x, t1, M, d, eps, s, h16));
@@ -1997,6 +2007,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "attn_fold") g_attn_fold = value;
   else if (k == "x6_conv_order") g_x6_conv_order = value;
   else if (k == "x6_linear") g_x6_linear = value;
+  else if (k == "x6_linear_min") g_x6_linear_min = value;
   else if (k == "x6_af32") g_x6_af32 = value;
   else if (k == "beam_prio") g_beam_prio = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
@@ -2591,8 +2602,8 @@ int wn_attention_beam_search(wn_model* m, int32_t beam, int32_t maxlen, float le
   WN_ENTER(m);
   PrecisionScope prec_scope(m);
   WN_CHECK(!m->left.layers.empty(), "attention beam search: the model has no attention decoder");
-  WN_CHECK(beam >= 1 && beam <= 16 && maxlen >= 1 && tokens_host && lens_host,
-           "attention beam search: beam_size in [1, 16], maxlen >= 1");
+  WN_CHECK(beam >= 1 && beam <= 64 && maxlen >= 1 && tokens_host && lens_host,
+           "attention beam search: beam_size in [1, 64], maxlen >= 1");
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));
   const wn_config& c = m->cfg;
@@ -2620,8 +2631,29 @@ int wn_attention_beam_search(wn_model* m, int32_t beam, int32_t maxlen, float le
   WN_TRY(m->r_h.ensure((size_t)BN * c.dec_ffn_dim * sizeof(float)));
   WN_TRY(m->r_logits.ensure((size_t)BN * V * sizeof(float)));
   WN_TRY(m->r_out.ensure((size_t)2 * BN * N * sizeof(float)));
-  const size_t cache_layer = (size_t)maxlen * BN * 2 * d;
+  // self-attention K | V cache [layer][step][slot][2d]: sized for the steps actually run,
+  // not for maxlen = T' (the reference's cache grows with the decoded length too,
+  // decoder.py:226-281): starts at 32 steps and doubles, the used prefix of every layer is
+  // carried over
+  int cap_steps = std::min(maxlen, 32);
+  size_t cache_layer = (size_t)cap_steps * BN * 2 * d;
   WN_TRY(m->ab_cache.ensure(nl * cache_layer * sizeof(float)));
+  auto grow_cache = [&](int used_steps) -> int {
+    const int cap2 = std::min(maxlen, cap_steps * 2);
+    const size_t layer2 = (size_t)cap2 * BN * 2 * d;
+    DevBuf nb;
+    WN_TRY(nb.ensure(nl * layer2 * sizeof(float)));
+    for (int li = 0; li < nl; ++li)
+      WN_HIP(hipMemcpyAsync(nb.as<float>() + li * layer2, m->ab_cache.as<float>() + li * cache_layer,
+                            (size_t)used_steps * BN * 2 * d * sizeof(float),
+                            hipMemcpyDeviceToDevice, s));
+    WN_HIP(hipStreamSynchronize(s));            // before the old buffer is freed
+    std::swap(m->ab_cache.p, nb.p);
+    std::swap(m->ab_cache.cap, nb.cap);
+    cap_steps = cap2;
+    cache_layer = layer2;
+    return 0;
+  };
   const size_t mem_layer = (size_t)Menc * 2 * d;
   WN_TRY(m->r_mem_all.ensure(nl * mem_layer * sizeof(float)));
   // state: 2 x {score, end, tok, path} + last_tok + n_done + out_tok + out_len
@@ -2653,6 +2685,7 @@ int wn_attention_beam_search(wn_model* m, int32_t beam, int32_t maxlen, float le
   for (int i = 1; i <= maxlen; ++i) {
     if (done_host == BN) break;
     const int step = i - 1;                       // position of the newest token
+    if (step >= cap_steps) WN_TRY(grow_cache(step));
     WN_TRY(attn_step_embed(last_tok, step, D.embed, D.pe, sqrtf((float)d), d, BN, x, s));
     for (int li = 0; li < nl; ++li) {
       const DecLayer& L = D.layers[li];
@@ -2688,13 +2721,19 @@ int wn_attention_beam_search(wn_model* m, int32_t beam, int32_t maxlen, float le
     r.topk_val = tv; r.topk_idx = ti; r.logp = nullptr; r.ld_out = V;
     WN_TRY(ctc_logsoftmax_topk(r, s));
     WN_HIP(hipMemsetAsync(n_done, 0, sizeof(int), s));
-    WN_TRY(attn_beam_update(B, N, i, W, c.eos, tv, ti, score[cur], endf[cur], tok[cur],
+    WN_TRY(attn_beam_update(B, N, i, W, c.eos, V, tv, ti, score[cur], endf[cur], tok[cur],
                             path[cur], score[cur ^ 1], endf[cur ^ 1], tok[cur ^ 1],
                             path[cur ^ 1], last_tok, n_done, s));
     cur ^= 1;
     len = i + 1;
-    WN_HIP(hipMemcpyAsync(&done_host, n_done, sizeof(int), hipMemcpyDeviceToHost, s));
-    WN_HIP(hipStreamSynchronize(s));
+    // "all hypotheses ended" is polled every 4th step: a step run after the end only appends
+    // eos to finished hypotheses and leaves their scores alone (mask_finished_scores /
+    // _preds), and the result strips eos (search.py:355-371) -- same output, 3 of 4 host
+    // round trips fewer
+    if ((i & 3) == 0 || i == maxlen) {
+      WN_HIP(hipMemcpyAsync(&done_host, n_done, sizeof(int), hipMemcpyDeviceToHost, s));
+      WN_HIP(hipStreamSynchronize(s));
+    }
   }
   WN_TRY(attn_beam_finish(B, N, len, W, c.eos, length_penalty, score[cur], tok[cur], out_tok,
                           out_len, s));
