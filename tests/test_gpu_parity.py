@@ -255,6 +255,37 @@ def test_prefix_beam_small_vocab_stress(V, T, beam):
                                    rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize('V,T,beam,ctx', [(4, 50, 3, False), (7, 60, 6, True), (6, 120, 5, False),
+                                          (8, 33, 8, True), (300, 40, 32, False),
+                                          (20, 60, 20, True)])
+def test_prefix_identity_is_exact_behind_a_2_bit_hash(V, T, beam, ctx):
+    """Prefix identity = token sequence, exactly: with wn_tune_set("beam_weak_hash", 1) the
+    64-bit prefix hash is replaced by a 2-bit one, so nearly every pair of prefixes passes the
+    hash filter and the search is right only if the exact test behind it -- same node, else
+    the token-by-token walk through the node pool -- is.  Both kernels (beam <= 16 and the
+    general one), with and without a context graph: n-best lists, order, time stamps and
+    fp64 scores identical to the oracle's."""
+    from wenet_amd import _lib, search as S, synthetic
+    from wenet_amd.context_graph import ContextGraph
+    O = _oracle()
+    logp, lens = synthetic.peaky_logprobs(32, (max(1, T // 2), T), V, 2.5, V * 11 + T + beam)
+    og = gg = None
+    if ctx:
+        rng = np.random.RandomState(beam)
+        phrases = [[int(t) for t in rng.randint(1, V, rng.randint(1, 4))] for _ in range(8)]
+        og = O.ContextGraph(phrases, 2.0)
+        gg = ContextGraph(context_list=phrases, context_score=2.0)
+    ref = O.ctc_prefix_beam_search(logp, lens, beam, 0, og)
+    L = _lib.lib()
+    try:
+        _lib.check(L.wn_tune_set(b'beam_weak_hash', 1), 'tune')
+        got = S.ctc_prefix_beam_search(logp.cuda(), lens, beam, gg, 0)
+    finally:
+        L.wn_tune_set(b'beam_weak_hash', 0)
+    for b in range(32):
+        _same_nbest(got[b], ref[b].nbest, ref[b].nbest_scores, ref[b].nbest_times, f'utt {b}')
+
+
 def test_prefix_beam_known_answer_gpu():
     """runtime/core/test/ctc_prefix_beam_search_test.cc:29-72 on the GPU."""
     from wenet_amd import search as S

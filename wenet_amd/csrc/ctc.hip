@@ -197,20 +197,43 @@ constexpr double NEG_INF = -HUGE_VAL;
 // tuple).  A physical node id is NOT an identity: a prefix that left the beam
 // can be re-created later as a new node while its old children are still
 // alive.  Every prefix therefore carries a 64-bit hash of its token sequence
-// (chained splitmix64), and all "is this the same prefix / is this its parent"
-// tests compare hashes.  This is the one place where "identical to the reference" is
-// probabilistic: two DIFFERENT prefixes alive in the same frame's candidate set (<= beam +
-// beam^2 = 272 entries) with equal 64-bit hashes would be merged; there is no fallback
-// token-by-token compare.  Per frame that is < 272^2 / 2^65 ~ 2e-15, i.e. ~2e-4 over a
-// million hours of audio at 25 frames per second.
+// (chained splitmix64) -- as a FILTER only (round 3): two prefixes are the same iff their
+// hashes are equal AND their token sequences are.  The sequence test is exact and almost
+// always free: equal physical nodes are the same sequence (the common case: the parent of a
+// beam member is usually still the very node it was created from); only hash-equal prefixes
+// with DIFFERENT physical nodes -- a re-created prefix, or a 2^-64 collision -- are walked
+// token by token through the node pool (same_prefix_nodes).  The pool is written with plain
+// stores inside the frame loop; every wave drains its stores of frame t - 1 (s_waitcnt vmcnt(0),
+// a frame after they were issued: no stall) before it writes frame t's and passes the frame's
+// last barrier, and a walk only visits nodes created at least two frames ago, so what it
+// reads (sc1 loads: L2, not a possibly stale L1 line) is complete.
 typedef unsigned long long u64;
-__device__ __forceinline__ u64 prefix_hash(u64 h, int tok) {
+// weak (test knob "beam_weak_hash"): a 2-bit hash -- almost every pair of prefixes collides, so
+// the results are right only if the exact sequence test behind the filter is
+__device__ __forceinline__ u64 prefix_hash(u64 h, int tok, int weak = 0) {
+  if (weak) return (h * 31u + (u64)tok) & 3u;
   u64 z = h ^ ((u64)(tok + 1) * 0x9E3779B97F4A7C15ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
 constexpr u64 ROOT_HASH = 0x243F6A8885A308D3ull;
+
+// Token sequences of two prefix nodes equal?  Lock-step walk towards the root (node 0, parent
+// -1): equal node ids end it (same node = same sequence), a different token or one side at the
+// root first = different.
+__device__ __noinline__ bool same_prefix_nodes(const int* n_parent, const int* n_token, int x,
+                                               int y) {
+  while (x != y) {
+    if (x <= 0 || y <= 0) return false;
+    const int tx = __hip_atomic_load(n_token + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ty = __hip_atomic_load(n_token + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tx != ty) return false;
+    x = __hip_atomic_load(n_parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    y = __hip_atomic_load(n_parent + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return true;
+}
 
 // Latency design (the search is T' dependent steps per utterance; nothing
 // here is bandwidth- or FLOP-bound):
@@ -473,9 +496,19 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
         qb = (inb & (tq[q] == a.blank)) ? q : qb;
         ql = (inb & (Klast >= 0) & (tq[q] == Klast)) ? q : ql;
       }
+      // parent of K inside the beam: hash filter, then the exact test (same node, else walk)
+      unsigned rp_hits = 0;
 #pragma unroll
       for (int j = 0; j < MAXB; ++j)
-        rp = ((j < nb) & (hh[j] == Eparh)) ? j : rp;
+        rp_hits |= ((j < nb) & (hh[j] == Eparh)) ? (1u << j) : 0u;
+      if (rp_hits) {
+        const int Kpar = H.par[r];
+        for (unsigned mk = rp_hits; mk; mk &= mk - 1) {
+          const int j = __ffs(mk) - 1;
+          const int nj = H.node[j];
+          if (nj == Kpar || same_prefix_nodes(n_parent, n_token, nj, Kpar)) rp = j;
+        }
+      }
       if (qb >= 0 || ql >= 0) {
         valid = 1;
         Ekey = H.node[r]; Epar = H.par[r]; Etoken = Klast; Edepth = H.depth[r];
@@ -540,13 +573,25 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
       const int r = x_r, q = x_q;
       const int u = tk[q];
       const u64 Ph = H.hash[r];
-      const u64 ch = prefix_hash(Ph, u);
+      const u64 ch = prefix_hash(Ph, u, a.weak_hash);
       u64 hh[MAXB];
 #pragma unroll
       for (int j = 0; j < MAXB; ++j) hh[j] = H.hash[j];  // unconditional, see above
-      bool merged = false;
+      // does P + u land on a beam member?  hash filter, then exact: same last token and the
+      // member's parent IS P (same node, else walk)
+      unsigned mg_hits = 0;
 #pragma unroll
-      for (int j = 0; j < MAXB; ++j) merged |= (j < nb) & (hh[j] == ch);
+      for (int j = 0; j < MAXB; ++j) mg_hits |= ((j < nb) & (hh[j] == ch)) ? (1u << j) : 0u;
+      bool merged = false;
+      if (mg_hits) {
+        const int Pn = H.node[r];
+        for (unsigned mk = mg_hits; mk; mk &= mk - 1) {
+          const int j = __ffs(mk) - 1;
+          const int pj = H.par[j];
+          merged |= H.last[j] == u &&
+                    (pj == Pn || same_prefix_nodes(n_parent, n_token, pj, Pn));
+        }
+      }
       if (u != a.blank && !merged) {
         const double p = (double)lq[q];
         double x, v; int tb, sub;
@@ -635,6 +680,9 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
     const long long c2 = dbg ? __builtin_amdgcn_s_memtime() : 0;
     if (tid < MAXB) s_claim[(t + 1) & 1][tid] = 0;
     if (tid == 0) { s_nvalid[(t + 1) & 1] = 0; s_tie[(t + 1) & 1] = 0; }
+    // the node-pool stores of the PREVIOUS frame are complete before this frame's are issued
+    // (they had a whole frame: no stall) -- see the prefix-identity note above
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (valid) {
       const int rank = e_rank[my_slot];
       if (rank < beam) {
@@ -758,7 +806,8 @@ struct BigEntry {
 // arithmetic, same order rules as prefix_beam_kernel above.
 template <bool CTX>
 __device__ BigEntry big_eval(const BigHyp& H, int nb, int beam, int blank,
-                             const int* tk, const float* lq, int e, const CtxGraph& cg) {
+                             const int* tk, const float* lq, int e, const CtxGraph& cg,
+                             const int* n_parent, const int* n_token, int weak_hash) {
   BigEntry E;
   E.valid = 0;
   E.s = E.ns = E.vs = E.vns = NEG_INF; E.cx = 0.0;
@@ -776,7 +825,9 @@ __device__ BigEntry big_eval(const BigHyp& H, int nb, int beam, int blank,
       if (Klast >= 0 && tk[q] == Klast) ql = q;
     }
     for (int j = 0; j < nb; ++j)
-      if (H.hash[j] == E.parh) rp = j;
+      if (H.hash[j] == E.parh &&
+          (H.node[j] == H.par[r] || same_prefix_nodes(n_parent, n_token, H.node[j], H.par[r])))
+        rp = j;
     if (qb < 0 && ql < 0) return E;
     E.valid = 1;
     E.key = H.node[r]; E.par = H.par[r]; E.token = Klast; E.depth = H.depth[r];
@@ -837,9 +888,11 @@ __device__ BigEntry big_eval(const BigHyp& H, int nb, int beam, int blank,
   const int u = tk[q];
   if (u == blank) return E;
   const u64 Ph = H.hash[r];
-  const u64 ch = prefix_hash(Ph, u);
+  const u64 ch = prefix_hash(Ph, u, weak_hash);
   for (int j = 0; j < nb; ++j)
-    if (H.hash[j] == ch) return E;  // lands on a beam member: that entry owns it
+    if (H.hash[j] == ch && H.last[j] == u &&
+        (H.par[j] == H.node[r] || same_prefix_nodes(n_parent, n_token, H.par[j], H.node[r])))
+      return E;  // lands on a beam member: that entry owns it
   const double p = (double)lq[q];
   double xx, v; int tb, sub;
   if (u == H.last[r]) { xx = H.s[r] + p; v = H.vs[r] + p; tb = H.ts[r]; sub = 1; }
@@ -904,7 +957,7 @@ __global__ __launch_bounds__(BIG_THREADS) void prefix_beam_big_kernel(PrefixBeam
       const int e = tid + i * BIG_THREADS;
       ks[i] = NEG_INF; kq[i] = 0x7fffffff; kr[i] = -1;
       if (e < n_ent) {
-        const BigEntry E = big_eval<CTX>(H, nb, beam, a.blank, tk, lq, e, a.cg);
+        const BigEntry E = big_eval<CTX>(H, nb, beam, a.blank, tk, lq, e, a.cg, n_parent, n_token, a.weak_hash);
         if (E.valid) {
           const double sc = log_add2_fast(E.s, E.ns);
           ks[i] = CTX ? sc + E.cx : sc;   // total_score(), search.py:93-94
@@ -945,12 +998,15 @@ __global__ __launch_bounds__(BIG_THREADS) void prefix_beam_big_kernel(PrefixBeam
           if (j == i) { kq[j] = 0x7fffffff; ks[j] = NEG_INF; kr[j] = k; }
       }
     }
-    // survivors: evaluate in full, write beam member `rank`
+    // survivors: evaluate in full, write beam member `rank` (the previous frame's node-pool
+    // stores are complete first: prefix-identity note at the top)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < BIG_EPT; ++i) {
       if (kr[i] < 0) continue;
       const int rank = kr[i];
-      const BigEntry E = big_eval<CTX>(H, nb, beam, a.blank, tk, lq, tid + i * BIG_THREADS, a.cg);
+      const BigEntry E = big_eval<CTX>(H, nb, beam, a.blank, tk, lq, tid + i * BIG_THREADS, a.cg, n_parent,
+                                          n_token, a.weak_hash);
       BigHyp& Hn = hyp[cur ^ 1];
       const int slot = 1 + t * beam + rank;
       int node = E.key;
@@ -1058,10 +1114,12 @@ int64_t prefix_beam_pool_ints(int max_len, int beam) {
 }
 
 int g_beam_prio = 0;   // s_setprio for the search waves: measured no effect (r02l), off
+int g_beam_weak_hash = 0;   // tests: 2-bit prefix hash (exercises the exact sequence test)
 
 int ctc_prefix_beam(const PrefixBeamArgs& a_in, hipStream_t s) {
   PrefixBeamArgs a = a_in;
   a.prio = g_beam_prio;
+  a.weak_hash = g_beam_weak_hash;
   WN_CHECK(a.B > 0, "prefix beam: empty batch");
   WN_CHECK(a.beam >= 1 && a.beam <= BIGB,
            "prefix beam: beam_size must be in [1, 64]");

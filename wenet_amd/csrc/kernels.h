@@ -109,6 +109,7 @@ struct FfnArgs {
 };
 extern int g_ffn_fused, g_ffn_ring, g_ffn_bm64;
 extern int g_beam_prio;   // wn_tune_set("beam_prio")
+extern int g_beam_weak_hash;   // wn_tune_set("beam_weak_hash")
 extern int g_ctc_wave;    // wn_tune_set("ctc_wave")
 int ffn_fused_split(int M, int D, int F);
 bool ffn_fused_supported(int M, int D, int F, int act);
@@ -254,6 +255,7 @@ struct PrefixBeamArgs {
   long long* dbg_cycles = nullptr;
   CtxGraph cg;  // keys == nullptr: no context biasing
   int prio = 0; // > 0: the search waves raise their issue priority (s_setprio; experiment)
+  int weak_hash = 0;  // tests: 2-bit prefix hash, so that the exact sequence test decides
 };
 int64_t prefix_beam_pool_ints(int max_len, int beam);
 // out[i] = log_add(a[i], b[i]) with the search's own fp64 routine (parity test)

@@ -2010,6 +2010,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_linear_min") g_x6_linear_min = value;
   else if (k == "x6_af32") g_x6_af32 = value;
   else if (k == "beam_prio") g_beam_prio = value;
+  else if (k == "beam_weak_hash") g_beam_weak_hash = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "gemm_rowln") g_gemm_rowln = value;
   else if (k == "ffn_ring") g_ffn_ring = value;
