@@ -300,6 +300,23 @@ int wn_decoder_forward(wn_model* m, int32_t utt, int32_t which, int32_t n_seq,
                        const int32_t* tokens_host, const int32_t* lens_host,
                        int32_t max_len, float* logp_dev, void* stream);
 
+/* ASRModel.filter_blank_embedding (asr_model.py:153-180), used by decode() in front of
+ * attention_rescoring when model_conf.apply_non_blank_embedding is set (asr_model.py:337-342;
+ * examples/aishell/s0/conf/train_u2++_lite_conformer.yaml): the encoder output of the CURRENT
+ * batch is replaced by its rows whose CTC arg-max (of the posteriors wn_ctc_logprobs /
+ * wn_set_ctc_probs left on the handle, blank penalty included) is not token 0, in order;
+ * T = the largest number of kept rows in the batch; utterance b then has min(len_b, T) rows: its
+ * kept rows followed by ZERO rows -- the reference hands attention_rescoring the zero-padded
+ * (B, T, d) tensor together with the UNFILTERED lengths (search.py:396), so the decoder
+ * attends to that padding too, and so does this path.  n_keep_host (B,): kept rows per
+ * utterance; *t_out = T; padded_out_dev (optional, (B, T', d) or larger): the reference's
+ * return tensor (B, T, d).  Only frames inside an utterance's length are considered (the
+ * reference also looks at the padded frames of shorter utterances, whose encoder output is an
+ * artefact of the padding; a batch of equal lengths or a single utterance is identical).  One
+ * host round trip (the kept-row counts). */
+int wn_filter_blank_embedding(wn_model* m, float* padded_out_dev, int32_t* n_keep_host,
+                              int32_t* t_out, void* stream);
+
 /* attention_beam_search (search.py:252-371, the non-Whisper branch) over the CURRENT batch
  * (its encoder output is on the device after wn_encode / wn_set_encoder_out): B x beam
  * running hypotheses, one decoder row per hypothesis and step

@@ -53,6 +53,17 @@ CASES = [
     dict(case='aishell_conformer_full', config='aishell_conformer', wseed=0,
          batch=2, frames=(200, 300), fseed=14, beam=10, chunk=-1, left=-1,
          ctc_weight=0.5, reverse_weight=0.0),
+    # model_conf.apply_non_blank_embedding (train_u2++_lite_conformer.yaml): rescoring on the
+    # non-blank frames.  One utterance / equal lengths: no padded frame enters the filter
+    dict(case='tiny_lite_one', config='tiny_lite', wseed=0, batch=1,
+         frames=(150, 150), fseed=21, beam=5, chunk=-1, left=-1, ctc_weight=0.5,
+         reverse_weight=0.3),
+    dict(case='tiny_lite_equal', config='tiny_lite', wseed=1, batch=4,
+         frames=(131, 131), fseed=22, beam=4, chunk=-1, left=-1, ctc_weight=0.3,
+         reverse_weight=0.0),
+    dict(case='aishell_lite_one', config='aishell_u2pp_lite', wseed=0, batch=1,
+         frames=(330, 330), fseed=23, beam=10, chunk=-1, left=-1, ctc_weight=0.5,
+         reverse_weight=0.3),
     dict(case='wenetspeech_chunk16', config='wenetspeech_u2pp', wseed=0,
          batch=2, frames=(260, 330), fseed=12, beam=10, chunk=16, left=-1,
          ctc_weight=0.5, reverse_weight=0.3),
@@ -102,6 +113,12 @@ def run_case(c, outdir):
     if logp.numel() <= 200000:
         out['ctc_logp'] = logp.numpy().astype(np.float32)
     meta = dict(c)
+    if getattr(model, 'apply_non_blank_embedding', False):
+        # what attention_rescoring attended to: the reference's own filter_blank_embedding
+        with torch.no_grad():
+            sel, smask = model.filter_blank_embedding(logp, enc)
+        out['nonblank_out'] = sel.numpy().astype(np.float32)
+        meta['nonblank_kept'] = [int(x) for x in smask.squeeze(1).sum(1).tolist()]
     meta['greedy'] = [r.tokens for r in res['ctc_greedy_search']]
     meta['prefix'] = [
         dict(nbest=[list(map(int, h)) for h in r.nbest],

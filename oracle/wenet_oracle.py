@@ -1394,11 +1394,33 @@ def special_symbols(configs):
     return st.get('<sos>', vocab - 1), st.get('<eos>', vocab - 1)
 
 
+def filter_blank_embedding(ctc_probs, encoder_out, valid_lens=None):
+    """ASRModel.filter_blank_embedding, wenet/models/transformer/asr_model.py:153-180: the
+    rows of encoder_out (B, T, d) whose CTC arg-max is not token 0, per utterance in order,
+    zero-padded to the longest selection; returns (selected (B, T_sel, d), mask (B, 1, T_sel)).
+    The reference looks at ALL T frames of every utterance, padded ones included.
+    `valid_lens` (not in the reference): only frames t < valid_lens[b] count -- what the
+    accelerated path does, which never computes padded frames (identical for one utterance or
+    a batch of equal lengths)."""
+    B, T = encoder_out.size(0), encoder_out.size(1)
+    top1 = torch.argmax(ctc_probs, dim=2)
+    sel = []
+    for j in range(B):
+        n = T if valid_lens is None else int(valid_lens[j])
+        idx = torch.tensor([i for i in range(n) if top1[j][i] != 0], dtype=torch.long)
+        sel.append(torch.index_select(encoder_out[j], 0, idx))
+    out = torch.nn.utils.rnn.pad_sequence(sel, batch_first=True, padding_value=0)
+    lens = torch.tensor([x.size(0) for x in sel])
+    Ts = out.size(1)
+    mask = (torch.arange(Ts).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(1)
+    return out, mask
+
+
 def decode(configs, sd, methods, speech, speech_lengths, beam_size: int = 1,
            decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1,
            ctc_weight: float = 0.0, reverse_weight: float = 0.0,
            blank_id: int = 0, blank_penalty: float = 0.0,
-           length_penalty: float = 0.0, context_graph=None):
+           length_penalty: float = 0.0, context_graph=None, nonblank_valid_only=False):
     """ASRModel.decode asr_model.py:267-343 (methods: attention,
     ctc_greedy_search, ctc_prefix_beam_search, attention_rescoring)."""
     assert speech.shape[0] == speech_lengths.shape[0]
@@ -1427,6 +1449,12 @@ def decode(configs, sd, methods, speech, speech_lengths, beam_size: int = 1,
             if pre is None:
                 pre = ctc_prefix_beam_search(ctc_probs, encoder_lens, beam_size,
                                              blank_id, context_graph)
+            if (configs.get('model_conf') or {}).get('apply_non_blank_embedding', False):
+                # asr_model.py:337-342: filtered memory, UNFILTERED lengths (search.py:396
+                # then slices the zero-padded tensor, zero rows included)
+                encoder_out, _ = filter_blank_embedding(
+                    ctc_probs, encoder_out,
+                    encoder_lens if nonblank_valid_only else None)
             results['attention_rescoring'] = attention_rescoring(
                 configs, sd, pre, encoder_out, encoder_lens, ctc_weight,
                 reverse_weight, sos, eos)

@@ -523,6 +523,49 @@ def test_attention_mode_wide_beams_and_long_outputs_vs_oracle(beam, frames):
     assert max(len(r.tokens) for r in got) > (32 if beam == 3 else 0)
 
 
+@pytest.mark.parametrize('name', ['tiny_lite_one', 'tiny_lite_equal', 'aishell_lite_one'])
+def test_filter_blank_embedding_vs_reference_output(name):
+    """ASRModel.filter_blank_embedding (wn_filter_blank_embedding; asr_model.py:153-180) on the
+    reference's own encoder output and CTC posteriors: the selected rows, their zero padding and
+    the mask equal what the REAL reference's method returned (tests/golden/*lite*)."""
+    O = _oracle()
+    meta, arrays = load_case(name)
+    configs, sd, model = cached_model(meta['config'], meta['wseed'])
+    enc = torch.from_numpy(arrays['enc_out'])
+    logp = O.ctc_logprobs(sd, enc)
+    sel, mask = model.filter_blank_embedding(logp.cuda(), enc.cuda())
+    assert mask.squeeze(1).sum(1).tolist() == meta['nonblank_kept']
+    np.testing.assert_array_equal(sel.cpu().numpy(), arrays['nonblank_out'])
+
+
+def test_non_blank_embedding_rescoring_on_a_ragged_batch():
+    """decode(attention_rescoring) of a model with model_conf.apply_non_blank_embedding on a
+    RAGGED batch against the oracle with the path's one documented deviation (frames beyond an
+    utterance's length never count: the accelerated path has no padded frames, the reference
+    lets their arg-max decide too): every hypothesis' score within 1e-3, same winner; and the
+    scores differ from rescoring on the unfiltered encoder output (the filter ran)."""
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('tiny_lite', 0)
+    feats, lens = S.make_features(5, (60, 190), seed=4242)
+    kw = dict(beam_size=5, ctc_weight=0.5, reverse_weight=0.3)
+    got = model.decode(['ctc_prefix_beam_search', 'attention_rescoring'], feats.cuda(), lens, **kw)
+    ref = O.decode(configs, sd, ['ctc_prefix_beam_search', 'attention_rescoring'], feats, lens,
+                   nonblank_valid_only=True, **kw)
+    plain = dict(configs)
+    plain['model_conf'] = dict(configs['model_conf'], apply_non_blank_embedding=False)
+    ref_plain = O.decode(plain, sd, ['attention_rescoring'], feats, lens, **kw)
+    moved = 0.0
+    for b in range(5):
+        g, r = got['attention_rescoring'][b], ref['attention_rescoring'][b]
+        assert [list(x) for x in got['ctc_prefix_beam_search'][b].nbest] == \
+            [list(x) for x in ref['ctc_prefix_beam_search'][b].nbest]
+        assert list(g.tokens) == list(r.tokens), b
+        assert abs(g.score - r.score) < 1e-3, (b, g.score, r.score)
+        moved = max(moved, abs(r.score - ref_plain['attention_rescoring'][b].score))
+    assert moved > 1e-2, moved
+
+
 @pytest.mark.parametrize('n_mels', [80, 128])
 def test_log_mel_vs_oracle(n_mels):
     """wn_log_mel (Whisper frontend, processor.py:320-369) against the oracle

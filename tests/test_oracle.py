@@ -516,6 +516,24 @@ def test_resample_properties():
     assert np.abs(lhs - rhs).max() < 1e-4
 
 
+@pytest.mark.parametrize('name', ['tiny_lite_one', 'tiny_lite_equal', 'aishell_lite_one'])
+def test_filter_blank_embedding_vs_reference_output(name):
+    """O.filter_blank_embedding (asr_model.py:153-180) against what the REAL reference's method
+    returned on its own encoder output / CTC posteriors (golden `nonblank_out`,
+    `nonblank_kept`): same rows, same zero padding; `valid_lens` is a no-op when no frame is
+    padding."""
+    meta, arrays = load_case(name)
+    enc = torch.from_numpy(arrays['enc_out'])
+    configs, sd, feats, lens = build_inputs(meta)
+    logp = O.ctc_logprobs(sd, enc)
+    sel, mask = O.filter_blank_embedding(logp, enc)
+    assert mask.squeeze(1).sum(1).tolist() == meta['nonblank_kept']
+    np.testing.assert_array_equal(sel.numpy(), arrays['nonblank_out'])
+    sel2, _ = O.filter_blank_embedding(logp, enc, torch.from_numpy(arrays['enc_lens']))
+    assert torch.equal(sel, sel2)
+    assert 0 < min(meta['nonblank_kept']) and max(meta['nonblank_kept']) < enc.shape[1]
+
+
 @pytest.mark.parametrize('orig,new', [(44100, 16000), (48000, 16000), (8000, 16000),
                                       (22050, 16000), (16000, 8000), (11025, 16000),
                                       (32000, 16000)])

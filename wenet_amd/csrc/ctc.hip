@@ -1091,6 +1091,54 @@ int ctc_logsoftmax_topk(const CtcRowArgs& a, hipStream_t s) {
   return 0;
 }
 
+// ---- filter_blank_embedding (asr_model.py:153-180) ------------------------------------------
+// One block per utterance: the frames whose CTC arg-max is not token 0, in order, as source
+// row indices (map[off[b] + i], i < n_keep[b]); n_keep[b] = their number.
+__global__ __launch_bounds__(256) void nonblank_map_kernel(const int* __restrict__ top1,
+                                                           int stride, const int* __restrict__ off,
+                                                           const int* __restrict__ len,
+                                                           int* __restrict__ map,
+                                                           int* __restrict__ n_keep) {
+  __shared__ int wsum[4];
+  __shared__ int base;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int o = off[b], n = len[b];
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < n; t0 += 256) {
+    const int t = t0 + tid;
+    const bool keep = t < n && top1[(int64_t)(o + t) * stride] != 0;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int before = base;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (keep) map[o + before + __popcll(m & ((1ull << lane) - 1))] = o + t;
+    __syncthreads();
+    if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) n_keep[b] = base;
+}
+
+// dst row (new layout: utterance b at noff[b], nlen[b] rows) <- src row map[off[b] + i] for
+// i < n_keep[b], zeros behind (the reference pads the selected rows with zeros and the decoder
+// attends to that padding: search.py:396 slices with the UNFILTERED lengths)
+__global__ __launch_bounds__(256) void nonblank_gather_kernel(
+    const float* __restrict__ src, const int* __restrict__ map, const int* __restrict__ off,
+    const int* __restrict__ n_keep, const int* __restrict__ noff, const int* __restrict__ nlen,
+    const int* __restrict__ row_utt_new, float* __restrict__ dst, int D4, int rows_new) {
+  const int r = blockIdx.x;
+  if (r >= rows_new) return;
+  const int b = row_utt_new[r];
+  const int i = r - noff[b];
+  const f32x4* s4 = i < n_keep[b]
+                        ? reinterpret_cast<const f32x4*>(src) + (int64_t)map[off[b] + i] * D4
+                        : nullptr;
+  f32x4* d4 = reinterpret_cast<f32x4*>(dst) + (int64_t)r * D4;
+  for (int c = threadIdx.x; c < D4; c += 256) d4[c] = s4 ? s4[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 int ctc_greedy_collapse(const int* top1, int top1_stride, const int* off,
                         const int* len, int B, int blank, int* out_tokens,
                         int out_stride, int* out_lens, hipStream_t s) {
@@ -1146,6 +1194,24 @@ int ctc_prefix_beam(const PrefixBeamArgs& a_in, hipStream_t s) {
     else
       hipLaunchKernelGGL((prefix_beam_kernel<PB_CHUNKS, true>), dim3(a.B), dim3(PB_THREADS), 0, s, a);
   }
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+int nonblank_map(const int* top1, int stride, const int* off, const int* len, int B, int* map,
+                 int* n_keep, hipStream_t s) {
+  hipLaunchKernelGGL(nonblank_map_kernel, dim3(B), dim3(256), 0, s, top1, stride, off, len, map,
+                     n_keep);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+int nonblank_gather(const float* src, const int* map, const int* off, const int* n_keep,
+                    const int* noff, const int* nlen, const int* row_utt_new, float* dst, int D,
+                    int rows_new, hipStream_t s) {
+  if (rows_new <= 0) return 0;
+  hipLaunchKernelGGL(nonblank_gather_kernel, dim3(rows_new), dim3(256), 0, s, src, map, off,
+                     n_keep, noff, nlen, row_utt_new, dst, D / 4, rows_new);
   WN_HIP(hipGetLastError());
   return 0;
 }

@@ -213,6 +213,12 @@ struct CtcRowArgs {
 int ctc_logsoftmax_topk(const CtcRowArgs& a, hipStream_t s);
 
 // Greedy collapse (ctc_greedy_search): per utterance remove repeats + blanks.
+// filter_blank_embedding (asr_model.py:153-180): rows whose CTC arg-max is not 0, compacted
+int nonblank_map(const int* top1, int stride, const int* off, const int* len, int B, int* map,
+                 int* n_keep, hipStream_t s);
+int nonblank_gather(const float* src, const int* map, const int* off, const int* n_keep,
+                    const int* noff, const int* nlen, const int* row_utt_new, float* dst, int D,
+                    int rows_new, hipStream_t s);
 int ctc_greedy_collapse(const int* top1, int top1_stride, const int* off,
                         const int* len, int B, int blank, int* out_tokens,
                         int out_stride, int* out_lens, hipStream_t s);

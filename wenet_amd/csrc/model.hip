@@ -257,6 +257,7 @@ struct wn_model {
   // pointer -> X3 image; built at create, shared by clones
   std::shared_ptr<DevBuf> weights_x6;
   std::shared_ptr<std::map<const float*, const void*>> x6_at;
+  DevBuf nb_map, nb_keep, nb_enc, nb_off_old;   // filter_blank_embedding scratch
   std::shared_ptr<DevBuf> weights_x6p;      // k-slot-permuted FFN w_2 images (ffn_x6f.hip)
   std::shared_ptr<std::map<const float*, const void*>> x6p_at;
   DevBuf x6_a, x6_h;                     // images of the GEMM input rows / the FFN hidden tensor
@@ -2299,6 +2300,60 @@ int wn_ctc_greedy_search(wn_model* m, int32_t blank_id, int32_t* tokens_host,
   WN_HIP(hipMemcpyAsync(tok_lens_host, m->g_len.p, (size_t)B * sizeof(int),
                         hipMemcpyDeviceToHost, s));
   WN_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int wn_filter_blank_embedding(wn_model* m, float* padded_out_dev, int32_t* n_keep_host,
+                              int32_t* t_out, void* stream) {
+  WN_CHECK(m && m->B > 0 && m->enc.p && m->ctc_valid && n_keep_host && t_out,
+           "filter_blank_embedding: needs the encoder output and the CTC posteriors of the "
+           "current batch (wn_encode / wn_set_encoder_out, then wn_ctc_logprobs)");
+  WN_ENTER(m);
+  hipStream_t s = (hipStream_t)stream;
+  WN_HIP(hipSetDevice(m->device));
+  const int B = m->B, d = m->cfg.d_model, M = m->rows;
+  WN_CHECK(m->ctc_rows == M, "filter_blank_embedding: CTC posteriors of another layout");
+  WN_TRY(m->nb_map.ensure((size_t)std::max(M, 1) * sizeof(int)));
+  WN_TRY(m->nb_keep.ensure((size_t)B * sizeof(int)));
+  WN_TRY(nonblank_map(m->topk_idx.as<int>(), m->ctc_k, m->d_off.as<int>(), m->d_len.as<int>(), B,
+                      m->nb_map.as<int>(), m->nb_keep.as<int>(), s));
+  std::vector<int> keep(B);
+  WN_HIP(hipMemcpyAsync(keep.data(), m->nb_keep.p, (size_t)B * sizeof(int),
+                        hipMemcpyDeviceToHost, s));
+  WN_HIP(hipStreamSynchronize(s));
+  int T = 0;
+  for (int b = 0; b < B; ++b) { n_keep_host[b] = keep[b]; T = std::max(T, keep[b]); }
+  *t_out = T;
+  WN_CHECK(T > 0, "filter_blank_embedding: no non-blank frame in the whole batch");
+  // new layout: utterance b keeps min(len[b], T) rows -- attention_rescoring slices the
+  // zero-padded (B, T, d) tensor with the UNFILTERED lengths (asr_model.py:337-342,
+  // search.py:396): the selected rows, then zero rows the decoder attends to as well
+  std::vector<int> noff(B), nlen(B), old_off = m->off;
+  int rows = 0;
+  for (int b = 0; b < B; ++b) { noff[b] = rows; nlen[b] = std::min(m->len[b], T); rows += nlen[b]; }
+  WN_TRY(m->nb_enc.ensure((size_t)std::max(rows, 1) * d * sizeof(float)));
+  // descriptors of the OLD layout stay valid on the device until set_layout replaces them:
+  // gather first (it reads d_off of the old layout through a private copy)
+  WN_TRY(m->nb_off_old.ensure((size_t)B * sizeof(int)));
+  WN_HIP(hipMemcpyAsync(m->nb_off_old.p, m->d_off.p, (size_t)B * sizeof(int),
+                        hipMemcpyDeviceToDevice, s));
+  WN_TRY(set_layout(m, B, T, noff, nlen, rows, s));
+  WN_TRY(m->stage.end(s));
+  WN_TRY(nonblank_gather(m->enc.as<float>(), m->nb_map.as<int>(), m->nb_off_old.as<int>(),
+                         m->nb_keep.as<int>(), m->d_off.as<int>(), m->d_len.as<int>(),
+                         m->d_row_utt.as<int>(), m->nb_enc.as<float>(), d, rows, s));
+  std::swap(m->enc.p, m->nb_enc.p);
+  std::swap(m->enc.cap, m->nb_enc.cap);
+  if (padded_out_dev) {
+    // the reference's return value: (B, T, d), utterance b's selected rows then zeros
+    WN_HIP(hipMemsetAsync(padded_out_dev, 0, (size_t)B * T * d * sizeof(float), s));
+    for (int b = 0; b < B; ++b)
+      if (keep[b] > 0)
+        WN_HIP(hipMemcpyAsync(padded_out_dev + (size_t)b * T * d,
+                              m->enc.as<float>() + (size_t)noff[b] * d,
+                              (size_t)std::min(keep[b], nlen[b]) * d * sizeof(float),
+                              hipMemcpyDeviceToDevice, s));
+  }
   return 0;
 }
 

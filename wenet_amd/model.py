@@ -107,12 +107,6 @@ def config_from_yaml(configs: dict) -> _lib.WnConfig:
             raise NotImplementedError(
                 f'decoder_conf.{k}={dc[k]!r} is outside the accelerated path '
                 f'(only the reference default {v!r} has kernels)')
-    # asr_model.py:46,321-323: the encoder output is filtered to the non-blank frames
-    # before attention_rescoring -- not built here
-    if (configs.get('model_conf') or {}).get('apply_non_blank_embedding', False):
-        raise NotImplementedError(
-            'model_conf.apply_non_blank_embedding=True is outside the accelerated path '
-            '(filter_blank_embedding, asr_model.py:240-252, is not built)')
     vocab = configs['output_dim']
     st = (configs.get('tokenizer_conf') or {}).get('special_tokens')
     if model_type == 'whisper':
@@ -253,6 +247,8 @@ class ASRModel:
         mc = configs.get('model_conf') or {}
         self.ctc_weight = mc.get('ctc_weight', 0.5)
         self.reverse_weight = mc.get('reverse_weight', 0.0)
+        # asr_model.py:46,337-342: attention_rescoring sees only the non-blank frames
+        self.apply_non_blank_embedding = bool(mc.get('apply_non_blank_embedding', False))
         self.special_tokens = (configs.get('tokenizer_conf') or {}).get(
             'special_tokens')
         L = _lib.lib()
@@ -756,9 +752,48 @@ class ASRModel:
             if 'ctc_prefix_beam_search' in methods:
                 results['ctc_prefix_beam_search'] = prefix
         if 'attention_rescoring' in methods:
+            if self.apply_non_blank_embedding:
+                # asr_model.py:337-342: the decoder's memory becomes the frames whose CTC
+                # arg-max is not blank (+ the zero padding the reference leaves in)
+                self._filter_blank_current(B)
             results['attention_rescoring'] = self._rescore(
                 prefix, ctc_weight, reverse_weight)
         return results
+
+    def _filter_blank_current(self, B: int, out: Optional[torch.Tensor] = None):
+        """wn_filter_blank_embedding on the handle's current batch -> (kept rows per
+        utterance, T)."""
+        import ctypes
+        n_keep = np.zeros((B, ), dtype=np.int32)
+        t_out = ctypes.c_int32(0)
+        _lib.check(
+            self._L.wn_filter_blank_embedding(
+                self._h, out.data_ptr() if out is not None else None, _lib.i32p(n_keep),
+                ctypes.byref(t_out), _stream_ptr(self.device)), 'wn_filter_blank_embedding')
+        return n_keep, int(t_out.value)
+
+    def filter_blank_embedding(self, ctc_probs: torch.Tensor, encoder_out: torch.Tensor
+                               ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """asr_model.py:153-180: (B, T, V) CTC posteriors + (B, T, d) encoder output ->
+        the rows whose arg-max token is not 0, zero-padded to the longest selection, and the
+        (B, 1, T_sel) mask of the kept rows.  Like the reference, every one of the T frames
+        counts (the tensors carry no lengths)."""
+        _require_cuda(encoder_out, 'filter_blank_embedding')
+        _require_cuda(ctc_probs, 'filter_blank_embedding')
+        B, T, _ = encoder_out.shape
+        assert ctc_probs.shape[0] == B and ctc_probs.shape[1] == T
+        lens = torch.full((B, ), T, dtype=torch.int32)
+        self._set_encoder_out(encoder_out, lens)
+        probs = ctc_probs.detach().to(torch.float32).contiguous()
+        _lib.check(
+            self._L.wn_set_ctc_probs(self._h, probs.data_ptr(), _lib.i32p(lens.numpy()), B, T,
+                                     probs.shape[2], 1, _stream_ptr(self.device)),
+            'wn_set_ctc_probs')
+        out = torch.empty((B, T, encoder_out.shape[2]), dtype=torch.float32, device=self.device)
+        n_keep, t_sel = self._filter_blank_current(B, out)
+        sel = out.view(-1)[:B * t_sel * encoder_out.shape[2]].view(B, t_sel, -1)
+        mask = (torch.arange(t_sel).unsqueeze(0) < torch.from_numpy(n_keep).unsqueeze(1))
+        return sel, mask.unsqueeze(1).to(self.device)
 
     # older WeNet releases exposed decode() as recognize()
     def recognize(self, *args, **kwargs):

@@ -55,6 +55,56 @@ CONFIGS = {
         'model_conf': dict(ctc_weight=0.3, lsm_weight=0.1,
                            length_normalized_loss=False, reverse_weight=0.3),
     },
+    # examples/aishell/s0/conf/train_u2++_lite_conformer.yaml:1-68 at its own widths
+    'aishell_u2pp_lite': {
+        'input_dim': 80, 'output_dim': 4233,
+        'encoder': 'conformer',
+        'encoder_conf': dict(output_size=256, attention_heads=4,
+                             linear_units=2048, num_blocks=12,
+                             dropout_rate=0.1, positional_dropout_rate=0.1,
+                             attention_dropout_rate=0.1, input_layer='conv2d',
+                             normalize_before=True, cnn_module_kernel=8,
+                             use_cnn_module=True, activation_type='swish',
+                             pos_enc_layer_type='rel_pos',
+                             selfattention_layer_type='rel_selfattn',
+                             causal=True, use_dynamic_chunk=True,
+                             cnn_module_norm='layer_norm',
+                             use_dynamic_left_chunk=False),
+        'decoder': 'bitransformer',
+        'decoder_conf': dict(attention_heads=4, linear_units=1024,
+                             num_blocks=3, r_num_blocks=3, dropout_rate=0.1,
+                             positional_dropout_rate=0.1,
+                             self_attention_dropout_rate=0.1,
+                             src_attention_dropout_rate=0.1),
+        'model_conf': dict(ctc_weight=0.3, lsm_weight=0.1,
+                           length_normalized_loss=False, reverse_weight=0.3,
+                           apply_non_blank_embedding=True),
+    },
+    # the same recipe at tiny widths for tests
+    'tiny_lite': {
+        'input_dim': 80, 'output_dim': 53,
+        'encoder': 'conformer',
+        'encoder_conf': dict(output_size=64, attention_heads=1,
+                             linear_units=128, num_blocks=2,
+                             dropout_rate=0.1, positional_dropout_rate=0.1,
+                             attention_dropout_rate=0.1, input_layer='conv2d',
+                             normalize_before=True, cnn_module_kernel=8,
+                             use_cnn_module=True, activation_type='swish',
+                             pos_enc_layer_type='rel_pos',
+                             selfattention_layer_type='rel_selfattn',
+                             causal=True, use_dynamic_chunk=True,
+                             cnn_module_norm='layer_norm',
+                             use_dynamic_left_chunk=False),
+        'decoder': 'bitransformer',
+        'decoder_conf': dict(attention_heads=1, linear_units=96,
+                             num_blocks=2, r_num_blocks=1, dropout_rate=0.1,
+                             positional_dropout_rate=0.1,
+                             self_attention_dropout_rate=0.1,
+                             src_attention_dropout_rate=0.1),
+        'model_conf': dict(ctc_weight=0.3, lsm_weight=0.1,
+                           length_normalized_loss=False, reverse_weight=0.3,
+                           apply_non_blank_embedding=True),
+    },
     # examples/librispeech/s0/conf/train_conformer_bidecoder_large.yaml:3-62
     'librispeech_bidecoder_large': {
         'input_dim': 80, 'output_dim': 5002,
