@@ -408,6 +408,16 @@ int wn_op_ffn_x6(const float* X_dev, const float* W1_dev, const float* b1_dev,
                  const float* ln_w_dev, const float* ln_b_dev, float* y_out_dev, int32_t M,
                  int32_t D, int32_t F, int32_t act, float alpha, float eps, int32_t reps,
                  void* stream);
+/* Row-block six-product GEMM with the A rows in registers (csrc/gemm_x6r.hip), K = 256:
+ * epi 0: C (M, N) = A W^T + bias, N in {256, 512, 768} (the QKV projection,
+ * attention.py:109-131); epi 1 (N = 256): x <- x + alpha (A W^T + bias), y <- LayerNorm(x; ln_w,
+ * ln_b, eps) -- the attention output projection / pointwise_conv2 with the residual and the
+ * LayerNorm that follows (encoder_layer.py:238-240, 251-253).  `reps` launches (micro-benchmark;
+ * epi 1 then accumulates into x every time). */
+int wn_op_gemm_x6r(const float* A_dev, const float* W_dev, const float* bias_dev,
+                   float* x_inout_dev, const float* ln_w_dev, const float* ln_b_dev,
+                   float* y_dev, float* C_dev, int32_t M, int32_t N, int32_t epi, float alpha,
+                   float eps, int32_t reps, void* stream);
 /* out[i] = log_add(a[i], b[i]) (wenet/utils/common.py:302-310) in fp64 with the
  * routine the prefix beam search uses. */
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,

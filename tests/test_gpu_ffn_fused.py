@@ -101,6 +101,7 @@ def test_encoder_with_rowln_gemm_matches_gemm_plus_layernorm(B, frames, chunk):
     configs, sd, model = cached_model('aishell_u2pp', 0)
     feats, lens = S.make_features(B, frames, seed=73)
     try:
+        _lib.check(L.wn_tune_set(b'x6r', 0), 'tune')       # (the v_mfma_f32 forms under test)
         _lib.check(L.wn_tune_set(b'gemm_rowln', 0), 'tune')
         ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         ref = ref.cpu()
@@ -110,6 +111,7 @@ def test_encoder_with_rowln_gemm_matches_gemm_plus_layernorm(B, frames, chunk):
         got = got.cpu()
     finally:
         L.wn_tune_set(b'gemm_rowln', 1)
+        L.wn_tune_set(b'x6r', 1)
     assert torch.equal(got, got2.cpu())            # race screen
     err = (got - ref).abs().max().item()
     print(f'\n[B={B}] row-LN GEMM vs GEMM + LayerNorm: max |d enc| {err:.2e}')
@@ -148,3 +150,69 @@ def test_encoder_with_folded_relpos_attention_matches_the_two_contraction_form(c
     print(f'\n[{config} B={B}] folded rel-pos attention vs two contractions: max |d enc| '
           f'{err:.2e} (in the kernel), {err2:.2e} (separate pass)')
     assert 0 < err < 1e-4 and 0 < err2 < 1e-4
+
+
+@pytest.mark.parametrize('M,N,epi', [(7932, 256, 1), (7932, 768, 0), (7932, 512, 0), (33, 256, 1),
+                                     (1000, 256, 0), (31, 768, 0), (4097, 256, 1)])
+def test_gemm_x6r_vs_fp64(M, N, epi):
+    """csrc/gemm_x6r.hip (K = 256, A rows split in registers, W fragments straight from the
+    plane image) against fp64: epi 0 plain projection, epi 1 residual + LayerNorm over complete
+    rows; ragged row counts; deterministic."""
+    from wenet_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + N + epi)
+    A = torch.randn(M, 256, generator=g)
+    W = torch.randn(N, 256, generator=g) / 16.0
+    b = torch.randn(N, generator=g) * 0.3
+    x = torch.randn(M, N, generator=g)
+    lw = 1.0 + 0.2 * torch.randn(N, generator=g)
+    lb = 0.1 * torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T + b.double()
+    outs = []
+    for _ in range(2):
+        t = [v.cuda().contiguous() for v in (A, W, b, x.clone(), lw, lb)]
+        y = torch.empty((M, N), device='cuda')
+        C = torch.empty((M, N), device='cuda')
+        _lib.check(L.wn_op_gemm_x6r(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                    t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr(),
+                                    y.data_ptr(), C.data_ptr(), M, N, epi, 0.5, 1e-5, 1,
+                                    torch.cuda.current_stream().cuda_stream), 'x6r')
+        torch.cuda.synchronize()
+        outs.append((C.cpu(), t[3].cpu(), y.cpu()))
+    (C, xo, y), (C2, xo2, y2) = outs
+    if epi == 0:
+        err = (C.double() - ref).abs().max().item()
+        print(f'\n[{M}x{N}] max |err| {err:.2e}')
+        assert err < 5e-6 and torch.equal(C, C2)
+    else:
+        xr = x.double() + 0.5 * ref
+        yr = torch.nn.functional.layer_norm(xr, (N, ), lw.double(), lb.double(), 1e-5)
+        ex, ey = (xo.double() - xr).abs().max().item(), (y.double() - yr).abs().max().item()
+        print(f'\n[{M}x{N}] max |err| x {ex:.2e} y {ey:.2e}')
+        assert ex < 5e-6 and ey < 2e-5
+        assert torch.equal(xo, xo2) and torch.equal(y, y2)
+
+
+@pytest.mark.parametrize('B,frames,chunk', [(32, (800, 1200), -1), (8, (300, 700), 16)])
+def test_encoder_with_the_row_block_x6_gemms_matches_the_f32_forms(B, frames, chunk):
+    """QKV, attention output projection + LayerNorm and pointwise_conv2 + LayerNorm on
+    csrc/gemm_x6r.hip (default from 512 rows on) against the v_mfma_f32 forms: fp32
+    reassociation noise only, deterministic."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model('aishell_u2pp', 0)
+    feats, lens = S.make_features(B, frames, seed=74)
+    try:
+        _lib.check(L.wn_tune_set(b'x6r', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        ref = ref.cpu()
+        _lib.check(L.wn_tune_set(b'x6r', 1), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got = got.cpu()
+    finally:
+        L.wn_tune_set(b'x6r', 1)
+    assert torch.equal(got, got2.cpu())
+    err = (got - ref).abs().max().item()
+    print(f'\n[B={B}] row-block x6 GEMMs vs v_mfma_f32 forms: max |d enc| {err:.2e}')
+    assert 0 < err < 2e-4

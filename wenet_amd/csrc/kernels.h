@@ -195,6 +195,22 @@ struct RowLnArgs {
   float* y; int ldy;      // may alias A (a block reads only the rows it writes)
   int M, N, K;
 };
+// Row-block six-product GEMM, K = 256, A rows in registers (gemm_x6r.hip)
+struct X6RArgs {
+  const float* A = nullptr; int lda = 0;     // [M][lda] fp32
+  const void* W3 = nullptr;                  // X3 image of W (N x 256)
+  const float* bias = nullptr;               // [N] or null
+  int M = 0, N = 0;
+  int epi = 0;          // 0: C = acc + bias; 1: x_out = resid + alpha (acc + bias), y = LN(x_out)
+  float* C = nullptr; int ldc = 0;
+  const float* resid = nullptr; int ldr = 0; float alpha = 1.0f;   // resid may alias x_out
+  float* x_out = nullptr; int ldx = 0;
+  const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
+  float* y = nullptr; int ldy = 0;           // may alias A (a block reads its rows first)
+};
+extern int g_x6r;     // wn_tune_set("x6r")
+bool gemm_x6r_supported(int M, int N, int K, int epi);
+int gemm_x6r(const X6RArgs& a, hipStream_t s);
 extern int g_gemm_rowln;
 bool gemm_rowln_supported(int M, int N, int K);
 int gemm_rowln(const RowLnArgs& a, hipStream_t s);

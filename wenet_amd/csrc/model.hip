@@ -991,8 +991,21 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       // x += MHA(LN(x))                               encoder_layer.py:230-238
       WN_TRY(ln(L.norm_mha, x, t1, M, d, eps, s, h16));
     }
-    WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s, ACT_NONE, nullptr, 0, 1.0f, false,
-                  h16));
+    bool qkv_done = false;
+    if (!h16 && t_gemm_prec == PREC_F32 && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+        gemm_x6r_supported(M, 3 * d, L.qkv.in, 0)) {
+      auto it = t_x6->find(L.qkv.w);
+      if (it != t_x6->end()) {
+        X6RArgs g;
+        g.A = t1; g.lda = d; g.W3 = it->second; g.bias = L.qkv.b; g.M = M; g.N = 3 * d;
+        g.epi = 0; g.C = qkv; g.ldc = 3 * d;
+        WN_TRY(gemm_x6r(g, s));
+        qkv_done = true;
+      }
+    }
+    if (!qkv_done)
+      WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s, ACT_NONE, nullptr, 0, 1.0f, false,
+                    h16));
     AttnArgs a;
     a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d;
     a.ldq = a.ldk = a.ldv = 3 * d;
@@ -1020,7 +1033,23 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     WN_TRY(attention(a, s));
     // x += out_proj(context); t1 = LN_conv(x)       encoder_layer.py:236-240
     const bool rowln = !h16 && t_gemm_prec == PREC_F32 && gemm_rowln_supported(M, d, d);
-    if (rowln) {
+    // the same fusion as six bf16 plane products with the A rows in registers (gemm_x6r.hip)
+    auto x6r_rowln = [&](const Linear& l, const float* A, const Norm& nrm) -> int {
+      if (!(rowln && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+            gemm_x6r_supported(M, d, l.in, 1)))
+        return 1;
+      auto it = t_x6->find(l.w);
+      if (it == t_x6->end()) return 1;
+      X6RArgs g;
+      g.A = A; g.lda = d; g.W3 = it->second; g.bias = l.b; g.M = M; g.N = d; g.epi = 1;
+      g.resid = x; g.ldr = d; g.alpha = 1.0f; g.x_out = x; g.ldx = d;
+      g.ln_w = nrm.w; g.ln_b = nrm.b; g.eps = eps; g.y = t1; g.ldy = d;
+      return gemm_x6r(g, s) == 0 ? 0 : -1;
+    };
+    int xr = x6r_rowln(L.out, t2, L.norm_conv);
+    if (xr < 0) return -2;
+    if (xr == 0) {
+    } else if (rowln) {
       RowLnArgs g;
       g.A = t2; g.lda = d; g.W = L.out.w; g.bias = L.out.b; g.resid = x; g.ldr = d;
       g.alpha = 1.0f; g.x_out = x; g.ldx = d; g.ln_w = L.norm_conv.w; g.ln_b = L.norm_conv.b;
@@ -1042,7 +1071,10 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     dw.t_max = m->Tp; dw.eps = 1e-5f;
     WN_TRY(dwconv_ln_silu(dw, s));
     // x += pointwise_conv2(.); t1 = LN_ff(x)        encoder_layer.py:251-255
-    if (rowln) {
+    xr = x6r_rowln(L.pw2, t1, L.norm_ff);
+    if (xr < 0) return -2;
+    if (xr == 0) {
+    } else if (rowln) {
       RowLnArgs g;
       g.A = t1; g.lda = d; g.W = L.pw2.w; g.bias = L.pw2.b; g.resid = x; g.ldr = d;
       g.alpha = 1.0f; g.x_out = x; g.ldx = d; g.ln_w = L.norm_ff.w; g.ln_b = L.norm_ff.b;
@@ -2014,6 +2046,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "beam_weak_hash") g_beam_weak_hash = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "gemm_rowln") g_gemm_rowln = value;
+  else if (k == "x6r") g_x6r = value;
   else if (k == "ffn_ring") g_ffn_ring = value;
   else if (k == "ffn_x6f") g_ffn_x6f = value;
   else if (k == "ffn_x6f_ring") g_ffn_x6f_ring = value;
@@ -3140,6 +3173,22 @@ int wn_op_ffn_x6(const float* X, const float* W1, const float* b1, const float* 
     WN_TRY(ffn_reduce_ln(x, part.as<float>(), S, b2, alpha, ln_w, ln_b, nullptr, nullptr, y,
                          M, D, eps, 0, s));
   }
+  return 0;
+}
+
+int wn_op_gemm_x6r(const float* A, const float* W, const float* bias, float* x_inout,
+                   const float* ln_w, const float* ln_b, float* y, float* C, int32_t M,
+                   int32_t N, int32_t epi, float alpha, float eps, int32_t reps, void* stream) {
+  WN_CHECK(A && W && M > 0 && gemm_x6r_supported(M, N, 256, epi), "gemm_x6r: shape");
+  hipStream_t s = (hipStream_t)stream;
+  static thread_local DevBuf w3;
+  WN_TRY(w3.ensure(x6_bytes(N, 256)));
+  WN_TRY(x6_split(W, N, 256, 256, w3.as<char>(), s));
+  X6RArgs a;
+  a.A = A; a.lda = 256; a.W3 = w3.as<char>(); a.bias = bias; a.M = M; a.N = N; a.epi = epi;
+  a.C = C; a.ldc = N; a.resid = x_inout; a.ldr = N; a.alpha = alpha; a.x_out = x_inout;
+  a.ldx = N; a.ln_w = ln_w; a.ln_b = ln_b; a.eps = eps; a.y = y; a.ldy = N;
+  for (int r = 0; r < (reps > 0 ? reps : 1); ++r) WN_TRY(gemm_x6r(a, s));
   return 0;
 }
 
