@@ -14,11 +14,14 @@
 //   S^T = K (Q+u)^T [+ P (Q+v)^T]   4 (8) x v_mfma_f32_32x32x16_bf16
 //       lane l holds, for ITS query (l & 31), keys (r&3) + 8(r>>2) + 4(l>>5)
 //   online softmax on the lane's 16 scores (max / sum: one exchange with lane^32)
-//   O += P V                         4 x v_mfma_f32_32x32x16_bf16
-//       the lane's probabilities r = 8j .. 8j+7 ARE the A fragment of MFMA j
+//   O^T += V^T P^T                   4 x v_mfma_f32_32x32x16_bf16
+//       the lane's probabilities r = 8j .. 8j+7 ARE the "B" fragment of MFMA j
 //       (k slot (hi, e) <-> key 16j + 4hi + (e&3) + 8(e>>2)); V is stored
-//       TRANSPOSED in LDS, Vt[dim][slot], slot = 16j + 8hi + e, so the B fragment
-//       (8 keys of one dim) is one 16-byte read.
+//       TRANSPOSED in LDS, Vt[dim][slot], slot = 16j + 8hi + e, so the "A" fragment
+//       (8 keys of one dim) is one 16-byte read; the output stays transposed (lane =
+//       query, registers = dims): the online-softmax rescale and the final 1 / l are the
+//       lane's own scalars (round 3; before, O had the queries along the registers and
+//       every rescale cost 16 cross-lane reads).
 // With 16x the MFMA rate the softmax VALU work (16 scores per lane and tile)
 // bounds the kernel; NW grows with the sequence length so that the fp32 K / V
 // stream from L2 is shared by more queries (64 B/clk/CU budget).
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = -1e30f, l_run = 0.f;      // running maximum of the RAW scores, running sum
 
   // ---- tile staging ---------------------------------------------------------
   // K (and P): 32 rows x 16 float4 chunks, natural mapping (coalesced rows).
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
   }
   __syncthreads();
 
-  // scores are kept in the log2 domain: one multiply by scale * log2(e), v_exp_f32 directly
+  // exponent in the log2 domain: exp2((s - m) * scale * log2(e)), v_exp_f32 directly
   const float cs = a.scale * 1.4426950408889634f;
   for (int it = 0; it < n_it; ++it) {
     const int cur = it & 1;
@@ -267,36 +270,57 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
         }
       }
       // ---- online softmax on this lane's query ----------------------------------
-      // interior tiles of an unmasked sequence need no per-key window test (uniform)
+      // The running maximum is kept on the RAW scores (scale > 0: same arg-max); the scale and
+      // log2(e) enter through ONE fma per score, exp2(s cs - m cs), instead of a multiply, a
+      // subtract and the window select: the loop is bound by this VALU work (16 scores per
+      // lane and 32-key tile against 8 MFMAs), not by the matrix pipe.  Interior tiles of an
+      // unmasked sequence take the branch without any per-key window test (uniform).
       const bool full = a.mask_mode == 0 && j0 + KT <= kvlen;
-      float tmax = -1e30f;
-      bool ok[16];
+      float psum = 0.f, alpha;
+      if (full) {
+        float t0 = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        float t1 = fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]));
+        float t2 = fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11]));
+        float t3 = fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]));
+        float tmax = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+        const float mc = -m_new * cs;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        ok[r] = full || ((j >= jmin) && (j < jmax));
-        sc[r] *= cs;
-        if (ok[r]) tmax = fmaxf(tmax, sc[r]);
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      float psum = 0.f;
+        for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], cs, mc));
+        psum = ((sc[0] + sc[1]) + (sc[2] + sc[3])) + ((sc[4] + sc[5]) + (sc[6] + sc[7])) +
+               (((sc[8] + sc[9]) + (sc[10] + sc[11])) + ((sc[12] + sc[13]) + (sc[14] + sc[15])));
+        m_run = m_new;
+      } else {
+        float tmax = -1e30f;
+        bool ok[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = ok[r] ? __builtin_amdgcn_exp2f(sc[r] - m_new) : 0.f;
-        sc[r] = p;
-        psum += p;
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          ok[r] = (j >= jmin) && (j < jmax);
+          if (ok[r]) tmax = fmaxf(tmax, sc[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+        const float mc = -m_new * cs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = ok[r] ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], cs, mc)) : 0.f;
+          sc[r] = p;
+          psum += p;
+        }
+        m_run = m_new;
       }
       l_run = l_run * alpha + psum;
-      m_run = m_new;
-      // rescale the running output: its rows are queries (r&3)+8(r>>2)+4hi
+      // rescale the running output: O is kept TRANSPOSED (rows = dims, column = this lane's
+      // query), so the factor is the lane's own -- no exchange between lanes
       if (!__all(alpha == 1.0f)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * hi, 64);
-          o0[r] *= ar;
-          o1[r] *= ar;
+          o0[r] *= alpha;
+          o1[r] *= alpha;
         }
       }
       // ---- O += P V ---------------------------------------------------------------
@@ -308,8 +332,10 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
         const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(sV + li * VSTR + j * 16 + hi * 8);
         const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(sV + (32 + li) * VSTR + j * 16 +
                                                            hi * 8);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, v0, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, v1, o1, 0, 0, 0);
+        // O^T += V^T P^T: the Vt fragment is the "A" operand (rows = dims), the lane's own
+        // probabilities the "B" operand (column = its query)
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pa, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pa, o1, 0, 0, 0);
       }
     }
     if (it + 1 < n_it) lstore(cur ^ 1);
@@ -318,21 +344,26 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   // ---- normalise and store ---------------------------------------------------
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;  // fully-masked row -> 0
+  // lane = query row, registers = dims (r&3) + 8(r>>2) + 4 hi (o0) / 32 + ... (o1): four
+  // consecutive dims per register quad
+  const int qrow = q0 + wave * 32 + li;
+  if (qrow < qlen) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int qr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-    const float ir = __shfl(inv, qr, 64);
-    const int qrow = q0 + wave * 32 + qr;
-    if (qrow < qlen) {
+    for (int g = 0; g < 4; ++g) {
+      const int d = 8 * g + 4 * hi;
+      const f32x4 a0 = f32x4{o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]} * inv;
+      const f32x4 a1 = f32x4{o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]} * inv;
       if (a.o_bf16) {  // bf16-storage mode: the context only feeds the out-proj GEMM
-        __bf16* op = reinterpret_cast<__bf16*>(a.O) + (int64_t)(qoff + qrow) * a.ldo +
-                     h * 64;
-        op[li] = (__bf16)(o0[r] * ir);
-        op[32 + li] = (__bf16)(o1[r] * ir);
+        __bf16* op = reinterpret_cast<__bf16*>(a.O) + (int64_t)(qoff + qrow) * a.ldo + h * 64;
+        bf16x4 b0, b1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b0[e] = (__bf16)a0[e]; b1[e] = (__bf16)a1[e]; }
+        *reinterpret_cast<bf16x4*>(op + d) = b0;
+        *reinterpret_cast<bf16x4*>(op + 32 + d) = b1;
       } else {
         float* op = a.O + (int64_t)(qoff + qrow) * a.ldo + h * 64;
-        op[li] = o0[r] * ir;
-        op[32 + li] = o1[r] * ir;
+        *reinterpret_cast<f32x4*>(op + d) = a0;
+        *reinterpret_cast<f32x4*>(op + 32 + d) = a1;
       }
     }
   }
