@@ -333,18 +333,36 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs a) {
   RowRegs<E> acc, cp;
   acc.load(a.bias, lane);
   cp.load(a.cpad, lane);
-  for (int k = 0; k < a.K; ++k) {
-    const int tt = t + k - lpad;
-    RowRegs<E> wk;
-    wk.load(a.wt + (int64_t)k * (E * 64), lane);
-    if (tt >= 0 && tt < len) {
-      RowRegs<E> xv;
-      xv.load(a.x + (int64_t)(off + tt) * a.ldx, lane);
+  // taps in groups of 8: ALL loads of a group (taps + the 8 neighbour rows) are issued before
+  // the first fma -- one memory round trip per group instead of one per tap (13.9 -> 13.1 us at
+  // M = 7932, K = 8, r03t; the order of the fmas is unchanged)
+  constexpr int TG = E <= 8 ? 8 : 4;
+  for (int k0 = 0; k0 < a.K; k0 += TG) {
+    RowRegs<E> wk[TG], xv[TG];
+    int kind[TG];          // 0: outside (nothing), 1: row of the utterance, 2: the pad frame
 #pragma unroll
-      for (int e = 0; e < E; ++e) acc.v[e] = fmaf(wk.v[e], xv.v[e], acc.v[e]);
-    } else if ((tt < 0 && a.causal) || (tt >= len && tt < a.t_max)) {
+    for (int i = 0; i < TG; ++i) {
+      const int k = k0 + i, tt = t + k - lpad;
+      kind[i] = 0;
+      if (k < a.K) {
+        wk[i].load(a.wt + (int64_t)k * (E * 64), lane);
+        if (tt >= 0 && tt < len) {
+          kind[i] = 1;
+          xv[i].load(a.x + (int64_t)(off + tt) * a.ldx, lane);
+        } else if ((tt < 0 && a.causal) || (tt >= len && tt < a.t_max)) {
+          kind[i] = 2;
+        }
+      }
+    }
 #pragma unroll
-      for (int e = 0; e < E; ++e) acc.v[e] = fmaf(wk.v[e], cp.v[e], acc.v[e]);
+    for (int i = 0; i < TG; ++i) {
+      if (kind[i] == 1) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc.v[e] = fmaf(wk[i].v[e], xv[i].v[e], acc.v[e]);
+      } else if (kind[i] == 2) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc.v[e] = fmaf(wk[i].v[e], cp.v[e], acc.v[e]);
+      }
     }
   }
   if (a.norm_mode == 0) {
