@@ -182,8 +182,10 @@ int build_x6_images(wn_model* m) {
       ws.push_back(&L.src_kv); ws.push_back(&L.src_out); ws.push_back(&L.ff1);
       ws.push_back(&L.ff2);
     }
-  // (the Transformer encoder of the Whisper configuration runs its GEMMs on v_mfma_f32 or,
-  // in the bf16 / fp8 modes, on the low-precision kernels: no images for tf_layers)
+  // the Transformer encoder of the Whisper configuration (round 3): its fp32 mode goes through
+  // linear() -> split pass + six-product GEMM like every other large fp32 GEMM
+  for (const auto& L : m->tf_layers) { ws.push_back(&L.qkv); ws.push_back(&L.out);
+                                       ws.push_back(&L.ff1); ws.push_back(&L.ff2); }
   if (m->conv2.w) ws.push_back(&m->conv2);   // [d][(ky*3+kx)*d + c]: 16-channel k blocks per tap
   std::vector<const Linear*> vocab;          // V rows; the image pads them to a multiple of 32
   if (m->ctc.w) vocab.push_back(&m->ctc);
