@@ -39,6 +39,8 @@
 // Arithmetic: identical products to gemm_x6.hip (six of the nine plane products, small ones
 // first); what differs from the two-GEMM path is only the fp32 summation order (two
 // accumulators per hidden tile over even / odd k blocks; the hidden sum per 16-unit block).
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "kernels.h"
@@ -367,8 +369,13 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
   Frag6 fc;
 #pragma unroll
   for (int q = 0; q < 6; ++q) fc.p[RT[q]][RP[q]] = read_frag(0, 0, RT[q], RP[q]);
-  for (int c = 0; c < NC; ++c) {
-    const bool last = c + 1 == NC;
+  // One chunk of 64 hidden units = 8 sub-stages.  Two straight-line copies: the steady state
+  // (every stage that follows exists: constant wait counts, unconditional DMA issue) and the
+  // block's LAST chunk (static tail counts).  Conditional branches on `last` inside the body
+  // cost ~15 us per launch in the MFMA-only variant (r03w): with one wave per SIMD an
+  // instruction-fetch bubble behind a branch drains the matrix pipe.
+  auto chunk = [&](auto last_tag, int c) {
+    constexpr bool last = decltype(last_tag)::value;
     f32x4 bq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sub = 0; sub < 8; ++sub) {
@@ -406,10 +413,12 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
             // younger stages stay in flight), the barrier publishes t + 1 and frees t's buffer
             __builtin_amdgcn_sched_barrier(0);
             if (!(VAR & 8)) {
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              const int tail = SPC - 2 - st < 0 ? 0 : (SPC - 2 - st > RING - 2 ? RING - 2 : SPC - 2 - st);
-              if (last) wait_vm_stages(tail * HALF); else wait_vm_stages((RING - 2) * HALF);
-              __builtin_amdgcn_s_barrier();
+              if (!(VAR & 1024)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int tail = SPC - 2 - st < 0 ? 0 : (SPC - 2 - st > RING - 2 ? RING - 2 : SPC - 2 - st);
+                if (last) wait_vm_stages(tail * HALF); else wait_vm_stages((RING - 2) * HALF);
+              }
+              if (!(VAR & 2048)) __builtin_amdgcn_s_barrier();
             }
             if (!(VAR & 2)) {
               if (st + RING < SPC) issue(c, st + RING, buf);
@@ -423,7 +432,13 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
           if (VAR & 64) {
             fn = fc;
           } else if (g < 3 || !sync_sub) {
-            if (tl == 1) fn.p[RT[q]][RP[q]] = read_frag(buf, gs + 1, RT[q], RP[q]);
+            if (VAR & 4096) {           // measurement: the six reads of the next group as one burst
+              if (k == 0)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) fn.p[RT[i]][RP[i]] = read_frag(buf, gs + 1, RT[i], RP[i]);
+            } else if (tl == 1) {
+              fn.p[RT[q]][RP[q]] = read_frag(buf, gs + 1, RT[q], RP[q]);
+            }
           } else if (k >= 6 && (sub < 7 || !last)) {
             fn.p[RT[k - 6]][RP[k - 6]] = read_frag(buf, 0, RT[k - 6], RP[k - 6]);
           }
@@ -448,7 +463,9 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
         fc = fn;
       }
     }
-  }
+  };
+  for (int c = 0; c + 1 < NC; ++c) chunk(std::false_type{}, c);
+  chunk(std::true_type{}, NC - 1);
 
   // ---- epilogue: lane = row of X, registers = d 32 i + 8 g + 4 hi + e ------------------------
   const int row = tm * 128 + wave * 32 + li;
@@ -543,6 +560,10 @@ int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
       case 14: return launch_x6f<ACT_SILU, 6, 14>(a, s);
       case 76: return launch_x6f<ACT_SILU, 6, 76>(a, s);
       case 70: return launch_x6f<ACT_SILU, 6, 70>(a, s);
+      case 1094: return launch_x6f<ACT_SILU, 6, 1094>(a, s);
+      case 4096: return launch_x6f<ACT_SILU, 6, 4096>(a, s);
+      case 4110: return launch_x6f<ACT_SILU, 6, 4110>(a, s);
+      case 2118: return launch_x6f<ACT_SILU, 6, 2118>(a, s);
       case 128: return launch_x6f<ACT_SILU, 6, 128>(a, s);
       default: break;
     }
