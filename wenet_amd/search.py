@@ -113,14 +113,22 @@ def _prefix_beam(handle: int, B: int, max_len: int, beam_size: int,
             _lib.i32p(hyp_lens), _lib.i32p(hyp_tlens), _lib.i32p(hyp_tokens),
             _lib.i32p(hyp_times), _lib.f64p(hyp_scores), max_len,
             _stream_ptr(device)), 'wn_ctc_prefix_beam_search')
+    # one bulk conversion of the used corner of each array (a per-hypothesis
+    # ndarray.tolist() costs more than the GPU search of a 32-utterance batch)
+    L = max(int(hyp_lens.max(initial=0)), 1)
+    Lt = max(int(hyp_tlens.max(initial=0)), 1)
+    tok_l = hyp_tokens[:, :, :L].tolist()
+    tim_l = hyp_times[:, :, :Lt].tolist()
+    len_l, tlen_l = hyp_lens.tolist(), hyp_tlens.tolist()
+    sc_l, n_l = hyp_scores.tolist(), n_hyps.tolist()
     results = []
     for b in range(B):
-        n = int(n_hyps[b])
-        nbest = [tuple(hyp_tokens[b, i, :hyp_lens[b, i]].tolist())
-                 for i in range(n)]
-        nbest_scores = [float(hyp_scores[b, i]) for i in range(n)]
-        nbest_times = [hyp_times[b, i, :hyp_tlens[b, i]].tolist()
-                       for i in range(n)]
+        n = n_l[b]
+        tb, lb = tok_l[b], len_l[b]
+        mb, ub = tim_l[b], tlen_l[b]
+        nbest = [tuple(tb[i][:lb[i]]) for i in range(n)]
+        nbest_scores = sc_l[b][:n]
+        nbest_times = [mb[i][:ub[i]] for i in range(n)]
         results.append(
             DecodeResult(tokens=nbest[0], score=nbest_scores[0],
                          times=nbest_times[0], nbest=nbest,
