@@ -443,6 +443,10 @@ const char* wn_profile_kernel_name(const wn_model* m);
  * algorithmic bytes of the roofline kernel with (positionwise_feed_forward.py:50-58 has no such
  * notion: it is a property of the launch geometry). */
 int32_t wn_profile_ffn_split(const wn_model* m);
+/* Measurement: shader-clock stamps [4 waves][16] written by the clock-stamp variants of the fused
+ * feed-forward kernel (wn_tune_set("ffn_x6f_var", 8704 ...), tools/bench_x6.py --clocks): entry
+ * i = start of sub-stage i of one block's last steady-state chunk, entry 8 = its end. */
+int wn_profile_ffn_clocks(uint64_t* out64);
 
 /* Test hook: "n_layers" = run only the first n encoder layers (-1: all),
  * "skip_after_norm" = 1 leaves out encoder.after_norm; lets the parity tests

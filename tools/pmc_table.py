@@ -17,7 +17,7 @@ import sys
 # the roofline kernel of bench.py: the six-product FFN w_1 GEMM (round 2, gemm_x6.hip; before
 # it the fused feed-forward kernel 'ffn_fused_kernel<1, 1, 4>'; round 1: the FFN w_1 GEMM
 # 'gemm_f32_kernel<128, 128, 2, 4, 1, false, false, false, 32, 1>')
-ROOFLINE_KERNEL = 'ffn_x6f_kernel<1, 3, 512>'
+ROOFLINE_KERNEL = 'ffn_x6f_kernel<1, 3, 16896>'
 
 
 def load(dirname):

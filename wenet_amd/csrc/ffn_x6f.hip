@@ -50,6 +50,10 @@ namespace wn {
 
 namespace {
 
+// VAR & 8192 (measurement): shader-clock stamps of one block's waves at the sub-stage boundaries
+// of its last steady-state chunk (tools/bench_x6.py --clocks)
+__device__ unsigned long long g_x6f_clk[4][16];
+
 constexpr int REC = X3_REC;
 constexpr int XSTAGE = 24 * REC;     // 24 records per stage
 constexpr int XD = 256;              // d_model of this kernel
@@ -130,6 +134,11 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
   }
   if (tm >= tiles_m) return;
 
+  unsigned long long clk[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr ((VAR & 8192) != 0) {
+    clk[9] = __builtin_readcyclecounter();
+    clk[12] = __builtin_amdgcn_s_memrealtime();
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < 4);
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
   }
   for (int i = tid; i < NC * 64; i += 256) b1s[i] = p.b1[cg0 * 64 + i];
 #pragma unroll
-  for (int t = 0; t < RING; ++t) issue(0, t, t);     // (RING <= SPC)
+  for (int t = 0; t < ((VAR & 16384) ? RING - 1 : RING); ++t) issue(0, t, t);     // (RING <= SPC)
   // exact three-way bf16 split of the rows in registers (x6.h): the operand fragments of
   // phase A for the whole launch; no plane image of LN(x) is ever written
   bf16x8 X[XKB][3];
@@ -374,11 +383,17 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
   // block's LAST chunk (static tail counts).  Conditional branches on `last` inside the body
   // cost ~15 us per launch in the MFMA-only variant (r03w): with one wave per SIMD an
   // instruction-fetch bubble behind a branch drains the matrix pipe.
+  if constexpr ((VAR & 8192) != 0) clk[10] = __builtin_readcyclecounter();
   auto chunk = [&](auto last_tag, int c) {
     constexpr bool last = decltype(last_tag)::value;
     f32x4 bq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sub = 0; sub < 8; ++sub) {
+      if constexpr ((VAR & 8192) != 0 && !last) {
+        __builtin_amdgcn_sched_barrier(0);
+        clk[sub] = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         Frag6 fn;
@@ -420,12 +435,28 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
               }
               if (!(VAR & 2048)) __builtin_amdgcn_s_barrier();
             }
-            if (!(VAR & 2)) {
+            if (!(VAR & 2) && !(VAR & 16384)) {
               if (st + RING < SPC) issue(c, st + RING, buf);
               else if (!last) issue(c + 1, st + RING - SPC, buf);
             }
             buf = buf + 1 == RING ? 0 : buf + 1;
             __builtin_amdgcn_sched_barrier(0);
+          }
+          // VAR & 16384: the DMA of stage st + RING - 1 (into the buffer the previous barrier
+          // freed) rides on the MFMAs of stage st, one 1-KB piece per six MFMAs -- twelve
+          // buffer_load ... lds in a row right behind the barrier keep all four waves in the
+          // issue queue of the CU's one address unit for ~700 cycles (r03x clock stamps)
+          if constexpr ((VAR & 16384) != 0 && !(VAR & 2)) {
+            static_assert(!(VAR & 16384) || HALF == 2, "spread DMA: 48-record stages");
+            // (piece groups: the two lightest slots of the twelve)
+            const int ka = do_piece ? 9 : 2, kb = do_piece ? 11 : 8;
+            if ((k == ka || k == kb) && gs < 6) {
+              const int j12 = gs * 2 + (k == kb ? 1 : 0);
+              const int tst = st + RING - 1;
+              const int bufp = buf == 0 ? RING - 1 : buf - 1;
+              if (tst < SPC) issue_one(c, tst * HALF + j12 / 6, bufp, j12 % 6);
+              else if (!last) issue_one(c + 1, (tst - SPC) * HALF + j12 / 6, bufp, j12 % 6);
+            }
           }
           // fragment reads of the next group: one per MFMA pair; in the last group of a stage
           // all six behind the barrier, one per MFMA
@@ -463,10 +494,12 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
         fc = fn;
       }
     }
+    if constexpr ((VAR & 8192) != 0 && !last) clk[8] = __builtin_readcyclecounter();
   };
   for (int c = 0; c + 1 < NC; ++c) chunk(std::false_type{}, c);
   chunk(std::true_type{}, NC - 1);
 
+  if constexpr ((VAR & 8192) != 0) clk[11] = __builtin_readcyclecounter();
   // ---- epilogue: lane = row of X, registers = d 32 i + 8 g + 4 hi + e ------------------------
   const int row = tm * 128 + wave * 32 + li;
   if (row < p.M) {
@@ -482,6 +515,18 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
         else if (VAR & 256) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(o), "v"(v) : "memory");
         else *reinterpret_cast<f32x4*>(o) = v;
       }
+  }
+  if constexpr ((VAR & 8192) != 0) {
+    // entries 0..8: sub-stage boundaries of the last steady-state chunk; 9 kernel entry, 10 loop
+    // start, 11 loop end, 12 / 13 the 100-MHz real-time counter at entry / after the stores landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    clk[13] = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 14; ++i) g_x6f_clk[wave][i] = clk[i];
+      g_x6f_clk[wave][14] = t_end;
+    }
   }
 }
 
@@ -508,6 +553,11 @@ int launch_x6f(const FfnX6Args& a, hipStream_t s) {
 int g_ffn_x6f = 1;        // wn_tune_set("ffn_x6f"): 0 = the two six-product GEMMs (A/B, tests)
 int g_ffn_x6f_ring = 3;   // wn_tune_set("ffn_x6f_ring"): 3 = three stages of 48 records (default), 4..6 = stages of 24
 int g_ffn_x6f_var = 0;    // wn_tune_set("ffn_x6f_var"): measurement variants of the kernel (VAR)
+
+int ffn_x6f_clocks(unsigned long long* out) {
+  WN_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x6f_clk), sizeof(g_x6f_clk)));
+  return 0;
+}
 
 int x6_split_perm(const float* src, int R, int K, int ld, void* dst, hipStream_t s) {
   WN_CHECK(src && dst && R > 0 && K > 0 && K % 16 == 0 && ld % 4 == 0, "x6_split_perm: shape");
@@ -565,11 +615,18 @@ int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
       case 4110: return launch_x6f<ACT_SILU, 6, 4110>(a, s);
       case 2118: return launch_x6f<ACT_SILU, 6, 2118>(a, s);
       case 128: return launch_x6f<ACT_SILU, 6, 128>(a, s);
+      case 8704: return launch_x6f<ACT_SILU, 3, 8704>(a, s);     // burst-DMA kernel + clock stamps
+      case 512: return launch_x6f<ACT_SILU, 3, 512>(a, s);       // DMA of a stage as one burst behind the barrier
+      case 25088: return launch_x6f<ACT_SILU, 3, 25088>(a, s);   // default kernel + clock stamps
+      case 8768: return launch_x6f<ACT_SILU, 3, 8768>(a, s);     // ... without fragment reads
+      case 8708: return launch_x6f<ACT_SILU, 3, 8708>(a, s);     // ... without pieces
+      case 8706: return launch_x6f<ACT_SILU, 3, 8706>(a, s);     // ... without DMA
+      case 8782: return launch_x6f<ACT_SILU, 3, 8782>(a, s);     // ... MFMAs only
       default: break;
     }
   }
   // ring 3 (default): three stages of 48 records; 4..6: stages of 24 records
-  if (g_ffn_x6f_ring <= 3) { WN_X6F(3, 512) }
+  if (g_ffn_x6f_ring <= 3) { WN_X6F(3, 16896) }
   else if (g_ffn_x6f_ring == 4) { WN_X6F(4, 0) }
   else if (g_ffn_x6f_ring == 5) { WN_X6F(5, 0) }
   else { WN_X6F(6, 0) }
