@@ -443,7 +443,7 @@ const char* wn_profile_kernel_name(const wn_model* m);
  * algorithmic bytes of the roofline kernel with (positionwise_feed_forward.py:50-58 has no such
  * notion: it is a property of the launch geometry). */
 int32_t wn_profile_ffn_split(const wn_model* m);
-/* Measurement: shader-clock stamps [4 waves][16] written by the clock-stamp variants of the fused
+/* Measurement: shader-clock stamps [4 waves][24] written by the clock-stamp variants of the fused
  * feed-forward kernel (wn_tune_set("ffn_x6f_var", 8704 ...), tools/bench_x6.py --clocks): entry
  * i = start of sub-stage i of one block's last steady-state chunk, entry 8 = its end. */
 int wn_profile_ffn_clocks(uint64_t* out64);

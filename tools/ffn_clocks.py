@@ -28,7 +28,9 @@ def main():
     lw, lb = torch.ones(D, device='cuda'), torch.zeros(D, device='cuda')
     y = torch.empty(M, D, device='cuda')
     _lib.check(L.wn_tune_set(b'ffn_x6f', 1), 'tune')
-    out = np.zeros((4, 16), dtype=np.uint64)
+    if len(sys.argv) > 1:
+        _lib.check(L.wn_tune_set(b'ffn_x6f_map', int(sys.argv[1])), 'tune')
+    out = np.zeros((4, 24), dtype=np.uint64)
     for var, what in ((8704, 'stage DMA as one burst behind the barrier (r03 first form)'), (25088, 'default kernel (DMA spread over the stage)'), (8768, 'no fragment reads'),
                       (8708, 'no pieces'), (8706, 'no DMA'), (8782, 'MFMAs only')):
         _lib.check(L.wn_tune_set(b'ffn_x6f_var', var), 'tune')
@@ -43,11 +45,14 @@ def main():
             rows.append(np.diff(out[:, :9].astype(np.int64), axis=1))
         d = np.median(np.stack(rows), axis=0)          # [wave][sub]
         o = out.astype(np.int64)
-        cyc = o[:, 14] - o[:, 9]
+        cyc = o[:, 20] - o[:, 9]
         ns = (o[:, 13] - o[:, 12]) * 10.0
+        print('  prologue of wave 0: entry -> loads + DMA issued %d -> split done %d -> all landed %d -> '
+              'bias stored + barrier %d -> loop %d cycles' % tuple(
+                  int(o[0, b] - o[0, a]) for a, b in ((9, 15), (15, 16), (16, 17), (17, 18), (18, 10))))
         print('  last launch, per wave: prologue %s | loop %s | epilogue %s cycles; kernel %s cycles in '
               '%s ns -> %s GHz' % ((o[:, 10] - o[:, 9]).tolist(), (o[:, 11] - o[:, 10]).tolist(),
-                                   (o[:, 14] - o[:, 11]).tolist(), cyc.tolist(), ns.tolist(),
+                                   (o[:, 20] - o[:, 11]).tolist(), cyc.tolist(), ns.tolist(),
                                    np.round(cyc / ns, 2).tolist()))
         print(f'var {var} ({what}): cycles per sub-stage (ideal 1536), median of 5 launches')
         for w in range(4):

@@ -52,7 +52,7 @@ namespace {
 
 // VAR & 8192 (measurement): shader-clock stamps of one block's waves at the sub-stage boundaries
 // of its last steady-state chunk (tools/bench_x6.py --clocks)
-__device__ unsigned long long g_x6f_clk[4][16];
+__device__ unsigned long long g_x6f_clk[4][24];
 
 constexpr int REC = X3_REC;
 constexpr int XSTAGE = 24 * REC;     // 24 records per stage
@@ -110,7 +110,7 @@ __device__ __forceinline__ void wait_vm_stages(int stages) {
 // activation / split pieces, 8 no waits / barrier inside the loop, 64 no fragment reads; 128 /
 // 256 = partials stored sc0 sc1 / nt; 512 = stages of 48 records (ring of 3).
 template <int ACT, int RING, int VAR>
-__global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_m) {
+__global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_m, int pairmap) {
   extern __shared__ __attribute__((aligned(16))) char smem_g[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   // VAR & 512: stages of 48 records (two "sub-stages" of 24: one barrier per 96 MFMAs of a wave)
@@ -124,7 +124,14 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
   // one slice (S <= 8) or two (S = 16)
   const int bid = blockIdx.x, xcd = bid & 7, rr = bid >> 3;
   int slice, tm;
-  if (p.S <= 8) {
+  if (pairmap && p.S >= 2 && p.S <= 8) {
+    // two slices per XCD: the two blocks of a row tile that share an XCD (consecutive rr) fetch
+    // its X rows from HBM once -- 16 MB instead of 32 at config 2 -- and the XCD's L2 holds
+    // two W slices (3 MB)
+    const int nsp = p.S >> 1, pair = xcd % nsp, tg = xcd / nsp;
+    slice = 2 * pair + (rr & 1);
+    tm = (rr >> 1) * (8 / nsp) + tg;
+  } else if (p.S <= 8) {
     slice = xcd & (p.S - 1);
     tm = rr * (8 / p.S) + xcd / p.S;
   } else {
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
   }
   if (tm >= tiles_m) return;
 
-  unsigned long long clk[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long clk[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if constexpr ((VAR & 8192) != 0) {
     clk[9] = __builtin_readcyclecounter();
     clk[12] = __builtin_amdgcn_s_memrealtime();
@@ -213,23 +220,65 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
   };
 
   // ---- prologue: X fragments, bias slice, the first RING stages ------------------------------
-  // X rows as fp32 (lane = row li of the wave's 32, k half hi): 8 consecutive floats per k block
+  // X rows as fp32.  The fragment layout wants lane = row (li of the wave's 32 rows, k half hi: 8
+  // consecutive floats per k block) -- but a global load with lane = row touches 64 different
+  // 128-byte lines per instruction: 32 such loads per wave took ~10 k cycles of this prologue
+  // (r03x stamps).  So the rows are loaded COALESCED -- pass q = k blocks 4 q .. 4 q + 3 = a
+  // 256-byte segment of every row, instruction j = rows 4 j .. 4 j + 3, 16 lanes per segment --
+  // and turned into the fragment layout through the ring buffer that is still idle (the DMA of
+  // stage RING - 1 starts behind the first barrier): a wave-private 32 x (256 + 16)-byte patch,
+  // row stride 68 dwords = conflict-free ds_read_b128 for lane = row.
+  constexpr bool XT = (VAR & 16384) != 0;
+  bf16x8 X[XKB][3];
   const int xrow = min(tm * 128 + wave * 32 + li, p.M - 1);
   f32x4 xa[XKB], xb[XKB];
-  {
-    const float* xr = p.X + (int64_t)xrow * p.ldx + hi * 8;
+  f32x4 xr[4][8];
+  if constexpr (XT) {
+    const int r4 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = min(tm * 128 + wave * 32 + 4 * j + r4, p.M - 1);
+        xr[q][j] = *reinterpret_cast<const f32x4*>(p.X + (int64_t)row * p.ldx + q * 64 + c16 * 4);
+      }
+  } else {
+    const float* xr0 = p.X + (int64_t)xrow * p.ldx + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < XKB; ++ks) {
-      xa[ks] = *reinterpret_cast<const f32x4*>(xr + ks * 16);
-      xb[ks] = *reinterpret_cast<const f32x4*>(xr + ks * 16 + 4);
+      xa[ks] = *reinterpret_cast<const f32x4*>(xr0 + ks * 16);
+      xb[ks] = *reinterpret_cast<const f32x4*>(xr0 + ks * 16 + 4);
     }
   }
-  for (int i = tid; i < NC * 64; i += 256) b1s[i] = p.b1[cg0 * 64 + i];
 #pragma unroll
   for (int t = 0; t < ((VAR & 16384) ? RING - 1 : RING); ++t) issue(0, t, t);     // (RING <= SPC)
+  // the bias slice: loaded behind the X rows and the first stages (the counter that orders
+  // them retires in issue order -- a wait for these values in front of the DMA issue would hold
+  // the DMA back until every X row has arrived), stored to LDS after the split
+  float b1v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    b1v[i] = tid + 256 * i < NC * 64 ? p.b1[cg0 * 64 + tid + 256 * i] : 0.f;
+  if constexpr ((VAR & 8192) != 0) { __builtin_amdgcn_sched_barrier(0); clk[15] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
   // exact three-way bf16 split of the rows in registers (x6.h): the operand fragments of
   // phase A for the whole launch; no plane image of LN(x) is ever written
-  bf16x8 X[XKB][3];
+  if constexpr (XT) {
+    char* patch = smem_g + (RING - 1) * STG + wave * (32 * 272);
+    const int r4 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<f32x4*>(patch + (4 * j + r4) * 272 + c16 * 16) = xr[q][j];
+      // (wave-private patch: the wave's own LDS operations complete in order)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        xa[4 * q + k4] = *reinterpret_cast<const f32x4*>(patch + li * 272 + k4 * 64 + hi * 32);
+        xb[4 * q + k4] = *reinterpret_cast<const f32x4*>(patch + li * 272 + k4 * 64 + hi * 32 + 16);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next pass overwrites the patch
+    }
+  }
 #pragma unroll
   for (int ks = 0; ks < XKB; ++ks) {
 #pragma unroll
@@ -239,12 +288,18 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
       X[ks][0][4 + e] = sb.h0; X[ks][1][4 + e] = sb.h1; X[ks][2][4 + e] = sb.h2;
     }
   }
+  if constexpr ((VAR & 8192) != 0) { __builtin_amdgcn_sched_barrier(0); clk[16] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr ((VAR & 8192) != 0) { __builtin_amdgcn_sched_barrier(0); clk[17] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
   for (int ks = 0; ks < XKB; ++ks)
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(X[ks][pl]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (tid + 256 * i < NC * 64) b1s[tid + 256 * i] = b1v[i];
   __syncthreads();
+  if constexpr ((VAR & 8192) != 0) { __builtin_amdgcn_sched_barrier(0); clk[18] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 
   f32x16 Y[8];
 #pragma unroll
@@ -502,7 +557,27 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
   if constexpr ((VAR & 8192) != 0) clk[11] = __builtin_readcyclecounter();
   // ---- epilogue: lane = row of X, registers = d 32 i + 8 g + 4 hi + e ------------------------
   const int row = tm * 128 + wave * 32 + li;
-  if (row < p.M) {
+  if constexpr (XT) {
+    // A store with lane = row puts 32 bytes into each of 32 lines per instruction and the four
+    // waves' 128 of them queue up in the CU's one address unit (r03x stamps: 2.5 k cycles per
+    // wave, one after the other).  The ring is free now: the wave's 32 x 256 tile goes through a
+    // private patch (row stride 1040 bytes: conflict-free both ways) and leaves as whole rows.
+    __syncthreads();                                    // every wave has left the last stage
+    char* patch = smem_g + wave * (32 * 1040);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(patch + li * 1040 + (i * 32 + 8 * g + 4 * hi) * 4) =
+            f32x4{Y[i][4 * g], Y[i][4 * g + 1], Y[i][4 * g + 2], Y[i][4 * g + 3]};
+    float* P0 = p.P + ((int64_t)slice * p.M + tm * 128 + wave * 32) * XD + lane * 4;
+    const int nrow = min(32, p.M - (tm * 128 + wave * 32));
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(patch + r * 1040 + lane * 16);
+      if (r < nrow) *reinterpret_cast<f32x4*>(P0 + (int64_t)r * XD) = v;
+    }
+  } else if (row < p.M) {
     float* P = p.P + ((int64_t)slice * p.M + row) * XD;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -524,8 +599,8 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
     const unsigned long long t_end = __builtin_readcyclecounter();
     if (blockIdx.x == gridDim.x / 2 && lane == 0) {
 #pragma unroll
-      for (int i = 0; i < 14; ++i) g_x6f_clk[wave][i] = clk[i];
-      g_x6f_clk[wave][14] = t_end;
+      for (int i = 0; i < 20; ++i) g_x6f_clk[wave][i] = clk[i];
+      g_x6f_clk[wave][20] = t_end;
     }
   }
 }
@@ -535,7 +610,10 @@ int launch_x6f(const FfnX6Args& a, hipStream_t s) {
   const int tiles_m = cdiv(a.M, 128);
   const int NC = a.F / a.S / 64;
   const size_t lds = (size_t)RING * XSTAGE * ((VAR & 512) ? 2 : 1) + (size_t)NC * 64 * sizeof(float);
-  const int grid = a.S <= 8 ? cdiv(tiles_m, 8 / a.S) * 8 : tiles_m * a.S;
+  const int pairmap = g_ffn_x6f_map != 0 && a.S >= 2 && a.S <= 8;
+  const int grid = pairmap      ? cdiv(tiles_m, 16 / a.S) * 16
+                   : a.S <= 8 ? cdiv(tiles_m, 8 / a.S) * 8
+                              : tiles_m * a.S;
   auto kern = ffn_x6f_kernel<ACT, RING, VAR>;
   static bool done = false;
   if (!done) {
@@ -543,7 +621,7 @@ int launch_x6f(const FfnX6Args& a, hipStream_t s) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, tiles_m);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, tiles_m, pairmap);
   WN_HIP(hipGetLastError());
   return 0;
 }
@@ -552,6 +630,7 @@ int launch_x6f(const FfnX6Args& a, hipStream_t s) {
 
 int g_ffn_x6f = 1;        // wn_tune_set("ffn_x6f"): 0 = the two six-product GEMMs (A/B, tests)
 int g_ffn_x6f_ring = 3;   // wn_tune_set("ffn_x6f_ring"): 3 = three stages of 48 records (default), 4..6 = stages of 24
+int g_ffn_x6f_map = 1;    // wn_tune_set("ffn_x6f_map"): 1 = two hidden slices per XCD (X rows fetched twice, not S times)
 int g_ffn_x6f_var = 0;    // wn_tune_set("ffn_x6f_var"): measurement variants of the kernel (VAR)
 
 int ffn_x6f_clocks(unsigned long long* out) {

@@ -169,11 +169,18 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
 #pragma unroll
     for (int q = 0; q < NPA; ++q) asm volatile("" : "+v"(pix[q]));
   }
-  auto issue = [&](int g) {
-    if (p.probe & 2) return;                       // ablation: no DMA (tools/bench_x6.py)
+  // DMA of stage g = k block kb0 + g: the stage's descriptors / offsets (scalar), then its
+  // pieces one by one -- piece q of this wave is record j = q NW + wave of the stage.
+  // (the descriptor pair lives in plain locals: a struct with buffer-resource members does not
+  // survive the host pass)
+  __amdgpu_buffer_rsrc_t d_ra = ra32, d_rb = ra32;
+  int d_sa = 0, d_sb = 0, d_delta = 0;
+  char* d_dst = smem_x;
+  auto make_desc = [&](int g) {
     const int kb = kb0 + g;
-    char* dst = smem_x + (g % RING) * STAGE;
-    int sa = (m0 >> 5) * TILE3, delta = 0, ka = kb, kw = kb;
+    d_dst = smem_x + (g % RING) * STAGE;
+    d_sa = (m0 >> 5) * TILE3; d_delta = 0;
+    int ka = kb, kw = kb;
     if (CONV) {
       // K is walked channel block by channel block with the taps inside (p.conv_taps > 0):
       // the 9 taps of a 16-channel block re-read the same input pixels, and the block tiles
@@ -184,46 +191,52 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
       ka = kb - tap * p.conv_kbc;
       if (p.conv_taps > 0) { ka = kb / p.conv_taps; tap = kb - ka * p.conv_taps; }
       kw = tap * p.conv_kbc + ka;
-      sa = AF32 ? ka * 64 : 0;
-      delta = p.tap_delta[tap];
+      d_sa = AF32 ? ka * 64 : 0;
+      d_delta = p.tap_delta[tap];
     } else if (AF32) {
-      sa = kb * 64;
+      d_sa = kb * 64;
     }
-    const __amdgpu_buffer_rsrc_t ra =
-        AF32 ? ra32
-             : __builtin_amdgcn_make_buffer_rsrc(
-                   const_cast<char*>(reinterpret_cast<const char*>(p.A3)) + ka * slab_a, 0,
-                   (int)min(slab_a, (int64_t)0x7fffffff), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+    if (!AF32)
+      d_ra = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(p.A3)) + ka * slab_a, 0,
+          (int)min(slab_a, (int64_t)0x7fffffff), 0x00020000);
+    d_rb = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.B3)) + kw * slab_b, 0,
         (int)min(slab_b, (int64_t)0x7fffffff), 0x00020000);
-    const int sb = (n0 >> 5) * TILE3;
-#pragma unroll
-    for (int j0 = 0; j0 < NP; j0 += NW) {
-      const int j = j0 + wave;
-      if (j < A_BYTES / REC) {
-        if (AF32) {
-          unsigned vo = (unsigned)pix[j0 / NW];
-          if (CONV) {
-            const int rl = (j & 1) * 16 + (lane >> 2);
-            vo = (unsigned)((pix[j0 / NW] + delta) * p.conv_kbc * 64 +
-                            (((lane & 3) ^ ((rl >> 2) & 3)) << 4));
-          }
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + j * REC), 16, vo, sa, 0,
-                                                   0);
-        } else if (CONV) {
-          const int P = pix[j0 / NW] + delta;
-          const unsigned vo = (unsigned)(((P >> 5) * 3 + j % 3) * REC + hi * 512 + (P & 31) * 16);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + j * REC), 16, vo, sa, 0,
-                                                   0);
-        } else {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + j * REC), 16, vlane,
-                                                   sa + j * REC, 0, 0);
+    d_sb = (n0 >> 5) * TILE3;
+  };
+  constexpr int NPW = (NP + NW - 1) / NW;          // pieces per wave and stage (at most)
+  auto issue_piece = [&](int q) {
+    if (p.probe & 2) return;                       // ablation: no DMA (tools/bench_x6.py)
+    const int j = q * NW + wave;
+    const int qa = q < NPA ? q : NPA - 1;          // (A pieces only: j < A_BYTES / REC)
+    if (j < A_BYTES / REC) {
+      if (AF32) {
+        unsigned vo = (unsigned)pix[qa];
+        if (CONV) {
+          const int rl = (j & 1) * 16 + (lane >> 2);
+          vo = (unsigned)((pix[qa] + d_delta) * p.conv_kbc * 64 +
+                          (((lane & 3) ^ ((rl >> 2) & 3)) << 4));
         }
-      } else if (j < NP)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(dst + j * REC), 16, vlane,
-                                                 sb + (j - A_BYTES / REC) * REC, 0, 0);
-    }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(d_ra, (lds_ptr)(d_dst + j * REC), 16, vo, d_sa, 0,
+                                                 0);
+      } else if (CONV) {
+        const int P = pix[qa] + d_delta;
+        const unsigned vo = (unsigned)(((P >> 5) * 3 + j % 3) * REC + hi * 512 + (P & 31) * 16);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(d_ra, (lds_ptr)(d_dst + j * REC), 16, vo, d_sa, 0,
+                                                 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(d_ra, (lds_ptr)(d_dst + j * REC), 16, vlane,
+                                                 d_sa + j * REC, 0, 0);
+      }
+    } else if (j < NP)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rb, (lds_ptr)(d_dst + j * REC), 16, vlane,
+                                               d_sb + (j - A_BYTES / REC) * REC, 0, 0);
+  };
+  auto issue = [&](int g) {
+    make_desc(g);
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) issue_piece(q);
   };
 
   struct FA { bf16x8 p[3]; };
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
   // six plane products, the small ones first, the two accumulators of the A tile
   // alternating (no MFMA waits for its predecessor's result); W fragment = MFMA "A" (rows
   // of the instruction's result = columns of C)
-  auto mma = [&](const FA& a, const FB& b, int i) {
+  auto mma = [&](const FA& a, const FB& b, int i, auto&& between) {
     constexpr int PB[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
     if (p.probe & 1) {                             // ablation: no MFMAs, keep the reads alive
       asm volatile("" :: "v"(a.p[0]), "v"(a.p[1]), "v"(a.p[2]));
@@ -280,11 +293,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
       return;
     }
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = 0; q < 6; ++q) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.p[j][PB[q]], a.p[PA[q]],
                                                             acc[i][j], 0, 0, 0);
+      between(q);
+    }
   };
 
   // ---- pipeline ----------------------------------------------------------------------------
@@ -320,18 +335,42 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
   __builtin_amdgcn_s_barrier();
   FB fb = loadB(0);
   FA fa = loadA(0, 0);
+  // The DMA of stage g + RING does not follow the barrier as one burst: the CU has ONE address
+  // unit, a 1-KB piece occupies it for ~16 cycles, and NP pieces issued by all waves at once
+  // hold every wave in the issue queue for NP x 16 cycles per stage (ffn_x6f.hip, clock stamps
+  // r03x: ~700 of ~3800 cycles).  The pieces ride on the MFMAs instead: slot 0 = the A tiles
+  // behind the barrier of stage g, slots 1.. = the tiles of stage g + 1 in front of ITS
+  // barrier, PP pieces per slot between the plane products -- all of them issued before the
+  // counted wait of stage g + 1, so the wait counts do not change.
+  constexpr int NS = TA - 1 > 0 ? TA - 1 : 1;      // tiles (slots) between two barriers' waits
+  constexpr int PP = (NPW + NS - 1) / NS;          // pieces per slot
+  bool dnext_ok = false;
   for (int g = 0; g < nkb; ++g) {
 #pragma unroll
     for (int i = 0; i < TA; ++i) {
       FA na; FB nb;
       if (i + 1 < TA) na = loadA(g, i + 1);
       else if (g + 1 < nkb) { nb = loadB(g + 1); na = loadA(g + 1, 0); }
-      mma(fa, fb, i);
+      const int slot = i > BAR ? i - BAR - 1 : i < BAR ? TA - 1 - BAR + i : -1;
+      mma(fa, fb, i, [&](int q) {
+        if (TA < 3 || slot < 0 || !dnext_ok) return;
+#pragma unroll
+        for (int r = 0; r < PP; ++r) {
+          const int qq = PP <= 3 ? (r * 6) / PP + 1 : r;     // after which plane product
+          const int pc = slot * PP + r;
+          if (q == qq && pc < NPW) issue_piece(pc);
+        }
+      });
       if (i == BAR) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stage g fully read
         wait_pieces(max(0, min(nkb - 2 - g, RING - 2)));
         __builtin_amdgcn_s_barrier();
-        if (g + RING < nkb) issue(g + RING);
+        if (TA < 3) {
+          if (g + RING < nkb) issue(g + RING);
+        } else {
+          dnext_ok = g + RING < nkb;
+          if (dnext_ok) make_desc(g + RING);
+        }
       }
       if (i + 1 < TA) fa = na;
       else if (g + 1 < nkb) { fa = na; fb = nb; }

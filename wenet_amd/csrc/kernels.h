@@ -176,7 +176,8 @@ struct FfnX6Args {
 extern int g_ffn_x6f;        // wn_tune_set("ffn_x6f"): 0 = two six-product GEMMs, 2 = force (tests)
 extern int g_ffn_x6f_var;    // wn_tune_set("ffn_x6f_var"): measurement variants (ffn_x6f.hip VAR)
 extern int g_ffn_x6f_ring;   // wn_tune_set("ffn_x6f_ring"): DMA ring depth 4..6
-int ffn_x6f_clocks(unsigned long long* out);   // VAR & 8192 stamps [4 waves][16]
+extern int g_ffn_x6f_map;    // wn_tune_set("ffn_x6f_map"): 1 = two hidden slices per XCD, 0 = one
+int ffn_x6f_clocks(unsigned long long* out);   // VAR & 8192 stamps [4 waves][24]
 int x6_split_perm(const float* src, int R, int K, int ld, void* dst, hipStream_t s);
 int ffn_x6f_split(int M, int F);
 bool ffn_x6f_supported(int M, int D, int F, int act);
