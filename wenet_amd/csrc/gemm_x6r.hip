@@ -8,19 +8,23 @@
 // 23-37 us per launch (MFMA busy 0.23-0.48, profiles/r03i): tile GEMMs at this size are all
 // prologue and epilogue, and the six-product tile GEMM needs a separate pass that writes the
 // plane image of A.  Here the structure of ffn_x6f.hip is reused instead:
-//   * a block = 4 waves = ONE wave per SIMD owns 32 rows of A; every wave loads those rows as
-//     fp32 (lane = row, its k half) and splits them into the three bf16 planes in registers --
-//     the "B" operand fragments of all 16 k blocks, 192 registers, no plane image of A;
+//   * a block = 4 waves = ONE wave per SIMD owns 32 rows of A; the block loads those rows once
+//     as fp32 (whole rows per instruction) and turns them through LDS into the fragment layout
+//     (lane = row, its k half); every wave splits them into the three bf16 planes in registers
+//     -- the "B" operand fragments of all 16 k blocks, 192 registers, no plane image of A;
 //   * the waves split N: wave w computes columns [w N / 4, (w + 1) N / 4) = NT tiles of 32, so
 //     each W fragment is read by exactly one wave -- straight from the weight plane image in
 //     L2 into registers (16 B per lane, one 1-KB record per instruction, PF k blocks ahead):
 //     no LDS, no DMA ring, no barrier in the main loop; 248 blocks re-read the same 0.4-1.2 MB
 //     image, which stays in every XCD's L2;
 //   * W fragment = the instruction's "A" operand, so a lane ends up with ONE row and the columns
-//     8 g + 4 (lane / 32) + q of every tile: bias / residual / stores are 16-byte pieces of a row,
-//     and a row's LayerNorm statistics are 32 NT values per lane, one exchange with lane ^ 32 and
-//     one LDS round between the four waves (two passes: mean, then the centred squares, like
-//     layernorm_kernel).
+//     8 g + 4 (lane / 32) + q of every tile: a row's LayerNorm statistics are 32 NT values per
+//     lane, one exchange with lane ^ 32 and one LDS round between the four waves (two passes:
+//     mean, then the centred squares, like layernorm_kernel);
+//   * no global access uses lane = row (32 bytes of 32 different lines per instruction: the A
+//     rows alone cost ~10 k cycles that way): residual, x_out, y and C tiles pass through a
+//     wave-private LDS patch and cross the memory pipe as contiguous row segments (round 3:
+//     out-projection + LayerNorm 17.8 -> 14.4 us, QKV 31.6 -> 30.4 us stand-alone).
 // Grid = ceil(M / 32) blocks (248 at M = 7932: the 256 CUs once).
 #include "common.h"
 #include "kernels.h"
@@ -37,6 +41,8 @@ constexpr int RKB = RK / 16;         // 16 k blocks
 template <int NT, int EPI, int PF>
 __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   __shared__ float red[2][4][32];
+  constexpr int PATCH = 4 * 32 * (NT * 128 + 16) > 32 * 1040 ? 4 * 32 * (NT * 128 + 16) : 32 * 1040;
+  __shared__ __attribute__((aligned(16))) char patch[PATCH];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < 4);
@@ -46,14 +52,21 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   const int rowc = min(row, p.M - 1);
 
   // ---- A rows: fp32, 8 consecutive floats per k block and lane ---------------------------------
+  // The fragment layout wants lane = row -- as a global load that is 64 different 128-byte lines
+  // per instruction, and every wave needs all 32 rows.  The block loads the rows ONCE, whole rows
+  // per instruction (wave w: rows 8 w .. 8 w + 7), and turns them through LDS: row stride 1040
+  // bytes = 260 dwords, conflict-free for the lane = row reads.
   f32x4 xa[RKB], xb[RKB];
   {
-    const float* ar = p.A + (int64_t)rowc * p.lda + hi * 8;
+    f32x4 rowv[8];
 #pragma unroll
-    for (int ks = 0; ks < RKB; ++ks) {
-      xa[ks] = *reinterpret_cast<const f32x4*>(ar + ks * 16);
-      xb[ks] = *reinterpret_cast<const f32x4*>(ar + ks * 16 + 4);
+    for (int j = 0; j < 8; ++j) {
+      const int r = min(m0 + wave * 8 + j, p.M - 1);
+      rowv[j] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + lane * 4);
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      *reinterpret_cast<f32x4*>(patch + (wave * 8 + j) * 1040 + lane * 16) = rowv[j];
   }
   // ---- W fragments: records [k block][tile][plane] of the weight image, this wave's NT tiles ---
   const int Tn = (p.N + 31) >> 5;
@@ -71,6 +84,12 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   };
 #pragma unroll
   for (int s = 0; s < PF; ++s) load_w(s);
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < RKB; ++ks) {
+    xa[ks] = *reinterpret_cast<const f32x4*>(patch + li * 1040 + ks * 64 + hi * 32);
+    xb[ks] = *reinterpret_cast<const f32x4*>(patch + li * 1040 + ks * 64 + hi * 32 + 16);
+  }
 
   // exact three-way bf16 split of the rows in registers (x6.h)
   bf16x8 X[RKB][3];
@@ -106,23 +125,64 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   }
 
   // ---- epilogue: lane = row, registers = columns col0 + 32 t + 8 g + 4 hi + e ------------------
+  // Global accesses with lane = row move 32 bytes of 32 different lines per instruction; every
+  // tile of C / x_out / y and of the residual goes through a wave-private LDS patch instead (32
+  // rows x NT * 128 bytes, row stride + 16 bytes: conflict-free for the lane = row side) and
+  // crosses the memory pipe as row segments of NT * 128 contiguous bytes.
   const int col0 = wave * NT * 32;
-  if constexpr (EPI == 0) {
-    if (row < p.M) {
-      float* crow = p.C + (int64_t)row * p.ldc;
+  constexpr int SEG = NT * 128;                 // bytes of a row this wave owns
+  constexpr int PST = SEG + 16;                 // patch row stride
+  constexpr int LPR = SEG / 16;                 // lanes per row segment (8 NT)
+  constexpr int NIT = 32 * LPR / 64;            // instructions per tile on the coalesced side
+  __syncthreads();                              // the A patch is dead
+  char* wp = patch + wave * (32 * PST);
+  auto put = [&](const f32x4 (&v)[NT][4]) {     // lane = row layout -> patch
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = col0 + t * 32 + 8 * g + 4 * hi;
-          if (c >= p.N) continue;
-          f32x4 v = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c);
-          *reinterpret_cast<f32x4*>(crow + c) = v;
-        }
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(wp + li * PST + (t * 32 + 8 * g + 4 * hi) * 4) = v[t][g];
+  };
+  auto get = [&](f32x4 (&v)[NT][4]) {           // patch -> lane = row layout
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        v[t][g] = *reinterpret_cast<const f32x4*>(wp + li * PST + (t * 32 + 8 * g + 4 * hi) * 4);
+  };
+  // coalesced side: piece q = it * 64 + lane of the tile = row q / LPR, 16-byte piece q % LPR
+  auto store_rows = [&](float* base, int ld) {  // patch -> global, whole segments
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 64 + lane, r = q / LPR, pc = q - r * LPR;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wp + r * PST + pc * 16);
+      if (m0 + r < p.M && col0 + pc * 4 < p.N)
+        *reinterpret_cast<f32x4*>(base + (int64_t)(m0 + r) * ld + col0 + pc * 4) = v;
     }
-  } else {
+  };
+  if constexpr (EPI == 0) {
     f32x4 v[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = col0 + t * 32 + 8 * g + 4 * hi;
+        v[t][g] = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+        if (p.bias && c < p.N) v[t][g] += *reinterpret_cast<const f32x4*>(p.bias + c);
+      }
+    put(v);
+    store_rows(p.C, p.ldc);
+  } else {
+    f32x4 v[NT][4], rs[NT][4];
+    // (loading these rows in the prologue instead, behind the A rows, was slower: 14.4 -> 15.8 us)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 64 + lane, r = q / LPR, pc = q - r * LPR;
+      const int rc = min(m0 + r, p.M - 1);
+      *reinterpret_cast<f32x4*>(wp + r * PST + pc * 16) =
+          *reinterpret_cast<const f32x4*>(p.resid + (int64_t)rc * p.ldr + col0 + pc * 4);
+    }
+    get(rs);
     float s1 = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -131,11 +191,11 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
         const int c = col0 + t * 32 + 8 * g + 4 * hi;
         f32x4 a = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
         if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c);
-        const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)rowc * p.ldr + c);
-        v[t][g] = r + p.alpha * a;
+        v[t][g] = rs[t][g] + p.alpha * a;
         s1 += (v[t][g][0] + v[t][g][1]) + (v[t][g][2] + v[t][g][3]);
-        if (row < p.M) *reinterpret_cast<f32x4*>(p.x_out + (int64_t)row * p.ldx + c) = v[t][g];
       }
+    put(v);
+    store_rows(p.x_out, p.ldx);
     // mean over the row's N columns: lane pair, then the four waves
     s1 += __shfl_xor(s1, 32, 64);
     if (hi == 0) red[0][wave][li] = s1;
@@ -158,20 +218,18 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
     const float var =
         ((red[1][0][li] + red[1][1][li]) + (red[1][2][li] + red[1][3][li])) / (float)p.N;
     const float rstd = 1.0f / sqrtf(var + p.eps);
-    if (row < p.M) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = col0 + t * 32 + 8 * g + 4 * hi;
-          const f32x4 w = *reinterpret_cast<const f32x4*>(p.ln_w + c);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(p.ln_b + c);
-          f32x4 o;
+      for (int g = 0; g < 4; ++g) {
+        const int c = col0 + t * 32 + 8 * g + 4 * hi;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p.ln_w + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.ln_b + c);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (v[t][g][e] - mean) * rstd * w[e] + b[e];
-          *reinterpret_cast<f32x4*>(p.y + (int64_t)row * p.ldy + c) = o;
-        }
-    }
+        for (int e = 0; e < 4; ++e) v[t][g][e] = (v[t][g][e] - mean) * rstd * w[e] + b[e];
+      }
+    put(v);
+    store_rows(p.y, p.ldy);
   }
 }
 
