@@ -193,6 +193,38 @@ def test_gemm_x6r_vs_fp64(M, N, epi):
         assert torch.equal(xo, xo2) and torch.equal(y, y2)
 
 
+@pytest.mark.parametrize('M', [7932, 45, 1000])
+def test_gemm_x6r_glu_vs_fp64(M):
+    """csrc/gemm_x6r.hip epi 2: pointwise_conv1 + GLU (convolution.py:115-118) over the weight
+    rows permuted per 64 as [32 values | 32 gates] (wn_model_create does that at load) against
+    fp64; only the N / 2 GLU columns of C are written."""
+    from wenet_amd import _lib
+    L = _lib.lib()
+    d = 256
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, d, generator=g)
+    W = torch.randn(2 * d, d, generator=g) / 16.0       # reference order: [values | gates]
+    b = torch.randn(2 * d, generator=g) * 0.3
+    pre = A.double() @ W.double().T + b.double()
+    ref = pre[:, :d] * torch.sigmoid(pre[:, d:])
+    perm = torch.cat([torch.cat([torch.arange(32) + 32 * u, torch.arange(32) + 32 * u + d])
+                      for u in range(d // 32)])
+    Wp, bp = W[perm].contiguous(), b[perm].contiguous()
+    outs = []
+    for _ in range(2):
+        t = [v.cuda().contiguous() for v in (A, Wp, bp)]
+        C = torch.full((M, 2 * d), float('nan'), device='cuda')
+        _lib.check(L.wn_op_gemm_x6r(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, None,
+                                    None, None, C.data_ptr(), M, 2 * d, 2, 1.0, 1e-5, 1,
+                                    torch.cuda.current_stream().cuda_stream), 'x6r')
+        torch.cuda.synchronize()
+        outs.append(C.cpu())
+    err = (outs[0][:, :d].double() - ref).abs().max().item()
+    print(f'\n[{M}] GLU max |err| {err:.2e}')
+    assert err < 5e-6 and torch.equal(outs[0][:, :d], outs[1][:, :d])
+    assert torch.isnan(outs[0][:, d:]).all()
+
+
 @pytest.mark.parametrize('B,frames,chunk', [(32, (800, 1200), -1), (8, (300, 700), 16)])
 def test_encoder_with_the_row_block_x6_gemms_matches_the_f32_forms(B, frames, chunk):
     """QKV, attention output projection + LayerNorm and pointwise_conv2 + LayerNorm on

@@ -27,7 +27,7 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     reps = 50
     for n, epi, what in ((256, 1, 'proj + residual + LayerNorm'), (256, 0, 'proj'),
-                         (512, 0, 'proj'), (768, 0, 'QKV')):
+                         (512, 0, 'proj'), (512, 2, 'pointwise_conv1 + GLU'), (768, 0, 'QKV')):
         A = torch.randn(M, 256, device='cuda')
         W = torch.randn(n, 256, device='cuda') / 16
         b = torch.randn(n, device='cuda')

@@ -37,7 +37,8 @@ namespace {
 constexpr int RK = 256;              // K of this kernel
 constexpr int RKB = RK / 16;         // 16 k blocks
 
-// EPI 0: C = acc + bias; EPI 1: x_out = resid + alpha (acc + bias), y = LayerNorm(x_out)
+// EPI 0: C = acc + bias; EPI 1: x_out = resid + alpha (acc + bias), y = LayerNorm(x_out);
+// EPI 2: C = GLU(acc + bias) (N / 2 columns)
 template <int NT, int EPI, int PF>
 __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   __shared__ float red[2][4][32];
@@ -172,6 +173,37 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
       }
     put(v);
     store_rows(p.C, p.ldc);
+  } else if constexpr (EPI == 2) {
+    // GLU (convolution.py:117-118) over a weight whose rows are permuted per 64 as [32 a | 32
+    // gate] (wn_model_create): tile 2 u of the wave = values, tile 2 u + 1 = their gates; the
+    // wave's NT / 2 output tiles are columns col0 / 2 .. of C
+    static_assert(EPI != 2 || NT % 2 == 0, "GLU: value / gate tile pairs");
+    constexpr int HT = NT / 2, HSEG = HT * 128, HLPR = HSEG / 16, HNIT = 32 * HLPR / 64;
+#pragma unroll
+    for (int u = 0; u < HT; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = col0 + 2 * u * 32 + 8 * g + 4 * hi;
+        f32x4 a = f32x4{acc[2 * u][4 * g], acc[2 * u][4 * g + 1], acc[2 * u][4 * g + 2],
+                        acc[2 * u][4 * g + 3]};
+        f32x4 gt = f32x4{acc[2 * u + 1][4 * g], acc[2 * u + 1][4 * g + 1],
+                         acc[2 * u + 1][4 * g + 2], acc[2 * u + 1][4 * g + 3]};
+        if (p.bias) {
+          a += *reinterpret_cast<const f32x4*>(p.bias + c);
+          gt += *reinterpret_cast<const f32x4*>(p.bias + c + 32);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
+        *reinterpret_cast<f32x4*>(wp + li * PST + (u * 32 + 8 * g + 4 * hi) * 4) = o;
+      }
+#pragma unroll
+    for (int it = 0; it < HNIT; ++it) {
+      const int q = it * 64 + lane, r = q / HLPR, pc = q - r * HLPR;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wp + r * PST + pc * 16);
+      if (m0 + r < p.M)
+        *reinterpret_cast<f32x4*>(p.C + (int64_t)(m0 + r) * p.ldc + col0 / 2 + pc * 4) = v;
+    }
   } else {
     f32x4 v[NT][4], rs[NT][4];
     // (loading these rows in the prologue instead, behind the A rows, was slower: 14.4 -> 15.8 us)
@@ -247,6 +279,7 @@ int g_x6r = 1;       // wn_tune_set("x6r"): 0 = the v_mfma_f32 row-LN GEMM / til
 bool gemm_x6r_supported(int M, int N, int K, int epi) {
   if (K != RK || M <= 0) return false;
   if (epi == 1) return N == 256;
+  if (epi == 2) return N == 512;
   return N == 256 || N == 512 || N == 768;
 }
 
@@ -259,6 +292,7 @@ int gemm_x6r(const X6RArgs& a, hipStream_t s) {
     return launch_x6r<2, 1, 3>(a, s);
   }
   WN_CHECK(a.C && a.ldc % 4 == 0, "gemm_x6r: no output");
+  if (a.epi == 2) return launch_x6r<4, 2, 2>(a, s);
   switch (a.N) {
     case 256: return launch_x6r<2, 0, 3>(a, s);
     case 512: return launch_x6r<4, 0, 2>(a, s);

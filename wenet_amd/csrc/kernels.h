@@ -203,7 +203,8 @@ struct X6RArgs {
   const void* W3 = nullptr;                  // X3 image of W (N x 256)
   const float* bias = nullptr;               // [N] or null
   int M = 0, N = 0;
-  int epi = 0;          // 0: C = acc + bias; 1: x_out = resid + alpha (acc + bias), y = LN(x_out)
+  int epi = 0;          // 0: C = acc + bias; 1: x_out = resid + alpha (acc + bias), y = LN(x_out);
+                        // 2: C = GLU(acc + bias), N / 2 columns (W rows permuted [32 a | 32 gate])
   float* C = nullptr; int ldc = 0;
   const float* resid = nullptr; int ldr = 0; float alpha = 1.0f;   // resid may alias x_out
   float* x_out = nullptr; int ldx = 0;

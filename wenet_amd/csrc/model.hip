@@ -175,7 +175,7 @@ int build_x6_images(wn_model* m) {
   for (const auto& L : m->layers) { ws.push_back(&L.ffm1); ws.push_back(&L.ffm2);
                                     ws.push_back(&L.ff1); ws.push_back(&L.ff2);
                                     ws.push_back(&L.qkv); ws.push_back(&L.out);
-                                    ws.push_back(&L.pw2); }
+                                    ws.push_back(&L.pw2); ws.push_back(&L.pw1); }
   for (const Decoder* D : {&m->left, &m->right})
     for (const auto& L : D->layers) {
       ws.push_back(&L.self_qkv); ws.push_back(&L.self_out); ws.push_back(&L.src_q);
@@ -684,7 +684,21 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       // x += Conv(LN(x))                              encoder_layer.py:240-251
       WN_TRY(ln(L.norm_conv, x, t1, M, d, eps, s, h16));
     }
-    WN_TRY(linear(L.pw1, t1, d, t2, d, M, s, ACT_NONE, nullptr, 0, 1.0f, true, h16));
+    // pointwise_conv1 + GLU                        convolution.py:115-118
+    bool pw1_done = false;
+    if (rowln && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+        gemm_x6r_supported(M, 2 * d, L.pw1.in, 2)) {
+      auto it = t_x6->find(L.pw1.w);
+      if (it != t_x6->end()) {
+        X6RArgs g;
+        g.A = t1; g.lda = d; g.W3 = it->second; g.bias = L.pw1.b; g.M = M; g.N = 2 * d;
+        g.epi = 2; g.C = t2; g.ldc = d;
+        WN_TRY(gemm_x6r(g, s));
+        pw1_done = true;
+      }
+    }
+    if (!pw1_done)
+      WN_TRY(linear(L.pw1, t1, d, t2, d, M, s, ACT_NONE, nullptr, 0, 1.0f, true, h16));
     DwConvArgs dw;
     dw.x = t2; dw.ldx = d; dw.wt = L.dw_wt; dw.bias = L.dw_b; dw.cpad = L.cpad;
     dw.ln_w = L.conv_norm.w; dw.ln_b = L.conv_norm.b; dw.norm_mode = c.cnn_norm;
