@@ -57,6 +57,7 @@ sys.path.insert(0, ROOT)
 _lib_mod = None
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md:41-43
 PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'fp8': 5000.0}
+NOMINAL_GHZ = 2.4      # peak engine clock the dense peaks are quoted at (MI355X_MICROARCH.md)
 MIN_TIMED_SECONDS = 2.0
 MAX_ROUNDS = 400
 
@@ -208,6 +209,9 @@ def main():
                          'configs[4]) -- extra data points, never the headline line')
     ap.add_argument('--no-f32-mfma-leg', action='store_true',
                     help='skip the extra round that runs every GEMM on v_mfma_f32')
+    ap.add_argument('--no-clock-sample', action='store_true',
+                    help='skip the two untimed steps that sample the shader clock of the '
+                         'roofline kernel')
     ap.add_argument('--no-plain-leg', action='store_true',
                     help='skip the extra round of plain back-to-back decode() calls')
     ap.add_argument('--tune', default='',
@@ -378,6 +382,25 @@ def main():
         barrier()
         plain = max_over_ranks(time.perf_counter() - t0)
     ffn_split = int(L.wn_profile_ffn_split(pipe.models[0]._h))
+    # the shader clock the roofline kernel actually ran at, sampled in the same pipeline: two
+    # more steps with the clock-stamp variant of the kernel (csrc/ffn_x6f.hip VAR & 8192: cycle
+    # counter and 100-MHz real-time counter at its entry and end) -- outside every timed region
+    clock_ghz = None
+    if 'ffn_x6f' in prof_name and not args.no_clock_sample:
+        _lib.check(L.wn_tune_set(b'ffn_x6f_var', 25088), 'tune')
+        try:
+            run_steps(2)
+            torch.cuda.synchronize()
+            import numpy as _np
+            ck = _np.zeros((4, 24), dtype=_np.uint64)
+            _lib.check(L.wn_profile_ffn_clocks(
+                ck.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))), 'clocks')
+            ck = ck.astype(_np.int64)
+            cyc, ns = ck[:, 20] - ck[:, 9], (ck[:, 13] - ck[:, 12]) * 10.0
+            if (ns > 0).all() and (cyc > 0).all():
+                clock_ghz = float((cyc / ns).mean())
+        finally:
+            _lib.check(L.wn_tune_set(b'ffn_x6f_var', 0), 'tune')
     pipe.close()
     assert len(out) == batch_per_gpu * world, 'result gather lost utterances'
 
@@ -511,6 +534,15 @@ def main():
             else:
                 line['roofline']['algorithmic_bytes'] = int(
                     4 * (enc_rows * d_model + ffn * d_model + enc_rows * ffn))
+        if clock_ghz is not None:
+            line['roofline']['shader_clock_ghz_sampled'] = round(clock_ghz, 3)
+            line['roofline']['frac_at_sampled_clock'] = round(
+                achieved / (peak * clock_ghz / NOMINAL_GHZ), 4)
+            line['roofline']['clock_note'] = (
+                f'peak is priced at the {NOMINAL_GHZ} GHz peak engine clock; the kernel\'s own '
+                'cycle / real-time stamps (one block, last launch of two extra untimed steps) give '
+                'the clock the power management held under this load -- frac_at_sampled_clock '
+                'prices the same achieved rate against the peak at that clock')
         if x6:
             line['roofline']['executed_mfma_tflops'] = round(6 * achieved, 1)
             line['roofline']['fp32_mfma_peak'] = PEAK_TFLOPS['fp32']

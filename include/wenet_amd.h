@@ -447,6 +447,9 @@ int32_t wn_profile_ffn_split(const wn_model* m);
  * feed-forward kernel (wn_tune_set("ffn_x6f_var", 8704 ...), tools/bench_x6.py --clocks): entry
  * i = start of sub-stage i of one block's last steady-state chunk, entry 8 = its end. */
 int wn_profile_ffn_clocks(uint64_t* out64);
+/* Same for the six-product tile GEMM (wn_tune_set("x6_probe", 4)): [8 waves][8] = entry, loop
+ * start, loop end, kernel end (shader clock), 100-MHz real time at entry / end, k blocks. */
+int wn_profile_gemm_clocks(uint64_t* out64);
 
 /* Test hook: "n_layers" = run only the first n encoder layers (-1: all),
  * "skip_after_norm" = 1 leaves out encoder.after_norm; lets the parity tests

@@ -125,7 +125,7 @@ def main():
                     print(f'ffn M={m} D={d} F={f} | x6 ON CHIP, hidden slices per XCD {mp + 1}: '
                           f'{usf:8.1f} us', flush=True)
                 # measurement variants of the kernel (results wrong by design except 16)
-                for var, what in ((512, 'full, stage DMA as one burst behind the barrier'), (1, 'no MFMAs'),
+                for var, what in ((82432, 'three of the six products (wrong results: what half the MFMAs would cost)'), (512, 'full, stage DMA as one burst behind the barrier'), (1, 'no MFMAs'),
                                   (2, 'no DMA in the loop'), (4, 'no bias/act/split pieces'), (64, 'no fragment reads'), (10, 'no DMA, no waits'), (78, 'MFMAs only'), (74, 'MFMAs + pieces'), (14, 'MFMAs + fragment reads'), (76, 'MFMAs + DMA'), (70, 'MFMAs + waits/barriers'), (1094, 'MFMAs + s_barrier only'), (4096, 'full, fragment reads of a group as one burst'), (4110, 'MFMAs + burst fragment reads'), (2118, 'MFMAs + waitcnts only'), (128, 'partials stored sc0 sc1'),
                                   (8, 'no waits / barriers in the loop')):
                     _lib.check(L.wn_tune_set(b'ffn_x6f_var', var), 'tune')

@@ -31,7 +31,7 @@ def main():
     if len(sys.argv) > 1:
         _lib.check(L.wn_tune_set(b'ffn_x6f_map', int(sys.argv[1])), 'tune')
     out = np.zeros((4, 24), dtype=np.uint64)
-    for var, what in ((8704, 'stage DMA as one burst behind the barrier (r03 first form)'), (25088, 'default kernel (DMA spread over the stage)'), (8768, 'no fragment reads'),
+    for var, what in ((8704, 'stage DMA as one burst behind the barrier (r03 first form)'), (25088, 'default kernel (DMA spread over the stage)'), (90624, 'three of the six products'), (8768, 'no fragment reads'),
                       (8708, 'no pieces'), (8706, 'no DMA'), (8782, 'MFMAs only')):
         _lib.check(L.wn_tune_set(b'ffn_x6f_var', var), 'tune')
         rows = []

@@ -579,6 +579,11 @@ const char* wn_profile_kernel_name(const wn_model* m) {
 
 int32_t wn_profile_ffn_split(const wn_model* m) { return m ? m->prof_split : 0; }
 
+int wn_profile_gemm_clocks(uint64_t* out64) {
+  WN_CHECK(out64, "wn_profile_gemm_clocks: null output");
+  return wn::gemm_x6_clocks(reinterpret_cast<unsigned long long*>(out64));
+}
+
 int wn_profile_ffn_clocks(uint64_t* out64) {
   WN_CHECK(out64, "wn_profile_ffn_clocks: null output");
   return wn::ffn_x6f_clocks(reinterpret_cast<unsigned long long*>(out64));

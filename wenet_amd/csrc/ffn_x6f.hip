@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
           const int q = k >> 1, tl = k & 1;       // plane product, operand tile of the group
-          if (VAR & 1) {
+          if ((VAR & 1) || ((VAR & 65536) && q >= 3)) {     // (65536: three of the six products)
             asm volatile("" ::"v"(fc.p[tl][PW[q]]));
           } else if (sub < 4) {
             const int nt = sub >> 1, ks = (sub & 1) * 8 + 2 * g + tl;
@@ -695,6 +695,8 @@ int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
       case 2118: return launch_x6f<ACT_SILU, 6, 2118>(a, s);
       case 128: return launch_x6f<ACT_SILU, 6, 128>(a, s);
       case 8704: return launch_x6f<ACT_SILU, 3, 8704>(a, s);     // burst-DMA kernel + clock stamps
+      case 82432: return launch_x6f<ACT_SILU, 3, 82432>(a, s);   // measurement: half of the MFMAs
+      case 90624: return launch_x6f<ACT_SILU, 3, 90624>(a, s);   // ... + clock stamps
       case 512: return launch_x6f<ACT_SILU, 3, 512>(a, s);       // DMA of a stage as one burst behind the barrier
       case 25088: return launch_x6f<ACT_SILU, 3, 25088>(a, s);   // default kernel + clock stamps
       case 8768: return launch_x6f<ACT_SILU, 3, 8768>(a, s);     // ... without fragment reads

@@ -98,10 +98,16 @@ __global__ __launch_bounds__(256) void x6_split_kernel(const float* __restrict__
 // high-priority block of a CU takes the matrix pipe first and finishes first, and its
 // store burst drains while the other block multiplies -- two co-resident blocks that start
 // together would otherwise finish, and store, together.
+// probe & 4 (measurement): shader-clock stamps of block gridDim.x / 2: per wave entry, loop
+// start, loop end, kernel end and the 100-MHz real-time counter at entry / end
+__device__ unsigned long long g_x6_clk[8][8];
+
 template <int BM, int EPI, int ACT, bool CONV = false, bool AF32 = false, int NW = 8>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
+  unsigned long long ck0 = 0, ck1 = 0, ck2 = 0, rt0 = 0;
+  if (p.probe & 4) { ck0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   static_assert(NW == 8 || (NW == 4 && BM == 128), "4 waves: 128-row tiles");
   constexpr int TA = BM / 32 / (NW / 4);       // A tiles (32 rows) per wave
   constexpr int A_TILE = AF32 ? 2048 : TILE3;  // bytes of a 32-row A tile and k block
@@ -335,6 +341,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
   __builtin_amdgcn_s_barrier();
   FB fb = loadB(0);
   FA fa = loadA(0, 0);
+  if (p.probe & 4) ck1 = __builtin_readcyclecounter();
   // The DMA of stage g + RING does not follow the barrier as one burst: the CU has ONE address
   // unit, a 1-KB piece occupies it for ~16 cycles, and NP pieces issued by all waves at once
   // hold every wave in the issue queue for NP x 16 cycles per stage (ffn_x6f.hip, clock stamps
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
     }
   }
 
+  if (p.probe & 4) ck2 = __builtin_readcyclecounter();
   // ---- epilogue: lane = row of C, registers = columns 8 g + 4 hi + e ------------------------
   const int Tm = Ta;
 #pragma unroll
@@ -461,6 +469,15 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
       }
     }
   }
+  if (p.probe & 4) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ck3 = __builtin_readcyclecounter();
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) {
+      unsigned long long* o = g_x6_clk[wave & 7];
+      o[0] = ck0; o[1] = ck1; o[2] = ck2; o[3] = ck3; o[4] = rt0; o[5] = rt1; o[6] = nkb;
+    }
+  }
 }
 
 template <int BM, int EPI, int ACT, bool CONV = false, bool AF32 = false, int NW = 8>
@@ -510,6 +527,11 @@ int g_x6_linear = 1;
 // 4096 1124 -> 1312 us, decode step 7.28 -> 7.4-7.7 ms.
 int g_x6_af32 = 0;
 int g_x6_probe = 0;     // wn_tune_set("x6_probe"): 1 no MFMAs, 2 no DMA (ablation)
+
+int gemm_x6_clocks(unsigned long long* out) {
+  WN_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x6_clk), sizeof(g_x6_clk)));
+  return 0;
+}
 
 size_t x6_bytes(int R, int K) { return (size_t)(K / 16) * cdiv(R, 32) * TILE3; }
 

@@ -151,6 +151,7 @@ struct X6Args {
   int probe = 0;              // ablation bits (g_x6_probe)
 };
 extern int g_x6_probe;
+int gemm_x6_clocks(unsigned long long* out);   // probe & 4 stamps [8 waves][8]
 extern int g_x6_nw4;       // wn_tune_set("x6_nw4") A/B bits: 1 FFN w_1 on 256-row tiles, 2 FFN w_2 on the 8-wave 128-row tile, 4 priorities
 extern int g_x6_linear;    // wn_tune_set("x6_linear"): 0 = linear() never routes to the six-product GEMM
 extern int g_x6_conv_order;
