@@ -44,6 +44,11 @@ def main():
                        'clocks')
             rows.append(np.diff(out[:, :9].astype(np.int64), axis=1))
         d = np.median(np.stack(rows), axis=0)          # [wave][sub]
+        print(f'var {var} ({what}): cycles per sub-stage (ideal 1536), median of 5 launches')
+        print('  kinds : ' + ' | '.join(KINDS))
+        for w in range(4):
+            print(f'  wave {w}: ' + ' '.join(f'{int(v):6d}' for v in d[w]) +
+                  f' | chunk {int(d[w].sum())}')
         o = out.astype(np.int64)
         cyc = o[:, 20] - o[:, 9]
         ns = (o[:, 13] - o[:, 12]) * 10.0
@@ -54,11 +59,7 @@ def main():
               '%s ns -> %s GHz' % ((o[:, 10] - o[:, 9]).tolist(), (o[:, 11] - o[:, 10]).tolist(),
                                    (o[:, 20] - o[:, 11]).tolist(), cyc.tolist(), ns.tolist(),
                                    np.round(cyc / ns, 2).tolist()))
-        print(f'var {var} ({what}): cycles per sub-stage (ideal 1536), median of 5 launches')
-        for w in range(4):
-            print(f'  wave {w}: ' + ' '.join(f'{int(v):6d}' for v in d[w]) +
-                  f' | chunk {int(d[w].sum())}')
-        print('  kinds : ' + ' | '.join(KINDS), flush=True)
+        sys.stdout.flush()
     _lib.check(L.wn_tune_set(b'ffn_x6f_var', 0), 'tune')
 
 
