@@ -248,3 +248,25 @@ def test_encoder_with_the_row_block_x6_gemms_matches_the_f32_forms(B, frames, ch
     err = (got - ref).abs().max().item()
     print(f'\n[B={B}] row-block x6 GEMMs vs v_mfma_f32 forms: max |d enc| {err:.2e}')
     assert 0 < err < 2e-4
+
+
+@pytest.mark.parametrize('B,frames', [(32, (800, 1200)), (5, (300, 1100))])
+def test_chained_row_ln_glu_launch_is_bit_identical_to_the_two_launches(B, frames):
+    """gemm_x6r.hip epi 3 (out-projection + residual + LN_conv chained with pointwise_conv1 + GLU,
+    encoder_layer.py:236-251 / convolution.py:115-118, LN_conv(x) kept in LDS) runs the same
+    arithmetic in the same order as epi 1 followed by epi 2: the encoder output is the same bits."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model('aishell_u2pp', 0)
+    feats, lens = S.make_features(B, frames, seed=75)
+    try:
+        _lib.check(L.wn_tune_set(b'x6r_chain', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, -1, -1)
+        ref = ref.cpu()
+        _lib.check(L.wn_tune_set(b'x6r_chain', 1), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, -1, -1)
+        got = got.cpu()
+    finally:
+        L.wn_tune_set(b'x6r_chain', 1)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref)

@@ -654,6 +654,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "ffn_x6f") g_ffn_x6f = value;
   else if (k == "ffn_x6f_ring") g_ffn_x6f_ring = value;
   else if (k == "ffn_x6f_map") g_ffn_x6f_map = value;
+  else if (k == "x6r_chain") g_x6r_chain = value;
   else if (k == "ffn_x6f_var") g_ffn_x6f_var = value;
   else { set_error("wn_tune_set: unknown key " + k); return -1; }
   return 0;

@@ -38,7 +38,8 @@ constexpr int RK = 256;              // K of this kernel
 constexpr int RKB = RK / 16;         // 16 k blocks
 
 // EPI 0: C = acc + bias; EPI 1: x_out = resid + alpha (acc + bias), y = LayerNorm(x_out);
-// EPI 2: C = GLU(acc + bias) (N / 2 columns)
+// EPI 2: C = GLU(acc + bias) (N / 2 columns); EPI 3: EPI 1, then C = GLU(y W3b^T + bias2) from
+// the rows in LDS (y itself is stored only if p.y is set)
 template <int NT, int EPI, int PF>
 __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   __shared__ float red[2][4][32];
@@ -260,8 +261,99 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[t][g][e] = (v[t][g][e] - mean) * rstd * w[e] + b[e];
       }
-    put(v);
-    store_rows(p.y, p.ldy);
+    if (EPI == 1 || p.y != nullptr) {
+      put(v);
+      store_rows(p.y, p.ldy);
+    }
+    if constexpr (EPI == 3) {
+      // ---- chained: C = GLU(y W2^T + bias2), N2 = 512 (encoder_layer.py:240-251 /
+      // convolution.py:115-118): the LayerNorm rows never leave the CU -- every wave puts its 64
+      // columns of y into the shared A patch, reads the full rows back in the fragment layout,
+      // splits them, and the second GEMM runs like the first (wave w: tiles 4 w .. 4 w + 3 of
+      // the [32 values | 32 gates] image)
+      __syncthreads();                            // the wave patches are dead
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(patch + li * 1040 + (col0 + t * 32 + 8 * g + 4 * hi) * 4) =
+              v[t][g];
+      constexpr int NT2 = 4, PF2 = 2;
+      const char* wb2 = reinterpret_cast<const char*>(p.W3b) +
+                        ((int64_t)wave * NT2 * 3) * X3_REC + lane * 16;
+      const int64_t kstride2 = (int64_t)16 * X3_TILE;       // 512 / 32 tiles per k block
+      bf16x8 wf2[PF2 + 1][NT2][3];
+      auto load_w2 = [&](int ks) {
+        const char* q = wb2 + ks * kstride2;
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            wf2[ks % (PF2 + 1)][t][pl] =
+                *reinterpret_cast<const bf16x8*>(q + (t * 3 + pl) * X3_REC);
+      };
+#pragma unroll
+      for (int s2i = 0; s2i < PF2; ++s2i) load_w2(s2i);
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < RKB; ++ks) {
+        xa[ks] = *reinterpret_cast<const f32x4*>(patch + li * 1040 + ks * 64 + hi * 32);
+        xb[ks] = *reinterpret_cast<const f32x4*>(patch + li * 1040 + ks * 64 + hi * 32 + 16);
+      }
+#pragma unroll
+      for (int ks = 0; ks < RKB; ++ks) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const Split3 sa = split3(xa[ks][e]), sb = split3(xb[ks][e]);
+          X[ks][0][e] = sa.h0; X[ks][1][e] = sa.h1; X[ks][2][e] = sa.h2;
+          X[ks][0][4 + e] = sb.h0; X[ks][1][4 + e] = sb.h1; X[ks][2][4 + e] = sb.h2;
+        }
+      }
+      f32x16 acc2[NT2];
+#pragma unroll
+      for (int t = 0; t < NT2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < RKB; ++ks) {
+        if (ks + PF2 < RKB) load_w2(ks + PF2);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int t = 0; t < NT2; ++t)
+            acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[ks % (PF2 + 1)][t][PW[q]],
+                                                              X[ks][PX[q]], acc2[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();                            // the A patch is dead
+      const int c2 = wave * NT2 * 32;             // first column of the wave's tiles in the image
+      char* wp2 = patch + wave * (32 * 272);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = c2 + 2 * u * 32 + 8 * g + 4 * hi;
+          f32x4 a = f32x4{acc2[2 * u][4 * g], acc2[2 * u][4 * g + 1], acc2[2 * u][4 * g + 2],
+                          acc2[2 * u][4 * g + 3]};
+          f32x4 gt = f32x4{acc2[2 * u + 1][4 * g], acc2[2 * u + 1][4 * g + 1],
+                           acc2[2 * u + 1][4 * g + 2], acc2[2 * u + 1][4 * g + 3]};
+          if (p.bias2) {
+            a += *reinterpret_cast<const f32x4*>(p.bias2 + c);
+            gt += *reinterpret_cast<const f32x4*>(p.bias2 + c + 32);
+          }
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
+          *reinterpret_cast<f32x4*>(wp2 + li * 272 + (u * 32 + 8 * g + 4 * hi) * 4) = o;
+        }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {              // 32 rows x 16 pieces of 16 bytes
+        const int q = it * 64 + lane, r = q >> 4, pc = q & 15;
+        const f32x4 o = *reinterpret_cast<const f32x4*>(wp2 + r * 272 + pc * 16);
+        if (m0 + r < p.M)
+          *reinterpret_cast<f32x4*>(p.C + (int64_t)(m0 + r) * p.ldc + c2 / 2 + pc * 4) = o;
+      }
+    }
   }
 }
 
@@ -275,10 +367,11 @@ int launch_x6r(const X6RArgs& a, hipStream_t s) {
 }  // namespace
 
 int g_x6r = 1;       // wn_tune_set("x6r"): 0 = the v_mfma_f32 row-LN GEMM / tile GEMMs (A/B, tests)
+int g_x6r_chain = 1; // wn_tune_set("x6r_chain"): 0 = out-projection + LayerNorm and pointwise_conv1 + GLU as two launches
 
 bool gemm_x6r_supported(int M, int N, int K, int epi) {
   if (K != RK || M <= 0) return false;
-  if (epi == 1) return N == 256;
+  if (epi == 1 || epi == 3) return N == 256;
   if (epi == 2) return N == 512;
   return N == 256 || N == 512 || N == 768;
 }
@@ -290,6 +383,12 @@ int gemm_x6r(const X6RArgs& a, hipStream_t s) {
     WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && a.y && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
                  a.ldy % 4 == 0, "gemm_x6r: row-LN epilogue arguments");
     return launch_x6r<2, 1, 3>(a, s);
+  }
+  if (a.epi == 3) {
+    WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
+                 (a.y == nullptr || a.ldy % 4 == 0) && a.W3b && a.C && a.ldc % 4 == 0,
+             "gemm_x6r: chained row-LN + GLU arguments");
+    return launch_x6r<2, 3, 3>(a, s);
   }
   WN_CHECK(a.C && a.ldc % 4 == 0, "gemm_x6r: no output");
   if (a.epi == 2) return launch_x6r<4, 2, 2>(a, s);

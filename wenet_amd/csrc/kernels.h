@@ -211,8 +211,12 @@ struct X6RArgs {
   float* x_out = nullptr; int ldx = 0;
   const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
   float* y = nullptr; int ldy = 0;           // may alias A (a block reads its rows first)
+  // epi 3 = epi 1 chained with C = GLU(y W3b^T + bias2): W3b = X3 image of a 512 x 256 weight
+  // (rows [32 values | 32 gates] per 64), C [M][256]; y is stored only if set
+  const void* W3b = nullptr; const float* bias2 = nullptr;
 };
 extern int g_x6r;     // wn_tune_set("x6r")
+extern int g_x6r_chain;   // wn_tune_set("x6r_chain")
 bool gemm_x6r_supported(int M, int N, int K, int epi);
 int gemm_x6r(const X6RArgs& a, hipStream_t s);
 extern int g_gemm_rowln;

@@ -670,7 +670,24 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       g.ln_w = nrm.w; g.ln_b = nrm.b; g.eps = eps; g.y = t1; g.ldy = d;
       return gemm_x6r(g, s) == 0 ? 0 : -1;
     };
-    int xr = x6r_rowln(L.out, t2, L.norm_conv);
+    // out-projection + residual + LN_conv chained with pointwise_conv1 + GLU in ONE launch
+    // (gemm_x6r.hip epi 3): LN_conv(x) never reaches HBM
+    bool pw1_done = false;
+    int xr = 1;
+    if (rowln && g_x6r >= 1 && g_x6r_chain != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+        gemm_x6r_supported(M, d, L.out.in, 3) && gemm_x6r_supported(M, 2 * d, L.pw1.in, 2)) {
+      auto io = t_x6->find(L.out.w), ip = t_x6->find(L.pw1.w);
+      if (io != t_x6->end() && ip != t_x6->end()) {
+        X6RArgs g;
+        g.A = t2; g.lda = d; g.W3 = io->second; g.bias = L.out.b; g.M = M; g.N = d; g.epi = 3;
+        g.resid = x; g.ldr = d; g.alpha = 1.0f; g.x_out = x; g.ldx = d;
+        g.ln_w = L.norm_conv.w; g.ln_b = L.norm_conv.b; g.eps = eps; g.y = nullptr; g.ldy = d;
+        g.W3b = ip->second; g.bias2 = L.pw1.b; g.C = t2; g.ldc = d;   // (C aliases A: a block reads its rows first)
+        if (gemm_x6r(g, s) != 0) return -2;
+        xr = 0; pw1_done = true;
+      }
+    }
+    if (xr != 0) xr = x6r_rowln(L.out, t2, L.norm_conv);
     if (xr < 0) return -2;
     if (xr == 0) {
     } else if (rowln) {
@@ -685,8 +702,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       WN_TRY(ln(L.norm_conv, x, t1, M, d, eps, s, h16));
     }
     // pointwise_conv1 + GLU                        convolution.py:115-118
-    bool pw1_done = false;
-    if (rowln && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+    if (!pw1_done && rowln && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
         gemm_x6r_supported(M, 2 * d, L.pw1.in, 2)) {
       auto it = t_x6->find(L.pw1.w);
       if (it != t_x6->end()) {
