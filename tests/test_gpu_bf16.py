@@ -425,6 +425,47 @@ def test_bf16_attention_block_shapes(nw, config, chunk, left):
         assert err < 6e-3, (config, nw, b, err)
 
 
+@pytest.mark.parametrize('B,frames,seed', [
+    (2, (780, 900), 5),       # 4 query groups per block
+    (3, (900, 2600), 6),      # 8 per block, ragged: short sequences end stages early
+    (2, (2050, 2600), 7),
+    (4, (1290, 1300), 8),     # lengths reset to multiples of 64 keys and one past (below)
+])
+def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed):
+    """The LDS-DMA staged bf16 self attention (K rows of the QKV matrix + the packed V^T
+    image, attention_bf16_dma_kernel) does the register-staged kernel's arithmetic in the
+    same order: the encoder outputs of the two are the same bits, on ragged batches whose
+    last stage is partial; and both stay within the oracle's bf16 emulation."""
+    from wenet_amd import _lib, synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('whisper_tiny_like', 0)
+    feats, lens = S.make_features(B, frames, seed=seed, feat_dim=configs['input_dim'])
+    if B == 4:   # exact multiples of 128 frames = 64 encoder frames, and one past
+        lens = torch.tensor([1280, 1282, 1152, 770], dtype=torch.int32)
+        feats = feats[:, :1282]
+    L = _lib.lib()
+    _set_dtype(model, 'bf16')
+    try:
+        _lib.check(L.wn_tune_set(b'attn_bf16_dma', 1), 'tune')
+        enc1, _ = model._forward_encoder(feats.cuda(), lens)
+        enc1b, _ = model._forward_encoder(feats.cuda(), lens)
+        _lib.check(L.wn_tune_set(b'attn_bf16_dma', 0), 'tune')
+        enc0, _ = model._forward_encoder(feats.cuda(), lens)
+    finally:
+        L.wn_tune_set(b'attn_bf16_dma', 1)
+        _set_dtype(model, 'fp32')
+    assert torch.equal(enc1, enc1b), 'DMA-staged attention is not deterministic (race?)'
+    assert torch.equal(enc1, enc0), (enc1 - enc0).abs().max().item()
+    with torch.no_grad(), O.bf16_operands(sd):
+        ref, mask = O.encoder_forward(configs, sd, feats, lens, -1, -1)
+    ref_lens = mask.squeeze(1).sum(1).numpy()
+    enc1 = enc1.cpu()
+    for b in range(B):
+        nb = int(ref_lens[b])
+        scale = max(ref[b, :nb].abs().max().item(), 1.0)
+        assert (enc1[b, :nb] - ref[b, :nb]).abs().max().item() / scale < 6e-3
+
+
 def test_bf16_is_a_per_handle_switch_and_fp32_comes_back_bit_exact():
     """fp32 -> bf16 -> fp32 on one handle: the two fp32 runs are bit-identical, the
     bf16 run is not; clones inherit the mode of their source at clone time."""

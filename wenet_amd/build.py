@@ -24,7 +24,11 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
 # per-source extras: the one-wave-per-SIMD kernel pins its VALU slices between MFMA pairs;
 # SLP-packed f32 ops (v_pk_*) would undo the spacing (MI355X_MICROARCH.md: an anti-lever
 # beside MFMAs)
-EXTRA_FLAGS = {'ffn_x6f.hip': ['-fno-slp-vectorize'], 'gemm_x6r.hip': ['-fno-slp-vectorize']}
+EXTRA_FLAGS = {'ffn_x6f.hip': ['-fno-slp-vectorize'], 'gemm_x6r.hip': ['-fno-slp-vectorize'],
+               # the softmax of the bf16 attention kernels is VALU-bound: no v_pk_add + v_mov
+               # packing of the row sums, no canonicalising v_max x, x in front of every fmaxf
+               # on an MFMA result (scores are finite; the masks use -1e30, not inf)
+               'attention_bf16.hip': ['-fno-slp-vectorize', '-fno-honor-nans']}
 
 
 def _hipcc():

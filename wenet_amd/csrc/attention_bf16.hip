@@ -27,11 +27,13 @@
 // stream from L2 is shared by more queries (64 B/clk/CU budget).
 #include <type_traits>
 
+#include "gemm_epilogue.h"
 #include "kernels.h"
 
 namespace wn {
 
 extern int g_attn_bf16_sub;
+extern int g_attn_bf16_dma;
 
 namespace {
 
@@ -369,6 +371,266 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
   }
 }
 
+// ---- DMA-staged form (round 3): bf16 Q | K rows of the QKV GEMM + a packed V^T image --------
+// The register-staged kernel above spends ~45 of its ~135 VALU instructions per 32-key tile
+// on moving K / V (64-bit addresses, bf16 pair packing, five LDS stores) and hipcc waits for
+// the just-issued prefetch loads inside the first MFMAs of every stage.  Here a stage of 64
+// keys is FOUR 1-KB direct-to-LDS pieces per wave pair (buffer_load ... lds, no registers, no
+// VALU): K rows as they lie in the QKV matrix, and V from a V^T image [seq][head][dim][Tp]
+// (vt_pack_kernel, one pass over V per layer) whose rows are key-contiguous, the 16 keys of
+// a group already in the key order of the S^T registers.  Both tiles are [64 rows][128 B]
+// with the 16-byte slot swizzle slot ^ ((row >> 1) & 7) applied on the SOURCE side of the DMA
+// (the LDS image of a piece is lane-linear) and again on the fragment reads, as in
+// gemm_bf16p.hip: a ds_read_b128 of 32 consecutive rows touches 16 distinct slots per
+// service group.  Two stages of LDS (32 KB), one raw s_barrier per stage behind the issuing
+// waves' own vmcnt(0); the next stage's pieces fly during the whole compute of this one.
+// Same arithmetic, in the same order, as the register-staged kernel (bit-identical output).
+constexpr int DKT = 64;                 // keys per stage
+constexpr int DTILE = 64 * 128;         // one [64][128 B] tile
+constexpr int DSTAGE = 2 * DTILE;       // K tile | V^T tile
+
+__device__ __forceinline__ float pair_max(float v) {   // max over lanes l, l ^ 32
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v),
+                                                  false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pair_sum(float v) {   // sum over lanes l, l ^ 32
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v),
+                                                  false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// vt[((s * H + h) * 64 + dim) * Tp + 16 g + p] = V[off[s] + 16 g + key(p)][h * 64 + dim],
+// key(p) = 4 (p >> 3) + (p & 3) + 8 ((p >> 2) & 1); zeros beyond the sequence (the last
+// stage multiplies them by probabilities that are exactly 0).
+__global__ __launch_bounds__(256) void vt_pack_kernel(const __bf16* __restrict__ V, int ldv,
+                                                      const int* __restrict__ off,
+                                                      const int* __restrict__ len, int H, int Tp,
+                                                      __bf16* __restrict__ vt) {
+  const int kt = blockIdx.x, h = blockIdx.y, s = blockIdx.z;
+  const int n = len[s], t0 = kt * 64;
+  if (t0 >= n) return;                      // stages past the sequence are never read
+  __shared__ __attribute__((aligned(16))) __bf16 tile[64 * 72];   // [key][64 dims + 16 B]
+  const int tid = threadIdx.x;
+  {
+    const int key = tid >> 2, c = tid & 3;
+    bf16x8 x0, x1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { x0[e] = (__bf16)0.0f; x1[e] = (__bf16)0.0f; }
+    if (t0 + key < n) {
+      const __bf16* vp = V + (int64_t)(off[s] + t0 + key) * ldv + h * 64 + c * 16;
+      x0 = *reinterpret_cast<const bf16x8*>(vp);
+      x1 = *reinterpret_cast<const bf16x8*>(vp + 8);
+    }
+    *reinterpret_cast<bf16x8*>(tile + key * 72 + c * 16) = x0;
+    *reinterpret_cast<bf16x8*>(tile + key * 72 + c * 16 + 8) = x1;
+  }
+  __syncthreads();
+  {
+    const int dim = tid >> 2, g = tid & 3;
+    bf16x8 y0, y1;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      y0[p] = tile[(16 * g + (p & 3) + 8 * ((p >> 2) & 1)) * 72 + dim];
+      y1[p] = tile[(16 * g + 4 + (p & 3) + 8 * ((p >> 2) & 1)) * 72 + dim];
+    }
+    __bf16* op = vt + ((int64_t)(s * H + h) * 64 + dim) * Tp + t0 + 16 * g;
+    *reinterpret_cast<bf16x8*>(op) = y0;
+    *reinterpret_cast<bf16x8*>(op + 8) = y1;
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs a, int nqb) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  static_assert(NW == 4 || NW == 8, "4 or 8 query groups per block");
+  constexpr int NP = 8 / NW;              // 1-KB pieces of a tile per wave
+  __shared__ __attribute__((aligned(1024))) char sbuf[2 * DSTAGE];
+  // all query blocks of one (sequence, head) run on the same XCD, one after the other: its
+  // K / V^T rows (2 x 192 KB at T = 1500) come from HBM into one L2 instead of eight
+  const int bid = xcd_block_order(blockIdx.x, gridDim.x);
+  const int qb = bid % nqb;
+  const int h = (bid / nqb) % a.n_heads, s = bid / (nqb * a.n_heads);
+  const int q0 = qb * (NW * 32);
+  const int qlen = a.q_len[s];
+  if (q0 >= qlen) return;
+  const int kvlen = a.kv_len[s];
+  const int qoff = a.q_off[s], kvoff = a.kv_off[s];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const __bf16* Qh = reinterpret_cast<const __bf16*>(a.Q);
+
+  // ---- DMA descriptors and per-lane source offsets ------------------------------------
+  const unsigned ldk2 = (unsigned)a.ldk * 2u, tp2 = (unsigned)a.vt_tp * 2u;
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(reinterpret_cast<const __bf16*>(a.K) + (int64_t)kvoff * a.ldk + h * 64),
+      0, (int)((unsigned)kvlen * ldk2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(reinterpret_cast<const __bf16*>(a.vt) +
+                          (int64_t)(s * a.n_heads + h) * 64 * a.vt_tp),
+      0, (int)(64u * tp2), 0x00020000);
+  int prow[NP];
+  unsigned pslot[NP], vtoff[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    prow[p] = (p * NW + wave) * 8 + (lane >> 3);                       // row of the tile
+    pslot[p] = (unsigned)(((lane & 7) ^ ((prow[p] >> 1) & 7)) << 4);   // source 16-B slot
+    vtoff[p] = (unsigned)prow[p] * tp2 + pslot[p];
+  }
+  auto issue = [&](int it, int buf) {
+    const int j0 = it * DKT;
+    char* dst = sbuf + buf * DSTAGE + wave * 1024;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const unsigned vk = (unsigned)min(j0 + prow[p], kvlen - 1) * ldk2 + pslot[p];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(dst + p * NW * 1024), 16, vk, 0, 0,
+                                               0);
+      const unsigned vt_o = vtoff[p] + 0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(dst + DTILE + p * NW * 1024), 16,
+                                               vt_o, j0 * 2, 0, 0);
+    }
+  };
+  const int n_it = (kvlen + DKT - 1) / DKT;
+  issue(0, 0);
+
+  // ---- this lane's query row: dims kk*16 + hi*8 .. +7, kk = 0..3 ----------------------
+  const int qi = q0 + wave * 32 + li;
+  const int qc = qi < qlen ? qi : qlen - 1;
+  bf16x8 qu[4];
+  {
+    const __bf16* qp = Qh + (int64_t)(qoff + qc) * a.ldq + h * 64 + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qu[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 16);
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+  const float cs = a.scale * 1.4426950408889634f;
+  // fragment addresses: row li of a 32-row half (the swizzle term (row >> 1) & 7 is the same
+  // for rows li and 32 + li), 16-B slot c -> c ^ sw
+  const int sw = (li >> 1) & 7;
+  const int frow = li * 128;
+
+  for (int it = 0; it < n_it; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage `it`
+    __builtin_amdgcn_s_barrier();                      // everyone's; buffer (it+1)&1 is free
+    if (it + 1 < n_it) issue(it + 1, (it + 1) & 1);
+    const char* sK = sbuf + (it & 1) * DSTAGE;
+    const char* sV = sK + DTILE;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const int j0 = it * DKT + sb * KT;
+      if (sb == 1 && j0 >= kvlen) break;               // uniform
+      // ---- S^T tile ----------------------------------------------------------------
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 fk = *reinterpret_cast<const bf16x8*>(
+            sK + sb * (32 * 128) + frow + (((2 * kk + hi) ^ sw) << 4));
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, qu[kk], sc, 0, 0, 0);
+      }
+      // ---- online softmax on this lane's query (see the register-staged kernel) ----------
+      float psum, alpha;
+      if (j0 + KT <= kvlen) {
+        float t0 = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        float t1 = fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]));
+        float t2 = fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11]));
+        float t3 = fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]));
+        const float tmax = pair_max(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
+        const float m_new = fmaxf(m_run, tmax);
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+        const float mc = -m_new * cs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], cs, mc));
+        psum = ((sc[0] + sc[1]) + (sc[2] + sc[3])) + ((sc[4] + sc[5]) + (sc[6] + sc[7])) +
+               (((sc[8] + sc[9]) + (sc[10] + sc[11])) + ((sc[12] + sc[13]) + (sc[14] + sc[15])));
+        m_run = m_new;
+      } else {
+        float tmax = -1e30f;
+        bool ok[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          ok[r] = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi < kvlen;
+          if (ok[r]) tmax = fmaxf(tmax, sc[r]);
+        }
+        tmax = pair_max(tmax);
+        const float m_new = fmaxf(m_run, tmax);
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+        const float mc = -m_new * cs;
+        psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = ok[r] ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], cs, mc)) : 0.f;
+          sc[r] = p;
+          psum += p;
+        }
+        m_run = m_new;
+      }
+      l_run = l_run * alpha + psum;
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          o0[r] *= alpha;
+          o1[r] *= alpha;
+        }
+      }
+      // ---- O^T += V^T P^T ------------------------------------------------------------
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bf16x8 pa;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pa[e] = (__bf16)sc[8 * j + e];
+        const int vo = frow + (((4 * sb + 2 * j + hi) ^ sw) << 4);
+        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(sV + vo);
+        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(sV + 32 * 128 + vo);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pa, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pa, o1, 0, 0, 0);
+      }
+    }
+  }
+  const float l_tot = pair_sum(l_run);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  const int qrow = q0 + wave * 32 + li;
+  if (qrow < qlen) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 8 * g + 4 * hi;
+      const f32x4 a0 = f32x4{o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]} * inv;
+      const f32x4 a1 = f32x4{o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]} * inv;
+      if (a.o_bf16) {
+        __bf16* op = reinterpret_cast<__bf16*>(a.O) + (int64_t)(qoff + qrow) * a.ldo + h * 64;
+        bf16x4 b0, b1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b0[e] = (__bf16)a0[e]; b1[e] = (__bf16)a1[e]; }
+        *reinterpret_cast<bf16x4*>(op + d) = b0;
+        *reinterpret_cast<bf16x4*>(op + 32 + d) = b1;
+      } else {
+        float* op = a.O + (int64_t)(qoff + qrow) * a.ldo + h * 64;
+        *reinterpret_cast<f32x4*>(op + d) = a0;
+        *reinterpret_cast<f32x4*>(op + 32 + d) = a1;
+      }
+    }
+  }
+}
+
+template <int NW>
+int launch_dma(const AttnArgs& a, hipStream_t s) {
+  const int kt = cdiv(a.max_q_len, DKT);
+  hipLaunchKernelGGL(vt_pack_kernel, dim3(kt, a.n_heads, a.n_seq), dim3(256), 0, s,
+                     reinterpret_cast<const __bf16*>(a.V), a.ldv, a.kv_off, a.kv_len, a.n_heads,
+                     a.vt_tp, reinterpret_cast<__bf16*>(a.vt));
+  WN_HIP(hipGetLastError());
+  const int nqb = cdiv(a.max_q_len, NW * 32);
+  hipLaunchKernelGGL((attention_bf16_dma_kernel<NW>), dim3(nqb * a.n_heads * a.n_seq),
+                     dim3(NW * 64), 0, s, a, nqb);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int NW>
 int launch(const AttnArgs& a, hipStream_t s) {
   dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 64);
@@ -391,6 +653,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
 
 int g_attn_bf16_nw = 0;  // wn_tune_set("attn_bf16_nw"): 0 auto, else 2 / 4 / 8
 int g_attn_bf16_sub = 2; // 8-wave blocks: 32-key sub-tiles per barrier (1 or 2)
+int g_attn_bf16_dma = 1; // bf16 Q | K | V self attention: LDS-DMA staging from K rows and a V^T image
 
 int attention_bf16(const AttnArgs& a, hipStream_t s) {
   // argument checks are attention()'s (the only caller)
@@ -400,6 +663,12 @@ int attention_bf16(const AttnArgs& a, hipStream_t s) {
   int nw = g_attn_bf16_nw;
   if (nw != 2 && nw != 4 && nw != 8)
     nw = a.max_q_len >= 1024 ? 8 : a.max_q_len >= 384 ? 4 : 2;
+  // self attention over bf16 Q | K | V without masks: K and the packed V^T by LDS-DMA
+  if (g_attn_bf16_dma != 0 && a.qkv_bf16 && a.vt && !a.P && a.mask_mode == 0 && nw >= 4 &&
+      a.q_len == a.kv_len && a.q_off == a.kv_off && a.ldk % 8 == 0 && a.ldv % 8 == 0 &&
+      a.vt_tp % DKT == 0 && a.vt_tp >= a.max_q_len &&
+      (int64_t)a.max_q_len * a.ldk * 2 < (int64_t(1) << 31))
+    return nw == 8 ? launch_dma<8>(a, s) : launch_dma<4>(a, s);
   switch (nw) {
     case 8: return launch<8>(a, s);
     case 4: return launch<4>(a, s);

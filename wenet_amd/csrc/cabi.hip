@@ -630,6 +630,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "bf16_store") g_bf16_store = value;
   else if (k == "attn_bf16_nw") g_attn_bf16_nw = value;
   else if (k == "attn_bf16_sub") g_attn_bf16_sub = value;
+  else if (k == "attn_bf16_dma") g_attn_bf16_dma = value;
   else if (k == "qkv_bf16") g_qkv_bf16 = value;
   else if (k == "fp8_min_tiles") g_fp8_min_tiles = value;
   else if (k == "ffn_fused") g_ffn_fused = value;

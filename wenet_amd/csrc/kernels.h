@@ -80,6 +80,10 @@ struct AttnArgs {
   int n_seq, n_heads, max_q_len;
   bool o_bf16 = false; // bf16 kernel only: O is a bf16 matrix (ldo in elements)
   bool qkv_bf16 = false;  // bf16 kernel only, no rel-pos: Q / K / V are bf16 (ld* in elements)
+  // bf16 kernel, qkv_bf16 self attention without masks: scratch for the V^T image
+  // [n_seq][n_heads][64][vt_tp] bf16 (vt_tp: max length rounded up to 64) that the DMA-staged
+  // kernel reads instead of V; null: register-staged kernel
+  void* vt = nullptr; int vt_tp = 0;
   int mask_mode = 0;   // 0: keys < kv_len; 1: causal; 2: chunk window
   int chunk_size = 0, left_chunks = -1;
   float scale = 0.125f;
@@ -95,6 +99,7 @@ int attention_bf16(const AttnArgs& a, hipStream_t s);
 extern int g_attn_bf16;      // 1 (default): bf16 mode uses the bf16 attention kernel
 extern int g_attn_bf16_nw;   // 0 auto, else waves (32-query groups) per block
 extern int g_attn_bf16_sub;  // 8-wave blocks: 32-key sub-tiles per barrier
+extern int g_attn_bf16_dma;  // 1 (default): LDS-DMA staged kernel where it applies (AttnArgs::vt)
 
 // Fused feed-forward module, fp32 (ffn_fused.hip): P[s] (S, M, D) = partial
 // act(X W1^T + b1) W2^T over hidden slice s; ffn_reduce_ln then forms
