@@ -448,7 +448,10 @@ int32_t wn_profile_ffn_split(const wn_model* m);
  * i = start of sub-stage i of one block's last steady-state chunk, entry 8 = its end. */
 int wn_profile_ffn_clocks(uint64_t* out64);
 /* Same for the six-product tile GEMM (wn_tune_set("x6_probe", 4)): [8 waves][8] = entry, loop
- * start, loop end, kernel end (shader clock), 100-MHz real time at entry / end, k blocks. */
+ * start, loop end, kernel end (shader clock), 100-MHz real time at entry / end, k blocks.  While
+ * wn_tune_set("lp_probe", 4 [| 8 first block | 16 last block]) is set, the stamps of the pipelined
+ * bf16 / MXFP8 GEMM instead: entry, first tile landed, K loop end, last store issued, stores
+ * drained, real time at entry / end, K tiles (tools/lp_clocks.py). */
 int wn_profile_gemm_clocks(uint64_t* out64);
 
 /* Test hook: "n_layers" = run only the first n encoder layers (-1: all),

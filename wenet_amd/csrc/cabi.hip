@@ -581,6 +581,8 @@ int32_t wn_profile_ffn_split(const wn_model* m) { return m ? m->prof_split : 0; 
 
 int wn_profile_gemm_clocks(uint64_t* out64) {
   WN_CHECK(out64, "wn_profile_gemm_clocks: null output");
+  if (wn::g_lp_probe & 4)   // the pipelined bf16 / MXFP8 kernel stamped last (tools/lp_clocks.py)
+    return wn::gemm_lp_clocks(reinterpret_cast<unsigned long long*>(out64));
   return wn::gemm_x6_clocks(reinterpret_cast<unsigned long long*>(out64));
 }
 
@@ -631,6 +633,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "attn_bf16_nw") g_attn_bf16_nw = value;
   else if (k == "attn_bf16_sub") g_attn_bf16_sub = value;
   else if (k == "attn_bf16_dma") g_attn_bf16_dma = value;
+  else if (k == "lp_probe") g_lp_probe = value;
   else if (k == "qkv_bf16") g_qkv_bf16 = value;
   else if (k == "fp8_min_tiles") g_fp8_min_tiles = value;
   else if (k == "ffn_fused") g_ffn_fused = value;

@@ -98,6 +98,9 @@ struct GemmArgs {
   const unsigned* a_scale = nullptr; const unsigned* w_scale = nullptr;
   unsigned* c_scale = nullptr;
   int a_scale_pitch = 0, w_scale_pitch = 0, c_scale_pitch = 0;
+  // measurement (gemm_bf16p.hip, wn_tune_set("lp_probe")): bit 2 = shader-clock stamps of one
+  // block (bit 3: block 0 instead of the middle one, bit 4: the last one)
+  int probe = 0;
 };
 
 int gemm_f32(const GemmArgs& a, hipStream_t stream);
@@ -120,6 +123,8 @@ int gemm_bf16_stored(const GemmArgs& a, const void* Wh, hipStream_t stream);
 bool gemm_bf16p_supported(const GemmArgs& a);
 int gemm_bf16_pipelined(const GemmArgs& a, const void* Wh, hipStream_t stream);
 int gemm_mxfp8(const GemmArgs& a, const void* Wq, hipStream_t stream);
+extern int g_lp_probe;                         // wn_tune_set("lp_probe")
+int gemm_lp_clocks(unsigned long long* out);   // [8 waves][8] stamps of the pipelined kernel
 // fp32 [rows][ld] -> e4m3 [rows][K] + block scales [K/128][pitch] dwords
 int mx_quantize(const float* x, int ld, int rows, int K, void* q, unsigned* scale, int pitch,
                 hipStream_t s);

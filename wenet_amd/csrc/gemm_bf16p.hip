@@ -63,6 +63,8 @@ constexpr int KROW = 128;                     // bytes of one tile row
 constexpr int HALF_BYTES = 128 * KROW;        // 16 KB
 constexpr int TILE_BYTES = 4 * HALF_BYTES;    // 64 KB: A lo, A hi, W lo, W hi
 constexpr int SCALE_BYTES = 2048;             // per K tile: 256 A + 256 W dwords
+constexpr int EPI_PITCH = 128 + 16;           // epilogue patch: [128 rows][128 B + 16 B pad]
+constexpr int EPI_WAVE = 128 * EPI_PITCH;     // 18 KB per wave, 144 KB per block
 
 #define WN_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
                         __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -99,11 +101,18 @@ __device__ __forceinline__ float gelu_e5(float x) {
 
 // CM: 0 fp32 C, 1 bf16 C, 2 MXFP8 C (+ block scales); VAR bit 0: no wave stagger,
 // bit 4: DEEP issue order (experiments, tools/bench_gemm.py --variants)
+// p.probe & 4 (measurement, tools/lp_clocks.py): per wave the shader clock at entry, after the
+// prologue (first tile landed), after the K loop, after the epilogue's last store was issued and
+// after the stores drained, + the 100-MHz real-time counter at entry / end, of one block
+__device__ unsigned long long g_lp_clk[8][8];
+
 template <int ET, int ACT, bool RESID, int CM, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_lp_kernel(
     GemmArgs p, const void* __restrict__ Wq, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem_p[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
+  unsigned long long ck0 = 0, ck1 = 0, ck2 = 0, rt0 = 0;
+  if (p.probe & 4) { ck0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   constexpr bool FP8 = ET == 1;
   constexpr bool DEEP = (VAR & 16) != 0;
   constexpr int ESZ = FP8 ? 1 : 2;            // bytes per element
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(512) void gemm_lp_kernel(
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
+  if (p.probe & 4) ck1 = __builtin_readcyclecounter();
   // the second wave of each SIMD runs one barrier behind the first
   if (!(VAR & 1) && wm == 1) __builtin_amdgcn_s_barrier();
   int t = 0;
@@ -363,9 +373,138 @@ __global__ __launch_bounds__(512) void gemm_lp_kernel(
   if (t < nk) ktile(t, 0);
   if (!(VAR & 1) && wm == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped) DMA
+  if (p.probe & 4) ck2 = __builtin_readcyclecounter();
 
   // ---- epilogue: lane = output row, 4 consecutive columns per register quad ------
   const int hi4 = hi * 4;
+  if constexpr (CM != 2) {
+    // fp32 / bf16 C through LDS (round 3; clock stamps r05b: the direct form -- every lane its own
+    // row, 16 B (fp32) / 8 B (bf16) per store -- touched 32 cache lines per store instruction and
+    // took 22 k cycles for a 128-KB bf16 tile, 60 k for an fp32 tile + residual, against 44 k for
+    // the whole K = 1280 loop).  Each wave turns its 128 x 64 sub-tile through a private
+    // [128 rows][128 B + 16] LDS patch (fp32: one 32-column half at a time) and stores / loads
+    // the residual as whole 128-byte row segments: 8 rows per instruction.
+    __builtin_amdgcn_s_barrier();   // every wave's fragment reads and trailing DMA are over
+    char* wbuf = smem_p + wave * EPI_WAVE;
+    const int wrow = lane & 31, rrow = lane >> 3, rch = lane & 7;
+    const int row0 = m0 + wm * 128;
+    if constexpr (CM == 1) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int cb = n0 + wn_ * 64 + nb * 32 + hi4;
+        f32x4 bias4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = cb + 8 * g;
+          bias4[g] = (p.bias && c < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + c)
+                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            bf16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = acc[mb][nb][4 * g + e] + bias4[g][e];
+              if (ACT == ACT_SILU) x = silu_fast(x);
+              if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
+              if (ACT == ACT_GELU) x = gelu_e5(x);
+              h[e] = (__bf16)(x * p.alpha);
+            }
+            *reinterpret_cast<bf16x4*>(wbuf + (mb * 32 + wrow) * EPI_PITCH +
+                                       (nb * 32 + 8 * g + hi4) * 2) = h;
+          }
+      }
+      const int cc = n0 + wn_ * 64 + rch * 8;          // 8 bf16 columns = 16 B
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        i32x4 o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          o[i] = *reinterpret_cast<const i32x4*>(wbuf + (half * 64 + i * 8 + rrow) * EPI_PITCH +
+                                                 rch * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(o[i]));   // reads stay out of the guards
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = half * 64 + i * 8 + rrow;
+          if (row0 + r < p.M && cc < p.N)
+            *reinterpret_cast<i32x4*>(reinterpret_cast<__bf16*>(p.C) +
+                                      (int64_t)(row0 + r) * p.ldc + cc) = o[i];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int cb0 = n0 + wn_ * 64 + nb * 32;
+        f32x4 bias4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = cb0 + hi4 + 8 * g;
+          bias4[g] = (p.bias && c < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + c)
+                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int cc = cb0 + rch * 4;                  // 4 fp32 columns = 16 B
+        f32x4 rs[2][8];
+        if constexpr (RESID) {                         // first half's residual rows: in flight
+#pragma unroll                                         // while the tile turns through LDS
+          for (int i = 0; i < 8; ++i) {
+            const int r = i * 8 + rrow;
+            rs[0][i] = (row0 + r < p.M && cc < p.N)
+                           ? *reinterpret_cast<const f32x4*>(p.resid + (int64_t)(row0 + r) * p.ldr + cc)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = acc[mb][nb][4 * g + e] + bias4[g][e];
+              if (ACT == ACT_SILU) x = silu_fast(x);
+              if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
+              if (ACT == ACT_GELU) x = gelu_as(x);
+              v[e] = x * p.alpha;
+            }
+            *reinterpret_cast<f32x4*>(wbuf + (mb * 32 + wrow) * EPI_PITCH + (8 * g + hi4) * 4) = v;
+          }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if constexpr (RESID) {
+            if (half == 0) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const int r = 64 + i * 8 + rrow;
+                rs[1][i] = (row0 + r < p.M && cc < p.N)
+                               ? *reinterpret_cast<const f32x4*>(p.resid +
+                                                                 (int64_t)(row0 + r) * p.ldr + cc)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+              }
+            }
+          }
+          f32x4 o[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            o[i] = *reinterpret_cast<const f32x4*>(wbuf + (half * 64 + i * 8 + rrow) * EPI_PITCH +
+                                                   rch * 16);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(o[i]));   // reads stay out of the guards
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int r = half * 64 + i * 8 + rrow;
+            if constexpr (RESID) o[i] += rs[half][i];
+            if (row0 + r < p.M && cc < p.N)
+              *reinterpret_cast<f32x4*>(p.C + (int64_t)(row0 + r) * p.ldc + cc) = o[i];
+          }
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     const int cb0 = n0 + wn_ * 64 + nb * 32;          // the 32-column block
@@ -388,10 +527,10 @@ __global__ __launch_bounds__(512) void gemm_lp_kernel(
           float x = acc[mb][nb][4 * g + e] + bias4[g][e];
           if (ACT == ACT_SILU) x = silu_fast(x);
           if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
-          if (ACT == ACT_GELU) x = CM != 0 ? gelu_e5(x) : gelu_as(x);
+          if (ACT == ACT_GELU) x = gelu_e5(x);
           v[g][e] = x * p.alpha;
         }
-      if constexpr (CM == 2) {
+      {
         // MXFP8 C: the lane pair (l, l ^ 32) holds the 32 columns of one block
         float amax = 0.f;
 #pragma unroll
@@ -421,26 +560,20 @@ __global__ __launch_bounds__(512) void gemm_lp_kernel(
                                                          row) * 4 + ((cb0 >> 5) & 3)] =
                 (unsigned char)E;
         }
-      } else {
-        if (row >= p.M) continue;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = cb + 8 * g;
-          if (c >= p.N) continue;
-          if constexpr (CM == 1) {
-            bf16x4 h;
-            h[0] = (__bf16)v[g][0]; h[1] = (__bf16)v[g][1];
-            h[2] = (__bf16)v[g][2]; h[3] = (__bf16)v[g][3];
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C) + (int64_t)row * p.ldc +
-                                       c) = h;
-          } else {
-            f32x4 o = v[g];
-            if constexpr (RESID)
-              o += *reinterpret_cast<const f32x4*>(p.resid + (int64_t)row * p.ldr + c);
-            *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + c) = o;
-          }
-        }
       }
+    }
+  }
+  }
+  if (p.probe & 4) {
+    const unsigned long long ck3 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ck4 = __builtin_readcyclecounter();
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    const int want = (p.probe & 8) ? 0 : (p.probe & 16) ? (int)gridDim.x - 1 : (int)gridDim.x / 2;
+    if ((int)blockIdx.x == want && lane == 0) {
+      unsigned long long* o = g_lp_clk[wave & 7];
+      o[0] = ck0; o[1] = ck1; o[2] = ck2; o[3] = ck3; o[4] = ck4; o[5] = rt0; o[6] = rt1;
+      o[7] = (unsigned long long)nk;
     }
   }
 }
@@ -448,7 +581,8 @@ __global__ __launch_bounds__(512) void gemm_lp_kernel(
 template <int ET, int ACT, bool RESID, int CM, int VAR = 0>
 int launch_p(const GemmArgs& a, const void* Wq, hipStream_t stream) {
   const int tiles_m = cdiv(a.M, PBM), tiles_n = cdiv(a.N, PBN);
-  const size_t lds = 2 * TILE_BYTES + (ET == 1 ? 2 * SCALE_BYTES : 0);
+  size_t lds = 2 * TILE_BYTES + (ET == 1 ? 2 * SCALE_BYTES : 0);
+  if (CM != 2 && lds < (size_t)8 * EPI_WAVE) lds = (size_t)8 * EPI_WAVE;
   auto kern = gemm_lp_kernel<ET, ACT, RESID, CM, VAR>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
@@ -463,7 +597,9 @@ int launch_p(const GemmArgs& a, const void* Wq, hipStream_t stream) {
 }
 
 template <int ET>
-int dispatch_p(const GemmArgs& a, const void* W, hipStream_t stream) {
+int dispatch_p(const GemmArgs& args, const void* W, hipStream_t stream) {
+  GemmArgs a = args;
+  if (g_lp_probe) a.probe = g_lp_probe;
   const bool resid = a.resid != nullptr;
   if (g_gemm_variant != 0 && !a.c_bf16 && !a.c_mx && !resid && a.act == ACT_NONE) {
     switch (g_gemm_variant) {   // experiments (tools/bench_gemm.py --variants)
@@ -540,13 +676,19 @@ __global__ __launch_bounds__(256) void mx_quantize_kernel(
 
 }  // namespace
 
+int g_lp_probe = 0;
+int gemm_lp_clocks(unsigned long long* out) {
+  WN_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lp_clk), sizeof(g_lp_clk)));
+  return 0;
+}
+
 // Shapes the pipelined kernel takes (everything else stays on gemm_bf16s_kernel)
 bool gemm_bf16p_supported(const GemmArgs& a) {
   const int esz = a.fp8 ? 1 : 2;
   const int kt = 128 / esz;
   return !a.glu && a.a_row_off == nullptr && a.K % kt == 0 && a.K >= 2 * kt &&
          a.N % 8 == 0 && (a.lda * esz) % 16 == 0 &&
-         (a.c_mx ? (a.N % 32 == 0 && a.ldc % 16 == 0) : a.ldc % 4 == 0) &&
+         (a.c_mx ? (a.N % 32 == 0 && a.ldc % 16 == 0) : a.c_bf16 ? a.ldc % 8 == 0 : a.ldc % 4 == 0) &&
          (a.resid == nullptr || a.ldr % 4 == 0) && !((a.c_bf16 || a.c_mx) && a.resid) &&
          (int64_t)a.M * a.lda * esz < (int64_t(1) << 31) &&
          (int64_t)a.N * a.K * esz < (int64_t(1) << 31);
