@@ -451,6 +451,9 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed):
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 1), 'tune')
         enc1, _ = model._forward_encoder(feats.cuda(), lens)
         enc1b, _ = model._forward_encoder(feats.cuda(), lens)
+        _lib.check(L.wn_tune_set(b'attn_bf16_dma', 2), 'tune')   # grouped fragment reads
+        enc2, _ = model._forward_encoder(feats.cuda(), lens)
+        enc2b, _ = model._forward_encoder(feats.cuda(), lens)
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 0), 'tune')
         enc0, _ = model._forward_encoder(feats.cuda(), lens)
     finally:
@@ -458,6 +461,8 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed):
         _set_dtype(model, 'fp32')
     assert torch.equal(enc1, enc1b), 'DMA-staged attention is not deterministic (race?)'
     assert torch.equal(enc1, enc0), (enc1 - enc0).abs().max().item()
+    assert torch.equal(enc2, enc2b), 'DMA-staged attention (grouped reads) is not deterministic'
+    assert torch.equal(enc2, enc0), (enc2 - enc0).abs().max().item()
     with torch.no_grad(), O.bf16_operands(sd):
         ref, mask = O.encoder_forward(configs, sd, feats, lens, -1, -1)
     ref_lens = mask.squeeze(1).sum(1).numpy()

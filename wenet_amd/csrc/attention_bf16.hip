@@ -440,7 +440,11 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const __bf16* __restrict__
   }
 }
 
-template <int NW>
+// PIPE (attn_bf16_dma = 2): the stage loop unrolled over the two LDS buffers so that every
+// fragment address is ONE of four per-lane registers + an immediate, the K fragments of a
+// sub-tile read as a group before its MFMA chain (the second sub-tile's, and the V^T fragments,
+// under the softmax of the first) instead of read - wait - multiply one at a time.
+template <int NW, bool PIPE>
 __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs a, int nqb) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   static_assert(NW == 4 || NW == 8, "4 or 8 query groups per block");
@@ -513,6 +517,105 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
   const int sw = (li >> 1) & 7;
   const int frow = li * 128;
 
+  if constexpr (PIPE) {
+    // per-lane fragment offsets: 16-B slot 2 c + hi of row li, c = 0..3 (K: k step c; V^T: key
+    // group c = 2 sb + j)
+    int fo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fo[c] = frow + (((2 * c + hi) ^ sw) << 4);
+    auto softmax_tile = [&](f32x16& sc, int j0, float& alpha) {
+      float psum;
+      if (j0 + KT <= kvlen) {
+        float t0 = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        float t1 = fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]));
+        float t2 = fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11]));
+        float t3 = fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]));
+        const float tmax = pair_max(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
+        const float m_new = fmaxf(m_run, tmax);
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+        const float mc = -m_new * cs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], cs, mc));
+        psum = ((sc[0] + sc[1]) + (sc[2] + sc[3])) + ((sc[4] + sc[5]) + (sc[6] + sc[7])) +
+               (((sc[8] + sc[9]) + (sc[10] + sc[11])) + ((sc[12] + sc[13]) + (sc[14] + sc[15])));
+        m_run = m_new;
+      } else {
+        float tmax = -1e30f;
+        bool ok[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          ok[r] = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi < kvlen;
+          if (ok[r]) tmax = fmaxf(tmax, sc[r]);
+        }
+        tmax = pair_max(tmax);
+        const float m_new = fmaxf(m_run, tmax);
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+        const float mc = -m_new * cs;
+        psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = ok[r] ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], cs, mc)) : 0.f;
+          sc[r] = p;
+          psum += p;
+        }
+        m_run = m_new;
+      }
+      l_run = l_run * alpha + psum;
+    };
+    auto stage = [&](auto bufc, int it) {
+      constexpr int BUF = decltype(bufc)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage `it`
+      __builtin_amdgcn_s_barrier();                      // everyone's; the other buffer is free
+      if (it + 1 < n_it) issue(it + 1, BUF ^ 1);
+      const char* sK = sbuf + BUF * DSTAGE;
+      const char* sV = sK + DTILE;
+      const bool two = it * DKT + KT < kvlen;            // uniform: the stage has a second sub-tile
+      bf16x8 kf[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(sK + fo[kk]);
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        if (sb == 1 && !two) break;
+        const int j0 = it * DKT + sb * KT;
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qu[kk], sc, 0, 0, 0);
+        // under the MFMA chain's tail and the softmax: the next sub-tile's K fragments
+        if (sb == 0 && two) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            kf[kk] = *reinterpret_cast<const bf16x8*>(sK + 32 * 128 + fo[kk]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float alpha;
+        softmax_tile(sc, j0, alpha);
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf16x8 pa;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pa[e] = (__bf16)sc[8 * j + e];
+          const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(sV + fo[2 * sb + j]);
+          const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(sV + 32 * 128 + fo[2 * sb + j]);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pa, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pa, o1, 0, 0, 0);
+        }
+      }
+    };
+    for (int it = 0; it < n_it; it += 2) {
+      stage(std::integral_constant<int, 0>{}, it);
+      if (it + 1 < n_it) stage(std::integral_constant<int, 1>{}, it + 1);
+    }
+  } else
   for (int it = 0; it < n_it; ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage `it`
     __builtin_amdgcn_s_barrier();                      // everyone's; buffer (it+1)&1 is free
@@ -617,7 +720,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
   }
 }
 
-template <int NW>
+template <int NW, bool PIPE>
 int launch_dma(const AttnArgs& a, hipStream_t s) {
   const int kt = cdiv(a.max_q_len, DKT);
   hipLaunchKernelGGL(vt_pack_kernel, dim3(kt, a.n_heads, a.n_seq), dim3(256), 0, s,
@@ -625,7 +728,7 @@ int launch_dma(const AttnArgs& a, hipStream_t s) {
                      a.vt_tp, reinterpret_cast<__bf16*>(a.vt));
   WN_HIP(hipGetLastError());
   const int nqb = cdiv(a.max_q_len, NW * 32);
-  hipLaunchKernelGGL((attention_bf16_dma_kernel<NW>), dim3(nqb * a.n_heads * a.n_seq),
+  hipLaunchKernelGGL((attention_bf16_dma_kernel<NW, PIPE>), dim3(nqb * a.n_heads * a.n_seq),
                      dim3(NW * 64), 0, s, a, nqb);
   WN_HIP(hipGetLastError());
   return 0;
@@ -668,7 +771,10 @@ int attention_bf16(const AttnArgs& a, hipStream_t s) {
       a.q_len == a.kv_len && a.q_off == a.kv_off && a.ldk % 8 == 0 && a.ldv % 8 == 0 &&
       a.vt_tp % DKT == 0 && a.vt_tp >= a.max_q_len &&
       (int64_t)a.max_q_len * a.ldk * 2 < (int64_t(1) << 31))
-    return nw == 8 ? launch_dma<8>(a, s) : launch_dma<4>(a, s);
+  {
+    if (g_attn_bf16_dma == 2) return nw == 8 ? launch_dma<8, true>(a, s) : launch_dma<4, true>(a, s);
+    return nw == 8 ? launch_dma<8, false>(a, s) : launch_dma<4, false>(a, s);
+  }
   switch (nw) {
     case 8: return launch<8>(a, s);
     case 4: return launch<4>(a, s);

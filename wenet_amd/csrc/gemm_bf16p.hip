@@ -42,9 +42,9 @@
 //    4 x 4 consecutive columns per 32 x 32 tile, so the epilogue issues 16-byte
 //    (fp32 C) / 8-byte (bf16 C) stores and 16-byte residual loads, and a lane pair
 //    (l, l ^ 32) owns one whole 32-column MX block of the row.
-//  * GELU in the epilogue uses the Abramowitz-Stegun 7.1.26 erf (|err| < 1.5e-7,
-//    one v_exp + one v_rcp) instead of erff: the result is rounded to bf16 / e4m3
-//    or added into an fp32 stream that the next GEMM rounds.
+//  * GELU in the epilogue: gelu_e5 below (erfc as 2^(-z G(z)), one v_exp) instead of erff.
+//  * fp32 / bf16 C leaves through wave-private LDS patches as whole 128-byte row segments
+//    (epilogue comment below).
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "mxfp8.h"
@@ -69,24 +69,14 @@ constexpr int EPI_WAVE = 128 * EPI_PITCH;     // 18 KB per wave, 144 KB per bloc
 #define WN_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
                         __builtin_amdgcn_sched_barrier(0); } while (0)
 
-__device__ __forceinline__ float gelu_as(float x) {
-  // 0.5 x (1 + erf(x / sqrt 2)), erf by A&S 7.1.26 on |z|
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float e = 1.0f - poly * t * __expf(-z * z);   // erf(|z|)
-  return 0.5f * x * (1.0f + copysignf(e, x));
-}
-
-// GELU for a C that is rounded to bf16 / e4m3 (round 3): x Phi(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2)
-// with erfc(z) = 2^(-z G(z)), G a degree-5 fit of -log2(erfc z) / z on [0, 6.5] (z clamped
-// there: erfc(6.5) = 4e-20).  One v_exp, no v_rcp, 12 VALU operations against 15 + two
-// transcendentals of gelu_as; |error| < 4.7e-6 absolute and < 1.8e-3 of the value in the
-// negative tail, where 1 - erf(|z|) of the A&S form cancels (its bf16-rounded result differs
-// from the exact one's more often than this one's: 18 % vs 13 % of a fine grid on [-9, 12]).
+// GELU of this kernel (round 3; the result is rounded to bf16 / e4m3 or added into an fp32 stream
+// that the next GEMM rounds): x Phi(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2) with
+// erfc(z) = 2^(-z G(z)), G a degree-5 fit of -log2(erfc z) / z on [0, 6.5] (z clamped there:
+// erfc(6.5) = 4e-20).  One v_exp, no v_rcp, 12 VALU operations against 15 + two transcendentals
+// of the Abramowitz-Stegun 7.1.26 form used before (w_1 of the fp8 mode: 236 -> 198 us);
+// |error| < 4.7e-6 absolute and < 1.8e-3 of the value in the negative tail, where the A&S form's
+// 1 - erf(|z|) cancels (its bf16-rounded result differs from the exact one's more often than
+// this one's: 18 % vs 13 % of a fine grid on [-9, 12]).
 __device__ __forceinline__ float gelu_e5(float x) {
   const float ax = fabsf(x);
   const float z = fminf(ax * 0.70710678118654752f, 6.5f);
@@ -467,7 +457,7 @@ __global__ __launch_bounds__(512) void gemm_lp_kernel(
               float x = acc[mb][nb][4 * g + e] + bias4[g][e];
               if (ACT == ACT_SILU) x = silu_fast(x);
               if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
-              if (ACT == ACT_GELU) x = gelu_as(x);
+              if (ACT == ACT_GELU) x = gelu_e5(x);
               v[e] = x * p.alpha;
             }
             *reinterpret_cast<f32x4*>(wbuf + (mb * 32 + wrow) * EPI_PITCH + (8 * g + hi4) * 4) = v;
