@@ -457,7 +457,7 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed):
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 0), 'tune')
         enc0, _ = model._forward_encoder(feats.cuda(), lens)
     finally:
-        L.wn_tune_set(b'attn_bf16_dma', 1)
+        L.wn_tune_set(b'attn_bf16_dma', 2)      # the default
         _set_dtype(model, 'fp32')
     assert torch.equal(enc1, enc1b), 'DMA-staged attention is not deterministic (race?)'
     assert torch.equal(enc1, enc0), (enc1 - enc0).abs().max().item()

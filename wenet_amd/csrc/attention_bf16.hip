@@ -756,7 +756,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
 
 int g_attn_bf16_nw = 0;  // wn_tune_set("attn_bf16_nw"): 0 auto, else 2 / 4 / 8
 int g_attn_bf16_sub = 2; // 8-wave blocks: 32-key sub-tiles per barrier (1 or 2)
-int g_attn_bf16_dma = 1; // bf16 Q | K | V self attention: LDS-DMA staging from K rows and a V^T image
+int g_attn_bf16_dma = 2; // bf16 Q | K | V self attention: 0 register-staged, 1 LDS-DMA staged (K rows + V^T image), 2 + grouped fragment reads
 
 int attention_bf16(const AttnArgs& a, hipStream_t s) {
   // argument checks are attention()'s (the only caller)
