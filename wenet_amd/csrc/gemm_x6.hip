@@ -519,6 +519,7 @@ int g_x6_conv_bm = 0;
 int g_x6_ffn_s = 0;
 int g_x6_nw4 = 0;
 int g_x6_conv = 1;
+int g_x6_sub = 1;
 int g_x6_conv_order = 1;   // 1: channel blocks outside, taps inside (L2 reuse); 0: tap-major
 int g_x6_linear = 1;
 // 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in

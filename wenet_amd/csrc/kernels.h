@@ -161,6 +161,7 @@ extern int g_x6_nw4;       // wn_tune_set("x6_nw4") A/B bits: 1 FFN w_1 on 256-r
 extern int g_x6_linear;    // wn_tune_set("x6_linear"): 0 = linear() never routes to the six-product GEMM
 extern int g_x6_conv_order;
 extern int g_x6_conv;      // wn_tune_set("x6_conv"): 0 = conv2 stays on v_mfma_f32
+extern int g_x6_sub;       // wn_tune_set("x6_sub"): 0 = the subsampling's output Linear stays on v_mfma_f32, 1 K slices of 256-row tiles, 2 of 128-row tiles
 extern int g_x6_af32;      // wn_tune_set("x6_af32"): 0 plane images (default), 1 fp32 A rows split in registers
 extern int g_x6_ffn_s;     // wn_tune_set("x6_ffn_s"): K slices of the FFN w_2 GEMM (0 auto)
 extern int g_x6_conv_bm;   // wn_tune_set("x6_conv_bm"): block rows of the conv2 GEMM (0 auto)

@@ -187,6 +187,7 @@ int build_x6_images(wn_model* m) {
   for (const auto& L : m->tf_layers) { ws.push_back(&L.qkv); ws.push_back(&L.out);
                                        ws.push_back(&L.ff1); ws.push_back(&L.ff2); }
   if (m->conv2.w) ws.push_back(&m->conv2);   // [d][(ky*3+kx)*d + c]: 16-channel k blocks per tap
+  if (m->sub_out.w) ws.push_back(&m->sub_out);   // K slices straight from conv2's fp32 output
   std::vector<const Linear*> vocab;          // V rows; the image pads them to a multiple of 32
   if (m->ctc.w) vocab.push_back(&m->ctc);
   for (const Decoder* D : {&m->left, &m->right})
@@ -437,6 +438,43 @@ int set_layout(wn_model* m, int B, int Tp, const std::vector<int>& off,
 }
 
 // GlobalCMVN + Conv2dSubsampling4 + RelPositionalEncoding scale for a padded
+// Conv2dSubsampling's out Linear(d * F2 -> d) * sqrt(d) (subsampling.py:225-226, embedding.py:144)
+// on the six-product GEMM (round 3).  K = 4864 / 9728 and N = d give 31 row tiles at config 2: the
+// K dimension is cut into S slices (tiles x S fills the CUs once), the fp32 rows of conv2's output
+// are split into planes in registers (no plane image of the 154-MB tensor), the slice partials
+// are added by ffn_reduce_ln together with the bias, the scale and layer 0's norm_ff_macaron
+// (x starts as zeros: 0 + alpha (sum + b) is alpha (sum + b) exactly).  191 us on v_mfma_f32
+// (102 TF, r05e) before.  Returns 1 if it ran, 0 if the shape stays on linear().
+int sub_out_linear(wn_model* m, int M, int F2, hipStream_t s) {
+  const wn_config& c = m->cfg;
+  const int d = c.d_model, K = F2 * d;
+  if (t_gemm_prec != PREC_F32 || g_gemm_x6 == 0 || g_x6_sub == 0 || !m->x6_at || m->layers.empty() ||
+      (d != 256 && d != 512) || K % 16 != 0 || M < 512 || (int64_t)M * K * 4 >= ((int64_t)1 << 31) ||
+      bf16_store_active())
+    return 0;
+  auto it = m->x6_at->find(m->sub_out.w);
+  if (it == m->x6_at->end()) return 0;
+  const int bm = g_x6_sub == 2 ? 128 : 256;
+  const int tiles = cdiv(M, bm) * cdiv(d, 256), nkb = K / 16;
+  int S = 0;
+  for (int t = std::min(16, 256 / std::max(tiles, 1)); t >= 2; --t)
+    if (nkb % t == 0) { S = t; break; }
+  if (S < 2) return 0;
+  WN_TRY(m->ffn_part.ensure((size_t)S * M * d * sizeof(float)));
+  X6Args g;
+  g.A = m->c2.as<float>(); g.lda = K; g.a_bytes = (int64_t)M * K * 4;
+  g.B3 = it->second; g.M = M; g.N = d; g.K = K; g.epi = 1; g.ksplit = S; g.bm = bm;
+  g.C = m->ffn_part.as<float>();
+  WN_TRY(gemm_x6(g, s));
+  WN_HIP(hipMemsetAsync(m->x.p, 0, (size_t)M * d * sizeof(float), s));
+  const EncLayer& L0 = m->layers[0];
+  WN_TRY(ffn_reduce_ln(m->x.as<float>(), m->ffn_part.as<float>(), S, m->sub_out.b, sqrtf((float)d),
+                       L0.norm_ff_mac.w, L0.norm_ff_mac.b, nullptr, nullptr, m->t1.as<float>(), M,
+                       d, c.norm_eps, 0, s));
+  m->ln0_done = true;
+  return 1;
+}
+
 // (B, T, F) feature batch: sets the row layout and leaves x = embed(xs) in m->x
 // (encoder.py:155-157, subsampling.py:203-228, embedding.py:134-147).  `pos0` is
 // the position of the first output frame (streaming offset).
@@ -446,6 +484,7 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
   const wn_config& c = m->cfg;
   const int d = c.d_model, F1 = m->F1(), F2 = m->F2();
   const int Tp = ((T - 1) / 2 - 1) / 2;
+  m->ln0_done = false;
   WN_CHECK(pos0 + Tp <= c.max_pos, "utterance longer than the positional table");
   std::vector<int> off2(B), len2(B), off1(B), len1(B);
   int M = 0, M1 = 0, max_t1 = 0;
@@ -537,8 +576,11 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
         g.tap_delta[ky * 3 + 2] = ky * F1 + 1;        // f1 = 2 f2 + 2 (even, position f2 + 1)
       }
       WN_TRY(gemm_x6(g, s));
-      WN_TRY(linear(m->sub_out, m->c2.as<float>(), F2 * d, m->x.as<float>(), d, M,
-                    s, ACT_NONE, nullptr, 0, sqrtf((float)d)));
+      const int r = sub_out_linear(m, M, F2, s);
+      if (r < 0) return r;
+      if (r == 0)
+        WN_TRY(linear(m->sub_out, m->c2.as<float>(), F2 * d, m->x.as<float>(), d, M,
+                      s, ACT_NONE, nullptr, 0, sqrtf((float)d)));
       return 0;
     }
     // GlobalCMVN + conv1 + ReLU                        encoder.py:155, subsampling.py:188
@@ -599,7 +641,8 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     // residual add and the NEXT LayerNorm (norm_mha)
     int fS = 0;
     if (!h16 && t_gemm_prec == PREC_F32) {
-      if (li == 0) WN_TRY(ln(L.norm_ff_mac, x, t1, M, d, eps, s));
+      if (li == 0 && !m->ln0_done) WN_TRY(ln(L.norm_ff_mac, x, t1, M, d, eps, s));
+      m->ln0_done = false;
       fS = ffn_fused_try(m, L.ffm1, L.ffm2, ACT_SILU, s);
       if (fS < 0) return -2;
     }

@@ -307,6 +307,7 @@ struct wn_model {
   // ctc
   int ctc_rows = 0, ctc_k = 0;
   bool ctc_valid = false;
+  bool ln0_done = false;   // t1 already holds layer 0's norm_ff_macaron(x) (sub_out_linear)
   DevBuf logits, topk_val, topk_idx;
   // searches
   DevBuf pb_dbg;
