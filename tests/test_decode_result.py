@@ -1,0 +1,50 @@
+"""DecodeResult (wenet/models/transformer/search.py:30-61): the n-best fields of a prefix-beam
+result are built from the batch's raw arrays on first access -- what is read must be exactly what
+the eager construction gave."""
+import numpy as np
+
+from wenet_amd.search import DecodeResult, _NBestBatch
+
+
+def _batch(B=5, beam=4, T=9, seed=3):
+    rng = np.random.default_rng(seed)
+    n_hyps = rng.integers(1, beam + 1, (B, )).astype(np.int32)
+    hyp_lens = rng.integers(0, T + 1, (B, beam)).astype(np.int32)
+    hyp_tlens = hyp_lens.copy()
+    hyp_tokens = rng.integers(1, 100, (B, beam, T)).astype(np.int32)
+    hyp_times = rng.integers(0, 50, (B, beam, T)).astype(np.int32)
+    hyp_scores = -rng.random((B, beam))
+    return n_hyps, hyp_lens, hyp_tlens, hyp_tokens, hyp_times, hyp_scores
+
+
+def test_lazy_nbest_equals_eager_lists():
+    arrs = _batch()
+    n_hyps, hyp_lens, hyp_tlens, hyp_tokens, hyp_times, hyp_scores = arrs
+    batch = _NBestBatch(*arrs)
+    for b in range(len(n_hyps)):
+        r = DecodeResult(tokens=tuple(hyp_tokens[b, 0, :hyp_lens[b, 0]].tolist()),
+                         score=float(hyp_scores[b, 0]),
+                         times=hyp_times[b, 0, :hyp_tlens[b, 0]].tolist())
+        r._lazy, r._b = batch, b
+        n = int(n_hyps[b])
+        want = [tuple(hyp_tokens[b, i, :hyp_lens[b, i]].tolist()) for i in range(n)]
+        want_t = [hyp_times[b, i, :hyp_tlens[b, i]].tolist() for i in range(n)]
+        assert r.nbest == want and isinstance(r.nbest[0], tuple)
+        assert r.nbest_scores == hyp_scores[b, :n].tolist()
+        assert r.nbest_times == want_t
+        assert r.nbest[0] == r.tokens and r.nbest_times[0] == r.times
+        assert r.nbest_scores[0] == r.score
+        assert r.nbest is r.nbest            # built once
+
+
+def test_plain_construction_and_assignment_keep_working():
+    r = DecodeResult([1, 2, 3], 0.5, nbest=[[1, 2, 3]], nbest_scores=[0.5], nbest_times=[[4, 5, 6]])
+    assert r.nbest == [[1, 2, 3]] and r.nbest_scores == [0.5] and r.nbest_times == [[4, 5, 6]]
+    assert DecodeResult([7]).nbest is None
+    arrs = _batch(B=2)
+    r = DecodeResult((1, ))
+    r._lazy, r._b = _NBestBatch(*arrs), 1
+    r.nbest = 'mine'                        # assignment wins over the pending arrays
+    assert r.nbest == 'mine' and r.nbest_scores == arrs[5][1, :int(arrs[0][1])].tolist()
+    r.extra = 3                             # plain attributes stay assignable
+    assert r.extra == 3

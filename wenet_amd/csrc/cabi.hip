@@ -1092,20 +1092,25 @@ int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
   const int64_t pool = prefix_beam_pool_ints(max_len, beam);
   WN_TRY(m->pb_pool.ensure((size_t)B * pool * sizeof(int)));
   const size_t nb = (size_t)B * beam;
-  WN_TRY(m->pb_nh.ensure(B * sizeof(int)));
-  WN_TRY(m->pb_len.ensure(nb * sizeof(int)));
-  WN_TRY(m->pb_tlen.ensure(nb * sizeof(int)));
-  WN_TRY(m->pb_tok.ensure(nb * max_len * sizeof(int)));
-  WN_TRY(m->pb_tim.ensure(nb * max_len * sizeof(int)));
-  WN_TRY(m->pb_score.ensure(nb * sizeof(double)));
+  // the results in ONE device block -> one copy into pinned memory (six staged copies into the
+  // caller's pageable arrays took ~130 us of host round trips per batch, r05f trace)
+  const size_t o_sc = 0, o_nh = o_sc + nb * sizeof(double), o_len = o_nh + (size_t)B * sizeof(int),
+               o_tlen = o_len + nb * sizeof(int), o_tok = o_tlen + nb * sizeof(int),
+               o_tim = o_tok + nb * max_len * sizeof(int),
+               o_end = o_tim + nb * max_len * sizeof(int);
+  WN_TRY(m->pb_out.ensure(o_end));
+  WN_TRY(m->pb_host.ensure(o_end));
+  char* ob = m->pb_out.as<char>();
   PrefixBeamArgs a;
   a.topk_val = m->topk_val.as<float>(); a.topk_idx = m->topk_idx.as<int>();
   a.k = m->ctc_k; a.off = m->d_off.as<int>(); a.len = m->d_len.as<int>();
   a.B = B; a.beam = beam; a.blank = blank_id; a.max_len = max_len;
   a.pool = m->pb_pool.as<int>(); a.pool_stride = pool;
-  a.n_hyps = m->pb_nh.as<int>(); a.hyp_lens = m->pb_len.as<int>();
-  a.hyp_tlens = m->pb_tlen.as<int>(); a.hyp_tokens = m->pb_tok.as<int>();
-  a.hyp_times = m->pb_tim.as<int>(); a.hyp_scores = m->pb_score.as<double>();
+  a.n_hyps = reinterpret_cast<int*>(ob + o_nh); a.hyp_lens = reinterpret_cast<int*>(ob + o_len);
+  a.hyp_tlens = reinterpret_cast<int*>(ob + o_tlen);
+  a.hyp_tokens = reinterpret_cast<int*>(ob + o_tok);
+  a.hyp_times = reinterpret_cast<int*>(ob + o_tim);
+  a.hyp_scores = reinterpret_cast<double*>(ob + o_sc);
   a.cg = m->ctx;
   static const bool pb_dbg = getenv("WN_PB_CYCLES") != nullptr;  // debugging aid
   if (pb_dbg) {
@@ -1121,13 +1126,23 @@ int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
             "select %.0f; emit %lld cycles\n", h[3], (double)h[0] / h[3],
             (double)h[1] / h[3], (double)h[2] / h[3], h[4]);
   }
-  WN_HIP(hipMemcpyAsync(n_hyps_host, a.n_hyps, B * sizeof(int), hipMemcpyDeviceToHost, s));
-  WN_HIP(hipMemcpyAsync(hyp_lens_host, a.hyp_lens, nb * sizeof(int), hipMemcpyDeviceToHost, s));
-  WN_HIP(hipMemcpyAsync(hyp_tlens_host, a.hyp_tlens, nb * sizeof(int), hipMemcpyDeviceToHost, s));
-  WN_HIP(hipMemcpyAsync(hyp_tokens_host, a.hyp_tokens, nb * max_len * sizeof(int), hipMemcpyDeviceToHost, s));
-  WN_HIP(hipMemcpyAsync(hyp_times_host, a.hyp_times, nb * max_len * sizeof(int), hipMemcpyDeviceToHost, s));
-  WN_HIP(hipMemcpyAsync(hyp_scores_host, a.hyp_scores, nb * sizeof(double), hipMemcpyDeviceToHost, s));
+  WN_HIP(hipMemcpyAsync(m->pb_host.p, ob, o_end, hipMemcpyDeviceToHost, s));
   WN_HIP(hipStreamSynchronize(s));
+  const char* hb = m->pb_host.p;
+  memcpy(n_hyps_host, hb + o_nh, (size_t)B * sizeof(int));
+  memcpy(hyp_lens_host, hb + o_len, nb * sizeof(int));
+  memcpy(hyp_tlens_host, hb + o_tlen, nb * sizeof(int));
+  memcpy(hyp_scores_host, hb + o_sc, nb * sizeof(double));
+  // tokens / times: only the used corner of each [max_len] row (the caller's arrays are
+  // zero-initialised; the kernel writes nothing past a hypothesis' length that anyone reads)
+  const int* hl = reinterpret_cast<const int*>(hb + o_len);
+  const int* htl = reinterpret_cast<const int*>(hb + o_tlen);
+  for (size_t i = 0; i < nb; ++i) {
+    const int nl = std::min(std::max(hl[i], 0), (int)max_len);
+    const int ntl = std::min(std::max(htl[i], 0), (int)max_len);
+    memcpy(hyp_tokens_host + i * max_len, hb + o_tok + i * max_len * sizeof(int), nl * sizeof(int));
+    memcpy(hyp_times_host + i * max_len, hb + o_tim + i * max_len * sizeof(int), ntl * sizeof(int));
+  }
   return 0;
 }
 

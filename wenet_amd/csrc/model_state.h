@@ -86,6 +86,27 @@ struct Stager {
   }
 };
 
+// Pinned host memory that only grows: the landing area of result copies (ONE device -> host
+// copy per search instead of one staged copy per pageable result array).
+struct PinnedBuf {
+  char* p = nullptr;
+  size_t cap = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) WN_HIP(hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    WN_HIP(hipHostMalloc((void**)&p, want, hipHostMallocDefault));
+    cap = want;
+    return 0;
+  }
+};
+
 struct Linear { const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0; };
 struct Norm { const float* w = nullptr; const float* b = nullptr; };
 
@@ -311,7 +332,9 @@ struct wn_model {
   DevBuf logits, topk_val, topk_idx;
   // searches
   DevBuf pb_dbg;
-  DevBuf g_tok, g_len, pb_pool, pb_nh, pb_len, pb_tlen, pb_tok, pb_tim, pb_score;
+  DevBuf g_tok, g_len, pb_pool;
+  DevBuf pb_out;          // the prefix beam search's results, one block: counts | lengths | scores | tokens | times
+  PinnedBuf pb_host;      // ... and where they land on the host
   // rescoring
   DevBuf r_tok, r_rtok, r_pos, r_tgt, r_rtgt, r_qoff, r_qlen, r_kvoff, r_kvlen;
   DevBuf r_x, r_t1, r_t2, r_qkv, r_h, r_mem, r_logits, r_out;

@@ -20,7 +20,14 @@ from wenet_amd import _lib
 
 
 class DecodeResult:
-    """wenet/models/transformer/search.py:30-61 (same fields)."""
+    """wenet/models/transformer/search.py:30-61 (same fields).
+
+    The n-best fields of a prefix-beam result may be backed by the raw arrays of the
+    whole batch (`_NBestBatch`) and turned into the reference's Python lists on first
+    access: building 3 x B x beam lists per batch costs more host time than the GPU
+    search of that batch takes, and a caller that reads only the 1-best (or hands the
+    result to attention_rescoring later) should not wait for it before the next batch
+    can be queued.  What is read is the same objects as before."""
 
     def __init__(self,
                  tokens: List[int],
@@ -37,10 +44,78 @@ class DecodeResult:
         self.confidence = confidence
         self.tokens_confidence = tokens_confidence
         self.times = times
-        self.nbest = nbest
-        self.nbest_scores = nbest_scores
-        self.nbest_times = nbest_times
+        self._nbest = nbest
+        self._nbest_scores = nbest_scores
+        self._nbest_times = nbest_times
         self.text = text
+        self._lazy = None
+        self._b = 0
+
+    def _fill(self):
+        lazy = self._lazy
+        if lazy is not None:
+            self._lazy = None
+            self._nbest, self._nbest_scores, self._nbest_times = lazy.utterance(self._b)
+
+    @property
+    def nbest(self):
+        self._fill()
+        return self._nbest
+
+    @nbest.setter
+    def nbest(self, v):
+        self._fill()
+        self._nbest = v
+
+    @property
+    def nbest_scores(self):
+        self._fill()
+        return self._nbest_scores
+
+    @nbest_scores.setter
+    def nbest_scores(self, v):
+        self._fill()
+        self._nbest_scores = v
+
+    @property
+    def nbest_times(self):
+        self._fill()
+        return self._nbest_times
+
+    @nbest_times.setter
+    def nbest_times(self, v):
+        self._fill()
+        self._nbest_times = v
+
+
+class _NBestBatch:
+    """The n-best arrays wn_ctc_prefix_beam_search filled for one batch; `utterance(b)`
+    gives (nbest, nbest_scores, nbest_times) of utterance b as the reference's lists.
+    The bulk ndarray -> list conversion of the whole batch happens once, on the first
+    request (a per-hypothesis ndarray.tolist() costs more than the GPU search)."""
+
+    __slots__ = ('n_hyps', 'hyp_lens', 'hyp_tlens', 'hyp_tokens', 'hyp_times',
+                 'hyp_scores', '_lists')
+
+    def __init__(self, n_hyps, hyp_lens, hyp_tlens, hyp_tokens, hyp_times, hyp_scores):
+        self.n_hyps, self.hyp_lens, self.hyp_tlens = n_hyps, hyp_lens, hyp_tlens
+        self.hyp_tokens, self.hyp_times, self.hyp_scores = hyp_tokens, hyp_times, hyp_scores
+        self._lists = None
+
+    def utterance(self, b: int):
+        if self._lists is None:
+            L = max(int(self.hyp_lens.max(initial=0)), 1)
+            Lt = max(int(self.hyp_tlens.max(initial=0)), 1)
+            self._lists = (self.hyp_tokens[:, :, :L].tolist(),
+                           self.hyp_times[:, :, :Lt].tolist(), self.hyp_lens.tolist(),
+                           self.hyp_tlens.tolist(), self.hyp_scores.tolist(),
+                           self.n_hyps.tolist())
+        tok_l, tim_l, len_l, tlen_l, sc_l, n_l = self._lists
+        n = n_l[b]
+        tb, lb = tok_l[b], len_l[b]
+        mb, ub = tim_l[b], tlen_l[b]
+        return ([tuple(tb[i][:lb[i]]) for i in range(n)], sc_l[b][:n],
+                [mb[i][:ub[i]] for i in range(n)])
 
 
 def _stream_ptr(device) -> int:
@@ -113,26 +188,19 @@ def _prefix_beam(handle: int, B: int, max_len: int, beam_size: int,
             _lib.i32p(hyp_lens), _lib.i32p(hyp_tlens), _lib.i32p(hyp_tokens),
             _lib.i32p(hyp_times), _lib.f64p(hyp_scores), max_len,
             _stream_ptr(device)), 'wn_ctc_prefix_beam_search')
-    # one bulk conversion of the used corner of each array (a per-hypothesis
-    # ndarray.tolist() costs more than the GPU search of a 32-utterance batch)
-    L = max(int(hyp_lens.max(initial=0)), 1)
-    Lt = max(int(hyp_tlens.max(initial=0)), 1)
-    tok_l = hyp_tokens[:, :, :L].tolist()
-    tim_l = hyp_times[:, :, :Lt].tolist()
-    len_l, tlen_l = hyp_lens.tolist(), hyp_tlens.tolist()
-    sc_l, n_l = hyp_scores.tolist(), n_hyps.tolist()
+    # eagerly only the 1-best of every utterance (one bulk conversion of the used corner of
+    # the first hypotheses); the n-best lists are built on first access (_NBestBatch)
+    batch = _NBestBatch(n_hyps, hyp_lens, hyp_tlens, hyp_tokens, hyp_times, hyp_scores)
+    len0, tlen0 = hyp_lens[:, 0].tolist(), hyp_tlens[:, 0].tolist()
+    tok0 = hyp_tokens[:, 0, :max(max(len0, default=0), 1)].tolist()
+    tim0 = hyp_times[:, 0, :max(max(tlen0, default=0), 1)].tolist()
+    sc0 = hyp_scores[:, 0].tolist()
     results = []
     for b in range(B):
-        n = n_l[b]
-        tb, lb = tok_l[b], len_l[b]
-        mb, ub = tim_l[b], tlen_l[b]
-        nbest = [tuple(tb[i][:lb[i]]) for i in range(n)]
-        nbest_scores = sc_l[b][:n]
-        nbest_times = [mb[i][:ub[i]] for i in range(n)]
-        results.append(
-            DecodeResult(tokens=nbest[0], score=nbest_scores[0],
-                         times=nbest_times[0], nbest=nbest,
-                         nbest_scores=nbest_scores, nbest_times=nbest_times))
+        r = DecodeResult(tokens=tuple(tok0[b][:len0[b]]), score=sc0[b],
+                         times=tim0[b][:tlen0[b]])
+        r._lazy, r._b = batch, b
+        results.append(r)
     raw = dict(n_hyps=n_hyps, hyp_lens=hyp_lens, hyp_tokens=hyp_tokens,
                max_len=max_len)
     return results, raw
