@@ -270,3 +270,29 @@ def test_chained_row_ln_glu_launch_is_bit_identical_to_the_two_launches(B, frame
         L.wn_tune_set(b'x6r_chain', 1)
     assert torch.isfinite(got).all()
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize('B,frames,chunk', [(32, (800, 1200), -1), (5, (300, 1100), -1),
+                                            (8, (300, 700), 16)])
+def test_qkv_prologue_fold_is_bit_identical_to_the_reduce_launch(B, frames, chunk):
+    """gemm_x6r.hip PRO 1 (the QKV projection forms LN_mha(x + 0.5 FFN_macaron) itself from the
+    slice partials of the fused feed-forward kernel, encoder_layer.py:220-232) does
+    ffn_reduce_ln's arithmetic in the same order: the encoder output is the same bits as with
+    the separate launch; ragged row counts (a last block with rows past M)."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model('aishell_u2pp', 0)
+    feats, lens = S.make_features(B, frames, seed=76)
+    try:
+        _lib.check(L.wn_tune_set(b'x6r_pro', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        ref = ref.cpu()
+        _lib.check(L.wn_tune_set(b'x6r_pro', 1), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got = got.cpu()
+    finally:
+        L.wn_tune_set(b'x6r_pro', 1)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, got2.cpu())
+    assert torch.equal(got, ref), (got - ref).abs().max().item()

@@ -543,7 +543,10 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(
     const float mean = wave_sum(s) * (1.0f / D);
     float q = 0.f;
 #pragma unroll
-    for (int e = 0; e < E; ++e) { const float d = v[e] - mean; q += d * d; }
+    for (int e = 0; e < E; ++e) {   // an explicit fma chain: the same bits in every kernel that
+      const float d = v[e] - mean;  // forms this LayerNorm (gemm_x6r.hip PRO 1), whatever the
+      q = __builtin_fmaf(d, d, q);  // vectoriser would make of d * d + q
+    }
     const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
 #pragma unroll
     for (int j = 0; j < E / 4; ++j) {

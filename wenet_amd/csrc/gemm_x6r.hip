@@ -40,7 +40,12 @@ constexpr int RKB = RK / 16;         // 16 k blocks
 // EPI 0: C = acc + bias; EPI 1: x_out = resid + alpha (acc + bias), y = LayerNorm(x_out);
 // EPI 2: C = GLU(acc + bias) (N / 2 columns); EPI 3: EPI 1, then C = GLU(y W3b^T + bias2) from
 // the rows in LDS (y itself is stored only if p.y is set)
-template <int NT, int EPI, int PF>
+// PRO 1: the block forms its A rows itself from the slice partials of the fused feed-forward module
+// in front of it (X6RArgs::pro_*): the sum, the residual add and the LayerNorm of ffn_reduce_ln's
+// mode 0 -- same operations in the same order, a wave per row, 4 consecutive columns per lane --
+// on the rows the prologue holds as whole rows anyway (round 3: one launch and one round trip of
+// LN(x) through HBM less per layer).
+template <int NT, int EPI, int PF, int PRO = 0>
 __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   __shared__ float red[2][4][32];
   constexpr int PATCH = 4 * 32 * (NT * 128 + 16) > 32 * 1040 ? 4 * 32 * (NT * 128 + 16) : 32 * 1040;
@@ -61,10 +66,65 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   f32x4 xa[RKB], xb[RKB];
   {
     f32x4 rowv[8];
+    if constexpr (PRO == 1) {
+      const int c = lane * 4;
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.pro_b2 + c);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = min(m0 + wave * 8 + j, p.M - 1);
-      rowv[j] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + lane * 4);
+      for (int j = 0; j < 8; ++j) {
+        const int r = min(m0 + wave * 8 + j, p.M - 1);
+        f32x4 acc = b2;
+        for (int sl = 0; sl < p.pro_S; ++sl)
+          acc += *reinterpret_cast<const f32x4*>(p.pro_P + ((int64_t)sl * p.M + r) * RK + c);
+        const f32x4 xo = *reinterpret_cast<const f32x4*>(p.pro_x + (int64_t)r * RK + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rowv[j][e] = xo[e] + p.pro_alpha * acc[e];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)       // (rows past M are copies of row M - 1: never stored)
+        if (m0 + wave * 8 + j < p.M)
+          *reinterpret_cast<f32x4*>(p.pro_x + (int64_t)(m0 + wave * 8 + j) * RK + c) = rowv[j];
+      // LayerNorm of the 8 rows (ffn_reduce_ln_kernel's norm(), the eight butterflies side by side)
+      float sm[8], sq[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t += rowv[j][e];
+        sm[j] = t;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sm[j] += __shfl_xor(sm[j], o, 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sm[j] *= (1.0f / RK);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dd = rowv[j][e] - sm[j];
+          q = __builtin_fmaf(dd, dd, q);
+        }
+        sq[j] = q;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sq[j] += __shfl_xor(sq[j], o, 64);
+      const f32x4 gw = *reinterpret_cast<const f32x4*>(p.ln_w + c);
+      const f32x4 gb = *reinterpret_cast<const f32x4*>(p.ln_b + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float rstd = 1.0f / sqrtf(sq[j] * (1.0f / RK) + p.eps);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rowv[j][e] = (rowv[j][e] - sm[j]) * rstd * gw[e] + gb[e];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = min(m0 + wave * 8 + j, p.M - 1);
+        rowv[j] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + lane * 4);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -357,9 +417,9 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   }
 }
 
-template <int NT, int EPI, int PF>
+template <int NT, int EPI, int PF, int PRO = 0>
 int launch_x6r(const X6RArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((x6r_kernel<NT, EPI, PF>), dim3(cdiv(a.M, 32)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((x6r_kernel<NT, EPI, PF, PRO>), dim3(cdiv(a.M, 32)), dim3(256), 0, s, a);
   WN_HIP(hipGetLastError());
   return 0;
 }
@@ -368,6 +428,7 @@ int launch_x6r(const X6RArgs& a, hipStream_t s) {
 
 int g_x6r = 1;       // wn_tune_set("x6r"): 0 = the v_mfma_f32 row-LN GEMM / tile GEMMs (A/B, tests)
 int g_x6r_chain = 1; // wn_tune_set("x6r_chain"): 0 = out-projection + LayerNorm and pointwise_conv1 + GLU as two launches
+int g_x6r_pro = 1;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of the QKV projection
 
 bool gemm_x6r_supported(int M, int N, int K, int epi) {
   if (K != RK || M <= 0) return false;
@@ -377,6 +438,12 @@ bool gemm_x6r_supported(int M, int N, int K, int epi) {
 }
 
 int gemm_x6r(const X6RArgs& a, hipStream_t s) {
+  if (a.pro_P) {
+    WN_CHECK(a.epi == 0 && a.N == 768 && a.W3 && a.M > 0 && a.pro_S >= 1 && a.pro_b2 && a.pro_x &&
+                 a.ln_w && a.ln_b && a.C && a.ldc % 4 == 0,
+             "gemm_x6r: prologue fold arguments");
+    return launch_x6r<6, 0, 1, 1>(a, s);
+  }
   WN_CHECK(a.A && a.W3 && a.lda % 4 == 0 && gemm_x6r_supported(a.M, a.N, RK, a.epi),
            "gemm_x6r: shape");
   if (a.epi == 1) {

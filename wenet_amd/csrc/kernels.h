@@ -220,7 +220,14 @@ struct X6RArgs {
   // epi 3 = epi 1 chained with C = GLU(y W3b^T + bias2): W3b = X3 image of a 512 x 256 weight
   // (rows [32 values | 32 gates] per 64), C [M][256]; y is stored only if set
   const void* W3b = nullptr; const float* bias2 = nullptr;
+  // prologue fold (epi 0, N = 768 -- the QKV projection behind a fused feed-forward module): the
+  // A rows are NOT read from `A` but formed as ffn_reduce_ln (mode 0) forms them,
+  //   x_new = pro_x + pro_alpha (sum_s pro_P[s] + pro_b2),  A = LayerNorm(x_new; ln_w, ln_b, eps),
+  // x_new written back to pro_x ([M][256]); pro_P = [pro_S][M][256] slice partials
+  const float* pro_P = nullptr; int pro_S = 0; const float* pro_b2 = nullptr;
+  float pro_alpha = 0.f; float* pro_x = nullptr;
 };
+extern int g_x6r_pro;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of QKV
 extern int g_x6r;     // wn_tune_set("x6r")
 extern int g_x6r_chain;   // wn_tune_set("x6r_chain")
 bool gemm_x6r_supported(int M, int N, int K, int epi);

@@ -646,9 +646,19 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       fS = ffn_fused_try(m, L.ffm1, L.ffm2, ACT_SILU, s);
       if (fS < 0) return -2;
     }
+    // the QKV projection on the row-block kernel: it can form LN(x + 0.5 FFN) itself from the
+    // slice partials (gemm_x6r.hip, PRO 1) -- no ffn_reduce_ln launch, no t1 round trip
+    const void* qkv_w6 = nullptr;
+    if (!h16 && t_gemm_prec == PREC_F32 && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+        gemm_x6r_supported(M, 3 * d, L.qkv.in, 0)) {
+      auto it = t_x6->find(L.qkv.w);
+      if (it != t_x6->end()) qkv_w6 = it->second;
+    }
+    const bool pro = fS > 0 && qkv_w6 && g_x6r_pro != 0 && d == 256 && 3 * d == 768;
     if (fS > 0) {
-      WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ffm2.b, 0.5f, L.norm_mha.w,
-                           L.norm_mha.b, nullptr, nullptr, t1, M, d, eps, 0, s));
+      if (!pro)
+        WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ffm2.b, 0.5f, L.norm_mha.w,
+                             L.norm_mha.b, nullptr, nullptr, t1, M, d, eps, 0, s));
     } else {
       // (fp8 mode: every feed-forward module normalises for itself -- layernorm_mx writes the
       // MXFP8 operand -- so that ALL of them take the same path; the bf16 / fp32 modes get
@@ -659,16 +669,16 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       WN_TRY(ln(L.norm_mha, x, t1, M, d, eps, s, h16));
     }
     bool qkv_done = false;
-    if (!h16 && t_gemm_prec == PREC_F32 && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
-        gemm_x6r_supported(M, 3 * d, L.qkv.in, 0)) {
-      auto it = t_x6->find(L.qkv.w);
-      if (it != t_x6->end()) {
-        X6RArgs g;
-        g.A = t1; g.lda = d; g.W3 = it->second; g.bias = L.qkv.b; g.M = M; g.N = 3 * d;
-        g.epi = 0; g.C = qkv; g.ldc = 3 * d;
-        WN_TRY(gemm_x6r(g, s));
-        qkv_done = true;
+    if (qkv_w6) {
+      X6RArgs g;
+      g.A = t1; g.lda = d; g.W3 = qkv_w6; g.bias = L.qkv.b; g.M = M; g.N = 3 * d;
+      g.epi = 0; g.C = qkv; g.ldc = 3 * d;
+      if (pro) {
+        g.pro_P = m->ffn_part.as<float>(); g.pro_S = fS; g.pro_b2 = L.ffm2.b; g.pro_alpha = 0.5f;
+        g.pro_x = x; g.ln_w = L.norm_mha.w; g.ln_b = L.norm_mha.b; g.eps = eps;
       }
+      WN_TRY(gemm_x6r(g, s));
+      qkv_done = true;
     }
     if (!qkv_done)
       WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s, ACT_NONE, nullptr, 0, 1.0f, false,
