@@ -74,7 +74,8 @@ constexpr int EPI_WAVE = 128 * EPI_PITCH;     // 18 KB per wave, 144 KB per bloc
 // erfc(z) = 2^(-z G(z)), G a degree-5 fit of -log2(erfc z) / z on [0, 6.5] (z clamped there:
 // erfc(6.5) = 4e-20).  One v_exp, no v_rcp, 12 VALU operations against 15 + two transcendentals
 // of the Abramowitz-Stegun 7.1.26 form used before (w_1 of the fp8 mode: 236 -> 198 us);
-// |error| < 4.7e-6 absolute and < 1.8e-3 of the value in the negative tail, where the A&S form's
+// |error| < 4.7e-6 absolute and < 3.2e-3 of the value in the negative tail down to the clamp (1.8e-3
+// above x = -5.6; tests/test_gelu_form.py restates it from these constants), where the A&S form's
 // 1 - erf(|z|) cancels (its bf16-rounded result differs from the exact one's more often than
 // this one's: 18 % vs 13 % of a fine grid on [-9, 12]).
 __device__ __forceinline__ float gelu_e5(float x) {
