@@ -520,6 +520,7 @@ int g_x6_ffn_s = 0;
 int g_x6_nw4 = 0;
 int g_x6_conv = 1;
 int g_x6_sub = 1;
+int g_x6_conv_tail = 1;
 int g_x6_conv_order = 1;   // 1: channel blocks outside, taps inside (L2 reuse); 0: tap-major
 int g_x6_linear = 1;
 // 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in
@@ -528,6 +529,24 @@ int g_x6_linear = 1;
 // 4096 1124 -> 1312 us, decode step 7.28 -> 7.4-7.7 ms.
 int g_x6_af32 = 0;
 int g_x6_probe = 0;     // wn_tune_set("x6_probe"): 1 no MFMAs, 2 no DMA (ablation)
+
+namespace {
+// C[r][c] = relu(sum_s P[s][r][c] + bias[c]): the K-slice partials of conv2's last tiles
+__global__ __launch_bounds__(256) void conv_tail_reduce_kernel(const float* __restrict__ P, int S,
+                                                               int rows, int N4,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ C, int ldc) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * N4) return;
+  const int r = (int)(i / N4), c = (int)(i - (int64_t)r * N4) * 4;
+  f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < S; ++sl)
+    acc += *reinterpret_cast<const f32x4*>(P + ((int64_t)sl * rows + r) * (N4 * 4) + c);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.0f);
+  *reinterpret_cast<f32x4*>(C + (int64_t)r * ldc + c) = acc;
+}
+}  // namespace
 
 int gemm_x6_clocks(unsigned long long* out) {
   WN_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x6_clk), sizeof(g_x6_clk)));
@@ -591,6 +610,28 @@ int gemm_x6(const X6Args& args, hipStream_t s) {
       main.M = full * 256;
       rest.row0 = full * 256;
       if (run(main, 256) != 0) return -1;
+      // round 3: the remaining t256 - full tiles as K SLICES of 256-row tiles when tiles x
+      // slices still fit one round -- 77 tiles x 3 slices at config 2: a third of a round
+      // (+ a 60-MB reduction) instead of 154 half-height tiles that each take a whole tile's
+      // time on a wave per SIMD (207 us, r05e)
+      const int rem = t256 - full, nkb = a.K / 16;
+      int S = 0;
+      for (int t = std::min(4, 256 / rem); t >= 2; --t)
+        if (nkb % t == 0) { S = t; break; }
+      const int rows = a.M - full * 256;
+      if (g_x6_conv_tail != 0 && !af32 && S >= 2 && a.part &&
+          a.part_bytes >= (size_t)S * rows * a.N * sizeof(float) && a.N % 4 == 0) {
+        X6Args r = a;
+        r.a_pix = a.a_pix + (size_t)full * 256;
+        r.M = rows; r.row0 = 0; r.epi = 1; r.ksplit = S; r.C = a.part; r.bm = 256;
+        if (launch_x6<256, 1, ACT_NONE, true>(r, s) != 0) return -1;
+        const int64_t n4 = (int64_t)rows * (a.N / 4);
+        hipLaunchKernelGGL(conv_tail_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256),
+                           0, s, a.part, S, rows, a.N / 4, a.bias,
+                           a.C + (int64_t)full * 256 * a.ldc, a.ldc);
+        WN_HIP(hipGetLastError());
+        return 0;
+      }
       return run(rest, 128);
     }
     return run(a, bm);

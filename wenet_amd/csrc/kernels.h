@@ -154,7 +154,11 @@ struct X6Args {
   int conv_taps = 0;          // > 0: K order (channel block, tap) instead of (tap, channel block)
   int tap_delta[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int probe = 0;              // ablation bits (g_x6_probe)
+  // gathered A (conv2): scratch for the K-slice partials of the last, partial round of tiles
+  // (part_bytes >= slices x rows x N x 4); null: the remainder runs as 128-row tiles
+  float* part = nullptr; size_t part_bytes = 0;
 };
+extern int g_x6_conv_tail;  // wn_tune_set("x6_conv_tail"): 0 = the remainder of conv2's tiles as 128-row tiles
 extern int g_x6_probe;
 int gemm_x6_clocks(unsigned long long* out);   // probe & 4 stamps [8 waves][8]
 extern int g_x6_nw4;       // wn_tune_set("x6_nw4") A/B bits: 1 FFN w_1 on 256-row tiles, 2 FFN w_2 on the 8-wave 128-row tile, 4 priorities

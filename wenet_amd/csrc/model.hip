@@ -569,6 +569,15 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
       g.epi = 0; g.bias = m->conv2.b; g.act = ACT_RELU; g.C = m->c2.as<float>(); g.ldc = d;
       g.a_pix = pix; g.a_tiles = tiles; g.conv_kbc = d / 16; g.bm = g_x6_conv_bm;
       g.conv_taps = g_x6_conv_order ? 9 : 0;
+      {   // scratch for the K-slice partials of the last, partial round of tiles (gemm_x6.hip)
+        const int t256 = cdiv(M * F2, 256), rem = t256 - t256 / 256 * 256;
+        if (g_x6_conv_bm == 0 && d <= 256 && t256 >= 256 && rem > 0 && rem <= 128) {
+          const size_t need = (size_t)4 * ((size_t)M * F2 - (size_t)(t256 - rem) * 256) * d *
+                              sizeof(float);
+          WN_TRY(m->ffn_part.ensure(need));
+          g.part = m->ffn_part.as<float>(); g.part_bytes = m->ffn_part.cap;
+        }
+      }
       const int ne = (F1 + 1) / 2;
       for (int ky = 0; ky < 3; ++ky) {
         g.tap_delta[ky * 3 + 0] = ky * F1;            // f1 = 2 f2     (even, position f2)
