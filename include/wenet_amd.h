@@ -264,8 +264,10 @@ int wn_set_context_graph(wn_model* m, int32_t n_nodes, const int32_t* fail,
  * wn_set_context_graph, None by default).  Outputs,
  * all host: n_hyps (B); hyp_lens, hyp_tlens (B, beam); hyp_tokens, hyp_times
  * (B, beam, max_len); hyp_scores (B, beam) fp64.  beam <= 64 (<= 16 runs the
- * latency-tuned kernel).  The n-best list also stays
- * on the device for wn_attention_rescoring. */
+ * latency-tuned kernel).  Of every (max_len) row of hyp_tokens / hyp_times only the
+ * first hyp_lens / hyp_tlens entries are written (one device -> pinned-host copy, then the
+ * used corners): elements past a hypothesis' length keep what the caller put there.  The
+ * n-best list also stays on the device for wn_attention_rescoring. */
 int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
                               int32_t* n_hyps_host, int32_t* hyp_lens_host,
                               int32_t* hyp_tlens_host, int32_t* hyp_tokens_host,
