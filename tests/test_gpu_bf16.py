@@ -448,16 +448,25 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed):
     L = _lib.lib()
     _set_dtype(model, 'bf16')
     try:
+        _lib.check(L.wn_tune_set(b'attn_bf16_defer', 0), 'tune')   # rescale whenever a maximum moves
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 1), 'tune')
         enc1, _ = model._forward_encoder(feats.cuda(), lens)
         enc1b, _ = model._forward_encoder(feats.cuda(), lens)
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 2), 'tune')   # grouped fragment reads
         enc2, _ = model._forward_encoder(feats.cuda(), lens)
         enc2b, _ = model._forward_encoder(feats.cuda(), lens)
+        # deferred rescale (the default, threshold 8 in log2 units) and a threshold that makes the
+        # update branch fire in mid-sequence tiles: other roundings of P, the same softmax
+        deferred = []
+        for thr10 in (80, 5, 20):
+            _lib.check(L.wn_tune_set(b'attn_bf16_defer', thr10), 'tune')
+            e, _ = model._forward_encoder(feats.cuda(), lens)
+            deferred.append(e.cpu())
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 0), 'tune')
         enc0, _ = model._forward_encoder(feats.cuda(), lens)
     finally:
-        L.wn_tune_set(b'attn_bf16_dma', 2)      # the default
+        L.wn_tune_set(b'attn_bf16_dma', 2)      # the defaults
+        L.wn_tune_set(b'attn_bf16_defer', 80)
         _set_dtype(model, 'fp32')
     assert torch.equal(enc1, enc1b), 'DMA-staged attention is not deterministic (race?)'
     assert torch.equal(enc1, enc0), (enc1 - enc0).abs().max().item()
@@ -471,6 +480,10 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed):
         nb = int(ref_lens[b])
         scale = max(ref[b, :nb].abs().max().item(), 1.0)
         assert (enc1[b, :nb] - ref[b, :nb]).abs().max().item() / scale < 6e-3
+        for e in deferred:
+            assert torch.isfinite(e[b, :nb]).all()
+            assert (e[b, :nb] - ref[b, :nb]).abs().max().item() / scale < 6e-3
+            assert (e[b, :nb] - enc1[b, :nb]).abs().max().item() / scale < 4e-3
 
 
 def test_bf16_is_a_per_handle_switch_and_fp32_comes_back_bit_exact():

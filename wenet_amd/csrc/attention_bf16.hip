@@ -34,6 +34,7 @@ namespace wn {
 
 extern int g_attn_bf16_sub;
 extern int g_attn_bf16_dma;
+extern int g_attn_bf16_defer;
 
 namespace {
 
@@ -531,7 +532,15 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
         float t2 = fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11]));
         float t3 = fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]));
         const float tmax = pair_max(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
-        const float m_new = fmaxf(m_run, tmax);
+        float m_new = fmaxf(m_run, tmax);
+        // Deferred rescale (defer_thr > 0): with 64 queries per wave SOME lane's running maximum
+        // moves in almost every tile (probability 1 - (1 - 1/t)^64 at tile t), so the wave-uniform
+        // branch below rescaled the 32 output registers nearly always.  The reference maximum of a
+        // softmax is arbitrary: the wave keeps its old ones -- probabilities up to 2^thr instead
+        // of 1, the same RELATIVE bf16 rounding, fp32 sums -- until some lane's maximum grows by
+        // more than thr (in log2 units), and then every lane updates, in the textbook order
+        // (decide, rescale O and l, exponentiate this tile against the maximum in force).
+        if (a.defer_thr > 0.f && !__any((tmax - m_run) * cs > a.defer_thr)) m_new = m_run;
         alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
         const float mc = -m_new * cs;
 #pragma unroll
@@ -756,6 +765,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
 
 int g_attn_bf16_nw = 0;  // wn_tune_set("attn_bf16_nw"): 0 auto, else 2 / 4 / 8
 int g_attn_bf16_sub = 2; // 8-wave blocks: 32-key sub-tiles per barrier (1 or 2)
+int g_attn_bf16_defer = 80;  // wn_tune_set("attn_bf16_defer"): deferred-rescale threshold x 10 in log2 units (0 = rescale whenever a maximum moves)
 int g_attn_bf16_dma = 2; // bf16 Q | K | V self attention: 0 register-staged, 1 LDS-DMA staged (K rows + V^T image), 2 + grouped fragment reads
 
 int attention_bf16(const AttnArgs& a, hipStream_t s) {
@@ -772,7 +782,11 @@ int attention_bf16(const AttnArgs& a, hipStream_t s) {
       a.vt_tp % DKT == 0 && a.vt_tp >= a.max_q_len &&
       (int64_t)a.max_q_len * a.ldk * 2 < (int64_t(1) << 31))
   {
-    if (g_attn_bf16_dma == 2) return nw == 8 ? launch_dma<8, true>(a, s) : launch_dma<4, true>(a, s);
+    if (g_attn_bf16_dma == 2) {
+      AttnArgs d = a;
+      d.defer_thr = 0.1f * (float)g_attn_bf16_defer;
+      return nw == 8 ? launch_dma<8, true>(d, s) : launch_dma<4, true>(d, s);
+    }
     return nw == 8 ? launch_dma<8, false>(a, s) : launch_dma<4, false>(a, s);
   }
   switch (nw) {

@@ -633,6 +633,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "attn_bf16_nw") g_attn_bf16_nw = value;
   else if (k == "attn_bf16_sub") g_attn_bf16_sub = value;
   else if (k == "attn_bf16_dma") g_attn_bf16_dma = value;
+  else if (k == "attn_bf16_defer") g_attn_bf16_defer = value;
   else if (k == "lp_probe") g_lp_probe = value;
   else if (k == "qkv_bf16") g_qkv_bf16 = value;
   else if (k == "fp8_min_tiles") g_fp8_min_tiles = value;

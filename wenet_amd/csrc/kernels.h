@@ -84,6 +84,7 @@ struct AttnArgs {
   // [n_seq][n_heads][64][vt_tp] bf16 (vt_tp: max length rounded up to 64) that the DMA-staged
   // kernel reads instead of V; null: register-staged kernel
   void* vt = nullptr; int vt_tp = 0;
+  float defer_thr = 0.f;   // DMA-staged bf16 kernel: deferred-rescale threshold (log2 units, 0 = off)
   int mask_mode = 0;   // 0: keys < kv_len; 1: causal; 2: chunk window
   int chunk_size = 0, left_chunks = -1;
   float scale = 0.125f;
@@ -99,6 +100,7 @@ int attention_bf16(const AttnArgs& a, hipStream_t s);
 extern int g_attn_bf16;      // 1 (default): bf16 mode uses the bf16 attention kernel
 extern int g_attn_bf16_nw;   // 0 auto, else waves (32-query groups) per block
 extern int g_attn_bf16_sub;  // 8-wave blocks: 32-key sub-tiles per barrier
+extern int g_attn_bf16_defer;  // wn_tune_set("attn_bf16_defer"): threshold x 10 of the deferred rescale (0 = off)
 extern int g_attn_bf16_dma;  // 0 off, 1 LDS-DMA staged kernel where it applies (AttnArgs::vt), 2 (default) + grouped reads
 
 // Fused feed-forward module, fp32 (ffn_fused.hip): P[s] (S, M, D) = partial
