@@ -425,13 +425,13 @@ def test_bf16_attention_block_shapes(nw, config, chunk, left):
         assert err < 6e-3, (config, nw, b, err)
 
 
-@pytest.mark.parametrize('B,frames,seed', [
-    (2, (780, 900), 5),       # 4 query groups per block
-    (3, (900, 2600), 6),      # 8 per block, ragged: short sequences end stages early
-    (2, (2050, 2600), 7),
-    (4, (1290, 1300), 8),     # lengths reset to multiples of 64 keys and one past (below)
+@pytest.mark.parametrize('B,frames,seed,nw', [
+    (2, (780, 900), 5, 0),       # 4 query groups per block (the default at every length)
+    (3, (900, 2600), 6, 8),      # 8 per block, ragged: short sequences end stages early
+    (2, (2050, 2600), 7, 0),
+    (4, (1290, 1300), 8, 0),     # lengths reset to multiples of 64 keys and one past (below)
 ])
-def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed):
+def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed, nw):
     """The LDS-DMA staged bf16 self attention (K rows of the QKV matrix + the packed V^T
     image, attention_bf16_dma_kernel) does the register-staged kernel's arithmetic in the
     same order: the encoder outputs of the two are the same bits, on ragged batches whose
@@ -448,6 +448,7 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed):
     L = _lib.lib()
     _set_dtype(model, 'bf16')
     try:
+        _lib.check(L.wn_tune_set(b'attn_bf16_nw', nw), 'tune')
         _lib.check(L.wn_tune_set(b'attn_bf16_defer', 0), 'tune')   # rescale whenever a maximum moves
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 1), 'tune')
         enc1, _ = model._forward_encoder(feats.cuda(), lens)
@@ -467,6 +468,7 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed):
     finally:
         L.wn_tune_set(b'attn_bf16_dma', 2)      # the defaults
         L.wn_tune_set(b'attn_bf16_defer', 80)
+        L.wn_tune_set(b'attn_bf16_nw', 0)
         _set_dtype(model, 'fp32')
     assert torch.equal(enc1, enc1b), 'DMA-staged attention is not deterministic (race?)'
     assert torch.equal(enc1, enc0), (enc1 - enc0).abs().max().item()

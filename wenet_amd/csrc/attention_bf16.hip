@@ -782,6 +782,10 @@ int attention_bf16(const AttnArgs& a, hipStream_t s) {
       a.vt_tp % DKT == 0 && a.vt_tp >= a.max_q_len &&
       (int64_t)a.max_q_len * a.ldk * 2 < (int64_t(1) << 31))
   {
+    // 4-wave blocks (128 queries) also for long sequences: twice the K / V^T stream from L2, but
+    // barrier groups of four waves lose less to skew than groups of eight (config 5 fp8: 14.81 k
+    // vs 14.62 k, r05v); attn_bf16_nw = 8 forces the 256-query blocks
+    if (g_attn_bf16_nw != 8) nw = 4;
     if (g_attn_bf16_dma == 2) {
       AttnArgs d = a;
       d.defer_thr = 0.1f * (float)g_attn_bf16_defer;
