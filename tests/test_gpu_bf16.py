@@ -456,6 +456,9 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed, nw):
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 2), 'tune')   # grouped fragment reads
         enc2, _ = model._forward_encoder(feats.cuda(), lens)
         enc2b, _ = model._forward_encoder(feats.cuda(), lens)
+        _lib.check(L.wn_tune_set(b'attn_bf16_dma', 4), 'tune')   # V rows + transpose reads
+        enc4, _ = model._forward_encoder(feats.cuda(), lens)
+        enc4b, _ = model._forward_encoder(feats.cuda(), lens)
         # deferred rescale (the default, threshold 8 in log2 units) and a threshold that makes the
         # update branch fire in mid-sequence tiles: other roundings of P, the same softmax
         deferred = []
@@ -466,7 +469,7 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed, nw):
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 0), 'tune')
         enc0, _ = model._forward_encoder(feats.cuda(), lens)
     finally:
-        L.wn_tune_set(b'attn_bf16_dma', 2)      # the defaults
+        L.wn_tune_set(b'attn_bf16_dma', 4)      # the defaults
         L.wn_tune_set(b'attn_bf16_defer', 80)
         L.wn_tune_set(b'attn_bf16_nw', 0)
         _set_dtype(model, 'fp32')
@@ -474,6 +477,8 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed, nw):
     assert torch.equal(enc1, enc0), (enc1 - enc0).abs().max().item()
     assert torch.equal(enc2, enc2b), 'DMA-staged attention (grouped reads) is not deterministic'
     assert torch.equal(enc2, enc0), (enc2 - enc0).abs().max().item()
+    assert torch.equal(enc4, enc4b), 'DMA-staged attention (transpose reads) is not deterministic'
+    assert torch.equal(enc4, enc0), (enc4 - enc0).abs().max().item()
     with torch.no_grad(), O.bf16_operands(sd):
         ref, mask = O.encoder_forward(configs, sd, feats, lens, -1, -1)
     ref_lens = mask.squeeze(1).sum(1).numpy()

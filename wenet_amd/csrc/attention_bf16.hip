@@ -445,10 +445,18 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const __bf16* __restrict__
 // fragment address is ONE of four per-lane registers + an immediate, the K fragments of a
 // sub-tile read as a group before its MFMA chain (the second sub-tile's, and the V^T fragments,
 // under the softmax of the first) instead of read - wait - multiply one at a time.
-template <int NW, bool PIPE>
+// VTR (attn_bf16_dma = 4, with PIPE): no V^T image at all -- the V rows are staged by DMA exactly
+// like the K rows ([64 keys][128 B], same swizzle) and the PV "A" fragments (8 keys of one dim per
+// lane) come out of ds_read_b64_tr_b16, which hands lane j of a 16-lane group COLUMN j of the
+// [4 keys][16 dims] block the group's lanes address (probed on hardware:
+// tools/probes/tr16_probe.hip, profiles/r05z_tr16_probe.txt): two transpose reads per fragment
+// (keys 16 j + 4 hi + 0..3 and + 8..11 -- the register order of the S^T tile), four per-lane
+// offsets + immediates.  Saves the vt_pack pass (25 us and 123 MB per layer at config 5).
+template <int NW, bool PIPE, bool VTR = false>
 __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs a, int nqb) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   static_assert(NW == 4 || NW == 8, "4 or 8 query groups per block");
+  static_assert(!VTR || PIPE, "transpose-read form: grouped-read kernel only");
   constexpr int NP = 8 / NW;              // 1-KB pieces of a tile per wave
   __shared__ __attribute__((aligned(1024))) char sbuf[2 * DSTAGE];
   // all query blocks of one (sequence, head) run on the same XCD, one after the other: its
@@ -471,10 +479,15 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<__bf16*>(reinterpret_cast<const __bf16*>(a.K) + (int64_t)kvoff * a.ldk + h * 64),
       0, (int)((unsigned)kvlen * ldk2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__bf16*>(reinterpret_cast<const __bf16*>(a.vt) +
-                          (int64_t)(s * a.n_heads + h) * 64 * a.vt_tp),
-      0, (int)(64u * tp2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = VTR
+      ? __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<__bf16*>(reinterpret_cast<const __bf16*>(a.V) + (int64_t)kvoff * a.ldv +
+                                h * 64),
+            0, (int)((unsigned)kvlen * ldk2), 0x00020000)          // ldv == ldk (checked by the host)
+      : __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<__bf16*>(reinterpret_cast<const __bf16*>(a.vt) +
+                                (int64_t)(s * a.n_heads + h) * 64 * a.vt_tp),
+            0, (int)(64u * tp2), 0x00020000);
   int prow[NP];
   unsigned pslot[NP], vtoff[NP];
 #pragma unroll
@@ -491,9 +504,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
       const unsigned vk = (unsigned)min(j0 + prow[p], kvlen - 1) * ldk2 + pslot[p];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(dst + p * NW * 1024), 16, vk, 0, 0,
                                                0);
-      const unsigned vt_o = vtoff[p] + 0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(dst + DTILE + p * NW * 1024), 16,
-                                               vt_o, j0 * 2, 0, 0);
+      if constexpr (VTR) {         // the same rows of V
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(dst + DTILE + p * NW * 1024), 16,
+                                                 vk, 0, 0, 0);
+      } else {
+        const unsigned vt_o = vtoff[p] + 0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(dst + DTILE + p * NW * 1024), 16,
+                                                 vt_o, j0 * 2, 0, 0);
+      }
     }
   };
   const int n_it = (kvlen + DKT - 1) / DKT;
@@ -524,6 +542,23 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
     int fo[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) fo[c] = frow + (((2 * c + hi) ^ sw) << 4);
+    // VTR: this lane's address inside the [4 keys][16 dims] block its 16-lane group reads, for
+    // the first / second key quad of a fragment (w) and the low / high 32 dims (dblk): key row
+    // 4 hi + 8 w + (j' >> 2) of the 16-key group, dims 32 dblk + 16 (g & 1) + 4 (j' & 3) .. + 3;
+    // the row's swizzle term ((row >> 1) & 7) = (2 hi + 4 w + (j' >> 3)) & 7 for every group
+    int tro[2][2];
+    if constexpr (VTR) {
+      const int jj = lane & 15, g1 = (lane >> 4) & 1;
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk) {
+          const int row = 4 * hi + 8 * w + (jj >> 2);
+          const int swz = (2 * hi + 4 * w + (jj >> 3)) & 7;
+          const int slot = 4 * dblk + 2 * g1 + ((jj & 3) >> 1);
+          tro[w][dblk] = row * 128 + ((slot ^ swz) << 4) + (jj & 1) * 8;
+        }
+    }
     auto softmax_tile = [&](f32x16& sc, int j0, float& alpha) {
       float psum;
       if (j0 + KT <= kvlen) {
@@ -613,8 +648,22 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
           bf16x8 pa;
 #pragma unroll
           for (int e = 0; e < 8; ++e) pa[e] = (__bf16)sc[8 * j + e];
-          const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(sV + fo[2 * sb + j]);
-          const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(sV + 32 * 128 + fo[2 * sb + j]);
+          bf16x8 v0, v1;
+          if constexpr (VTR) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            typedef __attribute__((address_space(3))) s16x4* trp;
+            const char* vb = sV + (sb * 32 + j * 16) * 128;     // the 16-key group's rows
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(vb + tro[0][0]));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(vb + tro[1][0]));
+            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(vb + tro[0][1]));
+            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(vb + tro[1][1]));
+            v0 = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            v1 = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+          } else {
+            v0 = *reinterpret_cast<const bf16x8*>(sV + fo[2 * sb + j]);
+            v1 = *reinterpret_cast<const bf16x8*>(sV + 32 * 128 + fo[2 * sb + j]);
+          }
           o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pa, o0, 0, 0, 0);
           o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pa, o1, 0, 0, 0);
         }
@@ -729,15 +778,17 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
   }
 }
 
-template <int NW, bool PIPE>
+template <int NW, bool PIPE, bool VTR = false>
 int launch_dma(const AttnArgs& a, hipStream_t s) {
-  const int kt = cdiv(a.max_q_len, DKT);
-  hipLaunchKernelGGL(vt_pack_kernel, dim3(kt, a.n_heads, a.n_seq), dim3(256), 0, s,
-                     reinterpret_cast<const __bf16*>(a.V), a.ldv, a.kv_off, a.kv_len, a.n_heads,
-                     a.vt_tp, reinterpret_cast<__bf16*>(a.vt));
-  WN_HIP(hipGetLastError());
+  if (!VTR) {
+    const int kt = cdiv(a.max_q_len, DKT);
+    hipLaunchKernelGGL(vt_pack_kernel, dim3(kt, a.n_heads, a.n_seq), dim3(256), 0, s,
+                       reinterpret_cast<const __bf16*>(a.V), a.ldv, a.kv_off, a.kv_len, a.n_heads,
+                       a.vt_tp, reinterpret_cast<__bf16*>(a.vt));
+    WN_HIP(hipGetLastError());
+  }
   const int nqb = cdiv(a.max_q_len, NW * 32);
-  hipLaunchKernelGGL((attention_bf16_dma_kernel<NW, PIPE>), dim3(nqb * a.n_heads * a.n_seq),
+  hipLaunchKernelGGL((attention_bf16_dma_kernel<NW, PIPE, VTR>), dim3(nqb * a.n_heads * a.n_seq),
                      dim3(NW * 64), 0, s, a, nqb);
   WN_HIP(hipGetLastError());
   return 0;
@@ -766,7 +817,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
 int g_attn_bf16_nw = 0;  // wn_tune_set("attn_bf16_nw"): 0 auto, else 2 / 4 / 8
 int g_attn_bf16_sub = 2; // 8-wave blocks: 32-key sub-tiles per barrier (1 or 2)
 int g_attn_bf16_defer = 80;  // wn_tune_set("attn_bf16_defer"): deferred-rescale threshold x 10 in log2 units (0 = rescale whenever a maximum moves)
-int g_attn_bf16_dma = 2; // bf16 Q | K | V self attention: 0 register-staged, 1 LDS-DMA staged (K rows + V^T image), 2 + grouped fragment reads
+int g_attn_bf16_dma = 4; // bf16 Q | K | V self attention: 0 register-staged, 1 LDS-DMA staged (K rows + V^T image), 2 + grouped fragment reads, 4 V rows by DMA + ds_read_b64_tr_b16 (no V^T image)
 
 int attention_bf16(const AttnArgs& a, hipStream_t s) {
   // argument checks are attention()'s (the only caller)
@@ -777,18 +828,21 @@ int attention_bf16(const AttnArgs& a, hipStream_t s) {
   if (nw != 2 && nw != 4 && nw != 8)
     nw = a.max_q_len >= 1024 ? 8 : a.max_q_len >= 384 ? 4 : 2;
   // self attention over bf16 Q | K | V without masks: K and the packed V^T by LDS-DMA
-  if (g_attn_bf16_dma != 0 && a.qkv_bf16 && a.vt && !a.P && a.mask_mode == 0 && nw >= 4 &&
+  const bool vtr = g_attn_bf16_dma == 4 && a.ldv == a.ldk;    // V rows + transpose reads: no V^T image
+  if (g_attn_bf16_dma != 0 && a.qkv_bf16 && !a.P && a.mask_mode == 0 && nw >= 4 &&
       a.q_len == a.kv_len && a.q_off == a.kv_off && a.ldk % 8 == 0 && a.ldv % 8 == 0 &&
-      a.vt_tp % DKT == 0 && a.vt_tp >= a.max_q_len &&
+      (vtr || (a.vt && a.vt_tp % DKT == 0 && a.vt_tp >= a.max_q_len)) &&
       (int64_t)a.max_q_len * a.ldk * 2 < (int64_t(1) << 31))
   {
     // 4-wave blocks (128 queries) also for long sequences: twice the K / V^T stream from L2, but
     // barrier groups of four waves lose less to skew than groups of eight (config 5 fp8: 14.81 k
     // vs 14.62 k, r05v); attn_bf16_nw = 8 forces the 256-query blocks
     if (g_attn_bf16_nw != 8) nw = 4;
-    if (g_attn_bf16_dma == 2) {
+    if (g_attn_bf16_dma == 2 || g_attn_bf16_dma == 4) {
       AttnArgs d = a;
       d.defer_thr = 0.1f * (float)g_attn_bf16_defer;
+      if (vtr)
+        return nw == 8 ? launch_dma<8, true, true>(d, s) : launch_dma<4, true, true>(d, s);
       return nw == 8 ? launch_dma<8, true>(d, s) : launch_dma<4, true>(d, s);
     }
     return nw == 8 ? launch_dma<8, false>(a, s) : launch_dma<4, false>(a, s);

@@ -101,7 +101,7 @@ extern int g_attn_bf16;      // 1 (default): bf16 mode uses the bf16 attention k
 extern int g_attn_bf16_nw;   // 0 auto, else waves (32-query groups) per block
 extern int g_attn_bf16_sub;  // 8-wave blocks: 32-key sub-tiles per barrier
 extern int g_attn_bf16_defer;  // wn_tune_set("attn_bf16_defer"): threshold x 10 of the deferred rescale (0 = off)
-extern int g_attn_bf16_dma;  // 0 off, 1 LDS-DMA staged kernel where it applies (AttnArgs::vt), 2 (default) + grouped reads
+extern int g_attn_bf16_dma;  // 0 off, 1 LDS-DMA staged kernel where it applies (AttnArgs::vt), 2 + grouped reads, 4 (default) V rows + transpose reads, no V^T image
 
 // Fused feed-forward module, fp32 (ffn_fused.hip): P[s] (S, M, D) = partial
 // act(X W1^T + b1) W2^T over hidden slice s; ffn_reduce_ln then forms

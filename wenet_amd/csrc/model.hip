@@ -992,7 +992,9 @@ int transformer_layers(wn_model* m, hipStream_t s) {
     a.q_len = a.kv_len = m->d_len.as<int>();
     a.n_seq = m->B; a.n_heads = c.n_heads; a.max_q_len = max_len;
     a.mask_mode = 0;
-    if (q16 && max_len >= 384) {   // V^T scratch of the DMA-staged kernel (attention_bf16.hip)
+    if (q16 && max_len >= 384 && g_attn_bf16_dma >= 1 && g_attn_bf16_dma <= 3) {
+      // V^T scratch of the DMA-staged forms that read an image (attention_bf16.hip; the default
+      // form reads the V rows themselves through transpose reads)
       a.vt_tp = (max_len + 63) / 64 * 64;
       WN_TRY(m->attn_vt.ensure((size_t)m->B * c.n_heads * 64 * a.vt_tp * 2));
       a.vt = m->attn_vt.p;
