@@ -494,7 +494,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
   for (int p = 0; p < NP; ++p) {
     prow[p] = (p * NW + wave) * 8 + (lane >> 3);                       // row of the tile
     pslot[p] = (unsigned)(((lane & 7) ^ ((prow[p] >> 1) & 7)) << 4);   // source 16-B slot
-    vtoff[p] = (unsigned)prow[p] * tp2 + pslot[p];
+    // VTR: the V tile has its own swizzle -- slot bit 2 flipped on rows 2, 3 (mod 4): a half-wave
+    // of a transpose read touches 4 consecutive rows x 64 B, and with the K swizzle rows r and
+    // r + 2 of them met in the same banks (SQ_LDS_BANK_CONFLICT 11.6 M cycles per launch, r05ad);
+    // this field is then the V source slot minus the K one
+    vtoff[p] = VTR ? (unsigned)((((lane & 7) ^ (((prow[p] >> 1) & 1) << 2)) << 4)) - pslot[p]
+                   : (unsigned)prow[p] * tp2 + pslot[p];
   }
   auto issue = [&](int it, int buf) {
     const int j0 = it * DKT;
@@ -504,9 +509,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
       const unsigned vk = (unsigned)min(j0 + prow[p], kvlen - 1) * ldk2 + pslot[p];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(dst + p * NW * 1024), 16, vk, 0, 0,
                                                0);
-      if constexpr (VTR) {         // the same rows of V
+      if constexpr (VTR) {         // the same rows of V, its own slot swizzle
+        const unsigned vv = vk + vtoff[p];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(dst + DTILE + p * NW * 1024), 16,
-                                                 vk, 0, 0, 0);
+                                                 vv, 0, 0, 0);
       } else {
         const unsigned vt_o = vtoff[p] + 0u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(dst + DTILE + p * NW * 1024), 16,
@@ -544,8 +550,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
     for (int c = 0; c < 4; ++c) fo[c] = frow + (((2 * c + hi) ^ sw) << 4);
     // VTR: this lane's address inside the [4 keys][16 dims] block its 16-lane group reads, for
     // the first / second key quad of a fragment (w) and the low / high 32 dims (dblk): key row
-    // 4 hi + 8 w + (j' >> 2) of the 16-key group, dims 32 dblk + 16 (g & 1) + 4 (j' & 3) .. + 3;
-    // the row's swizzle term ((row >> 1) & 7) = (2 hi + 4 w + (j' >> 3)) & 7 for every group
+    // 4 hi + 8 w + (j' >> 2) of the 16-key group, dims 32 dblk + 16 (g & 1) + 4 (j' & 3) .. + 3
+    // (the 16-key groups start at multiples of 16 rows: the swizzle term depends on this row only)
     int tro[2][2];
     if constexpr (VTR) {
       const int jj = lane & 15, g1 = (lane >> 4) & 1;
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
 #pragma unroll
         for (int dblk = 0; dblk < 2; ++dblk) {
           const int row = 4 * hi + 8 * w + (jj >> 2);
-          const int swz = (2 * hi + 4 * w + (jj >> 3)) & 7;
+          const int swz = ((row >> 1) & 1) << 2;           // the V tile's swizzle (see issue)
           const int slot = 4 * dblk + 2 * g1 + ((jj & 3) >> 1);
           tro[w][dblk] = row * 128 + ((slot ^ swz) << 4) + (jj & 1) * 8;
         }
