@@ -469,7 +469,15 @@ int wn_debug_set(wn_model* m, const char* key, int32_t value);
  * v_mfma_f32_32x32x2_f32; 2: also for small batches), "x6_conv" / "x6_linear" (0: leave conv2 /
  * the linear() route on v_mfma_f32), "x6_af32" (1: fp32 A rows split in registers), "ffn_fused",
  * "gemm_rowln", "attn_fold" (1 default: rel-pos term folded into the keys inside the attention
- * kernel; 0: two contractions per score; 2: folded by a separate pass), "ctc_wave", ...
+ * kernel; 0: two contractions per score; 2: folded by a separate pass), "ctc_wave", "x6_sub"
+ * (1 default: the subsampling's output Linear as K slices of the six-product GEMM; 0:
+ * v_mfma_f32), "x6_conv_tail" (1 default: conv2's last partial round of tiles as K slices),
+ * "x6r_pro" (1 default: the QKV row-block GEMM forms LN(x + 0.5 FFN) itself from the fused FFN's
+ * slice partials); bf16 / fp8 modes: "attn_bf16_dma" (self attention over bf16 Q | K | V: 0
+ * register-staged, 1 / 2 LDS-DMA staged from K rows and a V^T image, 4 default: V rows by DMA +
+ * ds_read_b64_tr_b16), "attn_bf16_defer" (deferred-rescale threshold x 10 in log2 units, 80
+ * default, 0 off), "attn_bf16_nw" (query groups per block, 0 auto); measurement: "lp_probe",
+ * "x6_probe", "ffn_x6f_var" (clock stamps / ablations, see wn_profile_*_clocks), ...
  * Unknown keys are an error.  The defaults are the shipped configuration. */
 int wn_tune_set(const char* key, int32_t value);
 
