@@ -452,11 +452,32 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const __bf16* __restrict__
 // tools/probes/tr16_probe.hip, profiles/r05z_tr16_probe.txt): two transpose reads per fragment
 // (keys 16 j + 4 hi + 0..3 and + 8..11 -- the register order of the S^T tile), four per-lane
 // offsets + immediates.  Saves the vt_pack pass (25 us and 123 MB per layer at config 5).
-template <int NW, bool PIPE, bool VTR = false>
+//
+// TRA (attn_bf16_dma = 5, measurement form of VTR, not the default): the transpose reads as
+// inline asm.  Behind an LDS-DMA in flight the compiler orders every LDS read it cannot prove
+// disjoint from the DMA's destination with s_waitcnt vmcnt(0) (SIInsertWaitcnts: reads whose
+// memory operand carries no alias scope wait for ALL LDS-DMA) -- the plain K / V^T reads escape
+// that, the ds_read_tr16_b64 builtin does not: the VTR kernel's ISA has a vmcnt(0) in front of
+// the first V read of every stage, i.e. the prefetch of stage it + 1 issued behind the barrier
+// has to land under ONE score tile + softmax instead of a whole stage (found by reading the
+// ISA, end of round 3 -- no GPU minutes left to measure it).  The reads of stage `it` touch
+// buffer BUF only, the DMA in flight writes BUF ^ 1: no wait is needed.  An asm read is
+// invisible to the compiler's lgkmcnt bookkeeping, so the waits are explicit (LDS operations
+// of a wave return in order: a count that ignores younger compiler-issued reads is only ever
+// too strict).
+template <int OFF>
+__device__ __forceinline__ short __attribute__((ext_vector_type(4))) tr16_b64_asm(unsigned addr) {
+  short __attribute__((ext_vector_type(4))) r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+
+template <int NW, bool PIPE, bool VTR = false, bool TRA = false>
 __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs a, int nqb) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   static_assert(NW == 4 || NW == 8, "4 or 8 query groups per block");
   static_assert(!VTR || PIPE, "transpose-read form: grouped-read kernel only");
+  static_assert(!TRA || VTR, "asm transpose reads: a form of the transpose-read kernel");
   constexpr int NP = 8 / NW;              // 1-KB pieces of a tile per wave
   __shared__ __attribute__((aligned(1024))) char sbuf[2 * DSTAGE];
   // all query blocks of one (sequence, head) run on the same XCD, one after the other: its
@@ -565,6 +586,16 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
           tro[w][dblk] = row * 128 + ((slot ^ swz) << 4) + (jj & 1) * 8;
         }
     }
+    // TRA: the same four offsets as LDS byte addresses (buffer, tile and key group go into the
+    // instruction's immediate)
+    unsigned tra[2][2] = {{0u, 0u}, {0u, 0u}};
+    if constexpr (TRA) {
+      const unsigned base = (unsigned)(__UINTPTR_TYPE__)(lds_ptr)sbuf;
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk) tra[w][dblk] = base + (unsigned)tro[w][dblk];
+    }
     auto softmax_tile = [&](f32x16& sc, int j0, float& alpha) {
       float psum;
       if (j0 + KT <= kvlen) {
@@ -612,6 +643,37 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
       }
       l_run = l_run * alpha + psum;
     };
+    // TRA: O^T += V^T P^T of sub-tile (buffer, sb) = idx: the eight transpose reads of both
+    // 16-key groups go out together, the first group's MFMAs wait for the older four only
+    auto pv_tra = [&](auto idx, const f32x16& sc) {
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      constexpr int I = decltype(idx)::value;
+      constexpr int G0 = (I >> 1) * DSTAGE + DTILE + (I & 1) * 32 * 128, G1 = G0 + 16 * 128;
+      s16x4 a0 = tr16_b64_asm<G0>(tra[0][0]), a1 = tr16_b64_asm<G0>(tra[1][0]);
+      s16x4 b0 = tr16_b64_asm<G0>(tra[0][1]), b1 = tr16_b64_asm<G0>(tra[1][1]);
+      s16x4 c0 = tr16_b64_asm<G1>(tra[0][0]), c1 = tr16_b64_asm<G1>(tra[1][0]);
+      s16x4 d0 = tr16_b64_asm<G1>(tra[0][1]), d1 = tr16_b64_asm<G1>(tra[1][1]);
+      bf16x8 pa;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pa[e] = (__bf16)sc[e];
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+          __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7)),
+          pa, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+          __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7)),
+          pa, o1, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pa[e] = (__bf16)sc[8 + e];
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1));
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+          __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7)),
+          pa, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+          __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7)),
+          pa, o1, 0, 0, 0);
+    };
     auto stage = [&](auto bufc, int it) {
       constexpr int BUF = decltype(bufc)::value;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage `it`
@@ -649,6 +711,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
             o1[r] *= alpha;
           }
         }
+        if constexpr (TRA) {
+          if (sb == 0) pv_tra(std::integral_constant<int, 2 * BUF>{}, sc);
+          else pv_tra(std::integral_constant<int, 2 * BUF + 1>{}, sc);
+        } else
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           bf16x8 pa;
@@ -784,6 +850,15 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
   }
 }
 
+template <int NW>
+int launch_dma_tra(const AttnArgs& a, hipStream_t s) {
+  const int nqb = cdiv(a.max_q_len, NW * 32);
+  hipLaunchKernelGGL((attention_bf16_dma_kernel<NW, true, true, true>),
+                     dim3(nqb * a.n_heads * a.n_seq), dim3(NW * 64), 0, s, a, nqb);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int NW, bool PIPE, bool VTR = false>
 int launch_dma(const AttnArgs& a, hipStream_t s) {
   if (!VTR) {
@@ -823,7 +898,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
 int g_attn_bf16_nw = 0;  // wn_tune_set("attn_bf16_nw"): 0 auto, else 2 / 4 / 8
 int g_attn_bf16_sub = 2; // 8-wave blocks: 32-key sub-tiles per barrier (1 or 2)
 int g_attn_bf16_defer = 80;  // wn_tune_set("attn_bf16_defer"): deferred-rescale threshold x 10 in log2 units (0 = rescale whenever a maximum moves)
-int g_attn_bf16_dma = 4; // bf16 Q | K | V self attention: 0 register-staged, 1 LDS-DMA staged (K rows + V^T image), 2 + grouped fragment reads, 4 V rows by DMA + ds_read_b64_tr_b16 (no V^T image)
+int g_attn_bf16_dma = 4; // bf16 Q | K | V self attention: 0 register-staged, 1 LDS-DMA staged (K rows + V^T image), 2 + grouped fragment reads, 4 V rows by DMA + ds_read_b64_tr_b16 (no V^T image), 5 = 4 with the transpose reads as inline asm (TRA, measurement form)
 
 int attention_bf16(const AttnArgs& a, hipStream_t s) {
   // argument checks are attention()'s (the only caller)
@@ -834,7 +909,7 @@ int attention_bf16(const AttnArgs& a, hipStream_t s) {
   if (nw != 2 && nw != 4 && nw != 8)
     nw = a.max_q_len >= 1024 ? 8 : a.max_q_len >= 384 ? 4 : 2;
   // self attention over bf16 Q | K | V without masks: K and the packed V^T by LDS-DMA
-  const bool vtr = g_attn_bf16_dma == 4 && a.ldv == a.ldk;    // V rows + transpose reads: no V^T image
+  const bool vtr = (g_attn_bf16_dma == 4 || g_attn_bf16_dma == 5) && a.ldv == a.ldk;    // V rows + transpose reads: no V^T image
   if (g_attn_bf16_dma != 0 && a.qkv_bf16 && !a.P && a.mask_mode == 0 && nw >= 4 &&
       a.q_len == a.kv_len && a.q_off == a.kv_off && a.ldk % 8 == 0 && a.ldv % 8 == 0 &&
       (vtr || (a.vt && a.vt_tp % DKT == 0 && a.vt_tp >= a.max_q_len)) &&
@@ -844,9 +919,11 @@ int attention_bf16(const AttnArgs& a, hipStream_t s) {
     // barrier groups of four waves lose less to skew than groups of eight (config 5 fp8: 14.81 k
     // vs 14.62 k, r05v); attn_bf16_nw = 8 forces the 256-query blocks
     if (g_attn_bf16_nw != 8) nw = 4;
-    if (g_attn_bf16_dma == 2 || g_attn_bf16_dma == 4) {
+    if (g_attn_bf16_dma == 2 || g_attn_bf16_dma == 4 || g_attn_bf16_dma == 5) {
       AttnArgs d = a;
       d.defer_thr = 0.1f * (float)g_attn_bf16_defer;
+      if (vtr && g_attn_bf16_dma == 5)
+        return nw == 8 ? launch_dma_tra<8>(d, s) : launch_dma_tra<4>(d, s);
       if (vtr)
         return nw == 8 ? launch_dma<8, true, true>(d, s) : launch_dma<4, true, true>(d, s);
       return nw == 8 ? launch_dma<8, true>(d, s) : launch_dma<4, true>(d, s);
