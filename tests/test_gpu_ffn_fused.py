@@ -3,6 +3,8 @@ fp64 torch evaluation of PositionwiseFeedForward + residual + LayerNorm
 (positionwise_feed_forward.py:50-58, encoder_layer.py:220-228), and through the model
 against the two-GEMM path it replaces."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -142,8 +144,19 @@ def test_encoder_with_folded_relpos_attention_matches_the_two_contraction_form(c
         _lib.check(L.wn_tune_set(b'attn_fold', 2), 'tune')   # the fold as a separate pass
         sep, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         sep = sep.cpu()
+        glb = None
+        if os.environ.get('WN_EXPERIMENTAL') == '1':
+            # GLB (staging loads of all chunks issued together): written without a GPU at hand,
+            # checked on request only until it has run once
+            _lib.check(L.wn_tune_set(b'attn_fold', 1), 'tune')
+            _lib.check(L.wn_tune_set(b'attn_gload', 1), 'tune')
+            glb, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+            glb = glb.cpu()
     finally:
         L.wn_tune_set(b'attn_fold', 1)
+        L.wn_tune_set(b'attn_gload', 0)
+    if glb is not None:
+        assert torch.equal(glb, got), (glb - got).abs().max().item()
     assert torch.equal(got, got2.cpu())            # race screen
     err = (got - ref).abs().max().item()
     err2 = (sep - ref).abs().max().item()
@@ -291,8 +304,17 @@ def test_qkv_prologue_fold_is_bit_identical_to_the_reduce_launch(B, frames, chun
         got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got = got.cpu()
+        got_p2 = None
+        if os.environ.get('WN_EXPERIMENTAL') == '1':
+            # PRO 2 (slice loads in flight together): written without a GPU at hand, checked on
+            # request only until it has run once
+            _lib.check(L.wn_tune_set(b'x6r_pro', 2), 'tune')
+            got_p2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+            got_p2 = got_p2.cpu()
     finally:
         L.wn_tune_set(b'x6r_pro', 1)
     assert torch.isfinite(got).all()
     assert torch.equal(got, got2.cpu())
     assert torch.equal(got, ref), (got - ref).abs().max().item()
+    if got_p2 is not None:
+        assert torch.equal(got_p2, ref), (got_p2 - ref).abs().max().item()

@@ -411,7 +411,12 @@ constexpr int KSTR = 68;        // LDS row stride (floats): 64 + 4 pad
 // adds the same float4 of position row j (k <- k + p) and forms its share of u.k + v.p; 16
 // consecutive threads hold one key row, so four shuffles complete the scalar, which goes to
 // LDS next to the tile and is added to the score before the scale.
-template <int NW, bool RELPOS, int KS, bool FOLD = false>
+// GLB (attn_gload = 1, with FOLD; prepared without a GPU at hand, not the default): the K / V / P
+// loads of all of a thread's chunks are issued before the first fold.  In the default form every
+// chunk's three loads are followed by their own s_waitcnt and the chunk's dot product + four
+// shuffles before the next chunk's loads go out (read off the ISA at the end of round 3): NCH
+// dependent memory round trips per staging step instead of one; same arithmetic per element.
+template <int NW, bool RELPOS, int KS, bool FOLD = false, bool GLB = false>
 __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kernel(AttnArgs a) {
   const int s = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (NW * 32);
@@ -499,7 +504,40 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
     fu = *reinterpret_cast<const f32x4*>(a.bias_u + h * 64 + (tid & 15) * 4);
     fv = *reinterpret_cast<const f32x4*>(a.bias_v + h * 64 + (tid & 15) * 4);
   }
+  static_assert(!GLB || FOLD, "batched staging loads: a form of the folded kernel");
   auto gload = [&](int it) {
+    if constexpr (GLB) {
+      f32x4 rPf[NCH];
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * NTHR;
+        const int half = KS == 1 ? 0 : c / (KT * 16);
+        const int w = c % (KT * 16);
+        const int r = w >> 4, c4 = w & 15;
+        int j = (t_lo + half * n_it + it) * KT + r;
+        if (j > kvlen - 1) j = kvlen - 1;
+        const int64_t grow = kvoff + j;
+        rK[i] = *reinterpret_cast<const f32x4*>(a.K + grow * a.ldk + h * 64 + c4 * 4);
+        rV[i] = *reinterpret_cast<const f32x4*>(a.V + grow * a.ldv + h * 64 + c4 * 4);
+        rPf[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)(j + p_off) * a.ldp + h * 64 +
+                                                 c4 * 4);
+      }
+      // (keeps the loads above in front of the first fold)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(rK[i]), "+v"(rPf[i]));
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const f32x4 p = rPf[i];
+        const f32x4 k = rK[i];
+        float d = fu[0] * k[0] + fu[1] * k[1] + fu[2] * k[2] + fu[3] * k[3] +
+                  fv[0] * p[0] + fv[1] * p[1] + fv[2] * p[2] + fv[3] * p[3];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        rCf[i] = d;
+        rK[i] = k + p;
+      }
+      return;
+    }
     if (!FOLD && kb_on && tid < KT * KS) {
       int j = (t_lo + (tid / KT) * n_it + it) * KT + (tid % KT);
       if (j > kvlen - 1) j = kvlen - 1;
@@ -899,6 +937,7 @@ int relpos_fold(float* K, int ldk, const float* P, int ldp, const float* bias_u,
 }
 
 int g_attn_split = 0;  // wn_tune_set("attn_split")
+int g_attn_gload = 0;  // wn_tune_set("attn_gload"): 1 = folded key-split kernel with the staging loads of all chunks issued together (GLB)
 int g_attn_bf16 = 1;   // wn_tune_set("attn_bf16")
 
 int attention(const AttnArgs& a, hipStream_t s) {
@@ -917,7 +956,9 @@ int attention(const AttnArgs& a, hipStream_t s) {
   const bool fold = a.P != nullptr && a.fold && a.bias_u && a.bias_v;
   if (split) {
     dim3 t2(NW * 2 * 64);
-    if (fold)
+    if (fold && g_attn_gload == 1)
+      hipLaunchKernelGGL((attention_kernel<NW, false, 2, true, true>), g, t2, 0, s, a);
+    else if (fold)
       hipLaunchKernelGGL((attention_kernel<NW, false, 2, true>), g, t2, 0, s, a);
     else if (a.P)
       hipLaunchKernelGGL((attention_kernel<NW, true, 2>), g, t2, 0, s, a);
