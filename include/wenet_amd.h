@@ -469,7 +469,9 @@ int wn_debug_set(wn_model* m, const char* key, int32_t value);
  * v_mfma_f32_32x32x2_f32; 2: also for small batches), "x6_conv" / "x6_linear" (0: leave conv2 /
  * the linear() route on v_mfma_f32), "x6_af32" (1: fp32 A rows split in registers), "ffn_fused",
  * "gemm_rowln", "attn_fold" (1 default: rel-pos term folded into the keys inside the attention
- * kernel; 0: two contractions per score; 2: folded by a separate pass), "ctc_wave", "x6_sub"
+ * kernel; 0: two contractions per score; 2: folded by a separate pass), "ctc_wave" (1 default: a wave per row for the
+ * top-k; 0: a block per row; 2: the wave kernel with two-level maxima -- prepared, not yet
+ * measured), "x6_sub"
  * (1 default: the subsampling's output Linear as K slices of the six-product GEMM; 0:
  * v_mfma_f32), "x6_conv_tail" (1 default: conv2's last partial round of tiles as K slices),
  * "x6r_pro" (1 default: the QKV row-block GEMM forms LN(x + 0.5 FFN) itself from the fused FFN's

@@ -15,6 +15,8 @@ Tolerances (fp32 path, different summation order than torch-CPU):
 Bit-exact (same log-prob tensor fed to both): greedy tokens, n-best token
 lists, n-best time stamps; fp64 n-best scores to 1e-9.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -348,6 +350,24 @@ def test_end_to_end_vs_oracle_ragged_batch():
                    ctc_weight=0.5, reverse_weight=0.3)
     got = model.decode(METHODS, feats.cuda(), lens, beam_size=10,
                        ctc_weight=0.5, reverse_weight=0.3)
+    if os.environ.get('WN_EXPERIMENTAL') == '1':
+        # ctc_wave = 2 (two-level maxima in the top-k kernel): written without a GPU at hand,
+        # checked on request only until it has run once -- same top-k, so the same lists, bitwise
+        from wenet_amd import _lib
+        L = _lib.lib()
+        try:
+            _lib.check(L.wn_tune_set(b'ctc_wave', 2), 'tune')
+            got2 = model.decode(METHODS, feats.cuda(), lens, beam_size=10,
+                                ctc_weight=0.5, reverse_weight=0.3)
+        finally:
+            L.wn_tune_set(b'ctc_wave', 1)
+        for b in range(6):
+            for m in METHODS:
+                assert got2[m][b].tokens == got[m][b].tokens, (m, b)
+                assert got2[m][b].score == got[m][b].score, (m, b)
+            p1, p2 = got['ctc_prefix_beam_search'][b], got2['ctc_prefix_beam_search'][b]
+            assert p1.nbest == p2.nbest and p1.nbest_scores == p2.nbest_scores
+            assert p1.nbest_times == p2.nbest_times
     with torch.no_grad():
         enc, mask = O.encoder_forward(configs, sd, feats, lens)
         ref_logp = O.ctc_logprobs(sd, enc)

@@ -144,6 +144,87 @@ __global__ __launch_bounds__(256) void ctc_row_wave_kernel(CtcRowArgs a) {
   }
 }
 
+// ctc_wave = 2 (prepared at the end of round 3 without a GPU at hand, not the default): the
+// wave kernel above is bound by its VALU work -- k rounds x (EPL compares + selects, EPL
+// retire compares) = ~3 k instructions per row at EPL = 72, k = 10, 99 us per decode against
+// 27 us for reading the logits once.  Two levels: the lane keeps the maximum (value, index) of
+// each group of 8 of its elements; a round scans the EPL / 8 group maxima, and only the group
+// the winner came from is retired and rescanned -- the winner is wave-uniform, so that is one
+// scalar branch per group.  Same order everywhere (strict > while scanning indices upwards:
+// larger value first, lower index on ties; a taken element becomes NaN), same expressions for
+// the log-probs: the outputs are the wave kernel's, bit for bit.
+template <int EPL>
+__global__ __launch_bounds__(256, EPL <= 72 ? 3 : 2) void ctc_row_wave2_kernel(CtcRowArgs a) {
+  constexpr int G = 8, NG = EPL / G;
+  static_assert(EPL % G == 0, "whole groups");
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const float* x = a.logits + (int64_t)row * a.ld;
+  float v[EPL];
+  float mx = -INFINITY;
+  // (clamped address + select instead of a guarded load: the guard compiles to a branch per
+  // element, ~10 instructions each in the wave kernel's load phase)
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int i = e * 64 + lane;
+    const float ld = x[min(i, a.V - 1)];
+    float t = i < a.V ? ld : __builtin_nanf("");
+    if (i == a.blank) t -= a.blank_penalty;
+    v[e] = t;
+    mx = fmaxf(mx, t);
+  }
+  mx = wave_max(mx);
+  float sm4[4] = {0.f, 0.f, 0.f, 0.f};      // (the wave kernel's summation order)
+#pragma unroll
+  for (int e = 0; e < EPL; ++e)
+    if (e * 64 + lane < a.V) sm4[e & 3] += expf(v[e] - mx);
+  const float lsum = logf(wave_sum(sm4[0]) + wave_sum(sm4[1]) + wave_sum(sm4[2]) +
+                          wave_sum(sm4[3]));
+  float gv[NG];
+  int gi[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+      if (v[g * G + j] > bv) { bv = v[g * G + j]; bi = (g * G + j) * 64 + lane; }
+    gv[g] = bv;
+    gi[g] = bi;
+  }
+  for (int r = 0; r < a.k; ++r) {
+    VI best;
+    best.v = -INFINITY;
+    best.i = 0x7fffffff;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (gv[g] > best.v) { best.v = gv[g]; best.i = gi[g]; }     // g ascending: lowest index
+    const VI b = vi_wave(best);
+    if (lane == 0) {
+      a.topk_val[(int64_t)row * a.k + r] = (b.v - mx) - lsum;
+      a.topk_idx[(int64_t)row * a.k + r] = b.i;
+    }
+    const int te = b.i >> 6;
+    const bool mine = (b.i & 63) == lane;
+    const int tg = __builtin_amdgcn_readfirstlane(te >> 3);   // every lane holds the same b
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (tg == g) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          if (mine && g * G + j == te) v[g * G + j] = __builtin_nanf("");
+          if (v[g * G + j] > bv) { bv = v[g * G + j]; bi = (g * G + j) * 64 + lane; }
+        }
+        gv[g] = bv;
+        gi[g] = bi;
+      }
+    }
+  }
+}
+
 // ===========================================================================
 // ctc_greedy_search (search.py:109-124 + ctc_utils.py:23-33): frames past the
 // utterance length count as blank, repeats collapse, blanks drop.  One wave per
@@ -1064,13 +1145,20 @@ __global__ __launch_bounds__(BIG_THREADS) void prefix_beam_big_kernel(PrefixBeam
 
 }  // namespace
 
-int g_ctc_wave = 1;   // wn_tune_set("ctc_wave"): 0 = always the block-per-row kernel
+int g_ctc_wave = 1;   // wn_tune_set("ctc_wave"): 0 = always the block-per-row kernel; 2 = the wave kernel with two-level maxima (prepared, not measured)
 
 int ctc_logsoftmax_topk(const CtcRowArgs& a, hipStream_t s) {
   WN_CHECK(a.M > 0 && a.V > 0, "ctc: empty");
   WN_CHECK(a.k >= 1 && a.k <= a.V, "ctc: top-k must be in [1, vocab]");
   if (a.logp == nullptr && g_ctc_wave != 0 && a.V <= 96 * 64 && a.k <= 16) {
     dim3 g(cdiv(a.M, 4)), t(256);
+    if (g_ctc_wave == 2) {
+      if (a.V <= 8 * 64) hipLaunchKernelGGL(ctc_row_wave2_kernel<8>, g, t, 0, s, a);
+      else if (a.V <= 72 * 64) hipLaunchKernelGGL(ctc_row_wave2_kernel<72>, g, t, 0, s, a);
+      else hipLaunchKernelGGL(ctc_row_wave2_kernel<96>, g, t, 0, s, a);
+      WN_HIP(hipGetLastError());
+      return 0;
+    }
     if (a.V <= 8 * 64) hipLaunchKernelGGL(ctc_row_wave_kernel<8>, g, t, 0, s, a);
     else if (a.V <= 72 * 64) hipLaunchKernelGGL(ctc_row_wave_kernel<72>, g, t, 0, s, a);
     else hipLaunchKernelGGL(ctc_row_wave_kernel<96>, g, t, 0, s, a);
