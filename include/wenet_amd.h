@@ -477,7 +477,8 @@ int wn_debug_set(wn_model* m, const char* key, int32_t value);
  * "x6r_pro" (1 default: the QKV row-block GEMM forms LN(x + 0.5 FFN) itself from the fused FFN's
  * slice partials; 2: the same with the slice loads in flight together -- prepared, not yet
  * measured), "attn_gload" (1: fp32 folded attention with the staging loads of all chunks issued
- * together -- prepared, not yet measured; 0 default); bf16 / fp8 modes: "attn_bf16_dma" (self attention over bf16 Q | K | V: 0
+ * together -- prepared, not yet measured; 0 default), "dwconv_tiled" (1: depthwise convolution
+ * with four rows per wave -- prepared, not yet measured; 0 default); bf16 / fp8 modes: "attn_bf16_dma" (self attention over bf16 Q | K | V: 0
  * register-staged, 1 / 2 LDS-DMA staged from K rows and a V^T image, 4 default: V rows by DMA +
  * ds_read_b64_tr_b16, 5 the same with the transpose reads as inline asm -- a measurement form,
  * see csrc/attention_bf16.hip TRA), "attn_bf16_defer" (deferred-rescale threshold x 10 in log2 units, 80

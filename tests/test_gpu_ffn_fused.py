@@ -152,11 +152,18 @@ def test_encoder_with_folded_relpos_attention_matches_the_two_contraction_form(c
             _lib.check(L.wn_tune_set(b'attn_gload', 1), 'tune')
             glb, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
             glb = glb.cpu()
+            # ... and the depthwise convolution with four rows per wave (dwconv_tiled = 1)
+            _lib.check(L.wn_tune_set(b'attn_gload', 0), 'tune')
+            _lib.check(L.wn_tune_set(b'dwconv_tiled', 1), 'tune')
+            dwt, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+            dwt = dwt.cpu()
     finally:
         L.wn_tune_set(b'attn_fold', 1)
         L.wn_tune_set(b'attn_gload', 0)
+        L.wn_tune_set(b'dwconv_tiled', 0)
     if glb is not None:
         assert torch.equal(glb, got), (glb - got).abs().max().item()
+        assert torch.equal(dwt, got), (dwt - got).abs().max().item()
     assert torch.equal(got, got2.cpu())            # race screen
     err = (got - ref).abs().max().item()
     err2 = (sep - ref).abs().max().item()

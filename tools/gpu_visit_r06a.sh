@@ -15,7 +15,7 @@ WN_EXPERIMENTAL=1 timeout 900 python -m pytest -q -x \
   "tests/test_gpu_parity.py::test_end_to_end_vs_oracle_ragged_batch" > $OUT/pytest_experimental.log 2>&1
 echo "experimental legs exit $?"; tail -4 $OUT/pytest_experimental.log | cut -c1-300
 B="python bench.py --no-cpu-baseline --no-plain-leg --no-f32-mfma-leg --no-clock-sample"
-for t in "" "x6r_pro=2" "attn_gload=1" "ctc_wave=2" "x6r_pro=2,attn_gload=1,ctc_wave=2" ""; do
+for t in "" "x6r_pro=2" "attn_gload=1" "ctc_wave=2" "dwconv_tiled=1" "x6r_pro=2,attn_gload=1,ctc_wave=2,dwconv_tiled=1" ""; do
   n=$(echo "${t:-default}" | tr ',=' '__')
   timeout 300 $B ${t:+--tune $t} > $OUT/bench_config2_$n.json 2>> $OUT/b.err
   python -c "

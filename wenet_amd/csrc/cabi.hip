@@ -649,6 +649,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_conv_tail") g_x6_conv_tail = value;
   else if (k == "x6r_pro") g_x6r_pro = value;
   else if (k == "attn_gload") g_attn_gload = value;
+  else if (k == "dwconv_tiled") g_dwconv_tiled = value;
   else if (k == "attn_fold") g_attn_fold = value;
   else if (k == "x6_conv_order") g_x6_conv_order = value;
   else if (k == "x6_linear") g_x6_linear = value;

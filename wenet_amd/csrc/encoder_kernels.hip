@@ -379,6 +379,90 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs a) {
   acc.store(a.y + (int64_t)row * a.ldy, lane);
 }
 
+// dwconv_tiled = 1 (prepared at the end of round 3 without a GPU at hand, not the default): a wave
+// computes R = 4 consecutive packed rows.  The kernel above reads K neighbour rows per output
+// row -- 8 x 1 KB from L2 per row at config 2, 65 MB per launch for an 8-MB tensor; a tile of 4
+// rows shares its R + 7 window rows per group of 8 taps (11 row loads instead of 32, the taps
+// once instead of four times).  Per output row the operations and their order are the kernel
+// above's: bias, the taps in ascending order (a neighbour outside the utterance is the pad
+// frame or skipped by the same rule, evaluated against the OUTPUT row's own utterance -- a tile
+// may straddle two utterances of the packed batch), LayerNorm / affine, SiLU.
+template <int E>
+__global__ __launch_bounds__(256) void dwconv_tiled_kernel(DwConvArgs a) {
+  constexpr int R = 4, TG = 8, NWIN = R + TG - 1;
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= a.M) return;
+  const int lpad = a.causal ? a.K - 1 : (a.K - 1) / 2;
+  // utterance, first row and length of the R rows: lanes 0 .. R - 1 fetch them side by side (two
+  // dependent round trips for the tile, as for one row above), the wave reads them back as
+  // uniform values
+  int u_l = -1, off_l = 0, len_l = 0;
+  if (lane < R && row0 + lane < a.M) u_l = a.row_utt[row0 + lane];
+  if (u_l >= 0) {
+    off_l = a.off[u_l];
+    len_l = a.len[u_l];
+  }
+  int t_r[R], len_r[R];
+  bool on[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int u = __builtin_amdgcn_readlane(u_l, r);
+    t_r[r] = row0 + r - __builtin_amdgcn_readlane(off_l, r);
+    len_r[r] = __builtin_amdgcn_readlane(len_l, r);
+    on[r] = u >= 0 && t_r[r] < len_r[r];
+  }
+  RowRegs<E> acc[R], cp;
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r].load(a.bias, lane);
+  cp.load(a.cpad, lane);
+  for (int k0 = 0; k0 < a.K; k0 += TG) {
+    RowRegs<E> wk[TG], xw[NWIN];
+    // window row i = packed row row0 + k0 - lpad + i (output r, tap k0 + j: i = r + j); the
+    // address is clamped into the tensor, whether the row is USED is decided per output below
+#pragma unroll
+    for (int i = 0; i < NWIN; ++i) {
+      const int p = min(max(row0 + k0 - lpad + i, 0), a.M - 1);
+      xw[i].load(a.x + (int64_t)p * a.ldx, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < TG; ++i)
+      if (k0 + i < a.K) wk[i].load(a.wt + (int64_t)(k0 + i) * (E * 64), lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int j = 0; j < TG; ++j) {
+        const int k = k0 + j, tt = t_r[r] + k - lpad;
+        if (on[r] && k < a.K) {
+          if (tt >= 0 && tt < len_r[r]) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[r].v[e] = fmaf(wk[j].v[e], xw[r + j].v[e], acc[r].v[e]);
+          } else if ((tt < 0 && a.causal) || (tt >= len_r[r] && tt < a.t_max)) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[r].v[e] = fmaf(wk[j].v[e], cp.v[e], acc[r].v[e]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (!on[r]) continue;
+    if (a.norm_mode == 0) {
+      ln_inplace<E>(acc[r], a.ln_w, a.ln_b, lane, a.eps);
+    } else {
+      RowRegs<E> sc, sh;
+      sc.load(a.ln_w, lane);
+      sh.load(a.ln_b, lane);
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[r].v[e] = fmaf(acc[r].v[e], sc.v[e], sh.v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[r].v[e] = silu_f(acc[r].v[e]);
+    acc[r].store(a.y + (int64_t)(row0 + r) * a.ldy, lane);
+  }
+}
+
 // ===========================================================================
 // Attention.  Replaces RelPositionMultiHeadedAttention.forward /
 // MultiHeadedAttention.forward_attention (attention.py:133-178,364-438) and
@@ -901,7 +985,16 @@ int cmvn_conv1_relu(const Conv1Args& a, hipStream_t s) {
   return 0;
 }
 
+int g_dwconv_tiled = 0;   // wn_tune_set("dwconv_tiled"): 1 = four rows per wave (prepared, not measured)
+
 int dwconv_ln_silu(const DwConvArgs& a, hipStream_t s) {
+  if (g_dwconv_tiled == 1 && (a.D == 256 || a.D == 512)) {
+    dim3 gt(cdiv(cdiv(a.M, 4), 4)), tt(256);
+    if (a.D == 256) hipLaunchKernelGGL(dwconv_tiled_kernel<4>, gt, tt, 0, s, a);
+    else hipLaunchKernelGGL(dwconv_tiled_kernel<8>, gt, tt, 0, s, a);
+    WN_HIP(hipGetLastError());
+    return 0;
+  }
   dim3 g(cdiv(a.M, 4)), t(256);
 #define WN_DW(E)                                              \
   case E * 64:                                                \
