@@ -470,15 +470,15 @@ int wn_debug_set(wn_model* m, const char* key, int32_t value);
  * the linear() route on v_mfma_f32), "x6_af32" (1: fp32 A rows split in registers), "ffn_fused",
  * "gemm_rowln", "attn_fold" (1 default: rel-pos term folded into the keys inside the attention
  * kernel; 0: two contractions per score; 2: folded by a separate pass), "ctc_wave" (1 default: a wave per row for the
- * top-k; 0: a block per row; 2: the wave kernel with two-level maxima -- prepared, not yet
- * measured), "x6_sub"
+ * top-k; 0: a block per row; 2: the wave kernel with two-level maxima -- bit-identical,
+ * measured at the end of round 3, not the default yet), "x6_sub"
  * (1 default: the subsampling's output Linear as K slices of the six-product GEMM; 0:
  * v_mfma_f32), "x6_conv_tail" (1 default: conv2's last partial round of tiles as K slices),
  * "x6r_pro" (1 default: the QKV row-block GEMM forms LN(x + 0.5 FFN) itself from the fused FFN's
- * slice partials; 2: the same with the slice loads in flight together -- prepared, not yet
- * measured), "attn_gload" (1: fp32 folded attention with the staging loads of all chunks issued
- * together -- prepared, not yet measured; 0 default), "dwconv_tiled" (1: depthwise convolution
- * with four rows per wave -- prepared, not yet measured; 0 default); bf16 / fp8 modes: "attn_bf16_dma" (self attention over bf16 Q | K | V: 0
+ * slice partials; 2: the same with the slice loads in flight together -- bit-identical,
+ * measured at the end of round 3, not the default yet), "attn_gload" (1: fp32 folded attention with the staging loads of all chunks issued
+ * together -- bit-identical, not the default yet; 0 default), "dwconv_tiled" (1: depthwise convolution
+ * with four rows per wave -- bit-identical, not the default yet; 0 default); bf16 / fp8 modes: "attn_bf16_dma" (self attention over bf16 Q | K | V: 0
  * register-staged, 1 / 2 LDS-DMA staged from K rows and a V^T image, 4 default: V rows by DMA +
  * ds_read_b64_tr_b16, 5 the same with the transpose reads as inline asm -- a measurement form,
  * see csrc/attention_bf16.hip TRA), "attn_bf16_defer" (deferred-rescale threshold x 10 in log2 units, 80

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void ctc_row_wave_kernel(CtcRowArgs a) {
   }
 }
 
-// ctc_wave = 2 (prepared at the end of round 3 without a GPU at hand, not the default): the
+// ctc_wave = 2 (end of round 3; bit-identical on the GPU; not the default yet): the
 // wave kernel above is bound by its VALU work -- k rounds x (EPL compares + selects, EPL
 // retire compares) = ~3 k instructions per row at EPL = 72, k = 10, 99 us per decode against
 // 27 us for reading the logits once.  Two levels: the lane keeps the maximum (value, index) of
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(BIG_THREADS) void prefix_beam_big_kernel(PrefixBeam
 
 }  // namespace
 
-int g_ctc_wave = 1;   // wn_tune_set("ctc_wave"): 0 = always the block-per-row kernel; 2 = the wave kernel with two-level maxima (prepared, not measured)
+int g_ctc_wave = 1;   // wn_tune_set("ctc_wave"): 0 = always the block-per-row kernel; 2 = the wave kernel with two-level maxima
 
 int ctc_logsoftmax_topk(const CtcRowArgs& a, hipStream_t s) {
   WN_CHECK(a.M > 0 && a.V > 0, "ctc: empty");

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs a) {
   acc.store(a.y + (int64_t)row * a.ldy, lane);
 }
 
-// dwconv_tiled = 1 (prepared at the end of round 3 without a GPU at hand, not the default): a wave
+// dwconv_tiled = 1 (end of round 3; bit-identical on the GPU; not the default yet): a wave
 // computes R = 4 consecutive packed rows.  The kernel above reads K neighbour rows per output
 // row -- 8 x 1 KB from L2 per row at config 2, 65 MB per launch for an 8-MB tensor; a tile of 4
 // rows shares its R + 7 window rows per group of 8 taps (11 row loads instead of 32, the taps
@@ -495,7 +495,7 @@ constexpr int KSTR = 68;        // LDS row stride (floats): 64 + 4 pad
 // adds the same float4 of position row j (k <- k + p) and forms its share of u.k + v.p; 16
 // consecutive threads hold one key row, so four shuffles complete the scalar, which goes to
 // LDS next to the tile and is added to the score before the scale.
-// GLB (attn_gload = 1, with FOLD; prepared without a GPU at hand, not the default): the K / V / P
+// GLB (attn_gload = 1, with FOLD; end of round 3, bit-identical on the GPU, not the default yet): the K / V / P
 // loads of all of a thread's chunks are issued before the first fold.  In the default form every
 // chunk's three loads are followed by their own s_waitcnt and the chunk's dot product + four
 // shuffles before the next chunk's loads go out (read off the ISA at the end of round 3): NCH
@@ -985,7 +985,7 @@ int cmvn_conv1_relu(const Conv1Args& a, hipStream_t s) {
   return 0;
 }
 
-int g_dwconv_tiled = 0;   // wn_tune_set("dwconv_tiled"): 1 = four rows per wave (prepared, not measured)
+int g_dwconv_tiled = 0;   // wn_tune_set("dwconv_tiled"): 1 = four rows per wave
 
 int dwconv_ln_silu(const DwConvArgs& a, hipStream_t s) {
   if (g_dwconv_tiled == 1 && (a.D == 256 || a.D == 512)) {

@@ -44,7 +44,7 @@ constexpr int RKB = RK / 16;         // 16 k blocks
 // in front of it (X6RArgs::pro_*): the sum, the residual add and the LayerNorm of ffn_reduce_ln's
 // mode 0 -- same operations in the same order, a wave per row, 4 consecutive columns per lane --
 // on the rows the prologue holds as whole rows anyway (round 3: one launch and one round trip of
-// LN(x) through HBM less per layer).  PRO 2 (x6r_pro = 2, prepared without a GPU at hand, not the
+// LN(x) through HBM less per layer).  PRO 2 (x6r_pro = 2, end of round 3, bit-identical on the GPU, not the
 // default): PRO 1 with the slice loads of a row block in flight together.
 template <int NT, int EPI, int PF, int PRO = 0>
 __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
