@@ -1,8 +1,9 @@
 #!/bin/bash
-# GPU visit r06a (first visit of the next round): the four forms prepared at the end of round 3
-# without a GPU -- bit-identity legs first (WN_EXPERIMENTAL=1 adds them to
-# the existing tests), then each one A/B against the default on THIS box, then the kernel stats
-# with all of them on.  ~9 GPU-minutes.
+# GPU visit r06a (first visit of the next round): the five kernel forms of DESIGN.md section 7
+# (bit-identical and +2.1 % on the headline in the last seconds of round 3, profiles/r05af-r05al,
+# but never under the WHOLE suite): the WN_EXPERIMENTAL legs, each key A/B against the default
+# on THIS box.  Then: flip the defaults (g_x6r_pro = 2, g_attn_gload = 1, g_ctc_wave = 2,
+# g_dwconv_tiled = 1, g_attn_bf16_dma = 5) and run tools/gpu_visit_suite.sh.  ~9 GPU-minutes.
 TAG=${1:-r06a}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
