@@ -483,7 +483,9 @@ int wn_debug_set(wn_model* m, const char* key, int32_t value);
  * ds_read_b64_tr_b16, 5 the same with the transpose reads as inline asm -- a measurement form,
  * see csrc/attention_bf16.hip TRA), "attn_bf16_defer" (deferred-rescale threshold x 10 in log2 units, 80
  * default, 0 off), "attn_bf16_nw" (query groups per block, 0 auto); measurement: "lp_probe",
- * "x6_probe", "ffn_x6f_var" (clock stamps / ablations, see wn_profile_*_clocks), ...
+ * "x6_probe", "ffn_x6f_var" (clock stamps / ablations, see wn_profile_*_clocks); "beam_cu_mask"
+ * (n * 1000 + stride, 0 default = off: the prefix beam search kernel on a stream whose CU mask
+ * has n bits set -- prepared for decodes in flight, not yet run), ...
  * Unknown keys are an error.  The defaults are the shipped configuration. */
 int wn_tune_set(const char* key, int32_t value);
 

@@ -5,6 +5,7 @@
 #include "model_state.h"
 
 namespace {
+int g_beam_cu_mask = 0;   // wn_tune_set("beam_cu_mask"), see wn_ctc_prefix_beam_search
 
 // ---------------------------------------------------------------------------
 // weight ingestion
@@ -656,6 +657,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_linear_min") g_x6_linear_min = value;
   else if (k == "x6_af32") g_x6_af32 = value;
   else if (k == "beam_prio") g_beam_prio = value;
+  else if (k == "beam_cu_mask") g_beam_cu_mask = value;
   else if (k == "beam_weak_hash") g_beam_weak_hash = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "gemm_rowln") g_gemm_rowln = value;
@@ -1078,6 +1080,55 @@ int wn_set_context_graph(wn_model* m, int32_t n_nodes, const int32_t* fail,
   return 0;
 }
 
+// wn_tune_set("beam_cu_mask", n * 1000 + stride) (0 = off, the default; prepared at the end of
+// round 3, not yet run): the prefix beam search kernel -- T' dependent frames on B workgroups,
+// 1.13 ms at config 2 -- goes to a stream whose CU mask has n bits set, `stride` bits apart
+// (8001: bits 0..7, 8032: every 32nd bit).  Why: with two decodes in flight the search of batch
+// i runs under the encoder of batch i + 1, and its 32 workgroups land on 32 different CUs; the
+// fused feed-forward kernel needs a whole CU per block (512 registers per wave, 248 blocks at
+// config 2), so while a search is running only 224 CUs can take one and every such launch runs
+// a second round of 24 blocks.  The headline (5.66 ms per decode) sits 0.39 ms above the encoder
+// + CTC head chain (5.27 ms) -- about what four or five doubled FFN launches per search cost.
+// On 8 CUs the search shares SIMDs with itself (4 workgroups per CU) and the other 248 CUs are
+// exactly the FFN's 248 blocks.  Which CUs the mask bits name (one XCD or one CU of each) is
+// for the first measurement to find out: hence the stride.  (g_beam_cu_mask: top of this file.)
+
+namespace {
+int beam_stream_begin(wn_model* m, hipStream_t s, hipStream_t* out) {
+  *out = s;
+  if (g_beam_cu_mask <= 0) return 0;
+  MaskedStream& ms = m->pb_ms;
+  if (ms.cfg != g_beam_cu_mask) {
+    ms.reset();
+    int ncu = 0;
+    WN_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, m->device));
+    WN_CHECK(ncu > 0, "beam_cu_mask: no CU count");
+    const int n = std::min(std::max(g_beam_cu_mask / 1000, 1), ncu);
+    const int stride = std::max(g_beam_cu_mask % 1000, 1);
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = 0, bit = 0; i < n; ++i, bit += stride) {
+      int b = bit % ncu;
+      while (mask[b >> 5] & (1u << (b & 31))) b = (b + 1) % ncu;   // (wrapped onto a set bit)
+      mask[b >> 5] |= 1u << (b & 31);
+    }
+    WN_HIP(hipExtStreamCreateWithCUMask(&ms.st, (uint32_t)mask.size(), mask.data()));
+    WN_HIP(hipEventCreateWithFlags(&ms.e0, hipEventDisableTiming));
+    WN_HIP(hipEventCreateWithFlags(&ms.e1, hipEventDisableTiming));
+    ms.cfg = g_beam_cu_mask;
+  }
+  WN_HIP(hipEventRecord(ms.e0, s));
+  WN_HIP(hipStreamWaitEvent(ms.st, ms.e0, 0));
+  *out = ms.st;
+  return 0;
+}
+int beam_stream_end(wn_model* m, hipStream_t s, hipStream_t bs) {
+  if (bs == s) return 0;
+  WN_HIP(hipEventRecord(m->pb_ms.e1, bs));
+  WN_HIP(hipStreamWaitEvent(s, m->pb_ms.e1, 0));
+  return 0;
+}
+}  // namespace
+
 int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
                               int32_t* n_hyps_host, int32_t* hyp_lens_host,
                               int32_t* hyp_tlens_host, int32_t* hyp_tokens_host,
@@ -1122,7 +1173,10 @@ int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
     WN_TRY(m->pb_dbg.ensure(8 * sizeof(long long)));
     a.dbg_cycles = m->pb_dbg.as<long long>();
   }
-  WN_TRY(ctc_prefix_beam(a, s));
+  hipStream_t bs = s;
+  WN_TRY(beam_stream_begin(m, s, &bs));
+  WN_TRY(ctc_prefix_beam(a, bs));
+  WN_TRY(beam_stream_end(m, s, bs));
   if (pb_dbg) {
     long long h[5];
     WN_HIP(hipMemcpyAsync(h, a.dbg_cycles, sizeof(h), hipMemcpyDeviceToHost, s));

@@ -107,6 +107,24 @@ struct PinnedBuf {
   }
 };
 
+// A stream restricted to a few CUs (hipExtStreamCreateWithCUMask) + the two events that order
+// it with the caller's stream: see wn_tune_set("beam_cu_mask") in cabi.hip.
+struct MaskedStream {
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int cfg = 0;
+  MaskedStream() = default;
+  MaskedStream(const MaskedStream&) = delete;
+  MaskedStream& operator=(const MaskedStream&) = delete;
+  void reset() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+    st = nullptr; e0 = e1 = nullptr; cfg = 0;
+  }
+  ~MaskedStream() { reset(); }
+};
+
 struct Linear { const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0; };
 struct Norm { const float* w = nullptr; const float* b = nullptr; };
 
@@ -342,6 +360,7 @@ struct wn_model {
   DevBuf ab_cache, ab_state;   // `attention` mode: self-attention K|V cache, beam state
   bool mem_cache_valid = false;
 
+  MaskedStream pb_ms;          // prefix beam search on its own few CUs (beam_cu_mask)
   Stager stage;
   // optional HIP-event bracket around the FFN w_1 GEMM launches (the kernel
   // the roofline is quoted on); see wn_profile_*.
