@@ -1083,16 +1083,13 @@ int wn_set_context_graph(wn_model* m, int32_t n_nodes, const int32_t* fail,
 // wn_tune_set("beam_cu_mask", n * 1000 + stride) (0 = off, the default; prepared at the end of
 // round 3, not yet run): the prefix beam search kernel -- T' dependent frames on B workgroups,
 // 1.13 ms at config 2 -- goes to a stream whose CU mask has n bits set, `stride` bits apart
-// (8001: bits 0..7, 8032: every 32nd bit).  Why: with two decodes in flight the search of batch
-// i runs under the encoder of batch i + 1, and its 32 workgroups land on 32 different CUs; the
-// fused feed-forward kernel needs a whole CU per block (512 registers per wave, 248 blocks at
-// config 2), so while a search is running only 224 CUs can take one and every such launch runs
-// a second round of 24 blocks.  The headline (5.66 ms per decode) sits 0.39 ms above the encoder
-// + CTC head chain (5.27 ms) -- about what four or five doubled FFN launches per search cost.
-// On 8 CUs the search shares SIMDs with itself (4 workgroups per CU) and the other 248 CUs are
-// exactly the FFN's 248 blocks.  Which CUs the mask bits name (one XCD or one CU of each) is
-// for the first measurement to find out: hence the stride.  (g_beam_cu_mask: top of this file.)
-
+// (8001: bits 0..7, 8032: every 32nd bit).  A measurement aid for decodes in flight: the search
+// of batch i runs under the encoder of batch i + 1 with its 32 workgroups on 32 different CUs,
+// and the fused feed-forward kernel wants a whole CU per block (248 blocks at config 2); whether
+// that costs anything is open (the kernel trace says no).  On 8 CUs the
+// search shares SIMDs with itself and the other 248 CUs are exactly the FFN's blocks.  Which
+// CUs the mask bits name (one XCD or one CU of each) is for the measurement to find out: hence
+// the stride.  (g_beam_cu_mask: top of this file.)
 namespace {
 int beam_stream_begin(wn_model* m, hipStream_t s, hipStream_t* out) {
   *out = s;
