@@ -485,7 +485,8 @@ int wn_debug_set(wn_model* m, const char* key, int32_t value);
  * default, 0 off), "attn_bf16_nw" (query groups per block, 0 auto); measurement: "lp_probe",
  * "x6_probe", "ffn_x6f_var" (clock stamps / ablations, see wn_profile_*_clocks); "beam_cu_mask"
  * (n * 1000 + stride, 0 default = off: the prefix beam search kernel on a stream whose CU mask
- * has n bits set -- prepared for decodes in flight, not yet run), ...
+ * has n bits set -- prepared for decodes in flight, not yet run) and "x6_conv_cus" (256 default:
+ * the CUs a round of conv2's tiles may use; 248 with an 8-CU search mask), ...
  * Unknown keys are an error.  The defaults are the shipped configuration. */
 int wn_tune_set(const char* key, int32_t value);
 

@@ -658,6 +658,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_af32") g_x6_af32 = value;
   else if (k == "beam_prio") g_beam_prio = value;
   else if (k == "beam_cu_mask") g_beam_cu_mask = value;
+  else if (k == "x6_conv_cus") g_x6_conv_cus = value;
   else if (k == "beam_weak_hash") g_beam_weak_hash = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "gemm_rowln") g_gemm_rowln = value;
@@ -1083,13 +1084,13 @@ int wn_set_context_graph(wn_model* m, int32_t n_nodes, const int32_t* fail,
 // wn_tune_set("beam_cu_mask", n * 1000 + stride) (0 = off, the default; prepared at the end of
 // round 3, not yet run): the prefix beam search kernel -- T' dependent frames on B workgroups,
 // 1.13 ms at config 2 -- goes to a stream whose CU mask has n bits set, `stride` bits apart
-// (8001: bits 0..7, 8032: every 32nd bit).  A measurement aid for decodes in flight: the search
-// of batch i runs under the encoder of batch i + 1 with its 32 workgroups on 32 different CUs,
-// and the fused feed-forward kernel wants a whole CU per block (248 blocks at config 2); whether
-// that costs anything is open (the kernel trace says no).  On 8 CUs the
-// search shares SIMDs with itself and the other 248 CUs are exactly the FFN's blocks.  Which
-// CUs the mask bits name (one XCD or one CU of each) is for the measurement to find out: hence
-// the stride.  (g_beam_cu_mask: top of this file.)
+// (8001: bits 0..7, 8032: every 32nd bit).  With two decodes in flight the search of batch i
+// runs under the subsampling of batch i + 1, its 32 workgroups on 32 different CUs, and conv2's
+// one-block-per-CU tiles then need three rounds instead of two: 862 us against 663 us
+// (tools/timeline_two_streams.py).  On 8 CUs the search shares SIMDs with
+// itself; x6_conv_cus = 248 lets conv2 cut its rounds for the rest.  Which CUs the mask bits
+// name (one XCD or one CU of each) is for the measurement to find out: hence the stride.
+// (g_beam_cu_mask: top of this file.)
 namespace {
 int beam_stream_begin(wn_model* m, hipStream_t s, hipStream_t* out) {
   *out = s;

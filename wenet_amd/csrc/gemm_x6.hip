@@ -521,6 +521,7 @@ int g_x6_nw4 = 0;
 int g_x6_conv = 1;
 int g_x6_sub = 1;
 int g_x6_conv_tail = 1;
+int g_x6_conv_cus = 256;   // wn_tune_set("x6_conv_cus"): CUs per round of conv2's 256-row tiles (see gemm_x6())
 int g_x6_conv_order = 1;   // 1: channel blocks outside, taps inside (L2 reuse); 0: tap-major
 int g_x6_linear = 1;
 // 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in
@@ -598,14 +599,17 @@ int gemm_x6(const X6Args& args, hipStream_t s) {
     // One 256-row tile per CU and round: when the last round would be less than half
     // full, its rows go to a second launch of 128-row tiles (half as long) instead --
     // 589 tiles at config 2 = 2.3 rounds become 2 rounds + 154 half tiles.
-    const int t256 = cdiv(a.M, 256), full = t256 / 256 * 256;
+    // (g_x6_conv_cus: the CUs a round may use -- 256; fewer when the prefix beam search of the
+    // batch in front keeps some for itself, wn_tune_set("beam_cu_mask"))
+    const int ncu = std::min(std::max(g_x6_conv_cus, 64), 256);
+    const int t256 = cdiv(a.M, 256), full = t256 / ncu * ncu;
     auto run = [&](const X6Args& x, int rows) {
       if (af32) return rows == 256 ? launch_x6<256, 0, ACT_RELU, true, true>(x, s)
                                    : launch_x6<128, 0, ACT_RELU, true, true>(x, s);
       return rows == 256 ? launch_x6<256, 0, ACT_RELU, true>(x, s)
                          : launch_x6<128, 0, ACT_RELU, true, false, 4>(x, s);
     };
-    if (a.bm == 0 && a.N <= XBN && full > 0 && t256 - full > 0 && t256 - full <= 128) {
+    if (a.bm == 0 && a.N <= XBN && full > 0 && t256 - full > 0 && t256 - full <= ncu / 2) {
       X6Args main = a, rest = a;
       main.M = full * 256;
       rest.row0 = full * 256;
@@ -616,7 +620,7 @@ int gemm_x6(const X6Args& args, hipStream_t s) {
       // time on a wave per SIMD (207 us, r05e)
       const int rem = t256 - full, nkb = a.K / 16;
       int S = 0;
-      for (int t = std::min(4, 256 / rem); t >= 2; --t)
+      for (int t = std::min(4, ncu / rem); t >= 2; --t)
         if (nkb % t == 0) { S = t; break; }
       const int rows = a.M - full * 256;
       if (g_x6_conv_tail != 0 && !af32 && S >= 2 && a.part &&

@@ -570,8 +570,9 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
       g.a_pix = pix; g.a_tiles = tiles; g.conv_kbc = d / 16; g.bm = g_x6_conv_bm;
       g.conv_taps = g_x6_conv_order ? 9 : 0;
       {   // scratch for the K-slice partials of the last, partial round of tiles (gemm_x6.hip)
-        const int t256 = cdiv(M * F2, 256), rem = t256 - t256 / 256 * 256;
-        if (g_x6_conv_bm == 0 && d <= 256 && t256 >= 256 && rem > 0 && rem <= 128) {
+        const int ncu = std::min(std::max(g_x6_conv_cus, 64), 256);   // (as in gemm_x6())
+        const int t256 = cdiv(M * F2, 256), rem = t256 - t256 / ncu * ncu;
+        if (g_x6_conv_bm == 0 && d <= 256 && t256 >= ncu && rem > 0 && rem <= ncu / 2) {
           const size_t need = (size_t)4 * ((size_t)M * F2 - (size_t)(t256 - rem) * 256) * d *
                               sizeof(float);
           WN_TRY(m->ffn_part.ensure(need));
