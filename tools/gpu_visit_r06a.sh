@@ -22,7 +22,7 @@ for t in "" "x6r_pro=2" "attn_gload=1" "ctc_wave=2" "dwconv_tiled=1" "x6r_pro=2,
   python -c "
 import json; d=json.load(open('$OUT/bench_config2_$n.json')); print('config2 ${t:-default}', d['value'], d['ms_per_step'], d['verified'])"
 done
-for t in "beam_cu_mask=8001" "beam_cu_mask=8032" "beam_cu_mask=8032,x6_conv_cus=248" "beam_cu_mask=8001,x6_conv_cus=248" "beam_cu_mask=16016,x6_conv_cus=240" "x6_conv_cus=224" ""; do
+for t in "beam_cu_mask=8001" "beam_cu_mask=8032" "beam_cu_mask=8032,x6_conv_cus=248" "beam_cu_mask=8001,x6_conv_cus=248" "beam_cu_mask=16016,x6_conv_cus=240" ""; do
   n=$(echo "${t:-default_b}" | tr ',=' '__')
   timeout 300 $B ${t:+--tune $t} > $OUT/bench_config2_$n.json 2>> $OUT/b.err
   python -c "
