@@ -290,6 +290,30 @@ int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host
                            float reverse_weight, float* l2r_logp_host,
                            float* r2l_logp_host, void* stream);
 
+/* attention_rescoring COMPLETE on the device (search.py:374-458; SURVEY.md 8b `wn_rescore`):
+ * the decoder pass of wn_attention_rescoring, then one kernel does what search.py:424-457 does
+ * in Python -- per hypothesis the fp32 left-to-right sum of the gathered log-probs + <eos>
+ * (in the reference's order and dtypes), the right-to-left decoder's sum blended with
+ * reverse_weight, `confidence = exp(score / (len + 1))`, `+ ctc_score * ctc_weight`, the
+ * first-maximum arg-max over the hypotheses, and the winner's per-token confidences
+ * (batched form in the reference: wenet/bin/export_onnx_gpu.py:666-724).
+ *   n_hyps_host == NULL: the n-best is the one the LAST wn_ctc_prefix_beam_search of this
+ *     handle left on the device (tokens and fp64 scores are read there; no host round trip);
+ *     hyp_lens_host / hyp_tokens_host / ctc_scores_host must be NULL, beam / max_len the
+ *     values that search was called with.
+ *   otherwise: n_hyps (B), hyp_lens (B, beam), hyp_tokens (B, beam, max_len), ctc_scores
+ *     (B, beam) host arrays (DecodeResult.nbest / nbest_scores of any source).
+ * Outputs (host): best_idx (B) index into the utterance's n-best, best_score (B) fp32 (the
+ * `.item()` of the reference's fp32 tensor), confidence (B) fp64, tok_conf (B, max_len) fp64
+ * (first len(best hyp) entries), all_scores (B, beam) fp32 score of every hypothesis.
+ * confidence / tok_conf / all_scores may be NULL.  beam <= 64. */
+int wn_rescore(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
+               const int32_t* hyp_lens_host, const int32_t* hyp_tokens_host,
+               const double* ctc_scores_host, int32_t max_len, double ctc_weight,
+               double reverse_weight, int32_t* best_idx_host, float* best_score_host,
+               double* confidence_host, double* tok_conf_host, float* all_scores_host,
+               void* stream);
+
 /* The decoder half of ASRModel.forward_attention_decoder (asr_model.py:453-547):
  * one decoder (`which` 0: decoder / left_decoder, 1: right_decoder,
  * decoder.py:146-201,430-463) over a PADDED batch of n_seq token rows for

@@ -206,3 +206,44 @@ def rescoring_attention_part_check(got, got_pre, ref, ref_pre_nbest, ref_pre_sco
     assert max(errs) < tol, (f'{what}: attention part of the rescoring score off by '
                              f'{max(errs):.3e}', errs)
     return len(errs), max(errs)
+
+
+def rescore_replay(hyps_per_utt, ctc_scores_per_utt, l2r, r2l, ctc_weight, reverse_weight,
+                   use_r2l):
+    """The scalar tail of attention_rescoring (search.py:424-457) replayed on gathered
+    per-token log-probs with the reference's dtypes (np.float32 scalars, left-to-right sums,
+    Python floats rounded where they meet the fp32 tensor): the checker wn_rescore's reduce
+    kernel must agree with BIT FOR BIT.  -> per utterance (best_index, all_scores fp32,
+    confidences, tokens_confidences)."""
+    import math
+    f32 = np.float32
+    out = []
+    for b, hyps in enumerate(hyps_per_utt):
+        best_score, best_index = -float('inf'), 0
+        confs, tcs, scores = [], [], []
+        for i, hyp in enumerate(hyps):
+            L = len(hyp)
+            s_l = l2r[b, i, :L + 1].astype(f32)
+            score = f32(0.0)
+            for j in range(L):
+                score = f32(score + s_l[j])
+            tc = [math.exp(float(s_l[j])) for j in range(L)]
+            score = f32(score + s_l[L])
+            if reverse_weight > 0 and use_r2l:
+                s_r = r2l[b, i, :L + 1].astype(f32)
+                r_score = f32(0.0)
+                for j in range(L):
+                    s = s_r[L - j - 1]
+                    r_score = f32(r_score + s)
+                    tc[j] = (tc[j] + math.exp(float(s))) / 2
+                r_score = f32(r_score + s_r[L])
+                score = f32(f32(score * f32(1 - reverse_weight)) +
+                            f32(r_score * f32(reverse_weight)))
+            confs.append(math.exp(float(f32(score / f32(L + 1)))))
+            score = f32(score + f32(ctc_scores_per_utt[b][i] * ctc_weight))
+            scores.append(score)
+            if float(score) > best_score:
+                best_score, best_index = float(score), i
+            tcs.append(tc)
+        out.append((best_index, scores, confs, tcs))
+    return out

@@ -461,13 +461,10 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed, nw):
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 4), 'tune')   # V rows + transpose reads
         enc4, _ = model._forward_encoder(feats.cuda(), lens)
         enc4b, _ = model._forward_encoder(feats.cuda(), lens)
-        enc5 = enc5b = None
-        if os.environ.get('WN_EXPERIMENTAL') == '1':
-            # measurement form written without a GPU at hand (transpose reads as inline asm,
-            # csrc/attention_bf16.hip TRA): checked here on request only, until it has run once
-            _lib.check(L.wn_tune_set(b'attn_bf16_dma', 5), 'tune')
-            enc5, _ = model._forward_encoder(feats.cuda(), lens)
-            enc5b, _ = model._forward_encoder(feats.cuda(), lens)
+        # the default since round 4: transpose reads as inline asm (csrc/attention_bf16.hip TRA)
+        _lib.check(L.wn_tune_set(b'attn_bf16_dma', 5), 'tune')
+        enc5, _ = model._forward_encoder(feats.cuda(), lens)
+        enc5b, _ = model._forward_encoder(feats.cuda(), lens)
         # deferred rescale (the default, threshold 8 in log2 units) and a threshold that makes the
         # update branch fire in mid-sequence tiles: other roundings of P, the same softmax
         deferred = []
@@ -478,7 +475,7 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed, nw):
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 0), 'tune')
         enc0, _ = model._forward_encoder(feats.cuda(), lens)
     finally:
-        L.wn_tune_set(b'attn_bf16_dma', 4)      # the defaults
+        L.wn_tune_set(b'attn_bf16_dma', 5)      # the defaults
         L.wn_tune_set(b'attn_bf16_defer', 80)
         L.wn_tune_set(b'attn_bf16_nw', 0)
         _set_dtype(model, 'fp32')
@@ -488,9 +485,8 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed, nw):
     assert torch.equal(enc2, enc0), (enc2 - enc0).abs().max().item()
     assert torch.equal(enc4, enc4b), 'DMA-staged attention (transpose reads) is not deterministic'
     assert torch.equal(enc4, enc0), (enc4 - enc0).abs().max().item()
-    if enc5 is not None:
-        assert torch.equal(enc5, enc5b), 'DMA-staged attention (asm transpose reads) is not deterministic'
-        assert torch.equal(enc5, enc0), (enc5 - enc0).abs().max().item()
+    assert torch.equal(enc5, enc5b), 'DMA-staged attention (asm transpose reads) is not deterministic'
+    assert torch.equal(enc5, enc0), (enc5 - enc0).abs().max().item()
     with torch.no_grad(), O.bf16_operands(sd):
         ref, mask = O.encoder_forward(configs, sd, feats, lens, -1, -1)
     ref_lens = mask.squeeze(1).sum(1).numpy()

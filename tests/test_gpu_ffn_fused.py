@@ -144,26 +144,22 @@ def test_encoder_with_folded_relpos_attention_matches_the_two_contraction_form(c
         _lib.check(L.wn_tune_set(b'attn_fold', 2), 'tune')   # the fold as a separate pass
         sep, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         sep = sep.cpu()
-        glb = None
-        if os.environ.get('WN_EXPERIMENTAL') == '1':
-            # GLB (staging loads of all chunks issued together): written without a GPU at hand,
-            # checked on request only until it has run once
-            _lib.check(L.wn_tune_set(b'attn_fold', 1), 'tune')
-            _lib.check(L.wn_tune_set(b'attn_gload', 1), 'tune')
-            glb, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
-            glb = glb.cpu()
-            # ... and the depthwise convolution with four rows per wave (dwconv_tiled = 1)
-            _lib.check(L.wn_tune_set(b'attn_gload', 0), 'tune')
-            _lib.check(L.wn_tune_set(b'dwconv_tiled', 1), 'tune')
-            dwt, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
-            dwt = dwt.cpu()
+        # the older issue orders of the same arithmetic (defaults until round 4): staging loads
+        # chunk by chunk (attn_gload = 0), one depthwise-conv output row per wave (dwconv_tiled = 0)
+        _lib.check(L.wn_tune_set(b'attn_fold', 1), 'tune')
+        _lib.check(L.wn_tune_set(b'attn_gload', 0), 'tune')
+        glb, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        glb = glb.cpu()
+        _lib.check(L.wn_tune_set(b'attn_gload', 1), 'tune')
+        _lib.check(L.wn_tune_set(b'dwconv_tiled', 0), 'tune')
+        dwt, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        dwt = dwt.cpu()
     finally:
         L.wn_tune_set(b'attn_fold', 1)
-        L.wn_tune_set(b'attn_gload', 0)
-        L.wn_tune_set(b'dwconv_tiled', 0)
-    if glb is not None:
-        assert torch.equal(glb, got), (glb - got).abs().max().item()
-        assert torch.equal(dwt, got), (dwt - got).abs().max().item()
+        L.wn_tune_set(b'attn_gload', 1)
+        L.wn_tune_set(b'dwconv_tiled', 1)
+    assert torch.equal(glb, got), (glb - got).abs().max().item()
+    assert torch.equal(dwt, got), (dwt - got).abs().max().item()
     assert torch.equal(got, got2.cpu())            # race screen
     err = (got - ref).abs().max().item()
     err2 = (sep - ref).abs().max().item()
@@ -311,17 +307,13 @@ def test_qkv_prologue_fold_is_bit_identical_to_the_reduce_launch(B, frames, chun
         got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got = got.cpu()
-        got_p2 = None
-        if os.environ.get('WN_EXPERIMENTAL') == '1':
-            # PRO 2 (slice loads in flight together): written without a GPU at hand, checked on
-            # request only until it has run once
-            _lib.check(L.wn_tune_set(b'x6r_pro', 2), 'tune')
-            got_p2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
-            got_p2 = got_p2.cpu()
+        # PRO 2 (slice loads in flight together; the default since round 4)
+        _lib.check(L.wn_tune_set(b'x6r_pro', 2), 'tune')
+        got_p2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got_p2 = got_p2.cpu()
     finally:
-        L.wn_tune_set(b'x6r_pro', 1)
+        L.wn_tune_set(b'x6r_pro', 2)
     assert torch.isfinite(got).all()
     assert torch.equal(got, got2.cpu())
     assert torch.equal(got, ref), (got - ref).abs().max().item()
-    if got_p2 is not None:
-        assert torch.equal(got_p2, ref), (got_p2 - ref).abs().max().item()
+    assert torch.equal(got_p2, ref), (got_p2 - ref).abs().max().item()

@@ -1,0 +1,98 @@
+"""wn_rescore: attention_rescoring's score arithmetic, arg-max and confidences on the device
+(wenet/models/transformer/search.py:424-457).  The reduce kernel is held BIT FOR BIT to a numpy
+replay of the reference's scalar arithmetic on the per-token log-probs the same decoder pass
+produced (wn_attention_rescoring exports them); the decoder itself is held to the oracle and
+the real reference's goldens in test_gpu_parity.py / test_gpu_bench_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import cached_model, rescore_replay
+
+pytestmark = pytest.mark.gpu
+
+
+def _logps(model, raw, reverse_weight):
+    """per-token log-probs of every hypothesis through the diagnostic entry point"""
+    from wenet_amd import _lib
+    from wenet_amd.search import _stream_ptr
+    B, beam = raw['hyp_lens'].shape
+    max_len = raw['hyp_tokens'].shape[2]
+    l2r = np.zeros((B, beam, max_len + 1), dtype=np.float32)
+    r2l = np.zeros((B, beam, max_len + 1), dtype=np.float32)
+    _lib.check(_lib.lib().wn_attention_rescoring(
+        model._h, beam, _lib.i32p(raw['n_hyps']), _lib.i32p(raw['hyp_lens']),
+        _lib.i32p(raw['hyp_tokens']), max_len, float(reverse_weight), _lib.f32p(l2r),
+        _lib.f32p(r2l), _stream_ptr(model.device)), 'wn_attention_rescoring')
+    return l2r, r2l
+
+
+@pytest.mark.parametrize('config,beam,cw,rw', [
+    ('tiny_causal', 4, 0.5, 0.3), ('tiny_causal', 10, 0.3, 0.0), ('tiny_sym', 6, 0.0, 0.0),
+    ('aishell_u2pp', 10, 0.5, 0.4), ('librispeech_bidecoder_large', 10, 0.5, 0.3),
+    ('tiny_causal', 16, 0.7, 1.0)])
+def test_rescore_bit_exact_vs_replay(config, beam, cw, rw):
+    from wenet_amd import synthetic as S
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(5, (90, 330), seed=23)
+    got = model.decode(['ctc_prefix_beam_search', 'attention_rescoring'], feats.cuda(), lens,
+                       beam_size=beam, ctc_weight=cw, reverse_weight=rw)
+    raw = model._last_prefix_raw
+    pre, res = got['ctc_prefix_beam_search'], got['attention_rescoring']
+    l2r, r2l = _logps(model, raw, rw)
+    use_r2l = bool(configs['decoder'] == 'bitransformer'
+                   and configs['decoder_conf'].get('r_num_blocks', 0) > 0)
+    rep = rescore_replay([r.nbest for r in pre], [r.nbest_scores for r in pre], l2r, r2l, cw, rw,
+                         use_r2l)
+    for b, (bi, scores, confs, tcs) in enumerate(rep):
+        r = res[b]
+        assert np.array_equal(np.asarray(r.all_scores, dtype=np.float32),
+                              np.asarray(scores, dtype=np.float32)), (config, b)
+        assert tuple(r.tokens) == tuple(pre[b].nbest[bi])
+        assert r.score == float(scores[bi])
+        assert list(r.times) == list(pre[b].nbest_times[bi])
+        np.testing.assert_allclose(r.confidence, confs[bi], rtol=1e-13)
+        np.testing.assert_allclose(r.tokens_confidence, tcs[bi], rtol=1e-13, atol=0)
+        assert isinstance(r.score, float) and isinstance(r.tokens, tuple)
+        assert isinstance(r.tokens_confidence, list)
+
+
+def test_rescore_uploaded_nbest_equals_device_nbest():
+    """the same n-best handed over as Python lists (search.attention_rescoring on results of any
+    origin) and taken from the prefix beam search's device block give identical records"""
+    from wenet_amd import search as SR, synthetic as S
+    configs, sd, model = cached_model('tiny_causal', 0)
+    feats, lens = S.make_features(4, (80, 260), seed=5)
+    enc, mask = model._forward_encoder(feats.cuda(), lens)
+    enc_lens = mask.squeeze(1).sum(1)
+    got = model.decode(['ctc_prefix_beam_search', 'attention_rescoring'], feats.cuda(), lens,
+                       beam_size=5, ctc_weight=0.4, reverse_weight=0.25)
+    pre, dev = got['ctc_prefix_beam_search'], got['attention_rescoring']
+    for r in pre:
+        r.nbest  # materialise the lists: the free function must not find raw arrays
+    via_lists = SR.attention_rescoring(model, pre, enc, enc_lens, 0.4, 0.25)
+    plain = [SR.DecodeResult(r.tokens, nbest=r.nbest, nbest_scores=r.nbest_scores,
+                             nbest_times=r.nbest_times) for r in pre]
+    via_plain = SR.attention_rescoring(model, plain, enc, enc_lens, 0.4, 0.25)
+    for a, b, c in zip(dev, via_lists, via_plain):
+        for o in (b, c):
+            assert a.tokens == o.tokens and a.score == o.score and a.times == o.times
+            assert a.all_scores == o.all_scores
+            assert a.confidence == o.confidence and a.tokens_confidence == o.tokens_confidence
+
+
+def test_rescore_needs_a_prefix_beam_result():
+    import ctypes
+    from wenet_amd import _lib, synthetic as S
+    from wenet_amd.search import _stream_ptr
+    configs, sd, model = cached_model('tiny_causal', 0)
+    feats, lens = S.make_features(2, (80, 120), seed=1)
+    model._forward_encoder(feats.cuda(), lens)      # new batch: the old n-best is void
+    best = np.zeros((2, ), dtype=np.int32)
+    score = np.zeros((2, ), dtype=np.float32)
+    ni, nd = ctypes.POINTER(ctypes.c_int32)(), ctypes.POINTER(ctypes.c_double)()
+    nf = ctypes.POINTER(ctypes.c_float)()
+    rc = _lib.lib().wn_rescore(model._h, 4, ni, ni, ni, nd, 30, 0.5, 0.0, _lib.i32p(best),
+                               _lib.f32p(score), nd, nd, nf, _stream_ptr(model.device))
+    assert rc != 0
+    assert b'prefix beam' in _lib.lib().wn_last_error()

@@ -899,7 +899,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
 int g_attn_bf16_nw = 0;  // wn_tune_set("attn_bf16_nw"): 0 auto, else 2 / 4 / 8
 int g_attn_bf16_sub = 2; // 8-wave blocks: 32-key sub-tiles per barrier (1 or 2)
 int g_attn_bf16_defer = 80;  // wn_tune_set("attn_bf16_defer"): deferred-rescale threshold x 10 in log2 units (0 = rescale whenever a maximum moves)
-int g_attn_bf16_dma = 4; // bf16 Q | K | V self attention: 0 register-staged, 1 LDS-DMA staged (K rows + V^T image), 2 + grouped fragment reads, 4 V rows by DMA + ds_read_b64_tr_b16 (no V^T image), 5 = 4 with the transpose reads as inline asm (TRA, measurement form)
+int g_attn_bf16_dma = 5; // bf16 Q | K | V self attention: 0 register-staged, 1 LDS-DMA staged (K rows + V^T image), 2 + grouped fragment reads, 4 V rows by DMA + ds_read_b64_tr_b16 (no V^T image), 5 = 4 with the transpose reads as inline asm (TRA, measurement form)
 
 int attention_bf16(const AttnArgs& a, hipStream_t s) {
   // argument checks are attention()'s (the only caller)

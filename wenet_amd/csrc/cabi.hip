@@ -689,6 +689,7 @@ int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host
               float* enc_out_dev, int32_t* enc_lens_host, void* stream) {
   WN_CHECK(m && feats_dev && feat_lens_host, "wn_encode: null argument");
   WN_ENTER(m);
+  m->pb_valid = false;
   PrecisionScope prec_scope(m);
   WN_CHECK(!m->layers.empty() || !m->tf_layers.empty(),
            "wn_encode: this handle has no weights");
@@ -797,6 +798,7 @@ int wn_set_encoder_out(wn_model* m, const float* enc_out_dev,
   WN_CHECK(m && enc_out_dev && enc_lens_host && B > 0 && Tp > 0,
            "wn_set_encoder_out: bad argument");
   WN_ENTER(m);
+  m->pb_valid = false;
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));
   std::vector<int> off(B), len(B);
@@ -818,6 +820,7 @@ int wn_ctc_logprobs(wn_model* m, int32_t topk, int32_t blank_id,
                     void* stream) {
   WN_CHECK(m && m->B > 0, "wn_ctc_logprobs: no current batch (call wn_encode)");
   WN_ENTER(m);
+  m->pb_valid = false;
   PrecisionScope prec_scope(m);
   WN_CHECK(m->ctc.w, "wn_ctc_logprobs: this handle has no weights");
   hipStream_t s = (hipStream_t)stream;
@@ -908,6 +911,7 @@ int wn_set_ctc_probs(wn_model* m, const float* logp_dev, const int32_t* lens_hos
   WN_CHECK(m && logp_dev && lens_host && B > 0 && Tp > 0 && V > 0,
            "wn_set_ctc_probs: bad argument");
   WN_ENTER(m);
+  m->pb_valid = false;
   hipStream_t s = (hipStream_t)stream;
   WN_HIP(hipSetDevice(m->device));
   const int k = std::max(1, topk);
@@ -1183,8 +1187,11 @@ int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
             "select %.0f; emit %lld cycles\n", h[3], (double)h[0] / h[3],
             (double)h[1] / h[3], (double)h[2] / h[3], h[4]);
   }
+  m->pb_valid = false;
   WN_HIP(hipMemcpyAsync(m->pb_host.p, ob, o_end, hipMemcpyDeviceToHost, s));
   WN_HIP(hipStreamSynchronize(s));
+  m->pb_valid = true; m->pb_B = B; m->pb_beam = beam; m->pb_max_len = max_len;
+  m->pb_o_sc = o_sc; m->pb_o_nh = o_nh; m->pb_o_len = o_len; m->pb_o_tok = o_tok;
   const char* hb = m->pb_host.p;
   memcpy(n_hyps_host, hb + o_nh, (size_t)B * sizeof(int));
   memcpy(hyp_lens_host, hb + o_len, nb * sizeof(int));
@@ -1671,6 +1678,246 @@ int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host
     l2r_logp_host[out_index[r]] = hl[r];
     r2l_logp_host[out_index[r]] = hr[r];
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+namespace {
+// Decoder input / target rows of one hypothesis sequence q = (utterance, hypothesis slot):
+// ys_in = [sos] + hyp (add_sos_eos, common.py:113-155), the reversed sequence for the
+// right-to-left decoder (asr_model.py:491-536), and what each position is scored on
+// (search.py:431-449: hyp[j] at position j, eos at position L; r_decoder_out[L-1-j] scores
+// hyp[j], so the reversed rows score their own next token).  The n-best is read where the
+// prefix beam search left it on the device (or where wn_rescore uploaded it).
+__global__ void rescore_rows_kernel(const int* __restrict__ seq_src, const int* __restrict__ qoff,
+                                    const int* __restrict__ qlen,
+                                    const int* __restrict__ hyp_tokens, int max_len, int sos,
+                                    int eos, int V, int* __restrict__ tok, int* __restrict__ rtok,
+                                    int* __restrict__ pos, int* __restrict__ tgt,
+                                    int* __restrict__ rtgt) {
+  const int q = blockIdx.x;
+  const int L = qlen[q] - 1, o = qoff[q];
+  const int* h = hyp_tokens + (int64_t)seq_src[q] * max_len;
+  for (int j = threadIdx.x; j <= L; j += blockDim.x) {
+    // ids are < V by construction (top-k indices / host-checked); the clamp only keeps a
+    // corrupted buffer from indexing outside the embedding table
+    const int a = j == 0 ? sos : min(max(h[j - 1], 0), V - 1);
+    const int r = j == 0 ? sos : min(max(h[L - j], 0), V - 1);
+    tok[o + j] = a;
+    rtok[o + j] = r;
+    pos[o + j] = j;
+    tgt[o + j] = j < L ? min(max(h[j], 0), V - 1) : eos;
+    rtgt[o + j] = j < L ? min(max(h[L - 1 - j], 0), V - 1) : eos;
+  }
+}
+
+struct RescoreArgs {
+  const float* lp_l; const float* lp_r;      // [R] log-prob of each row's target, both decoders
+  const int* seq_first;                      // [B + 1] first sequence of each utterance
+  const int* seq_src;                        // [n_seq] (utt * beam + hyp slot)
+  const int* qoff; const int* qlen;          // [n_seq] first row, rows (= len(hyp) + 1)
+  const double* ctc_scores;                  // [B][beam] (DecodeResult.nbest_scores)
+  int beam, max_len, use_r2l;
+  double ctc_weight;
+  float w_l, w_r;                            // fp32(1 - reverse_weight), fp32(reverse_weight)
+  int* best_idx; float* best_score; double* conf; float* all_scores; double* tok_conf;
+};
+
+// The score arithmetic of attention_rescoring (search.py:424-457) for one utterance per
+// wavefront, one hypothesis per lane, in the reference's dtypes and ORDER: the gathered
+// log-probs are fp32 tensor elements, `score` accumulates them in fp32 left to right (the
+// right-to-left decoder's from position L-1 down), Python-float operands are rounded to fp32
+// where they meet the fp32 tensor (1 - reverse_weight, reverse_weight, ctc_score * ctc_weight
+// -- that product itself is fp64), math.exp() is fp64.  __f*_rn: no FMA contraction.
+__global__ __launch_bounds__(64) void rescore_reduce_kernel(RescoreArgs a) {
+  __shared__ float s_score[64];
+  __shared__ double s_conf[64];
+  __shared__ int s_best;
+  const int b = blockIdx.x, i = threadIdx.x;
+  const int q0 = a.seq_first[b], n = a.seq_first[b + 1] - q0;
+  if (i < n) {
+    const int q = q0 + i, L = a.qlen[q] - 1;
+    const float* l = a.lp_l + a.qoff[q];
+    float score = 0.f;
+    for (int j = 0; j < L; ++j) score = __fadd_rn(score, l[j]);
+    score = __fadd_rn(score, l[L]);
+    if (a.use_r2l) {
+      const float* r = a.lp_r + a.qoff[q];
+      float rs = 0.f;
+      for (int j = 0; j < L; ++j) rs = __fadd_rn(rs, r[L - 1 - j]);
+      rs = __fadd_rn(rs, r[L]);
+      score = __fadd_rn(__fmul_rn(score, a.w_l), __fmul_rn(rs, a.w_r));
+    }
+    s_conf[i] = exp((double)__fdiv_rn(score, (float)(L + 1)));
+    const int slot = a.seq_src[q];
+    score = __fadd_rn(score, (float)(a.ctc_scores[slot] * a.ctc_weight));
+    s_score[i] = score;
+    a.all_scores[slot] = score;
+  }
+  __syncthreads();
+  if (i == 0) {
+    // `if score > best_score` from -inf, first maximum wins, NaN never does
+    int best = 0;
+    float bs = -INFINITY;
+    for (int k = 0; k < n; ++k)
+      if (s_score[k] > bs) { bs = s_score[k]; best = k; }
+    s_best = best;
+    a.best_idx[b] = n > 0 ? a.seq_src[q0 + best] - b * a.beam : 0;
+    a.best_score[b] = bs;
+    a.conf[b] = n > 0 ? s_conf[best] : 0.0;
+  }
+  __syncthreads();
+  if (n <= 0) return;
+  const int q = q0 + s_best, L = a.qlen[q] - 1;
+  const float* l = a.lp_l + a.qoff[q];
+  const float* r = a.lp_r + a.qoff[q];
+  for (int j = i; j < L; j += 64) {
+    double c = exp((double)l[j]);
+    if (a.use_r2l) c = (c + exp((double)r[L - 1 - j])) / 2;
+    a.tok_conf[(int64_t)b * a.max_len + j] = c;
+  }
+}
+}  // namespace
+
+int wn_rescore(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
+               const int32_t* hyp_lens_host, const int32_t* hyp_tokens_host,
+               const double* ctc_scores_host, int32_t max_len, double ctc_weight,
+               double reverse_weight, int32_t* best_idx_host, float* best_score_host,
+               double* confidence_host, double* tok_conf_host, float* all_scores_host,
+               void* stream) {
+  WN_CHECK(m && m->B > 0 && m->enc.p, "wn_rescore: no current batch");
+  WN_ENTER(m);
+  PrecisionScope prec_scope(m);
+  WN_CHECK(!m->left.layers.empty(), "wn_rescore: the model has no attention decoder");
+  WN_CHECK(best_idx_host && best_score_host, "wn_rescore: null output");
+  hipStream_t s = (hipStream_t)stream;
+  WN_HIP(hipSetDevice(m->device));
+  const wn_config& c = m->cfg;
+  const int B = m->B, d = c.d_model, V = c.vocab;
+  // ---- where the n-best comes from -----------------------------------------------------
+  const bool from_beam = n_hyps_host == nullptr;
+  const int* d_tokens = nullptr;
+  const double* d_scores = nullptr;
+  if (from_beam) {
+    // the last wn_ctc_prefix_beam_search of this handle: tokens and scores are still in its
+    // device block, counts and lengths in the pinned copy of it
+    WN_CHECK(m->pb_valid && m->pb_B == B,
+             "wn_rescore: no prefix beam result of the current batch on this handle (pass the "
+             "n-best explicitly, or call wn_ctc_prefix_beam_search first)");
+    WN_CHECK(!hyp_lens_host && !hyp_tokens_host && !ctc_scores_host,
+             "wn_rescore: n_hyps == NULL takes the whole n-best from the handle");
+    WN_CHECK(beam == m->pb_beam && max_len == m->pb_max_len,
+             "wn_rescore: beam / max_len differ from the prefix beam search's");
+    n_hyps_host = reinterpret_cast<const int*>(m->pb_host.p + m->pb_o_nh);
+    hyp_lens_host = reinterpret_cast<const int*>(m->pb_host.p + m->pb_o_len);
+    d_tokens = reinterpret_cast<const int*>(m->pb_out.as<char>() + m->pb_o_tok);
+    d_scores = reinterpret_cast<const double*>(m->pb_out.as<char>() + m->pb_o_sc);
+  } else {
+    WN_CHECK(hyp_lens_host && hyp_tokens_host && ctc_scores_host, "wn_rescore: null n-best");
+  }
+  WN_CHECK(beam >= 1 && beam <= 64 && max_len >= 1, "wn_rescore: beam must be 1..64");
+  const bool use_r2l = reverse_weight > 0.0 && !m->right.layers.empty();
+  // ---- ragged hypothesis batch: one sequence per (utterance, hypothesis) ----------------
+  std::vector<int> seq_src, seq_first(B + 1), qoff, qlen, kvoff, kvlen;
+  int R = 0, max_q = 0;
+  for (int b = 0; b < B; ++b) {
+    seq_first[b] = (int)seq_src.size();
+    WN_CHECK(n_hyps_host[b] >= 0 && n_hyps_host[b] <= beam, "wn_rescore: n_hyps");
+    if (n_hyps_host[b] > 0)
+      WN_CHECK(m->len[b] > 0, "wn_rescore: utterance without encoder frames");
+    for (int i = 0; i < n_hyps_host[b]; ++i) {
+      const int L = hyp_lens_host[b * beam + i];
+      WN_CHECK(L >= 0 && L <= max_len, "wn_rescore: hypothesis length");
+      WN_CHECK(L + 1 <= c.max_pos, "wn_rescore: hypothesis longer than the positional table");
+      if (!from_beam) {
+        const int32_t* h = hyp_tokens_host + ((int64_t)b * beam + i) * max_len;
+        for (int j = 0; j < L; ++j)
+          WN_CHECK(h[j] >= 0 && h[j] < V, "wn_rescore: token id out of range");
+      }
+      seq_src.push_back(b * beam + i);
+      qoff.push_back(R); qlen.push_back(L + 1);
+      kvoff.push_back(m->off[b]); kvlen.push_back(m->len[b]);
+      R += L + 1;
+      max_q = std::max(max_q, L + 1);
+    }
+  }
+  const int n_seq = (int)seq_src.size();
+  seq_first[B] = n_seq;
+  const size_t nb = (size_t)B * beam;
+  WN_TRY(m->stage.begin((size_t)(5 * n_seq + B + 64) * sizeof(int) + 4096 +
+                        (from_beam ? 0 : nb * max_len * sizeof(int) + nb * sizeof(double) + 256)));
+  if (!from_beam) {
+    // tokens | scores in one device block, the prefix beam search's own row pitch
+    const size_t tok_bytes = (nb * max_len * sizeof(int) + 7) / 8 * 8;
+    WN_TRY(m->r_hyp.ensure(tok_bytes + nb * sizeof(double)));
+    WN_TRY(m->stage.put_at(m->r_hyp.p, hyp_tokens_host, nb * max_len * sizeof(int), s));
+    WN_TRY(m->stage.put_at(m->r_hyp.as<char>() + tok_bytes, ctc_scores_host,
+                           nb * sizeof(double), s));
+    d_tokens = m->r_hyp.as<int>();
+    d_scores = reinterpret_cast<const double*>(m->r_hyp.as<char>() + tok_bytes);
+  }
+  WN_TRY(upload_desc(m, m->r_seqsrc, seq_src, s));
+  WN_TRY(upload_desc(m, m->r_seqfirst, seq_first, s));
+  WN_TRY(upload_desc(m, m->r_qoff, qoff, s));
+  WN_TRY(upload_desc(m, m->r_qlen, qlen, s));
+  WN_TRY(upload_desc(m, m->r_kvoff, kvoff, s));
+  WN_TRY(upload_desc(m, m->r_kvlen, kvlen, s));
+  WN_TRY(m->stage.end(s));
+  // results, one block: tok_conf | conf | best_score | best_idx | all_scores
+  const size_t o_tc = 0, o_cf = o_tc + (size_t)B * max_len * sizeof(double),
+               o_bs = o_cf + (size_t)B * sizeof(double), o_bi = o_bs + (size_t)B * sizeof(float),
+               o_as = o_bi + (size_t)B * sizeof(int), o_end = o_as + nb * sizeof(float);
+  WN_TRY(m->r_res.ensure(o_end));
+  WN_TRY(m->r_host.ensure(o_end));
+  WN_HIP(hipMemsetAsync(m->r_res.p, 0, o_end, s));
+  const int Rp = std::max(R, 1);
+  for (DevBuf* bf : {&m->r_tok, &m->r_rtok, &m->r_pos, &m->r_tgt, &m->r_rtgt})
+    WN_TRY(bf->ensure((size_t)Rp * sizeof(int)));
+  WN_TRY(m->r_out.ensure((size_t)2 * Rp * sizeof(float)));
+  float* o_l = m->r_out.as<float>();
+  float* o_r = o_l + Rp;
+  if (n_seq > 0) {
+    hipLaunchKernelGGL(rescore_rows_kernel, dim3(n_seq), dim3(64), 0, s, m->r_seqsrc.as<int>(),
+                       m->r_qoff.as<int>(), m->r_qlen.as<int>(), d_tokens, max_len, c.sos, c.eos,
+                       V, m->r_tok.as<int>(), m->r_rtok.as<int>(), m->r_pos.as<int>(),
+                       m->r_tgt.as<int>(), m->r_rtgt.as<int>());
+    WN_HIP(hipGetLastError());
+    WN_TRY(m->r_x.ensure((size_t)R * d * sizeof(float)));
+    WN_TRY(m->r_t1.ensure((size_t)R * d * sizeof(float)));
+    WN_TRY(m->r_t2.ensure((size_t)R * d * sizeof(float)));
+    WN_TRY(m->r_qkv.ensure((size_t)R * 3 * d * sizeof(float)));
+    WN_TRY(m->r_h.ensure((size_t)R * c.dec_ffn_dim * sizeof(float)));
+    WN_TRY(m->r_mem.ensure((size_t)m->rows * 2 * d * sizeof(float)));
+    WN_TRY(m->r_logits.ensure((size_t)R * ((V + 3) / 4 * 4) * sizeof(float)));
+    WN_TRY(run_decoder(m, m->left, R, n_seq, max_q, m->r_tok.as<int>(), m->r_tgt.as<int>(), o_l,
+                       s));
+    if (use_r2l)
+      WN_TRY(run_decoder(m, m->right, R, n_seq, max_q, m->r_rtok.as<int>(),
+                         m->r_rtgt.as<int>(), o_r, s));
+  }
+  char* rb = m->r_res.as<char>();
+  RescoreArgs a;
+  a.lp_l = o_l; a.lp_r = o_r;
+  a.seq_first = m->r_seqfirst.as<int>(); a.seq_src = m->r_seqsrc.as<int>();
+  a.qoff = m->r_qoff.as<int>(); a.qlen = m->r_qlen.as<int>();
+  a.ctc_scores = d_scores; a.beam = beam; a.max_len = max_len; a.use_r2l = use_r2l ? 1 : 0;
+  a.ctc_weight = ctc_weight;
+  a.w_l = (float)(1.0 - reverse_weight); a.w_r = (float)reverse_weight;
+  a.best_idx = reinterpret_cast<int*>(rb + o_bi);
+  a.best_score = reinterpret_cast<float*>(rb + o_bs);
+  a.conf = reinterpret_cast<double*>(rb + o_cf);
+  a.all_scores = reinterpret_cast<float*>(rb + o_as);
+  a.tok_conf = reinterpret_cast<double*>(rb + o_tc);
+  hipLaunchKernelGGL(rescore_reduce_kernel, dim3(B), dim3(64), 0, s, a);
+  WN_HIP(hipGetLastError());
+  WN_HIP(hipMemcpyAsync(m->r_host.p, rb, o_end, hipMemcpyDeviceToHost, s));
+  WN_HIP(hipStreamSynchronize(s));
+  const char* hb = m->r_host.p;
+  memcpy(best_idx_host, hb + o_bi, (size_t)B * sizeof(int));
+  memcpy(best_score_host, hb + o_bs, (size_t)B * sizeof(float));
+  if (confidence_host) memcpy(confidence_host, hb + o_cf, (size_t)B * sizeof(double));
+  if (tok_conf_host) memcpy(tok_conf_host, hb + o_tc, (size_t)B * max_len * sizeof(double));
+  if (all_scores_host) memcpy(all_scores_host, hb + o_as, nb * sizeof(float));
   return 0;
 }
 

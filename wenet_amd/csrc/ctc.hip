@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(BIG_THREADS) void prefix_beam_big_kernel(PrefixBeam
 
 }  // namespace
 
-int g_ctc_wave = 1;   // wn_tune_set("ctc_wave"): 0 = always the block-per-row kernel; 2 = the wave kernel with two-level maxima
+int g_ctc_wave = 2;   // wn_tune_set("ctc_wave"): 0 = always the block-per-row kernel; 2 = the wave kernel with two-level maxima
 
 int ctc_logsoftmax_topk(const CtcRowArgs& a, hipStream_t s) {
   WN_CHECK(a.M > 0 && a.V > 0, "ctc: empty");

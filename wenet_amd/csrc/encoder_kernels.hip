@@ -985,7 +985,7 @@ int cmvn_conv1_relu(const Conv1Args& a, hipStream_t s) {
   return 0;
 }
 
-int g_dwconv_tiled = 0;   // wn_tune_set("dwconv_tiled"): 1 = four rows per wave
+int g_dwconv_tiled = 1;   // wn_tune_set("dwconv_tiled"): 1 = four rows per wave
 
 int dwconv_ln_silu(const DwConvArgs& a, hipStream_t s) {
   if (g_dwconv_tiled == 1 && (a.D == 256 || a.D == 512)) {
@@ -1030,7 +1030,7 @@ int relpos_fold(float* K, int ldk, const float* P, int ldp, const float* bias_u,
 }
 
 int g_attn_split = 0;  // wn_tune_set("attn_split")
-int g_attn_gload = 0;  // wn_tune_set("attn_gload"): 1 = folded key-split kernel with the staging loads of all chunks issued together (GLB)
+int g_attn_gload = 1;  // wn_tune_set("attn_gload"): 1 = folded key-split kernel with the staging loads of all chunks issued together (GLB)
 int g_attn_bf16 = 1;   // wn_tune_set("attn_bf16")
 
 int attention(const AttnArgs& a, hipStream_t s) {

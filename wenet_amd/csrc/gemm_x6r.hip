@@ -470,7 +470,7 @@ int launch_x6r(const X6RArgs& a, hipStream_t s) {
 
 int g_x6r = 1;       // wn_tune_set("x6r"): 0 = the v_mfma_f32 row-LN GEMM / tile GEMMs (A/B, tests)
 int g_x6r_chain = 1; // wn_tune_set("x6r_chain"): 0 = out-projection + LayerNorm and pointwise_conv1 + GLU as two launches
-int g_x6r_pro = 1;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of the QKV projection; 2 = the fold with the slice loads in flight together (PRO 2)
+int g_x6r_pro = 2;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of the QKV projection; 2 = the fold with the slice loads in flight together (PRO 2)
 
 bool gemm_x6r_supported(int M, int N, int K, int epi) {
   if (K != RK || M <= 0) return false;

@@ -79,6 +79,16 @@ struct Stager {
     WN_HIP(hipMemcpyAsync(buf.p, host + o, bytes, hipMemcpyHostToDevice, s));
     return 0;
   }
+  // the same staged copy into a window of a buffer the caller sized
+  int put_at(void* dst, const void* data, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return 0;
+    const size_t o = (used + 63) / 64 * 64;
+    WN_CHECK(o + bytes <= cap, "descriptor staging overflow");
+    memcpy(host + o, data, bytes);
+    used = o + bytes;
+    WN_HIP(hipMemcpyAsync(dst, host + o, bytes, hipMemcpyHostToDevice, s));
+    return 0;
+  }
   int end(hipStream_t s) {
     WN_HIP(hipEventRecord(ev, s));
     pending = true;
@@ -353,10 +363,19 @@ struct wn_model {
   DevBuf g_tok, g_len, pb_pool;
   DevBuf pb_out;          // the prefix beam search's results, one block: counts | lengths | scores | tokens | times
   PinnedBuf pb_host;      // ... and where they land on the host
+  // the n-best of the last wn_ctc_prefix_beam_search, still in pb_out / pb_host, for wn_rescore:
+  // batch size, beam, row pitch and the byte offsets of the fields inside the block
+  bool pb_valid = false;
+  int pb_B = 0, pb_beam = 0, pb_max_len = 0;
+  size_t pb_o_sc = 0, pb_o_nh = 0, pb_o_len = 0, pb_o_tok = 0;
   // rescoring
   DevBuf r_tok, r_rtok, r_pos, r_tgt, r_rtgt, r_qoff, r_qlen, r_kvoff, r_kvlen;
   DevBuf r_x, r_t1, r_t2, r_qkv, r_h, r_mem, r_logits, r_out;
   DevBuf r_mem_all;            // per-layer cross-attention K/V of the current batch
+  DevBuf r_seqsrc, r_seqfirst; // wn_rescore: sequence -> (utt, hyp) slot, first sequence per utterance
+  DevBuf r_hyp;                // wn_rescore: host-given n-best (tokens | ctc scores) on the device
+  DevBuf r_res;                // wn_rescore: results, one block
+  PinnedBuf r_host;            // ... and where they land on the host
   DevBuf ab_cache, ab_state;   // `attention` mode: self-attention K|V cache, beam state
   bool mem_cache_valid = false;
 

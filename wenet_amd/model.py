@@ -24,7 +24,8 @@ import torch
 
 from wenet_amd import _lib
 from wenet_amd.search import (DecodeResult, _greedy, _prefix_beam,
-                              _require_cuda, _stream_ptr, rescore_from_logps)
+                              _nbest_arrays, _require_cuda, _stream_ptr,
+                              rescore_nbest)
 
 _SUPPORTED = ('ctc_greedy_search', 'ctc_prefix_beam_search',
               'attention_rescoring')
@@ -634,35 +635,20 @@ class ASRModel:
         return decoder_out, r_decoder_out
 
     def _rescore(self, ctc_prefix_results: List[DecodeResult],
-                 ctc_weight: float, reverse_weight: float):
-        B = len(ctc_prefix_results)
-        beam = max(max(len(r.nbest) for r in ctc_prefix_results), 1)
-        max_len = max(
-            max((len(h) for h in r.nbest), default=0)
-            for r in ctc_prefix_results)
-        max_len = max(max_len, 1)
-        n_hyps = np.zeros((B, ), dtype=np.int32)
-        hyp_lens = np.zeros((B, beam), dtype=np.int32)
-        hyp_tokens = np.zeros((B, beam, max_len), dtype=np.int32)
-        for b, r in enumerate(ctc_prefix_results):
-            n_hyps[b] = len(r.nbest)
-            for i, h in enumerate(r.nbest):
-                hyp_lens[b, i] = len(h)
-                hyp_tokens[b, i, :len(h)] = np.asarray(h, dtype=np.int32)
-        l2r = np.zeros((B, beam, max_len + 1), dtype=np.float32)
-        r2l = np.zeros((B, beam, max_len + 1), dtype=np.float32)
-        _lib.check(
-            self._L.wn_attention_rescoring(
-                self._h, beam, _lib.i32p(n_hyps), _lib.i32p(hyp_lens),
-                _lib.i32p(hyp_tokens), max_len, float(reverse_weight),
-                _lib.f32p(l2r), _lib.f32p(r2l), _stream_ptr(self.device)),
-            'wn_attention_rescoring')
-        use_r2l = bool(self._cfg.bidirectional and self._cfg.dec_r_layers > 0)
-        return rescore_from_logps(
-            [r.nbest for r in ctc_prefix_results],
-            [r.nbest_scores for r in ctc_prefix_results],
-            [r.nbest_times for r in ctc_prefix_results], l2r, r2l, ctc_weight,
-            reverse_weight, use_r2l)
+                 ctc_weight: float, reverse_weight: float, raw=None):
+        """attention_rescoring over the current batch.  `raw`: the arrays of the prefix beam
+        search decode() just ran on this handle -- its n-best is still in HBM and is rescored
+        there (no Python lists, no upload)."""
+        if raw is not None:
+            def times_of(b, i):
+                return raw['hyp_times'][b, i, :raw['hyp_tlens'][b, i]].tolist()
+            return rescore_nbest(self, raw['n_hyps'], raw['hyp_lens'], raw['hyp_tokens'],
+                                 raw['hyp_scores'], times_of, ctc_weight, reverse_weight,
+                                 True)
+        n_hyps, hyp_lens, hyp_tokens, hyp_scores, times_of = _nbest_arrays(
+            ctc_prefix_results)
+        return rescore_nbest(self, n_hyps, hyp_lens, hyp_tokens, hyp_scores, times_of,
+                             ctc_weight, reverse_weight, False)
 
     # ---- the drop-in entry point -----------------------------------------
     def decode(self,
@@ -757,7 +743,7 @@ class ASRModel:
                 # arg-max is not blank (+ the zero padding the reference leaves in)
                 self._filter_blank_current(B)
             results['attention_rescoring'] = self._rescore(
-                prefix, ctc_weight, reverse_weight)
+                prefix, ctc_weight, reverse_weight, raw=self._last_prefix_raw)
         return results
 
     def _filter_blank_current(self, B: int, out: Optional[torch.Tensor] = None):

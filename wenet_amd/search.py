@@ -6,11 +6,11 @@ kernels of libwenet_amd (csrc/ctc.hip, csrc/model.hip).
 resident in HBM and return `DecodeResult`s; the per-frame top-k, the blank /
 repeat collapse and the whole prefix-beam bookkeeping run on the GPU (fp64 like
 the reference's Python floats).  `attention_rescoring` runs every hypothesis of
-every utterance through the attention decoder(s) in ONE batched pass and then
-replays the reference's scalar fp32 score arithmetic on the handful of gathered
-log-probs.
+every utterance through the attention decoder(s) in ONE batched pass; the
+reference's scalar fp32 score arithmetic, the arg-max and the confidences are one
+more kernel on the gathered log-probs (wn_rescore) -- the host builds B records.
 """
-import math
+import ctypes
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -201,8 +201,8 @@ def _prefix_beam(handle: int, B: int, max_len: int, beam_size: int,
                          times=tim0[b][:tlen0[b]])
         r._lazy, r._b = batch, b
         results.append(r)
-    raw = dict(n_hyps=n_hyps, hyp_lens=hyp_lens, hyp_tokens=hyp_tokens,
-               max_len=max_len)
+    raw = dict(n_hyps=n_hyps, hyp_lens=hyp_lens, hyp_tlens=hyp_tlens, hyp_tokens=hyp_tokens,
+               hyp_times=hyp_times, hyp_scores=hyp_scores, max_len=max_len)
     return results, raw
 
 
@@ -232,52 +232,71 @@ def ctc_prefix_beam_search(ctc_probs: torch.Tensor,
         cg.install(_lib.lib(), h, None, sp)
 
 
-def rescore_from_logps(hyps_per_utt, ctc_scores_per_utt, times_per_utt,
-                       l2r: np.ndarray, r2l: np.ndarray, ctc_weight: float,
-                       reverse_weight: float, use_r2l: bool
-                       ) -> List[DecodeResult]:
-    """The scalar tail of attention_rescoring (search.py:424-457), replayed
-    with the reference's dtypes: the per-token log-probs are fp32 tensor
-    elements, `score` accumulates in fp32 left to right, Python-float operands
-    are rounded to fp32 when they meet the fp32 tensor."""
-    f32 = np.float32
+def rescore_nbest(model, n_hyps, hyp_lens, hyp_tokens, hyp_scores, times_of, ctc_weight: float,
+                  reverse_weight: float, from_beam: bool) -> List[DecodeResult]:
+    """attention_rescoring (search.py:374-458) for the model's current batch through
+    wn_rescore: decoder passes, the reference's fp32 score arithmetic, arg-max and
+    confidences all run on the device; this function only shapes the B result records.
+    `from_beam`: the n-best is the one the handle's last prefix beam search left in HBM (the
+    arrays passed here are the host copies of the same search, used for the records only);
+    otherwise the arrays are uploaded.  `times_of(b, i)` -> nbest_times[i] of utterance b."""
+    B, beam = hyp_lens.shape
+    max_len = hyp_tokens.shape[2]
+    best = np.zeros((B, ), dtype=np.int32)
+    score = np.zeros((B, ), dtype=np.float32)
+    conf = np.zeros((B, ), dtype=np.float64)
+    tok_conf = np.zeros((B, max_len), dtype=np.float64)
+    all_scores = np.zeros((B, beam), dtype=np.float32)
+    null_i, null_d = ctypes.POINTER(ctypes.c_int32)(), ctypes.POINTER(ctypes.c_double)()
+    _lib.check(
+        _lib.lib().wn_rescore(
+            model._h, beam, null_i if from_beam else _lib.i32p(n_hyps),
+            null_i if from_beam else _lib.i32p(hyp_lens),
+            null_i if from_beam else _lib.i32p(hyp_tokens),
+            null_d if from_beam else _lib.f64p(hyp_scores), max_len, float(ctc_weight),
+            float(reverse_weight), _lib.i32p(best), _lib.f32p(score), _lib.f64p(conf),
+            _lib.f64p(tok_conf), _lib.f32p(all_scores), _stream_ptr(model.device)),
+        'wn_rescore')
+    best_l, score_l, conf_l = best.tolist(), score.tolist(), conf.tolist()
+    n_l = n_hyps.tolist()
+    len_best = hyp_lens[np.arange(B), best].tolist() if B else []
     results = []
-    for b, hyps in enumerate(hyps_per_utt):
-        best_score = -float('inf')
-        best_index = 0
-        confidences, tokens_confidences, all_scores = [], [], []
-        for i, hyp in enumerate(hyps):
-            L = len(hyp)
-            s_l = l2r[b, i, :L + 1].astype(f32)
-            score = f32(0.0)
-            for j in range(L):
-                score = f32(score + s_l[j])
-            tc = [math.exp(float(s_l[j])) for j in range(L)]
-            score = f32(score + s_l[L])
-            if reverse_weight > 0 and use_r2l:
-                s_r = r2l[b, i, :L + 1].astype(f32)
-                r_score = f32(0.0)
-                for j in range(L):
-                    s = s_r[L - j - 1]
-                    r_score = f32(r_score + s)
-                    tc[j] = (tc[j] + math.exp(float(s))) / 2
-                r_score = f32(r_score + s_r[L])
-                score = f32(f32(score * f32(1 - reverse_weight)) +
-                            f32(r_score * f32(reverse_weight)))
-            confidences.append(math.exp(float(f32(score / f32(L + 1)))))
-            score = f32(score + f32(ctc_scores_per_utt[b][i] * ctc_weight))
-            all_scores.append(float(score))
-            if float(score) > best_score:
-                best_score = float(score)
-                best_index = i
-            tokens_confidences.append(tc)
-        r = DecodeResult(hyps[best_index], best_score,
-                         confidence=confidences[best_index],
-                         times=times_per_utt[b][best_index],
-                         tokens_confidence=tokens_confidences[best_index])
-        r.all_scores = all_scores  # extra: score of every hypothesis
+    for b in range(B):
+        i, L = best_l[b], len_best[b]
+        r = DecodeResult(tuple(hyp_tokens[b, i, :L].tolist()), score_l[b],
+                         confidence=conf_l[b], times=times_of(b, i),
+                         tokens_confidence=tok_conf[b, :L].tolist())
+        r.all_scores = all_scores[b, :n_l[b]].tolist()  # extra: score of every hypothesis
         results.append(r)
     return results
+
+
+def _nbest_arrays(ctc_prefix_results: List[DecodeResult]):
+    """(n_hyps, hyp_lens, hyp_tokens, hyp_scores, times_of) of a list of prefix beam results:
+    the raw arrays of the search when the records still carry them, else built from the
+    records' Python lists (results of any other origin)."""
+    lazies = [getattr(r, '_lazy', None) for r in ctc_prefix_results]
+    nb = lazies[0] if lazies else None
+    if nb is not None and all(z is nb for z in lazies) and \
+            [r._b for r in ctc_prefix_results] == list(range(len(nb.n_hyps))):
+        def times_of(b, i):
+            return nb.hyp_times[b, i, :nb.hyp_tlens[b, i]].tolist()
+        return nb.n_hyps, nb.hyp_lens, nb.hyp_tokens, nb.hyp_scores, times_of
+    B = len(ctc_prefix_results)
+    beam = max(max((len(r.nbest) for r in ctc_prefix_results), default=0), 1)
+    max_len = max(max((len(h) for r in ctc_prefix_results for h in r.nbest), default=0), 1)
+    n_hyps = np.zeros((B, ), dtype=np.int32)
+    hyp_lens = np.zeros((B, beam), dtype=np.int32)
+    hyp_tokens = np.zeros((B, beam, max_len), dtype=np.int32)
+    hyp_scores = np.zeros((B, beam), dtype=np.float64)
+    for b, r in enumerate(ctc_prefix_results):
+        n_hyps[b] = len(r.nbest)
+        for i, h in enumerate(r.nbest):
+            hyp_lens[b, i] = len(h)
+            hyp_tokens[b, i, :len(h)] = np.asarray(h, dtype=np.int32)
+            hyp_scores[b, i] = r.nbest_scores[i]
+    return (n_hyps, hyp_lens, hyp_tokens, hyp_scores,
+            lambda b, i: ctc_prefix_results[b].nbest_times[i])
 
 
 def attention_beam_search(model, batch_size: int, maxlen: int, beam_size: int = 10,
