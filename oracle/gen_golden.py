@@ -64,6 +64,19 @@ CASES = [
     dict(case='aishell_lite_one', config='aishell_u2pp_lite', wseed=0, batch=1,
          frames=(330, 330), fseed=23, beam=10, chunk=-1, left=-1, ctc_weight=0.5,
          reverse_weight=0.3),
+    # ... and a RAGGED batch: the reference's filter_blank_embedding takes the arg-max over all
+    # maxlen frames, the padded ones of the shorter utterances included (asr_model.py:153-180),
+    # and attention_rescoring slices the result with the unfiltered lengths.  The file prefix
+    # keeps it out of the generic case list (tests/golden_util.py): the accelerated path has
+    # no padded frames (tests/test_gpu_parity.py)
+    dict(case='raggedlite_tiny', config='tiny_lite', wseed=0, batch=5,
+         frames=(60, 190), fseed=4242, beam=5, chunk=-1, left=-1, ctc_weight=0.5,
+         reverse_weight=0.3),
+    # (weights under which padded frames DO come out non-blank: the reference keeps
+    # [19, 20, 29, 32, 31] rows where only [19, 20, 25, 12, 8] belong to the utterances)
+    dict(case='raggedlite_tiny_padded', config='tiny_lite', wseed=4, batch=5,
+         frames=(60, 190), fseed=4242, beam=5, chunk=-1, left=-1, ctc_weight=0.5,
+         reverse_weight=0.3),
     dict(case='wenetspeech_chunk16', config='wenetspeech_u2pp', wseed=0,
          batch=2, frames=(260, 330), fseed=12, beam=10, chunk=16, left=-1,
          ctc_weight=0.5, reverse_weight=0.3),

@@ -14,7 +14,7 @@ def case_names(prefix=''):
         os.path.basename(p)[:-4]
         for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + '*.npz'))
         if not os.path.basename(p).startswith(('fbank', 'whisper', 'stream_', 'attn_', 'ctx', 'chunk_',
-                                                 'cmvn_', 'bench_', 'resample_')))
+                                                 'cmvn_', 'bench_', 'resample_', 'raggedlite_')))
 
 
 def load_case(name):

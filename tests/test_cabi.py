@@ -49,7 +49,14 @@ def test_argument_validation_without_a_device():
     assert b'null' in L.wn_last_error()
     assert L.wn_tune_set(b'no_such_knob', 1) == -1
     assert b'unknown key' in L.wn_last_error()
-    assert L.wn_tune_set(b'gemm_tile', 0) == 0
+    assert L.wn_tune_set(b'gemm_x6', 1) == 0
+    # variants that leave out parts of a kernel (wrong results by design) exist in WN_ABLATION
+    # measurement builds only: the product library refuses their values
+    if L.wn_tune_set(b'ffn_x6f_ring', 3) != 0:          # (a product build)
+        assert L.wn_tune_set(b'ffn_x6f_var', 8706) == -1
+        assert b'WN_ABLATION' in L.wn_last_error()
+        assert L.wn_tune_set(b'x6_probe', 2) == -1
+        assert L.wn_tune_set(b'ffn_x6f_var', 0) == 0 and L.wn_tune_set(b'x6_probe', 0) == 0
 
 
 def test_product_path_never_imports_the_oracle():

@@ -48,3 +48,26 @@ def test_plain_construction_and_assignment_keep_working():
     assert r.nbest == 'mine' and r.nbest_scores == arrs[5][1, :int(arrs[0][1])].tolist()
     r.extra = 3                             # plain attributes stay assignable
     assert r.extra == 3
+
+
+def test_as_dict_and_pickle_carry_the_reference_field_names():
+    """vars() of the reference's DecodeResult lists its nine fields; here the n-best fields are
+    properties, so `as_dict()` / pickling / copy.deepcopy give the same names with the lists
+    materialised -- and never the batch-wide raw arrays."""
+    import copy
+    import pickle
+    arrs = _batch(B=3)
+    r = DecodeResult(tokens=(5, 6), score=-1.5, times=[1, 2])
+    r._lazy, r._b = _NBestBatch(*arrs), 2
+    r.all_scores = [0.25]
+    d = r.as_dict()
+    assert list(d)[:9] == ['tokens', 'score', 'confidence', 'tokens_confidence', 'times',
+                           'nbest', 'nbest_scores', 'nbest_times', 'text']
+    assert d['all_scores'] == [0.25] and not any(k.startswith('_') for k in d)
+    n = int(arrs[0][2])
+    assert d['nbest_scores'] == arrs[5][2, :n].tolist() and len(d['nbest']) == n
+    blob = pickle.dumps(r)
+    assert len(blob) < 4096                  # the (B, beam, T) arrays did not travel
+    for q in (pickle.loads(blob), copy.deepcopy(r)):
+        assert q.as_dict() == d and q._lazy is None
+        assert q.nbest == r.nbest and q.tokens == (5, 6) and q.all_scores == [0.25]

@@ -77,3 +77,48 @@ def test_shard_indices_single_rank_is_identity_order():
     from wenet_amd import dist as wdist
     lengths = [5, 9, 7]
     assert wdist.shard_indices(lengths, 1, 0) == [1, 2, 0]
+
+
+def _gather_worker(rank: int, world: int, port: int, lengths, out_dir: str):
+    from wenet_amd import dist as wdist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        mine = wdist.shard_indices(lengths, world, rank)
+        per_rank = (len(lengths) + world - 1) // world
+        g = wdist.ResultGatherer(world, per_rank, 16, 'cpu')
+        outs = []
+        for step in range(4):          # four "batches" queued back to back, gathered in order
+            toks = [[(t + step) % 4233 for t in _fake_result(gi)[0]] for gi in mine]
+            g.submit(mine, toks, [_fake_result(gi)[1] - step for gi in mine])
+            if step == 1:
+                outs.append(g.drain())  # a drain in mid-sequence (a timed round ending)
+                dist.barrier()          # main-thread collective only while the worker is idle
+        outs.append(g.drain())
+        g.close()
+        ok = all(len(o) == len(lengths) for o in outs)
+        for step, o in ((1, outs[0]), (3, outs[1])):
+            for gi, toks, score in o:
+                want, sc = _fake_result(gi)
+                ok &= toks == [(t + step) % 4233 for t in want]
+                ok &= abs(score - np.float32(sc - step)) < 1e-6
+        np.save(os.path.join(out_dir, f'ok{rank}.npy'), np.array([int(ok)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_result_gatherer_worker_thread_two_ranks(tmp_path):
+    """wenet_amd.dist.ResultGatherer (bench.py's per-step gather off the decode thread): batches
+    gathered in submission order on every rank, drain() as the fence in front of main-thread
+    collectives."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    lengths = rng.integers(800, 1201, size=19).tolist()
+    mp.spawn(_gather_worker, args=(2, _free_port(), lengths, str(tmp_path)), nprocs=2, join=True)
+    assert all(int(np.load(tmp_path / f'ok{r}.npy')[0]) == 1 for r in range(2))
+
+
+def test_gather_results_rejects_a_wrong_world_size():
+    from wenet_amd import dist as wdist
+    rec = wdist.pack_results([0], [[1, 2]], [0.5], 1, 4, 'cpu')
+    assert wdist.gather_results(rec, 1) == [(0, [1, 2], 0.5)]   # no process group: local path

@@ -434,9 +434,9 @@ def test_bf16_attention_block_shapes(nw, config, chunk, left):
     (4, (1290, 1300), 8, 0),     # lengths reset to multiples of 64 keys and one past (below)
 ])
 def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed, nw):
-    """The LDS-DMA staged bf16 self attention (K rows of the QKV matrix + the packed V^T
-    image, attention_bf16_dma_kernel) does the register-staged kernel's arithmetic in the
-    same order: the encoder outputs of the two are the same bits, on ragged batches whose
+    """The LDS-DMA staged bf16 self attention (K and V rows of the QKV matrix, PV fragments
+    through transpose reads, attention_bf16_dma_kernel) does the register-staged kernel's
+    arithmetic in the same order: the encoder outputs of the two are the same bits, on ragged batches whose
     last stage is partial; and both stay within the oracle's bf16 emulation."""
     from wenet_amd import _lib, synthetic as S
     O = _oracle()
@@ -452,19 +452,9 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed, nw):
     try:
         _lib.check(L.wn_tune_set(b'attn_bf16_nw', nw), 'tune')
         _lib.check(L.wn_tune_set(b'attn_bf16_defer', 0), 'tune')   # rescale whenever a maximum moves
-        _lib.check(L.wn_tune_set(b'attn_bf16_dma', 1), 'tune')
+        _lib.check(L.wn_tune_set(b'attn_bf16_dma', 1), 'tune')   # the LDS-DMA staged kernel
         enc1, _ = model._forward_encoder(feats.cuda(), lens)
         enc1b, _ = model._forward_encoder(feats.cuda(), lens)
-        _lib.check(L.wn_tune_set(b'attn_bf16_dma', 2), 'tune')   # grouped fragment reads
-        enc2, _ = model._forward_encoder(feats.cuda(), lens)
-        enc2b, _ = model._forward_encoder(feats.cuda(), lens)
-        _lib.check(L.wn_tune_set(b'attn_bf16_dma', 4), 'tune')   # V rows + transpose reads
-        enc4, _ = model._forward_encoder(feats.cuda(), lens)
-        enc4b, _ = model._forward_encoder(feats.cuda(), lens)
-        # the default since round 4: transpose reads as inline asm (csrc/attention_bf16.hip TRA)
-        _lib.check(L.wn_tune_set(b'attn_bf16_dma', 5), 'tune')
-        enc5, _ = model._forward_encoder(feats.cuda(), lens)
-        enc5b, _ = model._forward_encoder(feats.cuda(), lens)
         # deferred rescale (the default, threshold 8 in log2 units) and a threshold that makes the
         # update branch fire in mid-sequence tiles: other roundings of P, the same softmax
         deferred = []
@@ -475,18 +465,12 @@ def test_bf16_attention_dma_staging_is_bit_identical(B, frames, seed, nw):
         _lib.check(L.wn_tune_set(b'attn_bf16_dma', 0), 'tune')
         enc0, _ = model._forward_encoder(feats.cuda(), lens)
     finally:
-        L.wn_tune_set(b'attn_bf16_dma', 5)      # the defaults
+        L.wn_tune_set(b'attn_bf16_dma', 1)      # the defaults
         L.wn_tune_set(b'attn_bf16_defer', 80)
         L.wn_tune_set(b'attn_bf16_nw', 0)
         _set_dtype(model, 'fp32')
     assert torch.equal(enc1, enc1b), 'DMA-staged attention is not deterministic (race?)'
     assert torch.equal(enc1, enc0), (enc1 - enc0).abs().max().item()
-    assert torch.equal(enc2, enc2b), 'DMA-staged attention (grouped reads) is not deterministic'
-    assert torch.equal(enc2, enc0), (enc2 - enc0).abs().max().item()
-    assert torch.equal(enc4, enc4b), 'DMA-staged attention (transpose reads) is not deterministic'
-    assert torch.equal(enc4, enc0), (enc4 - enc0).abs().max().item()
-    assert torch.equal(enc5, enc5b), 'DMA-staged attention (asm transpose reads) is not deterministic'
-    assert torch.equal(enc5, enc0), (enc5 - enc0).abs().max().item()
     with torch.no_grad(), O.bf16_operands(sd):
         ref, mask = O.encoder_forward(configs, sd, feats, lens, -1, -1)
     ref_lens = mask.squeeze(1).sum(1).numpy()

@@ -53,6 +53,24 @@ def test_bench_two_ranks_on_one_gpu_equals_the_reference_per_utterance():
     assert d['verify']['identical'] + d['verify']['near_tie'] == 64
 
 
+@pytest.mark.parametrize('workload', ['config2', 'config4'])
+def test_bench_eight_ranks_on_one_gpu_equals_the_reference_per_utterance(workload):
+    """The shape of the driver's 8-GPU run (`bench.py --gpus 8`, BASELINE.json configs[3] names
+    8 MI355X): 8 ranks x 32 utterances, snake-dealt by length over the ranks, every rank's
+    results gathered by the worker-thread all_gather; all 256 token lists equal the REAL
+    reference's (tests/golden/bench_<workload>_w8.npz)."""
+    r = _torchrun(8, ['bench.py', '--gpus', '8', '--workload', workload, '--steps', '2',
+                      '--warmup', '1', '--no-cpu-baseline', '--no-f32-mfma-leg',
+                      '--no-clock-sample', '--no-plain-leg', '--no-nbest-leg',
+                      '--min-seconds', '0.1'], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 8 and d['config']['global_batch'] == 256
+    assert d['verified'] is True, d['verify']
+    assert d['verify']['utterances'] == 256
+    assert d['verify']['identical'] + d['verify']['near_tie'] == 256
+
+
 def test_bench_rccl_process_group_of_one_rank():
     """The `nccl` (= RCCL) branch of the N > 1 path executed on this 1-GPU box: bench.py with a
     process group of ONE rank -- backend initialisation on the device, the result all_gather,

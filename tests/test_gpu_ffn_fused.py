@@ -13,7 +13,7 @@ from gpu_util import cached_model
 pytestmark = pytest.mark.gpu
 
 
-def _run(X, W1, b1, W2, b2, x, lw, lb, act, alpha, bm64=0):
+def _run(X, W1, b1, W2, b2, x, lw, lb, act, alpha):
     from wenet_amd import _lib
     L = _lib.lib()
     M, D = X.shape
@@ -21,33 +21,27 @@ def _run(X, W1, b1, W2, b2, x, lw, lb, act, alpha, bm64=0):
     xo = x.clone().cuda()
     y = torch.empty((M, D), device='cuda')
     t = [t.cuda().contiguous() for t in (X, W1, b1, W2, b2, lw, lb)]
-    _lib.check(L.wn_tune_set(b'ffn_bm64', bm64), 'tune')
-    try:
-        _lib.check(L.wn_op_ffn_fused(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
-                                     t[3].data_ptr(), t[4].data_ptr(), xo.data_ptr(),
-                                     t[5].data_ptr(), t[6].data_ptr(), y.data_ptr(), M, D, F,
-                                     act, alpha, 1e-5,
-                                     torch.cuda.current_stream().cuda_stream), 'ffn_fused')
-        torch.cuda.synchronize()
-    finally:
-        L.wn_tune_set(b'ffn_bm64', 0)
+    _lib.check(L.wn_op_ffn_fused(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                 t[3].data_ptr(), t[4].data_ptr(), xo.data_ptr(),
+                                 t[5].data_ptr(), t[6].data_ptr(), y.data_ptr(), M, D, F,
+                                 act, alpha, 1e-5,
+                                 torch.cuda.current_stream().cuda_stream), 'ffn_fused')
+    torch.cuda.synchronize()
     return xo.cpu(), y.cpu()
 
 
-@pytest.mark.parametrize('M,D,F,act,bm64', [
-    (128, 256, 128, 1, 0),       # 128-row blocks: one block, two chunks
-    (700, 256, 2048, 1, 0),      # ragged M, S = 16
-    (7932, 256, 2048, 1, 0),     # BASELINE config 2: 62 x 4 blocks
-    (128, 256, 128, 1, 1),       # 64-row blocks (two per CU): two blocks, two chunks
-    (64, 256, 64, 2, 1),         # one block, one chunk, ReLU
-    (700, 256, 2048, 3, 1),      # ragged M, S = 16, GELU
-    (7932, 256, 2048, 1, 1),     # BASELINE config 2: 124 x 4 blocks
-    (33000, 256, 2048, 1, 1),    # more blocks than fit at once; S = 2 -> 16 chunks per block
-    (1000, 512, 2048, 2, 1),     # d = 512 (two W2 stages per k tile), ReLU
-    (333, 512, 1024, 3, 1),      # GELU
-    (16231, 512, 2048, 1, 1),    # BASELINE config 3: 127 x 2 blocks, 16 chunks per block
+@pytest.mark.parametrize('M,D,F,act', [
+    (128, 256, 128, 1),       # 128-row blocks: one block, two chunks
+    (64, 256, 64, 2),         # one block, one chunk, ReLU
+    (700, 256, 2048, 1),      # ragged M, S = 16
+    (700, 256, 2048, 3),      # ... GELU
+    (7932, 256, 2048, 1),     # BASELINE config 2: 62 x 4 blocks
+    (33000, 256, 2048, 1),    # more blocks than fit at once; S = 1 -> 32 chunks per block
+    (1000, 512, 2048, 2),     # d = 512 (two W2 stages per k tile), ReLU
+    (333, 512, 1024, 3),      # GELU
+    (16231, 512, 2048, 1),    # BASELINE config 3: 127 x 2 blocks, 16 chunks per block
 ])
-def test_ffn_fused_vs_fp64(M, D, F, act, bm64):
+def test_ffn_fused_vs_fp64(M, D, F, act):
     g = torch.Generator().manual_seed(M + D + F + act)
     X = torch.randn(M, D, generator=g)
     W1 = torch.randn(F, D, generator=g) / D ** 0.5
@@ -61,10 +55,10 @@ def test_ffn_fused_vs_fp64(M, D, F, act, bm64):
     h = {1: torch.nn.functional.silu, 2: torch.relu, 3: torch.nn.functional.gelu}[act](h)
     xr = x.double() + 0.5 * (h @ W2.double().T + b2.double())
     yr = torch.nn.functional.layer_norm(xr, (D, ), lw.double(), lb.double(), 1e-5)
-    xo, y = _run(X, W1, b1, W2, b2, x, lw, lb, act, 0.5, bm64)
+    xo, y = _run(X, W1, b1, W2, b2, x, lw, lb, act, 0.5)
     assert (xo.double() - xr).abs().max().item() < 2e-5
     assert (y.double() - yr).abs().max().item() < 2e-5
-    xo2, y2 = _run(X, W1, b1, W2, b2, x, lw, lb, act, 0.5, bm64)   # race screen
+    xo2, y2 = _run(X, W1, b1, W2, b2, x, lw, lb, act, 0.5)   # race screen
     assert torch.equal(xo, xo2) and torch.equal(y, y2)
 
 
@@ -144,21 +138,15 @@ def test_encoder_with_folded_relpos_attention_matches_the_two_contraction_form(c
         _lib.check(L.wn_tune_set(b'attn_fold', 2), 'tune')   # the fold as a separate pass
         sep, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         sep = sep.cpu()
-        # the older issue orders of the same arithmetic (defaults until round 4): staging loads
-        # chunk by chunk (attn_gload = 0), one depthwise-conv output row per wave (dwconv_tiled = 0)
+        # the other issue order of the same arithmetic: one depthwise-conv output row per wave
+        # (dwconv_tiled = 0; the kernel widths other than 256 / 512 run)
         _lib.check(L.wn_tune_set(b'attn_fold', 1), 'tune')
-        _lib.check(L.wn_tune_set(b'attn_gload', 0), 'tune')
-        glb, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
-        glb = glb.cpu()
-        _lib.check(L.wn_tune_set(b'attn_gload', 1), 'tune')
         _lib.check(L.wn_tune_set(b'dwconv_tiled', 0), 'tune')
         dwt, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         dwt = dwt.cpu()
     finally:
         L.wn_tune_set(b'attn_fold', 1)
-        L.wn_tune_set(b'attn_gload', 1)
         L.wn_tune_set(b'dwconv_tiled', 1)
-    assert torch.equal(glb, got), (glb - got).abs().max().item()
     assert torch.equal(dwt, got), (dwt - got).abs().max().item()
     assert torch.equal(got, got2.cpu())            # race screen
     err = (got - ref).abs().max().item()
@@ -291,7 +279,7 @@ def test_chained_row_ln_glu_launch_is_bit_identical_to_the_two_launches(B, frame
 @pytest.mark.parametrize('B,frames,chunk', [(32, (800, 1200), -1), (5, (300, 1100), -1),
                                             (8, (300, 700), 16)])
 def test_qkv_prologue_fold_is_bit_identical_to_the_reduce_launch(B, frames, chunk):
-    """gemm_x6r.hip PRO 1 (the QKV projection forms LN_mha(x + 0.5 FFN_macaron) itself from the
+    """gemm_x6r.hip PRO (the QKV projection forms LN_mha(x + 0.5 FFN_macaron) itself from the
     slice partials of the fused feed-forward kernel, encoder_layer.py:220-232) does
     ffn_reduce_ln's arithmetic in the same order: the encoder output is the same bits as with
     the separate launch; ragged row counts (a last block with rows past M)."""
@@ -307,13 +295,8 @@ def test_qkv_prologue_fold_is_bit_identical_to_the_reduce_launch(B, frames, chun
         got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got = got.cpu()
-        # PRO 2 (slice loads in flight together; the default since round 4)
-        _lib.check(L.wn_tune_set(b'x6r_pro', 2), 'tune')
-        got_p2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
-        got_p2 = got_p2.cpu()
     finally:
-        L.wn_tune_set(b'x6r_pro', 2)
+        L.wn_tune_set(b'x6r_pro', 1)
     assert torch.isfinite(got).all()
     assert torch.equal(got, got2.cpu())
     assert torch.equal(got, ref), (got - ref).abs().max().item()
-    assert torch.equal(got_p2, ref), (got_p2 - ref).abs().max().item()

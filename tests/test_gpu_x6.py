@@ -234,13 +234,9 @@ def test_encoder_with_x6_ffn_matches_the_f32_mfma_path(config, B, frames, chunk)
         got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         got = got.cpu()
-        _lib.check(L.wn_tune_set(b'x6_nw4', 7), 'tune')      # the other tile forms of the FFN GEMMs
-        got4, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
     finally:
         L.wn_tune_set(b'gemm_x6', 1)
-        L.wn_tune_set(b'x6_nw4', 0)
     assert torch.equal(got, got2.cpu())
-    assert torch.equal(got, got4.cpu())
     err = (got - ref).abs().max().item()
     print(f'\n[{config} B={B}] x6 FFN vs f32 MFMA: max |d enc| {err:.2e}')
     assert 0 < err < 1e-4
@@ -273,16 +269,22 @@ def test_ffn_on_chip_equals_itself_for_every_ring_depth(ring):
                                   torch.cuda.current_stream().cuda_stream), 'ffn_x6')
         torch.cuda.synchronize()
         return xo.cpu()
+    # the stages of 24 records (rings 4..6) are compiled in WN_ABLATION builds only; the default
+    # build runs the ring-3 leg as a determinism screen (3 runs, same bits)
+    ablation = L.wn_tune_set(b'ffn_x6f_ring', 6) == 0
+    if not ablation and ring != 3:
+        pytest.skip('rings 4..6: WN_ABLATION build only')
     try:
         _lib.check(L.wn_tune_set(b'ffn_x6f', 2), 'tune')
-        _lib.check(L.wn_tune_set(b'ffn_x6f_ring', 6), 'tune')
         ref = run()
-        _lib.check(L.wn_tune_set(b'ffn_x6f_ring', ring), 'tune')
+        if ablation:
+            _lib.check(L.wn_tune_set(b'ffn_x6f_ring', ring), 'tune')
         for _ in range(3):
             assert torch.equal(run(), ref)
     finally:
         L.wn_tune_set(b'ffn_x6f', 1)
-        L.wn_tune_set(b'ffn_x6f_ring', 3)
+        if ablation:
+            L.wn_tune_set(b'ffn_x6f_ring', 3)
 
 
 def test_encoder_with_the_on_chip_ffn_matches_the_gemm_pair():

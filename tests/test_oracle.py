@@ -534,6 +534,43 @@ def test_filter_blank_embedding_vs_reference_output(name):
     assert 0 < min(meta['nonblank_kept']) and max(meta['nonblank_kept']) < enc.shape[1]
 
 
+@pytest.mark.parametrize('name', ['raggedlite_tiny', 'raggedlite_tiny_padded'])
+def test_oracle_reproduces_the_reference_on_ragged_non_blank_embedding_batches(name):
+    """apply_non_blank_embedding on a RAGGED batch, real reference (oracle/gen_golden.py): the
+    reference's filter takes the arg-max over all maxlen frames -- in `raggedlite_tiny_padded`
+    the shorter utterances keep 4 .. 23 rows that are padding -- and rescoring then slices with
+    the unfiltered lengths.  The oracle's default mode reproduces that exactly (selected rows
+    bit for bit, scores within 1e-3); `nonblank_valid_only=True` (what the accelerated path
+    computes: it has no padded frames) differs by up to 0.1 in score on that case and not at all
+    where no padded frame is selected."""
+    meta, arrays = load_case(name)
+    configs, sd, feats, lens = build_inputs(meta)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        enc, mask = O.encoder_forward(configs, sd, feats, lens)
+        logp = O.ctc_logprobs(sd, enc)
+        sel, smask = O.filter_blank_embedding(logp, enc)
+        _, vmask = O.filter_blank_embedding(logp, enc, mask.squeeze(1).sum(1))
+    assert smask.squeeze(1).sum(1).tolist() == meta['nonblank_kept']
+    np.testing.assert_allclose(sel.numpy(), arrays['nonblank_out'], rtol=0, atol=2e-5)
+    padded_rows = [a - b for a, b in zip(meta['nonblank_kept'], vmask.squeeze(1).sum(1).tolist())]
+    kw = dict(beam_size=meta['beam'], ctc_weight=meta['ctc_weight'],
+              reverse_weight=meta['reverse_weight'])
+    res = O.decode(configs, sd, ['attention_rescoring', 'ctc_prefix_beam_search'], feats, lens, **kw)
+    val = O.decode(configs, sd, ['attention_rescoring', 'ctc_prefix_beam_search'], feats, lens,
+                   nonblank_valid_only=True, **kw)
+    dev = 0.0
+    for b in range(meta['batch']):
+        r, gr = res['attention_rescoring'][b], meta['rescoring'][b]
+        assert list(r.tokens) == gr['tokens']
+        assert abs(r.score - gr['score']) < 1e-3
+        dev = max(dev, abs(val['attention_rescoring'][b].score - gr['score']))
+    if name == 'raggedlite_tiny_padded':
+        assert max(padded_rows) >= 20 and 1e-2 < dev < 0.15, (padded_rows, dev)
+    else:
+        assert max(padded_rows) == 0 and dev < 1e-3, (padded_rows, dev)
+
+
 @pytest.mark.parametrize('orig,new', [(44100, 16000), (48000, 16000), (8000, 16000),
                                       (22050, 16000), (16000, 8000), (11025, 16000),
                                       (32000, 16000)])

@@ -5,7 +5,7 @@ B=32 x ~10 s -> M = 7932 encoder rows), through the C ABI (wn_op_gemm).
     python tools/bench_gemm.py [--reps 30] [--only w1] [--variants 0,1]
     python tools/bench_gemm.py --bf16 --tiles 0,1,7 --only wh_w1,wh_w2,w1
 
-Prints TFLOP/s per shape and variant (variants = wn_tune_set("gemm_variant")),
+Prints TFLOP/s per shape and tile rule (gemm_tile_bf16; the run-time epilogue variants were removed in round 4),
 interleaved within one process.
 """
 import argparse
@@ -113,7 +113,6 @@ def main():
         for rnd in range(3):
             for v in variants:
                 L.wn_tune_set(tile_key, v[0])
-                L.wn_tune_set(b'gemm_variant', v[1])
                 for _ in range(3):
                     run()
                 torch.cuda.synchronize()
@@ -133,7 +132,6 @@ def main():
                   f'{tf:6.1f} TF/s  (rounds {[round(x, 1) for x in res[v]]})', flush=True)
             out[f'{name}/t{v[0]}v{v[1]}'] = dict(us=us, tflops=tf)
     L.wn_tune_set(tile_key, 0)
-    L.wn_tune_set(b'gemm_variant', 0)
     print(json.dumps(out))
 
 

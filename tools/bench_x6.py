@@ -108,27 +108,21 @@ def main():
                 # hidden tensor on chip (csrc/ffn_x6f.hip); includes the split of X
                 for ring in (3, 4, 5, 6):
                     _lib.check(L.wn_tune_set(b'ffn_x6f', 1), 'tune')
-                    _lib.check(L.wn_tune_set(b'ffn_x6f_ring', ring), 'tune')
+                    if L.wn_tune_set(b'ffn_x6f_ring', ring) != 0 and ring != 3:
+                        continue      # rings 4..6: WN_ABLATION builds only
                     ffn(1)
                     t1f = timed(lambda: ffn(1))
                     tnf = timed(lambda: ffn(args.reps + 1))
                     usf = (tnf - t1f) / args.reps * 1e3
                     print(f'ffn M={m} D={d} F={f} | x6 ON CHIP ring {ring} (fp32 X split in registers): '
                           f'{usf:8.1f} us {4.0 * m * d * f / usf / 1e6:7.1f} TF-eq', flush=True)
-                _lib.check(L.wn_tune_set(b'ffn_x6f_ring', 3), 'tune')
-                for mp in (0, 1, 0, 1):
-                    _lib.check(L.wn_tune_set(b'ffn_x6f_map', mp), 'tune')
-                    ffn(1)
-                    t1f = timed(lambda: ffn(1))
-                    tnf = timed(lambda: ffn(args.reps + 1))
-                    usf = (tnf - t1f) / args.reps * 1e3
-                    print(f'ffn M={m} D={d} F={f} | x6 ON CHIP, hidden slices per XCD {mp + 1}: '
-                          f'{usf:8.1f} us', flush=True)
+                L.wn_tune_set(b'ffn_x6f_ring', 3)
                 # measurement variants of the kernel (results wrong by design except 16)
                 for var, what in ((82432, 'three of the six products (wrong results: what half the MFMAs would cost)'), (512, 'full, stage DMA as one burst behind the barrier'), (1, 'no MFMAs'),
                                   (2, 'no DMA in the loop'), (4, 'no bias/act/split pieces'), (64, 'no fragment reads'), (10, 'no DMA, no waits'), (78, 'MFMAs only'), (74, 'MFMAs + pieces'), (14, 'MFMAs + fragment reads'), (76, 'MFMAs + DMA'), (70, 'MFMAs + waits/barriers'), (1094, 'MFMAs + s_barrier only'), (4096, 'full, fragment reads of a group as one burst'), (4110, 'MFMAs + burst fragment reads'), (2118, 'MFMAs + waitcnts only'), (128, 'partials stored sc0 sc1'),
                                   (8, 'no waits / barriers in the loop')):
-                    _lib.check(L.wn_tune_set(b'ffn_x6f_var', var), 'tune')
+                    if L.wn_tune_set(b'ffn_x6f_var', var) != 0:
+                        continue      # WN_ABLATION builds only
                     ffn(1)
                     t1f = timed(lambda: ffn(1))
                     tnf = timed(lambda: ffn(args.reps + 1))

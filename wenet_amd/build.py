@@ -21,6 +21,11 @@ SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_bf16s.hip', 'gemm_bf16p.hip', 'ffn
            'logmel.hip', 'model.hip', 'cabi.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-fno-gpu-rdc', '-Wno-unused-result']
+# WN_ABLATION=1 python -m wenet_amd.build: a MEASUREMENT build that also compiles the kernel
+# variants which leave out parts of a kernel (wrong results by design) and superseded stage
+# shapes; the product build has none of them (wn_tune_set refuses their keys / values)
+if os.environ.get('WN_ABLATION') == '1':
+    FLAGS.append('-DWN_ABLATION')
 # per-source extras: the one-wave-per-SIMD kernel pins its VALU slices between MFMA pairs;
 # SLP-packed f32 ops (v_pk_*) would undo the spacing (MI355X_MICROARCH.md: an anti-lever
 # beside MFMAs)

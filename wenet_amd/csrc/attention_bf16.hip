@@ -32,7 +32,6 @@
 
 namespace wn {
 
-extern int g_attn_bf16_sub;
 extern int g_attn_bf16_dma;
 extern int g_attn_bf16_defer;
 
@@ -401,46 +400,6 @@ __device__ __forceinline__ float pair_sum(float v) {   // sum over lanes l, l ^ 
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// vt[((s * H + h) * 64 + dim) * Tp + 16 g + p] = V[off[s] + 16 g + key(p)][h * 64 + dim],
-// key(p) = 4 (p >> 3) + (p & 3) + 8 ((p >> 2) & 1); zeros beyond the sequence (the last
-// stage multiplies them by probabilities that are exactly 0).
-__global__ __launch_bounds__(256) void vt_pack_kernel(const __bf16* __restrict__ V, int ldv,
-                                                      const int* __restrict__ off,
-                                                      const int* __restrict__ len, int H, int Tp,
-                                                      __bf16* __restrict__ vt) {
-  const int kt = blockIdx.x, h = blockIdx.y, s = blockIdx.z;
-  const int n = len[s], t0 = kt * 64;
-  if (t0 >= n) return;                      // stages past the sequence are never read
-  __shared__ __attribute__((aligned(16))) __bf16 tile[64 * 72];   // [key][64 dims + 16 B]
-  const int tid = threadIdx.x;
-  {
-    const int key = tid >> 2, c = tid & 3;
-    bf16x8 x0, x1;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { x0[e] = (__bf16)0.0f; x1[e] = (__bf16)0.0f; }
-    if (t0 + key < n) {
-      const __bf16* vp = V + (int64_t)(off[s] + t0 + key) * ldv + h * 64 + c * 16;
-      x0 = *reinterpret_cast<const bf16x8*>(vp);
-      x1 = *reinterpret_cast<const bf16x8*>(vp + 8);
-    }
-    *reinterpret_cast<bf16x8*>(tile + key * 72 + c * 16) = x0;
-    *reinterpret_cast<bf16x8*>(tile + key * 72 + c * 16 + 8) = x1;
-  }
-  __syncthreads();
-  {
-    const int dim = tid >> 2, g = tid & 3;
-    bf16x8 y0, y1;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      y0[p] = tile[(16 * g + (p & 3) + 8 * ((p >> 2) & 1)) * 72 + dim];
-      y1[p] = tile[(16 * g + 4 + (p & 3) + 8 * ((p >> 2) & 1)) * 72 + dim];
-    }
-    __bf16* op = vt + ((int64_t)(s * H + h) * 64 + dim) * Tp + t0 + 16 * g;
-    *reinterpret_cast<bf16x8*>(op) = y0;
-    *reinterpret_cast<bf16x8*>(op + 8) = y1;
-  }
-}
-
 // PIPE (attn_bf16_dma = 2): the stage loop unrolled over the two LDS buffers so that every
 // fragment address is ONE of four per-lane registers + an immediate, the K fragments of a
 // sub-tile read as a group before its MFMA chain (the second sub-tile's, and the V^T fragments,
@@ -473,8 +432,12 @@ __device__ __forceinline__ short __attribute__((ext_vector_type(4))) tr16_b64_as
   return r;
 }
 
-template <int NW, bool PIPE, bool VTR = false, bool TRA = false>
+// Round 4: TRA is the only form built (the V^T-image forms attn_bf16_dma = 1 / 2 and the builtin
+// transpose reads = 4 were bit-identical and slower or equal: removed; the flags below keep the
+// kernel text readable against the descriptions above).
+template <int NW>
 __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs a, int nqb) {
+  constexpr bool PIPE = true, VTR = true, TRA = true;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   static_assert(NW == 4 || NW == 8, "4 or 8 query groups per block");
   static_assert(!VTR || PIPE, "transpose-read form: grouped-read kernel only");
@@ -497,19 +460,13 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
   const __bf16* Qh = reinterpret_cast<const __bf16*>(a.Q);
 
   // ---- DMA descriptors and per-lane source offsets ------------------------------------
-  const unsigned ldk2 = (unsigned)a.ldk * 2u, tp2 = (unsigned)a.vt_tp * 2u;
+  const unsigned ldk2 = (unsigned)a.ldk * 2u;
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<__bf16*>(reinterpret_cast<const __bf16*>(a.K) + (int64_t)kvoff * a.ldk + h * 64),
       0, (int)((unsigned)kvlen * ldk2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = VTR
-      ? __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<__bf16*>(reinterpret_cast<const __bf16*>(a.V) + (int64_t)kvoff * a.ldv +
-                                h * 64),
-            0, (int)((unsigned)kvlen * ldk2), 0x00020000)          // ldv == ldk (checked by the host)
-      : __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<__bf16*>(reinterpret_cast<const __bf16*>(a.vt) +
-                                (int64_t)(s * a.n_heads + h) * 64 * a.vt_tp),
-            0, (int)(64u * tp2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(reinterpret_cast<const __bf16*>(a.V) + (int64_t)kvoff * a.ldv + h * 64),
+      0, (int)((unsigned)kvlen * ldk2), 0x00020000);          // ldv == ldk (checked by the host)
   int prow[NP];
   unsigned pslot[NP], vtoff[NP];
 #pragma unroll
@@ -520,8 +477,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
     // of a transpose read touches 4 consecutive rows x 64 B, and with the K swizzle rows r and
     // r + 2 of them met in the same banks (SQ_LDS_BANK_CONFLICT 11.6 M cycles per launch, r05ad);
     // this field is then the V source slot minus the K one
-    vtoff[p] = VTR ? (unsigned)((((lane & 7) ^ (((prow[p] >> 1) & 1) << 2)) << 4)) - pslot[p]
-                   : (unsigned)prow[p] * tp2 + pslot[p];
+    vtoff[p] = (unsigned)((((lane & 7) ^ (((prow[p] >> 1) & 1) << 2)) << 4)) - pslot[p];
   }
   auto issue = [&](int it, int buf) {
     const int j0 = it * DKT;
@@ -531,15 +487,9 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
       const unsigned vk = (unsigned)min(j0 + prow[p], kvlen - 1) * ldk2 + pslot[p];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(dst + p * NW * 1024), 16, vk, 0, 0,
                                                0);
-      if constexpr (VTR) {         // the same rows of V, its own slot swizzle
-        const unsigned vv = vk + vtoff[p];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(dst + DTILE + p * NW * 1024), 16,
-                                                 vv, 0, 0, 0);
-      } else {
-        const unsigned vt_o = vtoff[p] + 0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(dst + DTILE + p * NW * 1024), 16,
-                                                 vt_o, j0 * 2, 0, 0);
-      }
+      const unsigned vv = vk + vtoff[p];         // the same rows of V, its own slot swizzle
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(dst + DTILE + p * NW * 1024), 16,
+                                               vv, 0, 0, 0);
     }
   };
   const int n_it = (kvlen + DKT - 1) / DKT;
@@ -854,23 +804,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
 template <int NW>
 int launch_dma_tra(const AttnArgs& a, hipStream_t s) {
   const int nqb = cdiv(a.max_q_len, NW * 32);
-  hipLaunchKernelGGL((attention_bf16_dma_kernel<NW, true, true, true>),
-                     dim3(nqb * a.n_heads * a.n_seq), dim3(NW * 64), 0, s, a, nqb);
-  WN_HIP(hipGetLastError());
-  return 0;
-}
-
-template <int NW, bool PIPE, bool VTR = false>
-int launch_dma(const AttnArgs& a, hipStream_t s) {
-  if (!VTR) {
-    const int kt = cdiv(a.max_q_len, DKT);
-    hipLaunchKernelGGL(vt_pack_kernel, dim3(kt, a.n_heads, a.n_seq), dim3(256), 0, s,
-                       reinterpret_cast<const __bf16*>(a.V), a.ldv, a.kv_off, a.kv_len, a.n_heads,
-                       a.vt_tp, reinterpret_cast<__bf16*>(a.vt));
-    WN_HIP(hipGetLastError());
-  }
-  const int nqb = cdiv(a.max_q_len, NW * 32);
-  hipLaunchKernelGGL((attention_bf16_dma_kernel<NW, PIPE, VTR>), dim3(nqb * a.n_heads * a.n_seq),
+  hipLaunchKernelGGL((attention_bf16_dma_kernel<NW>), dim3(nqb * a.n_heads * a.n_seq),
                      dim3(NW * 64), 0, s, a, nqb);
   WN_HIP(hipGetLastError());
   return 0;
@@ -886,7 +820,7 @@ int launch(const AttnArgs& a, hipStream_t s) {
       hipLaunchKernelGGL((attention_bf16_kernel<NW, false, 1, true>), g, t, 0, s, a);
   } else if (a.P)
     hipLaunchKernelGGL((attention_bf16_kernel<NW, true>), g, t, 0, s, a);
-  else if (NW == 8 && g_attn_bf16_sub == 2)
+  else if (NW == 8)
     hipLaunchKernelGGL((attention_bf16_kernel<NW, false, 2, false>), g, t, 0, s, a);
   else
     hipLaunchKernelGGL((attention_bf16_kernel<NW, false>), g, t, 0, s, a);
@@ -897,9 +831,8 @@ int launch(const AttnArgs& a, hipStream_t s) {
 }  // namespace
 
 int g_attn_bf16_nw = 0;  // wn_tune_set("attn_bf16_nw"): 0 auto, else 2 / 4 / 8
-int g_attn_bf16_sub = 2; // 8-wave blocks: 32-key sub-tiles per barrier (1 or 2)
 int g_attn_bf16_defer = 80;  // wn_tune_set("attn_bf16_defer"): deferred-rescale threshold x 10 in log2 units (0 = rescale whenever a maximum moves)
-int g_attn_bf16_dma = 5; // bf16 Q | K | V self attention: 0 register-staged, 1 LDS-DMA staged (K rows + V^T image), 2 + grouped fragment reads, 4 V rows by DMA + ds_read_b64_tr_b16 (no V^T image), 5 = 4 with the transpose reads as inline asm (TRA, measurement form)
+int g_attn_bf16_dma = 1; // bf16 Q | K | V self attention: 0 = register-staged kernel (A/B, tests), else K / V rows by LDS-DMA + asm transpose reads
 
 int attention_bf16(const AttnArgs& a, hipStream_t s) {
   // argument checks are attention()'s (the only caller)
@@ -909,27 +842,19 @@ int attention_bf16(const AttnArgs& a, hipStream_t s) {
   int nw = g_attn_bf16_nw;
   if (nw != 2 && nw != 4 && nw != 8)
     nw = a.max_q_len >= 1024 ? 8 : a.max_q_len >= 384 ? 4 : 2;
-  // self attention over bf16 Q | K | V without masks: K and the packed V^T by LDS-DMA
-  const bool vtr = (g_attn_bf16_dma == 4 || g_attn_bf16_dma == 5) && a.ldv == a.ldk;    // V rows + transpose reads: no V^T image
+  // self attention over bf16 Q | K | V without masks: K and V rows by LDS-DMA, the PV fragments
+  // through transpose reads
   if (g_attn_bf16_dma != 0 && a.qkv_bf16 && !a.P && a.mask_mode == 0 && nw >= 4 &&
-      a.q_len == a.kv_len && a.q_off == a.kv_off && a.ldk % 8 == 0 && a.ldv % 8 == 0 &&
-      (vtr || (a.vt && a.vt_tp % DKT == 0 && a.vt_tp >= a.max_q_len)) &&
+      a.q_len == a.kv_len && a.q_off == a.kv_off && a.ldk % 8 == 0 && a.ldv == a.ldk &&
       (int64_t)a.max_q_len * a.ldk * 2 < (int64_t(1) << 31))
   {
-    // 4-wave blocks (128 queries) also for long sequences: twice the K / V^T stream from L2, but
+    // 4-wave blocks (128 queries) also for long sequences: twice the K / V stream from L2, but
     // barrier groups of four waves lose less to skew than groups of eight (config 5 fp8: 14.81 k
     // vs 14.62 k, r05v); attn_bf16_nw = 8 forces the 256-query blocks
     if (g_attn_bf16_nw != 8) nw = 4;
-    if (g_attn_bf16_dma == 2 || g_attn_bf16_dma == 4 || g_attn_bf16_dma == 5) {
-      AttnArgs d = a;
-      d.defer_thr = 0.1f * (float)g_attn_bf16_defer;
-      if (vtr && g_attn_bf16_dma == 5)
-        return nw == 8 ? launch_dma_tra<8>(d, s) : launch_dma_tra<4>(d, s);
-      if (vtr)
-        return nw == 8 ? launch_dma<8, true, true>(d, s) : launch_dma<4, true, true>(d, s);
-      return nw == 8 ? launch_dma<8, true>(d, s) : launch_dma<4, true>(d, s);
-    }
-    return nw == 8 ? launch_dma<8, false>(a, s) : launch_dma<4, false>(a, s);
+    AttnArgs d = a;
+    d.defer_thr = 0.1f * (float)g_attn_bf16_defer;
+    return nw == 8 ? launch_dma_tra<8>(d, s) : launch_dma_tra<4>(d, s);
   }
   switch (nw) {
     case 8: return launch<8>(a, s);

@@ -137,9 +137,7 @@ extern int g_bf16_store;
 
 // Tuning knobs (wn_tune_set): experiments / A-B runs only, defaults are the
 // shipped configuration.
-extern int g_gemm_variant;  // bit mask, see gemm.hip
-extern int g_gemm_tile_conv, g_gemm_tile_glu;
-extern int g_gemm_tile;     // 0 auto, else force a block configuration (gemm.hip)
-extern int g_gemm_tile_bf16;  // same for the bf16-operand kernels (gemm_bf16.hip)
+extern int g_gemm_tile_bf16;  // tests: 1 = the 128-row tiles of gemm_bf16{,s}.hip only, 8 = force the
+                              // pipelined 256 x 256 kernel (gemm_bf16p.hip); 0 = the shape rule
 
 }  // namespace wn

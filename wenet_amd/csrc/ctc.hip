@@ -94,65 +94,20 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(CtcRowArgs a) {
 
 // One WAVE per row, the row in registers (lane owns elements lane + 64 e): used when only
 // the top-k is wanted (the decode path).  The block kernel above pays k block-wide
-// arg-max rounds (two __syncthreads each) per row and ran at 0.9 TB/s; here a round is a
-// register scan + one wave reduction.  Same order: larger value first, lower index on
-// ties; a taken element becomes NaN, which no comparison selects.
-template <int EPL>
-__global__ __launch_bounds__(256) void ctc_row_wave_kernel(CtcRowArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.M) return;
-  const float* x = a.logits + (int64_t)row * a.ld;
-  float v[EPL];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int e = 0; e < EPL; ++e) {
-    const int i = e * 64 + lane;
-    float t = i < a.V ? x[i] : __builtin_nanf("");
-    if (i == a.blank) t -= a.blank_penalty;
-    v[e] = t;
-    mx = fmaxf(mx, t);            // fmaxf ignores the NaN padding
-  }
-  mx = wave_max(mx);
-  // the sum runs in the order of the block kernel (its thread 64 w + lane owns the
-  // elements e = w mod 4 of this lane; four wave sums added left to right), so both
-  // kernels return bit-identical log-probs -- tests compare the decode path's top-k with
-  // searches on the full log-prob tensor bit for bit
-  float sm4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int e = 0; e < EPL; ++e)
-    if (e * 64 + lane < a.V) sm4[e & 3] += expf(v[e] - mx);
-  const float lsum = logf(wave_sum(sm4[0]) + wave_sum(sm4[1]) + wave_sum(sm4[2]) +
-                          wave_sum(sm4[3]));
-  for (int r = 0; r < a.k; ++r) {
-    VI best;
-    best.v = -INFINITY;
-    best.i = 0x7fffffff;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e)
-      if (v[e] > best.v) { best.v = v[e]; best.i = e * 64 + lane; }   // e ascending: lowest index
-    const VI b = vi_wave(best);
-    if (lane == 0) {
-      a.topk_val[(int64_t)row * a.k + r] = (b.v - mx) - lsum;
-      a.topk_idx[(int64_t)row * a.k + r] = b.i;
-    }
-    const int te = b.i >> 6;
-    const bool mine = (b.i & 63) == lane;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e)
-      if (mine && e == te) v[e] = __builtin_nanf("");
-  }
-}
-
-// ctc_wave = 2 (end of round 3; bit-identical on the GPU; not the default yet): the
-// wave kernel above is bound by its VALU work -- k rounds x (EPL compares + selects, EPL
-// retire compares) = ~3 k instructions per row at EPL = 72, k = 10, 99 us per decode against
-// 27 us for reading the logits once.  Two levels: the lane keeps the maximum (value, index) of
-// each group of 8 of its elements; a round scans the EPL / 8 group maxima, and only the group
-// the winner came from is retired and rescanned -- the winner is wave-uniform, so that is one
-// scalar branch per group.  Same order everywhere (strict > while scanning indices upwards:
-// larger value first, lower index on ties; a taken element becomes NaN), same expressions for
-// the log-probs: the outputs are the wave kernel's, bit for bit.
+// arg-max rounds (two __syncthreads each) per row and ran at 0.9 TB/s.  Same order: larger
+// value first, lower index on ties; a taken element becomes NaN, which no comparison selects.
+// The sum runs in the order of the block kernel (its thread 64 w + lane owns the elements
+// e = w mod 4 of this lane; four wave sums added left to right), so both kernels return
+// bit-identical log-probs -- tests compare the decode path's top-k with searches on the full
+// log-prob tensor bit for bit.
+// Two levels (round 4 default; the one-level form -- a round scanned all EPL elements: k rounds
+// x (EPL compares + selects, EPL retire compares) = ~3 k VALU instructions per row at EPL = 72,
+// k = 10, 99 us per decode against 27 us for reading the logits once -- was bit-identical and is
+// removed): the lane keeps the maximum (value, index) of each group of 8 of its elements; a
+// round scans the EPL / 8 group maxima, and only the group the winner came from is retired and
+// rescanned -- the winner is wave-uniform, so that is one scalar branch per group.  Same order
+// everywhere (strict > while scanning indices upwards).  The selection order is restated lane
+// by lane on the CPU against a stable top-k (tests/test_ctc_topk_form.py).
 template <int EPL>
 __global__ __launch_bounds__(256, EPL <= 72 ? 3 : 2) void ctc_row_wave2_kernel(CtcRowArgs a) {
   constexpr int G = 8, NG = EPL / G;
@@ -473,10 +428,6 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
   // wave-uniform values must be PROVABLY uniform (SGPRs) or every loop on
   // them is compiled as a divergent, exec-masked loop
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // latency-bound (T dependent frames on one workgroup): when it shares CUs with the
-  // next batch's encoder kernels (DecodePipeline) it should win the issue arbitration
-  // instead of stretching to twice its length next to MFMA-heavy waves
-  if (a.prio > 0) __builtin_amdgcn_s_setprio(3);
   const int T = a.len[b], off = a.off[b];
   const int beam = a.beam;
   __shared__ HypSoA hyp[2];
@@ -1145,23 +1096,16 @@ __global__ __launch_bounds__(BIG_THREADS) void prefix_beam_big_kernel(PrefixBeam
 
 }  // namespace
 
-int g_ctc_wave = 2;   // wn_tune_set("ctc_wave"): 0 = always the block-per-row kernel; 2 = the wave kernel with two-level maxima
+int g_ctc_wave = 1;   // wn_tune_set("ctc_wave"): 0 = always the block-per-row kernel (A/B, tests)
 
 int ctc_logsoftmax_topk(const CtcRowArgs& a, hipStream_t s) {
   WN_CHECK(a.M > 0 && a.V > 0, "ctc: empty");
   WN_CHECK(a.k >= 1 && a.k <= a.V, "ctc: top-k must be in [1, vocab]");
   if (a.logp == nullptr && g_ctc_wave != 0 && a.V <= 96 * 64 && a.k <= 16) {
     dim3 g(cdiv(a.M, 4)), t(256);
-    if (g_ctc_wave == 2) {
-      if (a.V <= 8 * 64) hipLaunchKernelGGL(ctc_row_wave2_kernel<8>, g, t, 0, s, a);
-      else if (a.V <= 72 * 64) hipLaunchKernelGGL(ctc_row_wave2_kernel<72>, g, t, 0, s, a);
-      else hipLaunchKernelGGL(ctc_row_wave2_kernel<96>, g, t, 0, s, a);
-      WN_HIP(hipGetLastError());
-      return 0;
-    }
-    if (a.V <= 8 * 64) hipLaunchKernelGGL(ctc_row_wave_kernel<8>, g, t, 0, s, a);
-    else if (a.V <= 72 * 64) hipLaunchKernelGGL(ctc_row_wave_kernel<72>, g, t, 0, s, a);
-    else hipLaunchKernelGGL(ctc_row_wave_kernel<96>, g, t, 0, s, a);
+    if (a.V <= 8 * 64) hipLaunchKernelGGL(ctc_row_wave2_kernel<8>, g, t, 0, s, a);
+    else if (a.V <= 72 * 64) hipLaunchKernelGGL(ctc_row_wave2_kernel<72>, g, t, 0, s, a);
+    else hipLaunchKernelGGL(ctc_row_wave2_kernel<96>, g, t, 0, s, a);
     WN_HIP(hipGetLastError());
     return 0;
   }
@@ -1249,12 +1193,10 @@ int64_t prefix_beam_pool_ints(int max_len, int beam) {
   return 4 * ((int64_t)max_len * beam + 1);
 }
 
-int g_beam_prio = 0;   // s_setprio for the search waves: measured no effect (r02l), off
 int g_beam_weak_hash = 0;   // tests: 2-bit prefix hash (exercises the exact sequence test)
 
 int ctc_prefix_beam(const PrefixBeamArgs& a_in, hipStream_t s) {
   PrefixBeamArgs a = a_in;
-  a.prio = g_beam_prio;
   a.weak_hash = g_beam_weak_hash;
   WN_CHECK(a.B > 0, "prefix beam: empty batch");
   WN_CHECK(a.beam >= 1 && a.beam <= BIGB,

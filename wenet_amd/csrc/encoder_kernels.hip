@@ -495,13 +495,16 @@ constexpr int KSTR = 68;        // LDS row stride (floats): 64 + 4 pad
 // adds the same float4 of position row j (k <- k + p) and forms its share of u.k + v.p; 16
 // consecutive threads hold one key row, so four shuffles complete the scalar, which goes to
 // LDS next to the tile and is added to the score before the scale.
-// GLB (attn_gload = 1, with FOLD; end of round 3, bit-identical on the GPU, not the default yet): the K / V / P
-// loads of all of a thread's chunks are issued before the first fold.  In the default form every
-// chunk's three loads are followed by their own s_waitcnt and the chunk's dot product + four
-// shuffles before the next chunk's loads go out (read off the ISA at the end of round 3): NCH
-// dependent memory round trips per staging step instead of one; same arithmetic per element.
-template <int NW, bool RELPOS, int KS, bool FOLD = false, bool GLB = false>
+// GLB (the folded key-split kernel; the default since round 4, bit-identical to the chunk-by-chunk
+// form it replaced): the K / V / P loads of all of a thread's chunks are issued before the first
+// fold.  Chunk by chunk, every chunk's three loads were followed by their own s_waitcnt and the
+// chunk's dot product + four shuffles before the next chunk's loads went out (read off the ISA at
+// the end of round 3): NCH dependent memory round trips per staging step instead of one; same
+// arithmetic per element.  (KS == 1 keeps the chunk-by-chunk order: its loads are a register
+// prefetch one tile ahead.)
+template <int NW, bool RELPOS, int KS, bool FOLD = false>
 __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kernel(AttnArgs a) {
+  constexpr bool GLB = FOLD && KS == 2;
   const int s = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (NW * 32);
   const int qlen = a.q_len[s];
@@ -588,7 +591,6 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
     fu = *reinterpret_cast<const f32x4*>(a.bias_u + h * 64 + (tid & 15) * 4);
     fv = *reinterpret_cast<const f32x4*>(a.bias_v + h * 64 + (tid & 15) * 4);
   }
-  static_assert(!GLB || FOLD, "batched staging loads: a form of the folded kernel");
   auto gload = [&](int it) {
     if constexpr (GLB) {
       f32x4 rPf[NCH];
@@ -860,8 +862,6 @@ __global__ void copy_rows_kernel(const float* src, int lds, const int* src_rows,
 
 }  // namespace
 
-int g_ln_rows = 0;  // wn_tune_set("ln_rows"): 0 auto, 1 or 2 rows per wave
-
 int layernorm_mx(const float* x, int ldx, const float* w, const float* b, void* q,
                  unsigned* scale, int pitch, int M, int D, float eps, hipStream_t s) {
   WN_CHECK(M > 0 && ldx % 4 == 0 && D % 256 == 0 && pitch >= M,
@@ -907,17 +907,12 @@ int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
     WN_HIP(hipGetLastError());
     return 0;
   }
-  // two rows per wave: only on request (no gain measured)
-  const bool two = g_ln_rows == 2;
-  dim3 g(cdiv(M, two ? 8 : 4)), t(256);
+  // (two rows per wave measured no gain, DESIGN.md section 6: one row per wave only)
+  dim3 g(cdiv(M, 4)), t(256);
 #define WN_LN(E)                                                                 \
   case E * 64:                                                                   \
-    if (two)                                                                     \
-      hipLaunchKernelGGL((layernorm_kernel<E, 2>), g, t, 0, s, x, ldx, w, b, y,  \
-                         ldy, M, eps);                                           \
-    else                                                                         \
-      hipLaunchKernelGGL((layernorm_kernel<E, 1>), g, t, 0, s, x, ldx, w, b, y,  \
-                         ldy, M, eps);                                           \
+    hipLaunchKernelGGL((layernorm_kernel<E, 1>), g, t, 0, s, x, ldx, w, b, y,    \
+                       ldy, M, eps);                                             \
     break;
   switch (D) {
     WN_LN(1) WN_LN(2) WN_LN(3) WN_LN(4) WN_LN(6) WN_LN(8) WN_LN(10) WN_LN(12)
@@ -1030,7 +1025,6 @@ int relpos_fold(float* K, int ldk, const float* P, int ldp, const float* bias_u,
 }
 
 int g_attn_split = 0;  // wn_tune_set("attn_split")
-int g_attn_gload = 1;  // wn_tune_set("attn_gload"): 1 = folded key-split kernel with the staging loads of all chunks issued together (GLB)
 int g_attn_bf16 = 1;   // wn_tune_set("attn_bf16")
 
 int attention(const AttnArgs& a, hipStream_t s) {
@@ -1049,9 +1043,7 @@ int attention(const AttnArgs& a, hipStream_t s) {
   const bool fold = a.P != nullptr && a.fold && a.bias_u && a.bias_v;
   if (split) {
     dim3 t2(NW * 2 * 64);
-    if (fold && g_attn_gload == 1)
-      hipLaunchKernelGGL((attention_kernel<NW, false, 2, true, true>), g, t2, 0, s, a);
-    else if (fold)
+    if (fold)
       hipLaunchKernelGGL((attention_kernel<NW, false, 2, true>), g, t2, 0, s, a);
     else if (a.P)
       hipLaunchKernelGGL((attention_kernel<NW, true, 2>), g, t2, 0, s, a);

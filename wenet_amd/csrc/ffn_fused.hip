@@ -290,218 +290,6 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       }
 }
 
-// ---- 64-row variant (d_model = 256): TWO blocks per CU -------------------------------------
-// The 128-row kernel above owns a whole CU (160 KB LDS, 8 waves behind one barrier):
-// whenever its waves meet at the barrier the matrix pipes idle (MFMA busy 0.75,
-// profiles/r02p), and a kernel of the other decode stream that holds LDS on a CU (the
-// prefix beam search) keeps a whole block from being placed there.  This variant halves
-// the block: 64 rows of X, 4 waves, 2 x 32 KB stages + 16 KB H chunk = 80 KB, so two
-// independent blocks share a CU and fill each other's barrier / DMA waits; the grid is
-// tiles_m x S ~ 2 x 248.  A stage is still 32 KB: in phase A {X 64 rows, W1 chunk 64 rows}
-// x 64 k as two 16-KB halves of 32 k each (the 128-B swizzled rows of above), in phase B
-// 256 rows of W2 x 32 k.  Ring of 2 with the barrier at the TOP of a stage: wait for the
-// stage's DMA (the only one in flight), barrier, issue the next stage into the buffer
-// every wave has just left, compute.
-constexpr int GBM = 64;
-constexpr int GHC_BYTES = GBM * FHC * 4;   // 16 KB
-
-template <int ACT>
-__global__ __launch_bounds__(256, 2) void ffn_fused64_kernel(FfnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_g[];
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  constexpr int D = 256;
-  constexpr int NA = D / 64;            // phase-A stages per chunk (64 k each)
-  constexpr int NB = FHC / 32;          // phase-B stages per chunk
-  constexpr int SPC = NA + NB;
-  char* hc = smem_g + 2 * STG;          // H chunk [64][64] fp32, swizzled
-
-  const int tile_m = blockIdx.x / p.S, slice = blockIdx.x % p.S;
-  const int m0 = tile_m * GBM;
-  const int hs = p.F / p.S;
-  const int h_base = slice * hs;
-  const int nchunk = hs / FHC;
-  const int total = nchunk * SPC;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, li = lane & 31;
-
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.X), 0, (int)min((int64_t)p.M * D * 4, (int64_t)0x7fffffff), 0x00020000);
-  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.W1), 0, (int)min((int64_t)p.F * D * 4, (int64_t)0x7fffffff), 0x00020000);
-  const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.W2), 0, (int)min((int64_t)D * p.F * 4, (int64_t)0x7fffffff), 0x00020000);
-  // 8 one-KB pieces per wave and stage.  Phase B: piece q*4 + wave = stage rows (q*4 +
-  // wave)*8 .. +8 of W2.  Phase A: half q >> 2, piece (q & 3)*4 + wave of the half's 16
-  // (rows 0-63 X, 64-127 W1).
-  unsigned vx[2], vw1[2], vw2[8];
-  {
-    const int rr = lane >> 3;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = (q * 4 + wave) * 8 + rr;              // stage row 0..255
-      const unsigned swz = (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
-      if (q < 2) vx[q] = (unsigned)min(m0 + r, p.M - 1) * (unsigned)(D * 4) + swz;
-      else if (q < 4) vw1[q - 2] = (unsigned)(r - 64) * (unsigned)(D * 4) + swz;
-      vw2[q] = (unsigned)r * (unsigned)p.F * 4u + swz;
-    }
-  }
-  auto issue = [&](int g) {
-    const int c = g / SPC, i = g - c * SPC;
-    const int h0 = h_base + c * FHC;
-    char* dst = smem_g + (g & 1) * STG + wave * 1024;
-    if (i < NA) {
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int koff = i * 256 + half * 128;
-        const int w1off = h0 * (D * 4) + koff;
-        char* dh = dst + half * 16384;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(dh), 16, vx[0], koff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(dh + 4096), 16, vx[1], koff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(dh + 8192), 16, vw1[0], w1off, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(dh + 12288), 16, vw1[1], w1off, 0, 0);
-      }
-    } else {
-      const int off = (h0 + (i - NA) * 32) * 4;
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr)(dst + q * 4096), 16, vw2[q], off,
-                                                 0, 0);
-    }
-  };
-
-  const int sw = (lane >> 1) & 7;
-  int foff[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) foff[kk] = li * 128 + (((kk * 2 + hi) ^ sw) << 4);
-  const int wm = wave >> 1, wn = wave & 1;     // phase A: 2 (M) x 2 (N) tiles of 32 x 32
-  const int hrow_sw = li & 15;                 // phase B: wave = 64-column slab of Y
-
-  constexpr int MAXC = 16;
-  float b1v[MAXC];
-#pragma unroll
-  for (int c = 0; c < MAXC; ++c)
-    b1v[c] = c < nchunk ? p.b1[h_base + c * FHC + wn * 32 + li] : 0.f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int c = 0; c < MAXC; ++c) asm volatile("" : "+v"(b1v[c]));
-
-  f32x16 yacc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) yacc[i][j][r] = 0.f;
-
-  struct FragA { f32x4 a, b; };
-  struct FragB { f32x4 a[2], b[2]; };
-  auto loadA = [&](int gg, int kg) {           // kg = 0..7: half kg >> 2, k-group kg & 3
-    const char* st = smem_g + (gg & 1) * STG + (kg >> 2) * 16384;
-    FragA f;
-    f.a = *reinterpret_cast<const f32x4*>(st + (wm * 32) * 128 + foff[kg & 3]);
-    f.b = *reinterpret_cast<const f32x4*>(st + (64 + wn * 32) * 128 + foff[kg & 3]);
-    return f;
-  };
-  auto loadB = [&](int gg, int kt, int kk) {
-    const char* st = smem_g + (gg & 1) * STG;
-    FragB f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int row = mt * 32 + li;
-      const int k4 = kt * 8 + kk * 2 + hi;
-      f.a[mt] = *reinterpret_cast<const f32x4*>(hc + row * 256 + ((k4 ^ hrow_sw) << 4));
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-      f.b[nt] = *reinterpret_cast<const f32x4*>(st + (wave * 64 + nt * 32) * 128 + foff[kk]);
-    return f;
-  };
-  auto stage_top = [&](int gg) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage gg
-    __builtin_amdgcn_s_barrier();                       // everyone's; stage gg-1 is free
-  };
-
-  issue(0);
-  int g = 0;
-  for (int c = 0; c < nchunk; ++c) {
-    f32x16 hacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
-    auto mmaA = [&](const FragA& f) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s], f.b[s], hacc, 0, 0, 0);
-    };
-    for (int i = 0; i < NA; ++i, ++g) {
-      stage_top(g);
-      FragA f0 = loadA(g, 0), f1 = loadA(g, 1);
-      issue(g + 1);                      // g + 1 < total: phase B follows
-#pragma unroll
-      for (int kg = 0; kg < 8; kg += 2) {
-        FragA n0, n1;
-        if (kg + 2 < 8) { n0 = loadA(g, kg + 2); n1 = loadA(g, kg + 3); }
-        mmaA(f0); mmaA(f1);
-        if (kg + 2 < 8) { f0 = n0; f1 = n1; }
-      }
-    }
-    {
-      float bias = 0.f;
-#pragma unroll
-      for (int cc = 0; cc < MAXC; ++cc) bias = cc == c ? b1v[cc] : bias;
-      const int col = wn * 32 + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float x = hacc[r] + bias;
-        if (ACT == ACT_SILU) x = silu_fast(x);
-        if (ACT == ACT_RELU) x = fmaxf(x, 0.f);
-        if (ACT == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        *reinterpret_cast<float*>(hc + row * 256 + ((((col >> 2) ^ (row & 15))) << 4) +
-                                  (col & 3) * 4) = x;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // H written before the next barrier
-#pragma unroll
-    for (int j = 0; j < NB; ++j, ++g) {
-      stage_top(g);                      // j == 0: also makes H visible
-      FragB f0 = loadB(g, j, 0);
-      if (g + 1 < total) issue(g + 1);
-      auto mmaB = [&](const FragB& f) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-              yacc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mt][s], f.b[nt][s],
-                                                                  yacc[mt][nt], 0, 0, 0);
-      };
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        FragB n;
-        if (kk + 1 < 4) n = loadB(g, j, kk + 1);
-        mmaB(f0);
-        if (kk + 1 < 4) f0 = n;
-      }
-    }
-  }
-
-  float* P = p.P + (int64_t)slice * p.M * D;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = wave * 64 + nt * 32 + li;
-      const int row0 = m0 + mt * 32 + 4 * hi;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
-        if (row < p.M) P[(int64_t)row * D + col] = yacc[mt][nt][r];
-      }
-    }
-}
 
 // x_new = x + alpha * (sum_s P[s] + b2); y = LN(x_new; w, b) [; y2 = LN(y; w2, b2)]
 // One wave per row (RowRegs layout of encoder_kernels.hip: 4 consecutive columns per lane
@@ -574,23 +362,12 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(
 }  // namespace
 
 int g_ffn_fused = 1;     // wn_tune_set("ffn_fused"): 0 = the two-GEMM path (A/B, tests)
-int g_ffn_ring = 4;      // DMA ring depth (4 stages; the knob is kept for A/B builds)
-
-// wn_tune_set("ffn_bm64"): 1 = 64-row blocks, two per CU, at d = 256.  Off by default:
-// alone it is 2 % faster (139.4 vs 142 us at config 2) and immune to the other decode
-// stream's LDS-holding kernels (bracketed 141 vs 168 us), but the two-stream decode step as
-// a whole got SLOWER (8.51 vs 8.31 ms, r02s): the other stream's latency-bound kernels now
-// share every CU with 8 FFN waves instead of waiting blocks.
-int g_ffn_bm64 = 0;
-
-static bool ffn_use64(int D) { return D == 256 && g_ffn_bm64 != 0; }
 
 // hidden split: the largest S in {1, 2, 4, 8, 16} with tiles_m * S blocks filling the CUs
-// once (128-row blocks, one per CU) or twice (64-row blocks, two per CU), at least one
+// once (128-row blocks, one per CU), at least one
 // 64-wide chunk and at most 16 per block
 int ffn_fused_split(int M, int D, int F) {
-  const bool v64 = ffn_use64(D);
-  const int tiles_m = cdiv(M, v64 ? GBM : FBM), cap = v64 ? 512 : 256;
+  const int tiles_m = cdiv(M, FBM), cap = 256;
   int S = 1;
   while (S < 16 && tiles_m * (S * 2) <= cap && F % (S * 2 * FHC) == 0) S *= 2;
   while (F / S / FHC > 16) {          // more chunks than the bias registers hold
@@ -608,23 +385,7 @@ bool ffn_fused_supported(int M, int D, int F, int act) {
   const int S = ffn_fused_split(M, D, F);
   if (S <= 0) return false;
   // fewer blocks: the GEMM pair fills the chip better (g_ffn_fused == 2: tests force it)
-  const bool v64 = ffn_use64(D);
-  return g_ffn_fused == 2 || cdiv(M, v64 ? GBM : FBM) * S >= (v64 ? 256 : 128);
-}
-
-template <int ACT>
-int launch_ffn64(const FfnArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)2 * STG + GHC_BYTES;      // 80 KB: two blocks per CU
-  auto kern = ffn_fused64_kernel<ACT>;
-  static bool done = false;
-  if (!done) {
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(cdiv(a.M, GBM) * a.S), dim3(256), lds, s, a);
-  WN_HIP(hipGetLastError());
-  return 0;
+  return g_ffn_fused == 2 || cdiv(M, FBM) * S >= 128;
 }
 
 template <int ND, int ACT>
@@ -655,14 +416,7 @@ int ffn_fused(const FfnArgs& a, hipStream_t s) {
     case ACT_GELU: return launch_ffn<ND, ACT_GELU>(a, s);                  \
     default: break;                                                        \
   }
-  if (ffn_use64(a.D)) {
-    switch (a.act) {
-      case ACT_SILU: return launch_ffn64<ACT_SILU>(a, s);
-      case ACT_RELU: return launch_ffn64<ACT_RELU>(a, s);
-      case ACT_GELU: return launch_ffn64<ACT_GELU>(a, s);
-      default: break;
-    }
-  } else if (a.D == 256) { WN_FFN(1) } else { WN_FFN(2) }
+  if (a.D == 256) { WN_FFN(1) } else { WN_FFN(2) }
 #undef WN_FFN
   set_error("ffn_fused: unsupported activation");
   return -1;

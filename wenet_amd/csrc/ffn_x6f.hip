@@ -610,7 +610,7 @@ int launch_x6f(const FfnX6Args& a, hipStream_t s) {
   const int tiles_m = cdiv(a.M, 128);
   const int NC = a.F / a.S / 64;
   const size_t lds = (size_t)RING * XSTAGE * ((VAR & 512) ? 2 : 1) + (size_t)NC * 64 * sizeof(float);
-  const int pairmap = g_ffn_x6f_map != 0 && a.S >= 2 && a.S <= 8;
+  const int pairmap = a.S >= 2 && a.S <= 8;   // two hidden slices per XCD: X rows fetched twice, not S times
   const int grid = pairmap      ? cdiv(tiles_m, 16 / a.S) * 16
                    : a.S <= 8 ? cdiv(tiles_m, 8 / a.S) * 8
                               : tiles_m * a.S;
@@ -629,9 +629,8 @@ int launch_x6f(const FfnX6Args& a, hipStream_t s) {
 }  // namespace
 
 int g_ffn_x6f = 1;        // wn_tune_set("ffn_x6f"): 0 = the two six-product GEMMs (A/B, tests)
-int g_ffn_x6f_ring = 3;   // wn_tune_set("ffn_x6f_ring"): 3 = three stages of 48 records (default), 4..6 = stages of 24
-int g_ffn_x6f_map = 1;    // wn_tune_set("ffn_x6f_map"): 1 = two hidden slices per XCD (X rows fetched twice, not S times)
-int g_ffn_x6f_var = 0;    // wn_tune_set("ffn_x6f_var"): measurement variants of the kernel (VAR)
+int g_ffn_x6f_ring = 3;   // WN_ABLATION builds: 4..6 = the older stages of 24 records
+int g_ffn_x6f_var = 0;    // wn_tune_set("ffn_x6f_var"): 25088 = clock stamps; WN_ABLATION builds: the VAR variants
 
 int ffn_x6f_clocks(unsigned long long* out) {
   WN_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x6f_clk), sizeof(g_x6f_clk)));
@@ -676,6 +675,12 @@ int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
     case ACT_RELU: return launch_x6f<ACT_RELU, RING, VAR>(a, s);     \
     default: break;                                                  \
   }
+  // the default kernel with shader-clock stamps (same results; bench.py samples the clock the
+  // kernel ran at through it, tools/ffn_clocks.py)
+  if (g_ffn_x6f_var == 25088 && a.act == ACT_SILU) return launch_x6f<ACT_SILU, 3, 25088>(a, s);
+#ifdef WN_ABLATION
+  // measurement builds only (python -m wenet_amd.build with WN_ABLATION=1): variants that leave
+  // out a part of the kernel -- WRONG RESULTS BY DESIGN -- and the older stage shapes
   if (g_ffn_x6f_var != 0 && a.act == ACT_SILU) {
     switch (g_ffn_x6f_var) {
       case 1: return launch_x6f<ACT_SILU, 6, 1>(a, s);
@@ -698,7 +703,6 @@ int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
       case 82432: return launch_x6f<ACT_SILU, 3, 82432>(a, s);   // measurement: half of the MFMAs
       case 90624: return launch_x6f<ACT_SILU, 3, 90624>(a, s);   // ... + clock stamps
       case 512: return launch_x6f<ACT_SILU, 3, 512>(a, s);       // DMA of a stage as one burst behind the barrier
-      case 25088: return launch_x6f<ACT_SILU, 3, 25088>(a, s);   // default kernel + clock stamps
       case 8768: return launch_x6f<ACT_SILU, 3, 8768>(a, s);     // ... without fragment reads
       case 8708: return launch_x6f<ACT_SILU, 3, 8708>(a, s);     // ... without pieces
       case 8706: return launch_x6f<ACT_SILU, 3, 8706>(a, s);     // ... without DMA
@@ -706,11 +710,12 @@ int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
       default: break;
     }
   }
-  // ring 3 (default): three stages of 48 records; 4..6: stages of 24 records
-  if (g_ffn_x6f_ring <= 3) { WN_X6F(3, 16896) }
-  else if (g_ffn_x6f_ring == 4) { WN_X6F(4, 0) }
+  if (g_ffn_x6f_ring == 4) { WN_X6F(4, 0) }
   else if (g_ffn_x6f_ring == 5) { WN_X6F(5, 0) }
-  else { WN_X6F(6, 0) }
+  else if (g_ffn_x6f_ring >= 6) { WN_X6F(6, 0) }
+#endif
+  // three stages of 48 records
+  WN_X6F(3, 16896)
 #undef WN_X6F
   set_error("ffn_x6f: unsupported activation");
   return -1;

@@ -28,10 +28,6 @@
 
 namespace wn {
 
-int g_gemm_variant = 0;
-int g_gemm_tile = 0;
-int g_gemm_tile_conv = 0;
-int g_gemm_tile_glu = 0;
 thread_local int t_gemm_prec = PREC_F32;
 
 namespace {
@@ -41,7 +37,7 @@ constexpr int BK = 32;  // K granularity every problem must respect
 template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
           bool CONV, int BK = 32, int PF = 1>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
-    GemmArgs p, int tiles_m, int tiles_n, int variant) {
+    GemmArgs p, int tiles_m, int tiles_n) {
   constexpr int LDS_STRIDE = BK + 4;  // floats; rows land on distinct 16-B slots
   constexpr int KC = BK / 4;          // float4 chunks per tile row
   constexpr int NTHR = WGM * WGN * 64;
@@ -190,8 +186,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f32_kernel(
     }
   }
 
-  gemm_epilogue<BM, BN, WGM, WGN, ACT, RESID, GLU>(p, acc, m0, n0, wm, wn_, lane,
-                                                   variant);
+  gemm_epilogue<BM, BN, WGM, WGN, ACT, RESID, GLU>(p, acc, m0, n0, wm, wn_, lane);
 }
 
 template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
@@ -208,24 +203,29 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WGM * WGN * 64), lds,
-                     stream, a, tiles_m, tiles_n, g_gemm_variant);
+                     stream, a, tiles_m, tiles_n);
   WN_HIP(hipGetLastError());
   return 0;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool CONV>
+// GLU_ONLY: the block shapes with a 64-wide wave tile exist for the GLU epilogue alone; every
+// other shape is instantiated for the plain epilogues only (the kernels the tile rule below can
+// reach, nothing else)
+template <int BM, int BN, int WGM, int WGN, bool CONV, bool GLU_ONLY = false>
 int dispatch_epi(const GemmArgs& a, hipStream_t s) {
   const bool resid = a.resid != nullptr;
   // long K loops stream an operand from HBM / Infinity Cache: prefetch two
   // tiles ahead there (measured +2..4 %); short ones (K = d) gain nothing
-  const bool pf2 = !CONV && ((a.K >= 1024) != ((g_gemm_variant & 128) != 0));
+  const bool pf2 = !CONV && a.K >= 1024;
+  if constexpr (GLU_ONLY) {
+    static_assert(BN / WGN == 64 && !CONV, "GLU epilogue needs a 64-wide wave tile");
+    if (a.glu) return launch<BM, BN, WGM, WGN, ACT_NONE, false, true, false>(a, s);
+    set_error("gemm: this block shape is built for the GLU epilogue only");
+    return -1;
+  } else {
   if (a.glu) {
-    if constexpr (BN / WGN == 64 && !CONV) {
-      return launch<BM, BN, WGM, WGN, ACT_NONE, false, true, false>(a, s);
-    } else {
-      set_error("gemm: GLU epilogue needs a 64-wide wave tile");
-      return -1;
-    }
+    set_error("gemm: GLU epilogue needs a 64-wide wave tile");
+    return -1;
   }
   switch (a.act) {
     case ACT_NONE:
@@ -248,6 +248,7 @@ int dispatch_epi(const GemmArgs& a, hipStream_t s) {
                      : launch<BM, BN, WGM, WGN, ACT_RELU, false, false, CONV, 32, 2>(a, s);
       return resid ? launch<BM, BN, WGM, WGN, ACT_RELU, true, false, CONV>(a, s)
                    : launch<BM, BN, WGM, WGN, ACT_RELU, false, false, CONV>(a, s);
+  }
   }
   set_error("gemm: unsupported epilogue");
   return -1;
@@ -274,40 +275,20 @@ int gemm_f32(const GemmArgs& a, hipStream_t stream) {
   // shrinks with the problem so that the grid still covers the 256 CUs.
   //   1: 128x128, 2x4 waves   2: 128x128, 4x2 waves (64-wide wave tile: GLU)
   //   3: 64x128, 2x4 waves    4: 64x128, 2x2 waves (GLU)   5: 64x64, 2x2 waves
-  //   6: 128x128, 2x2 waves
-  //   7: 256x256, 4x2 waves (144 KB LDS, 1 block per CU) -- only on request
-  //      (gemm_tile=7): +3.5 % on the isolated FFN-w1 shape (248 tiles, one
-  //      round), but -14 % inside the decode pipeline, where the other stream's
-  //      search kernel holds CUs and a 1-block-per-CU grid cannot rebalance
+  //   6: 128x128, 2x2 waves (conv)
+  // (a 256x256 one-block-per-CU tile was +3.5 % on the isolated FFN-w1 shape and -14 % inside
+  // the decode pipeline, where the other stream's search kernel holds CUs: removed)
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
   const int64_t t64x128 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 128);
-  int cfg;
-  if (a.glu) cfg = t128 >= 224 ? 2 : 4;
-  else if (conv) cfg = t128 >= 384 ? 6 : 4;  // K = 9C: the 4-wave block wins
-  else if (t128 >= 384) cfg = 1;
-  else if (t64x128 >= 384) cfg = 3;
-  else cfg = 5;
-  const int forced = a.glu ? g_gemm_tile_glu : conv ? g_gemm_tile_conv : g_gemm_tile;
-  if (forced > 0) {
-    const int t = forced;
-    const bool ok = a.glu ? (t == 2 || t == 4)
-                          : conv ? (t == 1 || t == 2 || t == 4 || t == 6)
-                                 : (t >= 1 && t <= 7);
-    if (ok) cfg = t;
-  }
-  switch (cfg) {
-    case 1: return conv ? dispatch_epi<128, 128, 2, 4, true>(a, stream)
-                        : dispatch_epi<128, 128, 2, 4, false>(a, stream);
-    case 2: return conv ? dispatch_epi<128, 128, 4, 2, true>(a, stream)
-                        : dispatch_epi<128, 128, 4, 2, false>(a, stream);
-    case 3: return dispatch_epi<64, 128, 2, 4, false>(a, stream);
-    case 4: return conv ? dispatch_epi<64, 128, 2, 2, true>(a, stream)
-                        : dispatch_epi<64, 128, 2, 2, false>(a, stream);
-    case 5: return dispatch_epi<64, 64, 2, 2, false>(a, stream);
-    case 7: return dispatch_epi<256, 256, 4, 2, false>(a, stream);
-    default: return conv ? dispatch_epi<128, 128, 2, 2, true>(a, stream)
-                         : dispatch_epi<128, 128, 2, 2, false>(a, stream);
-  }
+  if (a.glu)
+    return t128 >= 224 ? dispatch_epi<128, 128, 4, 2, false, true>(a, stream)
+                       : dispatch_epi<64, 128, 2, 2, false, true>(a, stream);
+  if (conv)   // K = 9C: the 4-wave block wins
+    return t128 >= 384 ? dispatch_epi<128, 128, 2, 2, true>(a, stream)
+                       : dispatch_epi<64, 128, 2, 2, true>(a, stream);
+  if (t128 >= 384) return dispatch_epi<128, 128, 2, 4, false>(a, stream);
+  if (t64x128 >= 384) return dispatch_epi<64, 128, 2, 4, false>(a, stream);
+  return dispatch_epi<64, 64, 2, 2, false>(a, stream);
 }
 
 }  // namespace wn

@@ -47,7 +47,7 @@ __device__ __forceinline__ bf16x4 to_bf16(const f32x4& v) {
 template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
           bool CONV, int BK>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel(
-    GemmArgs p, int tiles_m, int tiles_n, int variant) {
+    GemmArgs p, int tiles_m, int tiles_n) {
   constexpr int LDS_STRIDE = BK + 8;  // bf16 elements; +16 B per row
   constexpr int KC = BK / 4;          // 4-element chunks per tile row
   constexpr int NTHR = WGM * WGN * 64;
@@ -175,8 +175,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel(
     }
   }
 
-  gemm_epilogue<BM, BN, WGM, WGN, ACT, RESID, GLU>(p, acc, m0, n0, wm, wn_, lane,
-                                                   variant);
+  gemm_epilogue<BM, BN, WGM, WGN, ACT, RESID, GLU>(p, acc, m0, n0, wm, wn_, lane);
 }
 
 template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
@@ -193,21 +192,24 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WGM * WGN * 64), lds,
-                     stream, a, tiles_m, tiles_n, g_gemm_variant);
+                     stream, a, tiles_m, tiles_n);
   WN_HIP(hipGetLastError());
   return 0;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool CONV, int BKT>
+// GLU_ONLY: as in gemm.hip -- only the kernels the tile rule below can reach are instantiated
+template <int BM, int BN, int WGM, int WGN, bool CONV, int BKT, bool GLU_ONLY = false>
 int dispatch_epi(const GemmArgs& a, hipStream_t s) {
   const bool resid = a.resid != nullptr;
+  if constexpr (GLU_ONLY) {
+    static_assert(BN / WGN == 64 && !CONV, "GLU epilogue needs a 64-wide wave tile");
+    if (a.glu) return launch<BM, BN, WGM, WGN, ACT_NONE, false, true, false, BKT>(a, s);
+    set_error("gemm(bf16): this block shape is built for the GLU epilogue only");
+    return -1;
+  } else {
   if (a.glu) {
-    if constexpr (BN / WGN == 64 && !CONV) {
-      return launch<BM, BN, WGM, WGN, ACT_NONE, false, true, false, BKT>(a, s);
-    } else {
-      set_error("gemm(bf16): GLU epilogue needs a 64-wide wave tile");
-      return -1;
-    }
+    set_error("gemm(bf16): GLU epilogue needs a 64-wide wave tile");
+    return -1;
   }
   switch (a.act) {
     case ACT_NONE:
@@ -224,6 +226,7 @@ int dispatch_epi(const GemmArgs& a, hipStream_t s) {
     case ACT_RELU:
       return resid ? launch<BM, BN, WGM, WGN, ACT_RELU, true, false, CONV, BKT>(a, s)
                    : launch<BM, BN, WGM, WGN, ACT_RELU, false, false, CONV, BKT>(a, s);
+  }
   }
   set_error("gemm(bf16): unsupported epilogue");
   return -1;
@@ -243,31 +246,19 @@ int dispatch_tile(const GemmArgs& a, bool conv, hipStream_t stream) {
   // at 470 tiles with K=1280, and badly when it cannot cover the CUs.
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
   const int64_t t256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
-  int cfg;
-  if (a.glu) cfg = t128 >= 224 ? 2 : 4;
-  else if (conv) cfg = t128 >= 224 ? 1 : 4;
-  else if (BKT == 64 && t256 >= 256 && (t256 >= 1024 || a.K >= 2048)) cfg = 7;
-  else cfg = t128 >= 224 ? 1 : 5;
-  const int forced = g_gemm_tile_bf16;
-  if (forced > 0) {
-    const bool ok = a.glu ? (forced == 2 || forced == 4)
-                          : conv ? (forced == 1 || forced == 2 || forced == 4)
-                                 : (forced == 1 || forced == 2 || forced == 4 ||
-                                    forced == 5 || (forced == 7 && BKT == 64));
-    if (ok) cfg = forced;
+  // gemm_tile_bf16 = 1 (tests: the pipelined kernel against these): never the 256-row tile
+  if (a.glu)
+    return t128 >= 224 ? dispatch_epi<128, 128, 4, 2, false, BKT, true>(a, stream)
+                       : dispatch_epi<64, 128, 2, 2, false, BKT, true>(a, stream);
+  if (conv)
+    return t128 >= 224 ? dispatch_epi<128, 128, 2, 4, true, BKT>(a, stream)
+                       : dispatch_epi<64, 128, 2, 2, true, BKT>(a, stream);
+  if constexpr (BKT == 64) {
+    if (g_gemm_tile_bf16 != 1 && t256 >= 256 && (t256 >= 1024 || a.K >= 2048))
+      return dispatch_epi<256, 256, 4, 2, false, 64>(a, stream);
   }
-  switch (cfg) {
-    case 1: return conv ? dispatch_epi<128, 128, 2, 4, true, BKT>(a, stream)
-                        : dispatch_epi<128, 128, 2, 4, false, BKT>(a, stream);
-    case 2: return conv ? dispatch_epi<128, 128, 4, 2, true, BKT>(a, stream)
-                        : dispatch_epi<128, 128, 4, 2, false, BKT>(a, stream);
-    case 4: return conv ? dispatch_epi<64, 128, 2, 2, true, BKT>(a, stream)
-                        : dispatch_epi<64, 128, 2, 2, false, BKT>(a, stream);
-    case 7:
-      if constexpr (BKT == 64) return dispatch_epi<256, 256, 4, 2, false, 64>(a, stream);
-      [[fallthrough]];
-    default: return dispatch_epi<64, 64, 2, 2, false, BKT>(a, stream);
-  }
+  return t128 >= 224 ? dispatch_epi<128, 128, 2, 4, false, BKT>(a, stream)
+                     : dispatch_epi<64, 64, 2, 2, false, BKT>(a, stream);
 }
 
 }  // namespace

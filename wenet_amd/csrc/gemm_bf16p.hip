@@ -592,13 +592,6 @@ int dispatch_p(const GemmArgs& args, const void* W, hipStream_t stream) {
   GemmArgs a = args;
   if (g_lp_probe) a.probe = g_lp_probe;
   const bool resid = a.resid != nullptr;
-  if (g_gemm_variant != 0 && !a.c_bf16 && !a.c_mx && !resid && a.act == ACT_NONE) {
-    switch (g_gemm_variant) {   // experiments (tools/bench_gemm.py --variants)
-      case 1: return launch_p<ET, ACT_NONE, false, 0, 1>(a, W, stream);
-      case 16: return launch_p<ET, ACT_NONE, false, 0, 16>(a, W, stream);
-      default: break;
-    }
-  }
   if (a.c_mx) {
     if constexpr (ET == 1) {
       switch (a.act) {

@@ -25,7 +25,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU, bool CH,
           int BK>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16s_kernel(
-    GemmArgs p, const __bf16* __restrict__ Wh, int tiles_m, int tiles_n, int variant) {
+    GemmArgs p, const __bf16* __restrict__ Wh, int tiles_m, int tiles_n) {
   constexpr int LDS_STRIDE = BK + 8;  // bf16 elements; +16 B per row
   constexpr int KC = BK / 8;          // 8-element (16-byte) chunks per tile row
   constexpr int NTHR = WGM * WGN * 64;
@@ -148,8 +148,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16s_kernel(
     if (kt < nk) compute(0);        // odd tile count: the last tile is in buf 0
   }
 
-  gemm_epilogue<BM, BN, WGM, WGN, ACT, RESID, GLU, CH>(p, acc, m0, n0, wm, wn_, lane,
-                                                       variant);
+  gemm_epilogue<BM, BN, WGM, WGN, ACT, RESID, GLU, CH>(p, acc, m0, n0, wm, wn_, lane);
 }
 
 template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU, bool CH,
@@ -166,21 +165,24 @@ int launch(const GemmArgs& a, const __bf16* Wh, hipStream_t stream) {
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WGM * WGN * 64), lds,
-                     stream, a, Wh, tiles_m, tiles_n, g_gemm_variant);
+                     stream, a, Wh, tiles_m, tiles_n);
   WN_HIP(hipGetLastError());
   return 0;
 }
 
-template <int BM, int BN, int WGM, int WGN, int BKT>
+// GLU_ONLY: as in gemm.hip -- only the kernels the tile rule below can reach are instantiated
+template <int BM, int BN, int WGM, int WGN, int BKT, bool GLU_ONLY = false>
 int dispatch_epi(const GemmArgs& a, const __bf16* Wh, bool ch, hipStream_t s) {
   const bool resid = a.resid != nullptr;
+  if constexpr (GLU_ONLY) {
+    static_assert(BN / WGN == 64, "GLU epilogue needs a 64-wide wave tile");
+    if (a.glu) return launch<BM, BN, WGM, WGN, ACT_NONE, false, true, false, BKT>(a, Wh, s);
+    set_error("gemm(bf16 stored): this block shape is built for the GLU epilogue only");
+    return -1;
+  } else {
   if (a.glu) {
-    if constexpr (BN / WGN == 64) {
-      return launch<BM, BN, WGM, WGN, ACT_NONE, false, true, false, BKT>(a, Wh, s);
-    } else {
-      set_error("gemm(bf16 stored): GLU epilogue needs a 64-wide wave tile");
-      return -1;
-    }
+    set_error("gemm(bf16 stored): GLU epilogue needs a 64-wide wave tile");
+    return -1;
   }
   if (ch) {  // bf16 C: no residual (checked by the caller)
     switch (a.act) {
@@ -204,6 +206,7 @@ int dispatch_epi(const GemmArgs& a, const __bf16* Wh, bool ch, hipStream_t s) {
       return resid ? launch<BM, BN, WGM, WGN, ACT_RELU, true, false, false, BKT>(a, Wh, s)
                    : launch<BM, BN, WGM, WGN, ACT_RELU, false, false, false, BKT>(a, Wh, s);
   }
+  }
   set_error("gemm(bf16 stored): unsupported epilogue");
   return -1;
 }
@@ -213,26 +216,15 @@ int dispatch_tile(const GemmArgs& a, const __bf16* Wh, bool ch, hipStream_t stre
   // the block-shape rule of gemm_bf16.hip (same tiles, same measurements)
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
   const int64_t t256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
-  int cfg;
-  if (a.glu) cfg = t128 >= 224 ? 2 : 4;
-  else if (BKT == 64 && t256 >= 256 && (t256 >= 1024 || a.K >= 2048)) cfg = 7;
-  else cfg = t128 >= 224 ? 1 : 5;
-  const int forced = g_gemm_tile_bf16;
-  if (forced > 0) {
-    const bool ok = a.glu ? (forced == 2 || forced == 4)
-                          : (forced == 1 || forced == 2 || forced == 4 || forced == 5 ||
-                             (forced == 7 && BKT == 64));
-    if (ok) cfg = forced;
+  if (a.glu)
+    return t128 >= 224 ? dispatch_epi<128, 128, 4, 2, BKT, true>(a, Wh, ch, stream)
+                       : dispatch_epi<64, 128, 2, 2, BKT, true>(a, Wh, ch, stream);
+  if constexpr (BKT == 64) {
+    if (g_gemm_tile_bf16 != 1 && t256 >= 256 && (t256 >= 1024 || a.K >= 2048))
+      return dispatch_epi<256, 256, 4, 2, 64>(a, Wh, ch, stream);
   }
-  switch (cfg) {
-    case 1: return dispatch_epi<128, 128, 2, 4, BKT>(a, Wh, ch, stream);
-    case 2: return dispatch_epi<128, 128, 4, 2, BKT>(a, Wh, ch, stream);
-    case 4: return dispatch_epi<64, 128, 2, 2, BKT>(a, Wh, ch, stream);
-    case 7:
-      if constexpr (BKT == 64) return dispatch_epi<256, 256, 4, 2, 64>(a, Wh, ch, stream);
-      [[fallthrough]];
-    default: return dispatch_epi<64, 64, 2, 2, BKT>(a, Wh, ch, stream);
-  }
+  return t128 >= 224 ? dispatch_epi<128, 128, 2, 4, BKT>(a, Wh, ch, stream)
+                     : dispatch_epi<64, 64, 2, 2, BKT>(a, Wh, ch, stream);
 }
 
 __global__ void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y,

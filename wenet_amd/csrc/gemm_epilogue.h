@@ -21,7 +21,7 @@ template <int BM, int BN, int WGM, int WGN, int ACT, bool RESID, bool GLU,
           bool CH = false>
 __device__ __forceinline__ void gemm_epilogue(
     const GemmArgs& p, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0,
-    int n0, int wm, int wn_, int lane, int variant) {
+    int n0, int wm, int wn_, int lane) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
   static_assert(!CH || (!RESID && !GLU), "bf16 C: plain / activation epilogues only");
@@ -43,8 +43,7 @@ __device__ __forceinline__ void gemm_epilogue(
       for (int r = 0; r < 16; ++r) {
         const float a = acc[i][0][r] + ba;
         const float g = acc[i][1][r] + bg;
-        v[r] = (variant & 1) ? a * sigmoid_f(g)
-                             : a * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+        v[r] = a * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -72,7 +71,7 @@ __device__ __forceinline__ void gemm_epilogue(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float x = acc[i][j][r] + b;
-          if (ACT == ACT_SILU) x = (variant & 1) ? silu_f(x) : silu_fast(x);
+          if (ACT == ACT_SILU) x = silu_fast(x);
           if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
           if (ACT == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
           v[r] = x * p.alpha;

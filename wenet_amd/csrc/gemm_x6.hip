@@ -94,10 +94,7 @@ __global__ __launch_bounds__(256) void x6_split_kernel(const float* __restrict__
 // lane's 8 k values are conflict-free.
 // NW = 4: a 128-row tile run by FOUR waves side by side along N (each owns all four A tiles:
 // the 8-wave 256-row kernel's lower half), ring of 2 stages = 72 KB, <= 256 registers: two
-// blocks share a CU.  With p.prio_split the blocks below that index run at s_setprio 3: the
-// high-priority block of a CU takes the matrix pipe first and finishes first, and its
-// store burst drains while the other block multiplies -- two co-resident blocks that start
-// together would otherwise finish, and store, together.
+// blocks share a CU.
 // probe & 4 (measurement): shader-clock stamps of block gridDim.x / 2: per wave entry, loop
 // start, loop end, kernel end and the 100-MHz real-time counter at entry / end
 __device__ unsigned long long g_x6_clk[8][8];
@@ -131,14 +128,6 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < NW);
-  if (NW == 4 && p.prio_split != 0) {
-    // > 0: blocks below the index; -1: even blocks; -2: even groups of 8 blocks (experiments)
-    const bool hi_prio = p.prio_split > 0    ? (int)blockIdx.x < p.prio_split
-                         : p.prio_split == -1 ? (blockIdx.x & 1) == 0
-                                              : ((blockIdx.x >> 3) & 1) == 0;
-    if (hi_prio) __builtin_amdgcn_s_setprio(3);
-    else __builtin_amdgcn_s_setprio(0);
-  }
   const int wm = wave >> 2, wn = wave & 3;
   const int hi = lane >> 5, li = lane & 31;
 
@@ -213,7 +202,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
   };
   constexpr int NPW = (NP + NW - 1) / NW;          // pieces per wave and stage (at most)
   auto issue_piece = [&](int q) {
+#ifdef WN_ABLATION
     if (p.probe & 2) return;                       // ablation: no DMA (tools/bench_x6.py)
+#endif
     const int j = q * NW + wave;
     const int qa = q < NPA ? q : NPA - 1;          // (A pieces only: j < A_BYTES / REC)
     if (j < A_BYTES / REC) {
@@ -292,12 +283,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
   // of the instruction's result = columns of C)
   auto mma = [&](const FA& a, const FB& b, int i, auto&& between) {
     constexpr int PB[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
+#ifdef WN_ABLATION
     if (p.probe & 1) {                             // ablation: no MFMAs, keep the reads alive
       asm volatile("" :: "v"(a.p[0]), "v"(a.p[1]), "v"(a.p[2]));
 #pragma unroll
       for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(b.p[j][0]), "v"(b.p[j][1]), "v"(b.p[j][2]));
       return;
     }
+#endif
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
 #pragma unroll
@@ -515,21 +508,17 @@ int launch_x6_act(const X6Args& a, hipStream_t s) {
 }  // namespace
 
 int g_gemm_x6 = 1;
-int g_x6_conv_bm = 0;
-int g_x6_ffn_s = 0;
-int g_x6_nw4 = 0;
 int g_x6_conv = 1;
 int g_x6_sub = 1;
 int g_x6_conv_tail = 1;
 int g_x6_conv_cus = 256;   // wn_tune_set("x6_conv_cus"): CUs per round of conv2's 256-row tiles (see gemm_x6())
-int g_x6_conv_order = 1;   // 1: channel blocks outside, taps inside (L2 reuse); 0: tap-major
 int g_x6_linear = 1;
 // 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in
 // registers.  Measured (r02ag): the split costs more than the plane bytes it saves -- FFN w_1
 // 53.8 -> 63.7 us, w_2 54.6 -> 60.7, conv2 921 -> 1055 (+ conv1 185 -> 125), 8192 x 4096 x
 // 4096 1124 -> 1312 us, decode step 7.28 -> 7.4-7.7 ms.
 int g_x6_af32 = 0;
-int g_x6_probe = 0;     // wn_tune_set("x6_probe"): 1 no MFMAs, 2 no DMA (ablation)
+int g_x6_probe = 0;     // wn_tune_set("x6_probe"): 4 = clock stamps; WN_ABLATION builds: 1 no MFMAs, 2 no DMA
 
 namespace {
 // C[r][c] = relu(sum_s P[s][r][c] + bias[c]): the K-slice partials of conv2's last tiles

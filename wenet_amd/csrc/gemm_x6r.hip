@@ -40,12 +40,11 @@ constexpr int RKB = RK / 16;         // 16 k blocks
 // EPI 0: C = acc + bias; EPI 1: x_out = resid + alpha (acc + bias), y = LayerNorm(x_out);
 // EPI 2: C = GLU(acc + bias) (N / 2 columns); EPI 3: EPI 1, then C = GLU(y W3b^T + bias2) from
 // the rows in LDS (y itself is stored only if p.y is set)
-// PRO 1: the block forms its A rows itself from the slice partials of the fused feed-forward module
+// PRO: the block forms its A rows itself from the slice partials of the fused feed-forward module
 // in front of it (X6RArgs::pro_*): the sum, the residual add and the LayerNorm of ffn_reduce_ln's
 // mode 0 -- same operations in the same order, a wave per row, 4 consecutive columns per lane --
 // on the rows the prologue holds as whole rows anyway (round 3: one launch and one round trip of
-// LN(x) through HBM less per layer).  PRO 2 (x6r_pro = 2, end of round 3, bit-identical on the GPU, not the
-// default): PRO 1 with the slice loads of a row block in flight together.
+// LN(x) through HBM less per layer).
 template <int NT, int EPI, int PF, int PRO = 0>
 __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   __shared__ float red[2][4][32];
@@ -70,57 +69,44 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
     if constexpr (PRO != 0) {
       const int c = lane * 4;
       const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.pro_b2 + c);
-      if constexpr (PRO == 2) {
-        // the same sums with the slice loads IN FLIGHT together: four slices x eight rows per
-        // round.  (PRO 1 below walks a run-time slice loop per row: load, s_waitcnt vmcnt(0), add
-        // -- 8 S dependent memory round trips in front of the GEMM, seen in the ISA at the end of
-        // round 3; per row the additions are the same, in the same order.)
-        f32x4 acc8[8], xo8[8];
-        int r8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          r8[j] = min(m0 + wave * 8 + j, p.M - 1);
-          acc8[j] = b2;
-          xo8[j] = *reinterpret_cast<const f32x4*>(p.pro_x + (int64_t)r8[j] * RK + c);
-        }
-        int sl = 0;
-        for (; sl + 4 <= p.pro_S; sl += 4) {
-          f32x4 v[4][8];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              v[u][j] = *reinterpret_cast<const f32x4*>(
-                  p.pro_P + ((int64_t)(sl + u) * p.M + r8[j]) * RK + c);
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc8[j] += v[u][j];
-        }
-        for (; sl < p.pro_S; ++sl) {
-          f32x4 v[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            v[j] = *reinterpret_cast<const f32x4*>(p.pro_P + ((int64_t)sl * p.M + r8[j]) * RK + c);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc8[j] += v[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) rowv[j][e] = xo8[j][e] + p.pro_alpha * acc8[j][e];
-      } else {
+      // the slice loads of a row block IN FLIGHT together: four slices x eight rows per round;
+      // per row the additions of ffn_reduce_ln, in its order.  (The first form walked a
+      // run-time slice loop per row -- load, s_waitcnt vmcnt(0), add: 8 S dependent memory round
+      // trips in front of the GEMM; bit-identical, removed in round 4.)
+      f32x4 acc8[8], xo8[8];
+      int r8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int r = min(m0 + wave * 8 + j, p.M - 1);
-        f32x4 acc = b2;
-        for (int sl = 0; sl < p.pro_S; ++sl)
-          acc += *reinterpret_cast<const f32x4*>(p.pro_P + ((int64_t)sl * p.M + r) * RK + c);
-        const f32x4 xo = *reinterpret_cast<const f32x4*>(p.pro_x + (int64_t)r * RK + c);
+        r8[j] = min(m0 + wave * 8 + j, p.M - 1);
+        acc8[j] = b2;
+        xo8[j] = *reinterpret_cast<const f32x4*>(p.pro_x + (int64_t)r8[j] * RK + c);
+      }
+      int sl = 0;
+      for (; sl + 4 <= p.pro_S; sl += 4) {
+        f32x4 v[4][8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rowv[j][e] = xo[e] + p.pro_alpha * acc[e];
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            v[u][j] = *reinterpret_cast<const f32x4*>(
+                p.pro_P + ((int64_t)(sl + u) * p.M + r8[j]) * RK + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc8[j] += v[u][j];
       }
+      for (; sl < p.pro_S; ++sl) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = *reinterpret_cast<const f32x4*>(p.pro_P + ((int64_t)sl * p.M + r8[j]) * RK + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc8[j] += v[j];
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rowv[j][e] = xo8[j][e] + p.pro_alpha * acc8[j][e];
 #pragma unroll
       for (int j = 0; j < 8; ++j)       // (rows past M are copies of row M - 1: never stored)
         if (m0 + wave * 8 + j < p.M)
@@ -470,7 +456,7 @@ int launch_x6r(const X6RArgs& a, hipStream_t s) {
 
 int g_x6r = 1;       // wn_tune_set("x6r"): 0 = the v_mfma_f32 row-LN GEMM / tile GEMMs (A/B, tests)
 int g_x6r_chain = 1; // wn_tune_set("x6r_chain"): 0 = out-projection + LayerNorm and pointwise_conv1 + GLU as two launches
-int g_x6r_pro = 2;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of the QKV projection; 2 = the fold with the slice loads in flight together (PRO 2)
+int g_x6r_pro = 1;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of the QKV projection (A/B, tests)
 
 bool gemm_x6r_supported(int M, int N, int K, int epi) {
   if (K != RK || M <= 0) return false;
@@ -484,7 +470,6 @@ int gemm_x6r(const X6RArgs& a, hipStream_t s) {
     WN_CHECK(a.epi == 0 && a.N == 768 && a.W3 && a.M > 0 && a.pro_S >= 1 && a.pro_b2 && a.pro_x &&
                  a.ln_w && a.ln_b && a.C && a.ldc % 4 == 0,
              "gemm_x6r: prologue fold arguments");
-    if (g_x6r_pro == 2) return launch_x6r<6, 0, 1, 2>(a, s);
     return launch_x6r<6, 0, 1, 1>(a, s);
   }
   WN_CHECK(a.A && a.W3 && a.lda % 4 == 0 && gemm_x6r_supported(a.M, a.N, RK, a.epi),

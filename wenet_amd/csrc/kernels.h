@@ -16,7 +16,6 @@ int layernorm_mx(const float* x, int ldx, const float* w, const float* b, void* 
 
 // y1 = LN(x; w1,b1), y2 = LN(y1; w2,b2) in one pass over contiguous [M][D] rows
 // (y1 may alias x).
-extern int g_ln_rows;
 extern int g_attn_split;
 int layernorm2(const float* x, const float* w1, const float* b1, const float* w2,
                const float* b2, float* y1, float* y2, int M, int D, float eps,
@@ -80,10 +79,6 @@ struct AttnArgs {
   int n_seq, n_heads, max_q_len;
   bool o_bf16 = false; // bf16 kernel only: O is a bf16 matrix (ldo in elements)
   bool qkv_bf16 = false;  // bf16 kernel only, no rel-pos: Q / K / V are bf16 (ld* in elements)
-  // bf16 kernel, qkv_bf16 self attention without masks: scratch for the V^T image
-  // [n_seq][n_heads][64][vt_tp] bf16 (vt_tp: max length rounded up to 64) that the DMA-staged
-  // kernel reads instead of V; null: register-staged kernel
-  void* vt = nullptr; int vt_tp = 0;
   float defer_thr = 0.f;   // DMA-staged bf16 kernel: deferred-rescale threshold (log2 units, 0 = off)
   int mask_mode = 0;   // 0: keys < kv_len; 1: causal; 2: chunk window
   int chunk_size = 0, left_chunks = -1;
@@ -99,9 +94,8 @@ int relpos_fold(float* K, int ldk, const float* P, int ldp, const float* bias_u,
 int attention_bf16(const AttnArgs& a, hipStream_t s);
 extern int g_attn_bf16;      // 1 (default): bf16 mode uses the bf16 attention kernel
 extern int g_attn_bf16_nw;   // 0 auto, else waves (32-query groups) per block
-extern int g_attn_bf16_sub;  // 8-wave blocks: 32-key sub-tiles per barrier
 extern int g_attn_bf16_defer;  // wn_tune_set("attn_bf16_defer"): threshold x 10 of the deferred rescale (0 = off)
-extern int g_attn_bf16_dma;  // 0 off, 1 LDS-DMA staged kernel where it applies (AttnArgs::vt), 2 + grouped reads, 4 (default) V rows + transpose reads, no V^T image
+extern int g_attn_bf16_dma;  // 0 = register-staged kernel only (A/B, tests), else the LDS-DMA staged kernel where it applies
 
 // Fused feed-forward module, fp32 (ffn_fused.hip): P[s] (S, M, D) = partial
 // act(X W1^T + b1) W2^T over hidden slice s; ffn_reduce_ln then forms
@@ -114,8 +108,7 @@ struct FfnArgs {
   float* P;           // [S][M][D]
   int M, D, F, S, act;
 };
-extern int g_ffn_fused, g_ffn_ring, g_ffn_bm64;
-extern int g_beam_prio;   // wn_tune_set("beam_prio")
+extern int g_ffn_fused;
 extern int g_beam_weak_hash;   // wn_tune_set("beam_weak_hash")
 extern int g_ctc_wave;    // wn_tune_set("ctc_wave")
 int ffn_fused_split(int M, int D, int F);
@@ -140,7 +133,6 @@ struct X6Args {
   int ksplit = 1;             // K slices (epi 1 only)
   int bm = 0;                 // block rows 128 / 256, 0 = auto
   int nw = 0;                 // 128-row tiles: four waves, two blocks per CU; 8 forces the 8-wave form
-  int prio_split = 0;         // nw 4: blocks below this index run at s_setprio 3 (0 = off)
   int epi = 0;                // 0: C = resid + alpha act(acc + bias); 1: P[slice][M][N] = acc;
                               // 2: C3 = X3 image of act(acc + bias)
   const float* bias = nullptr;
@@ -163,14 +155,10 @@ struct X6Args {
 extern int g_x6_conv_tail;  // wn_tune_set("x6_conv_tail"): 0 = the remainder of conv2's tiles as 128-row tiles
 extern int g_x6_probe;
 int gemm_x6_clocks(unsigned long long* out);   // probe & 4 stamps [8 waves][8]
-extern int g_x6_nw4;       // wn_tune_set("x6_nw4") A/B bits: 1 FFN w_1 on 256-row tiles, 2 FFN w_2 on the 8-wave 128-row tile, 4 priorities
 extern int g_x6_linear;    // wn_tune_set("x6_linear"): 0 = linear() never routes to the six-product GEMM
-extern int g_x6_conv_order;
 extern int g_x6_conv;      // wn_tune_set("x6_conv"): 0 = conv2 stays on v_mfma_f32
 extern int g_x6_sub;       // wn_tune_set("x6_sub"): 0 = the subsampling's output Linear stays on v_mfma_f32, 1 K slices of 256-row tiles, 2 of 128-row tiles
 extern int g_x6_af32;      // wn_tune_set("x6_af32"): 0 plane images (default), 1 fp32 A rows split in registers
-extern int g_x6_ffn_s;     // wn_tune_set("x6_ffn_s"): K slices of the FFN w_2 GEMM (0 auto)
-extern int g_x6_conv_bm;   // wn_tune_set("x6_conv_bm"): block rows of the conv2 GEMM (0 auto)
 extern int g_gemm_x6;     // wn_tune_set("gemm_x6"): 0 = the v_mfma_f32 kernels (A/B, tests)
 size_t x6_bytes(int R, int K);
 int x6_split(const float* src, int R, int K, int ld, void* dst, hipStream_t s);
@@ -189,7 +177,6 @@ struct FfnX6Args {
 extern int g_ffn_x6f;        // wn_tune_set("ffn_x6f"): 0 = two six-product GEMMs, 2 = force (tests)
 extern int g_ffn_x6f_var;    // wn_tune_set("ffn_x6f_var"): measurement variants (ffn_x6f.hip VAR)
 extern int g_ffn_x6f_ring;   // wn_tune_set("ffn_x6f_ring"): DMA ring depth 4..6
-extern int g_ffn_x6f_map;    // wn_tune_set("ffn_x6f_map"): 1 = two hidden slices per XCD, 0 = one
 int ffn_x6f_clocks(unsigned long long* out);   // VAR & 8192 stamps [4 waves][24]
 int x6_split_perm(const float* src, int R, int K, int ld, void* dst, hipStream_t s);
 int ffn_x6f_split(int M, int F);
@@ -235,7 +222,6 @@ struct X6RArgs {
 };
 extern int g_x6_conv_cus;  // wn_tune_set("x6_conv_cus"): CUs per round of conv2's tiles (256)
 extern int g_dwconv_tiled; // wn_tune_set("dwconv_tiled"): 1 = depthwise convolution with four rows per wave
-extern int g_attn_gload;   // wn_tune_set("attn_gload"): 1 = fp32 folded attention with batched staging loads
 extern int g_x6r_pro;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of QKV
 extern int g_x6r;     // wn_tune_set("x6r")
 extern int g_x6r_chain;   // wn_tune_set("x6r_chain")
@@ -306,7 +292,6 @@ struct PrefixBeamArgs {
   // frames): [0] eval, [1] rank, [2] select/write, [3] frames, [4] emit
   long long* dbg_cycles = nullptr;
   CtxGraph cg;  // keys == nullptr: no context biasing
-  int prio = 0; // > 0: the search waves raise their issue priority (s_setprio; experiment)
   int weak_hash = 0;  // tests: 2-bit prefix hash, so that the exact sequence test decides
 };
 int64_t prefix_beam_pool_ints(int max_len, int beam);

@@ -291,7 +291,6 @@ int vocab_linear(wn_model* m, const Linear& l, const float* A, int lda, float* C
 // hidden split of the x6 FFN's second GEMM: K slices so that 128-row tiles x slices fill
 // the CUs once
 int ffn_x6_split(int M, int F) {
-  if (g_x6_ffn_s > 0 && (F / 16) % g_x6_ffn_s == 0) return g_x6_ffn_s;   // A/B knob
   int S = 1;
   while (S < 16 && cdiv(M, 128) * (S * 2) <= 256 && (F / 16) % (S * 2) == 0) S *= 2;
   return S;
@@ -355,8 +354,6 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
     if (x6_split(m->t1.as<float>(), M, d, d, m->x6_a.as<char>(), s) != 0) return -1;
     g1.A3 = m->x6_a.as<char>(); g1.epi = 2; g1.C3 = m->x6_h.as<char>();
   }
-  if (g_x6_nw4 & 1) g1.bm = 256;                      // A/B: the 256-row tiles for w_1
-  if (g_x6_nw4 & 4) g1.prio_split = cdiv(M, 128) * cdiv(F, 256) / 2;
   const bool bracket = m->prof_on && (tick++ % 6) == 0;
   if (bracket) {
     if (m->prof_used + 2 > m->prof_ev.size())
@@ -379,7 +376,6 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
   g2.epi = 1; g2.ksplit = S; g2.C = m->ffn_part.as<float>();
   if (af32) { g2.A = m->hbuf.as<float>(); g2.lda = F; g2.a_bytes = (int64_t)M * F * 4; }
   else g2.A3 = m->x6_h.as<char>();
-  if (g_x6_nw4 & 2) g2.nw = 8;                        // A/B: the 8-wave form of the 128-row tile
   if (gemm_x6(g2, s) != 0) return -1;
   m->prof_split = S;
   return S;
@@ -541,7 +537,7 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
       g.A = m->c1.as<float>(); g.a_bytes = (int64_t)M1 * F1 * d * 4;
       g.B3 = w6; g.M = M * F2; g.N = d; g.K = 9 * d;
       g.epi = 0; g.bias = m->conv2.b; g.act = ACT_RELU; g.C = m->c2.as<float>(); g.ldc = d;
-      g.a_pix = pix; g.conv_kbc = d / 16; g.bm = g_x6_conv_bm;
+      g.a_pix = pix; g.conv_kbc = d / 16;
       for (int ky = 0; ky < 3; ++ky)
         for (int kx = 0; kx < 3; ++kx) g.tap_delta[ky * 3 + kx] = ky * F1 + kx;
       WN_TRY(gemm_x6(g, s));
@@ -567,12 +563,12 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
       X6Args g;
       g.A3 = m->c1.as<char>(); g.B3 = w6; g.M = M * F2; g.N = d; g.K = 9 * d;
       g.epi = 0; g.bias = m->conv2.b; g.act = ACT_RELU; g.C = m->c2.as<float>(); g.ldc = d;
-      g.a_pix = pix; g.a_tiles = tiles; g.conv_kbc = d / 16; g.bm = g_x6_conv_bm;
-      g.conv_taps = g_x6_conv_order ? 9 : 0;
+      g.a_pix = pix; g.a_tiles = tiles; g.conv_kbc = d / 16;
+      g.conv_taps = 9;
       {   // scratch for the K-slice partials of the last, partial round of tiles (gemm_x6.hip)
         const int ncu = std::min(std::max(g_x6_conv_cus, 64), 256);   // (as in gemm_x6())
         const int t256 = cdiv(M * F2, 256), rem = t256 - t256 / ncu * ncu;
-        if (g_x6_conv_bm == 0 && d <= 256 && t256 >= ncu && rem > 0 && rem <= ncu / 2) {
+        if (d <= 256 && t256 >= ncu && rem > 0 && rem <= ncu / 2) {
           const size_t need = (size_t)4 * ((size_t)M * F2 - (size_t)(t256 - rem) * 256) * d *
                               sizeof(float);
           WN_TRY(m->ffn_part.ensure(need));
@@ -993,13 +989,6 @@ int transformer_layers(wn_model* m, hipStream_t s) {
     a.q_len = a.kv_len = m->d_len.as<int>();
     a.n_seq = m->B; a.n_heads = c.n_heads; a.max_q_len = max_len;
     a.mask_mode = 0;
-    if (q16 && max_len >= 384 && g_attn_bf16_dma >= 1 && g_attn_bf16_dma <= 3) {
-      // V^T scratch of the DMA-staged forms that read an image (attention_bf16.hip; the default
-      // form reads the V rows themselves through transpose reads)
-      a.vt_tp = (max_len + 63) / 64 * 64;
-      WN_TRY(m->attn_vt.ensure((size_t)m->B * c.n_heads * 64 * a.vt_tp * 2));
-      a.vt = m->attn_vt.p;
-    }
     a.scale = 1.0f / sqrtf(64.0f);
     WN_TRY(attention(a, s));
     WN_TRY(linear(L.out, t2, d, x, d, M, s, ACT_NONE, x, d, 1.0f, false, h16));

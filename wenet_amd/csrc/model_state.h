@@ -342,7 +342,6 @@ struct wn_model {
   DevBuf c1, c2, x, t1, t2, hbuf, qkv, enc;
   DevBuf ffn_part;                      // hidden-slice partials of the fused FFN
   DevBuf attn_kbias;                    // per-key score term of the folded rel-pos attention
-  DevBuf attn_vt;                       // V^T image of the DMA-staged bf16 attention
   DevBuf xpad, pos_rows, d_row_t, d_zero_rows;
   DevBuf ck_kv, ck_xext, ck_glu, ck_desc, ck_rowutt, ck_sess;  // forward_chunk scratch
   // Whisper log-mel: DFT / window tables (shared), mel matrix per bin count

@@ -9,6 +9,8 @@ rank decodes its shard with no data-path collective, and the fixed-shape
 results (token ids, lengths, scores -- a few KB) are gathered once per batch
 with a single all_gather (RCCL over xGMI on GPUs, gloo in the CPU tests).
 """
+import queue
+import threading
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -52,7 +54,11 @@ def gather_results(local: torch.Tensor, world_size: int
     (global index, tokens, score) sorted by global index, on every rank."""
     # (a process group of one rank still runs the collective: the world-1 RCCL self-test)
     if world_size > 1 or (dist.is_available() and dist.is_initialized()):
-        out = [torch.empty_like(local) for _ in range(world_size)]
+        # the group decides how many records come back, not the caller's argument
+        n = dist.get_world_size() if dist.is_initialized() else world_size
+        assert n == world_size, f'gather_results: world_size {world_size} but the process ' \
+                                f'group has {n} ranks'
+        out = [torch.empty_like(local) for _ in range(n)]
         dist.all_gather(out, local)
         allrec = torch.cat(out, dim=0)
     else:
@@ -67,3 +73,74 @@ def gather_results(local: torch.Tensor, world_size: int
                     float(row[2:3].view(np.float32)[0])))
     res.sort(key=lambda x: x[0])
     return res
+
+
+class ResultGatherer:
+    """The per-batch result gather off the decode thread: a worker thread packs the local
+    records, runs the ONE all_gather on its own stream and unpacks it, batch after batch in
+    submission order (every rank submits the same sequence, so the collectives line up), while
+    the caller already waits for the next batch's decode.  `drain()` returns when everything
+    submitted so far has been gathered -- call it before a barrier or before reading `last`:
+    the process group must not see collectives from two threads at once.
+
+    With a synchronous gather every step ends in a host-side rendezvous of all ranks (H2D copy,
+    collective, D2H copy on the decode thread); at 8 GPUs the ranks then advance in lockstep
+    per STEP and every step costs the slowest rank's time.  Off the decode thread the ranks
+    only meet at the barriers around a timed round."""
+
+    def __init__(self, world_size: int, max_utts: int, max_len: int, device):
+        self.world, self.max_utts, self.max_len = world_size, max_utts, max_len
+        self.device = torch.device(device)
+        self.last = None
+        self._q = queue.SimpleQueue()
+        self._err = None
+        self._pending = 0
+        self._cv = threading.Condition()
+        self._stream = None
+        self._t = threading.Thread(target=self._run, name='wn-gather', daemon=True)
+        self._t.start()
+
+    def _run(self):
+        if self.device.type == 'cuda':
+            torch.cuda.set_device(self.device)
+            self._stream = torch.cuda.Stream(device=self.device)
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            try:
+                indices, tokens, scores = item
+                if self._stream is not None:
+                    with torch.cuda.stream(self._stream):
+                        rec = pack_results(indices, tokens, scores, self.max_utts,
+                                           self.max_len, self.device)
+                        out = gather_results(rec, self.world)
+                else:
+                    rec = pack_results(indices, tokens, scores, self.max_utts, self.max_len,
+                                       self.device)
+                    out = gather_results(rec, self.world)
+                self.last = out
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
+                self._err = e
+            with self._cv:
+                self._pending -= 1
+                self._cv.notify_all()
+
+    def submit(self, indices: Sequence[int], tokens, scores) -> None:
+        with self._cv:
+            self._pending += 1
+        self._q.put((list(indices), list(tokens), list(scores)))
+
+    def drain(self):
+        with self._cv:
+            while self._pending > 0:
+                self._cv.wait()
+        if self._err is not None:
+            e, self._err = self._err, None
+            raise e
+        return self.last
+
+    def close(self):
+        self.drain()
+        self._q.put(None)
+        self._t.join()

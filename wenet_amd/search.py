@@ -57,6 +57,29 @@ class DecodeResult:
             self._lazy = None
             self._nbest, self._nbest_scores, self._nbest_times = lazy.utterance(self._b)
 
+    _FIELDS = ('tokens', 'score', 'confidence', 'tokens_confidence', 'times', 'nbest',
+               'nbest_scores', 'nbest_times', 'text')
+
+    def as_dict(self):
+        """The reference's attribute names -> values (what vars() of the reference's
+        DecodeResult gives), the n-best lists materialised; extra attributes a search attached
+        (e.g. `all_scores`) included."""
+        d = {k: getattr(self, k) for k in self._FIELDS}
+        d.update({k: v for k, v in self.__dict__.items()
+                  if not k.startswith('_') and k not in d})
+        return d
+
+    # pickling / copy: by the reference's field names, never the batch-wide raw arrays
+    def __getstate__(self):
+        return self.as_dict()
+
+    def __setstate__(self, state):
+        self._lazy, self._b = None, 0
+        self._nbest = state.pop('nbest', None)
+        self._nbest_scores = state.pop('nbest_scores', None)
+        self._nbest_times = state.pop('nbest_times', None)
+        self.__dict__.update(state)
+
     @property
     def nbest(self):
         self._fill()
