@@ -283,7 +283,14 @@ def main():
     gatherer = wdist.ResultGatherer(world, batch_per_gpu, max_tok,
                                     'cpu' if share_gpu else device)
 
+    sync_gather = os.environ.get('WN_BENCH_SYNC_GATHER') == '1'   # A/B: gather on the decode thread
+
     def finish(res):
+        if sync_gather:
+            rec = wdist.pack_results(mine, [r.tokens for r in res], [r.score for r in res],
+                                     batch_per_gpu, max_tok, 'cpu' if share_gpu else device)
+            gatherer.last = wdist.gather_results(rec, world)
+            return
         gatherer.submit(mine, [r.tokens for r in res], [r.score for r in res])
 
     def finish_nbest(res):

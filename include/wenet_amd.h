@@ -450,6 +450,16 @@ int wn_op_gemm_x6r(const float* A_dev, const float* W_dev, const float* bias_dev
                    float* x_inout_dev, const float* ln_w_dev, const float* ln_b_dev,
                    float* y_dev, float* C_dev, int32_t M, int32_t N, int32_t epi, float alpha,
                    float eps, int32_t reps, void* stream);
+
+/* The d_model = 512 row-block kernels (csrc/gemm_x6r512.hip), test / benchmark entry: K = 512;
+ * epi 0: C (M, N) = A W^T + bias, N in {512, 1024, 1536, 2048}; epi 1: x_inout += alpha (A W^T +
+ * bias), y = LayerNorm(x_inout), N = 512; epi 3: epi 1, then C (M, 512) = GLU(y W2^T + bias2)
+ * with W2 (1024, 512) in the [32 values | 32 gates]-per-64 row order wn_model_create gives
+ * pointwise_conv1 (y is written only if non-null). */
+int wn_op_gemm_x6r512(const float* A, const float* W, const float* bias, float* x_inout,
+                      const float* ln_w, const float* ln_b, float* y, const float* W2,
+                      const float* bias2, float* C, int32_t M, int32_t N, int32_t epi, float alpha,
+                      float eps, int32_t reps, void* stream);
 /* out[i] = log_add(a[i], b[i]) (wenet/utils/common.py:302-310) in fp64 with the
  * routine the prefix beam search uses. */
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,

@@ -300,3 +300,101 @@ def test_qkv_prologue_fold_is_bit_identical_to_the_reduce_launch(B, frames, chun
     assert torch.isfinite(got).all()
     assert torch.equal(got, got2.cpu())
     assert torch.equal(got, ref), (got - ref).abs().max().item()
+
+
+# ---- d_model = 512: the row-block kernels with the A image in LDS (csrc/gemm_x6r512.hip) ----------
+@pytest.mark.parametrize('M,N,epi', [(7932, 512, 1), (7932, 1536, 0), (16231, 512, 0), (33, 512, 1),
+                                     (1000, 1024, 0), (31, 1536, 0), (4097, 512, 1),
+                                     (7932, 512, 3), (45, 512, 3), (16231, 512, 3)])
+def test_gemm_x6r512_vs_fp64(M, N, epi):
+    """K = 512: epi 0 plain projection (one to three 512-column passes over the same A image),
+    epi 1 residual + LayerNorm over complete rows, epi 3 the same chained with pointwise_conv1 +
+    GLU (weight rows permuted per 64 as [32 values | 32 gates]) from the LayerNorm rows in LDS;
+    ragged row counts; deterministic."""
+    from wenet_amd import _lib
+    L = _lib.lib()
+    d = 512
+    g = torch.Generator().manual_seed(M + N + epi)
+    A = torch.randn(M, d, generator=g)
+    W = torch.randn(N, d, generator=g) / d ** 0.5
+    b = torch.randn(N, generator=g) * 0.3
+    x = torch.randn(M, N, generator=g)
+    lw = 1.0 + 0.2 * torch.randn(N, generator=g)
+    lb = 0.1 * torch.randn(N, generator=g)
+    W2 = torch.randn(2 * d, d, generator=g) / d ** 0.5     # reference order: [values | gates]
+    b2 = torch.randn(2 * d, generator=g) * 0.3
+    perm = torch.cat([torch.cat([torch.arange(32) + 32 * u, torch.arange(32) + 32 * u + d])
+                      for u in range(d // 32)])
+    ref = A.double() @ W.double().T + b.double()
+    outs = []
+    for _ in range(2):
+        t = [v.cuda().contiguous() for v in (A, W, b, x.clone(), lw, lb, W2[perm], b2[perm])]
+        y = torch.full((M, N), float('nan'), device='cuda')
+        C = torch.full((M, N), float('nan'), device='cuda')
+        _lib.check(L.wn_op_gemm_x6r512(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                       t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr(),
+                                       y.data_ptr(), t[6].data_ptr(), t[7].data_ptr(),
+                                       C.data_ptr(), M, N, epi, 0.5, 1e-5, 1,
+                                       torch.cuda.current_stream().cuda_stream), 'x6r512')
+        torch.cuda.synchronize()
+        outs.append((C.cpu(), t[3].cpu(), y.cpu()))
+    (C, xo, y), (C2, xo2, y2) = outs
+    if epi == 0:
+        err = (C.double() - ref).abs().max().item()
+        print(f'\n[{M}x{N}] max |err| {err:.2e}')
+        assert err < 8e-6 and torch.equal(C, C2)
+        return
+    xr = x.double() + 0.5 * ref
+    yr = torch.nn.functional.layer_norm(xr, (N, ), lw.double(), lb.double(), 1e-5)
+    ex, ey = (xo.double() - xr).abs().max().item(), (y.double() - yr).abs().max().item()
+    print(f'\n[{M}x{N}] max |err| x {ex:.2e} y {ey:.2e}')
+    assert ex < 8e-6 and ey < 3e-5
+    assert torch.equal(xo, xo2) and torch.equal(y, y2)
+    if epi == 3:
+        pre = yr @ W2.double().T + b2.double()
+        cr = pre[:, :d] * torch.sigmoid(pre[:, d:])
+        ec = (C.double() - cr).abs().max().item()
+        print(f'[{M}x{N}] GLU max |err| {ec:.2e}')
+        assert ec < 5e-5 and torch.equal(C, C2)
+
+
+@pytest.mark.parametrize('config,B,frames,chunk', [('wenetspeech_u2pp', 32, (800, 1200), 16),
+                                                   ('wenetspeech_u2pp', 5, (300, 1100), -1),
+                                                   ('librispeech_bidecoder_large', 8, (300, 700), -1)])
+def test_d512_row_block_kernels_match_the_other_forms(config, B, frames, chunk):
+    """d_model = 512 encoders on the row-block kernels (gemm_x6r512.hip: QKV with the prologue
+    fold, out-projection + LayerNorm + pointwise_conv1 + GLU chain, pointwise_conv2 + LayerNorm):
+      * the prologue fold is ffn_reduce_ln's arithmetic in the same order: encoder output
+        bit-identical to x6r_pro = 0 (the separate reduce launch);
+      * the chain against the two launches (x6r_chain = 0): same products, same sums (the GLU
+        GEMM then runs on the tile kernels): within fp32 rounding;
+      * everything against the tile GEMMs + separate LayerNorms (x6r = 0): fp32 summation order."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=77)
+    try:
+        got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got = got.cpu()
+        _lib.check(L.wn_tune_set(b'x6r_pro', 0), 'tune')
+        nopro, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        nopro = nopro.cpu()
+        _lib.check(L.wn_tune_set(b'x6r_pro', 1), 'tune')
+        _lib.check(L.wn_tune_set(b'x6r_chain', 0), 'tune')
+        nochain, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        nochain = nochain.cpu()
+        _lib.check(L.wn_tune_set(b'x6r_chain', 1), 'tune')
+        _lib.check(L.wn_tune_set(b'x6r', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        ref = ref.cpu()
+    finally:
+        L.wn_tune_set(b'x6r_pro', 1)
+        L.wn_tune_set(b'x6r_chain', 1)
+        L.wn_tune_set(b'x6r', 1)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, got2.cpu())                 # race screen
+    assert torch.equal(got, nopro), (got - nopro).abs().max().item()
+    e1, e2 = (got - nochain).abs().max().item(), (got - ref).abs().max().item()
+    print(f'\n[{config} B={B}] d512 row-block kernels: vs two launches {e1:.2e}, vs tile GEMMs {e2:.2e}')
+    assert e1 < 1e-4 and 0 < e2 < 2e-4

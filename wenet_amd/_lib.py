@@ -32,7 +32,7 @@ EXPORTS = [
     'wn_last_error', 'wn_version', 'wn_model_create', 'wn_model_destroy', 'wn_model_clone',
     'wn_model_set_precision', 'wn_model_get_precision', 'wn_op_gemm_bf16',
     'wn_op_gemm_bf16_stored',
-    'wn_attention_beam_search', 'wn_encode_chunk_batch', 'wn_op_gemm_lowp', 'wn_op_mx_quantize', 'wn_op_ffn_fused', 'wn_op_gemm_x6', 'wn_op_ffn_x6', 'wn_op_gemm_x6r', 'wn_profile_kernel_name', 'wn_profile_ffn_split', 'wn_profile_ffn_clocks', 'wn_profile_gemm_clocks', 'wn_filter_blank_embedding',
+    'wn_attention_beam_search', 'wn_encode_chunk_batch', 'wn_op_gemm_lowp', 'wn_op_mx_quantize', 'wn_op_ffn_fused', 'wn_op_gemm_x6', 'wn_op_ffn_x6', 'wn_op_gemm_x6r', 'wn_op_gemm_x6r512', 'wn_profile_kernel_name', 'wn_profile_ffn_split', 'wn_profile_ffn_clocks', 'wn_profile_gemm_clocks', 'wn_filter_blank_embedding',
     'wn_workspace_create', 'wn_resample_length', 'wn_resample', 'wn_fbank', 'wn_log_mel', 'wn_encode', 'wn_encode_chunk', 'wn_set_encoder_out',
     'wn_ctc_logprobs', 'wn_set_ctc_probs', 'wn_ctc_greedy_search',
     'wn_set_context_graph', 'wn_ctc_prefix_beam_search', 'wn_attention_rescoring', 'wn_rescore', 'wn_decoder_forward', 'wn_decoder_next_topk', 'wn_op_gemm',
@@ -112,6 +112,8 @@ def lib():
                                f32, i32, vp]
     L.wn_filter_blank_embedding.argtypes = [vp, vp, pi32, pi32, vp]
     L.wn_op_gemm_x6r.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, vp]
+    L.wn_op_gemm_x6r512.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32,
+                                    i32, vp]
     L.wn_model_set_precision.argtypes = [vp, i32]
     L.wn_model_get_precision.argtypes = [vp]
     L.wn_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, '..', 'build', 'obj')
 LIB = os.path.join(HERE, 'libwenet_amd.so')
-SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_bf16s.hip', 'gemm_bf16p.hip', 'ffn_fused.hip', 'gemm_rowln.hip', 'gemm_x6.hip', 'ffn_x6f.hip', 'gemm_x6r.hip', 'attn_search.hip', 'encoder_kernels.hip', 'attention_bf16.hip', 'ctc.hip', 'fbank.hip',
+SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_bf16s.hip', 'gemm_bf16p.hip', 'ffn_fused.hip', 'gemm_rowln.hip', 'gemm_x6.hip', 'ffn_x6f.hip', 'gemm_x6r.hip', 'gemm_x6r512.hip', 'attn_search.hip', 'encoder_kernels.hip', 'attention_bf16.hip', 'ctc.hip', 'fbank.hip',
            'logmel.hip', 'model.hip', 'cabi.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-fno-gpu-rdc', '-Wno-unused-result']
@@ -29,7 +29,7 @@ if os.environ.get('WN_ABLATION') == '1':
 # per-source extras: the one-wave-per-SIMD kernel pins its VALU slices between MFMA pairs;
 # SLP-packed f32 ops (v_pk_*) would undo the spacing (MI355X_MICROARCH.md: an anti-lever
 # beside MFMAs)
-EXTRA_FLAGS = {'ffn_x6f.hip': ['-fno-slp-vectorize'], 'gemm_x6r.hip': ['-fno-slp-vectorize'],
+EXTRA_FLAGS = {'ffn_x6f.hip': ['-fno-slp-vectorize'], 'gemm_x6r.hip': ['-fno-slp-vectorize'], 'gemm_x6r512.hip': ['-fno-slp-vectorize'],
                # the softmax of the bf16 attention kernels is VALU-bound: no v_pk_add + v_mov
                # packing of the row sums, no canonicalising v_max x, x in front of every fmaxf
                # on an MFMA result (scores are finite; the masks use -1e30, not inf)

@@ -2127,6 +2127,29 @@ int wn_op_gemm_x6r(const float* A, const float* W, const float* bias, float* x_i
   return 0;
 }
 
+int wn_op_gemm_x6r512(const float* A, const float* W, const float* bias, float* x_inout,
+                      const float* ln_w, const float* ln_b, float* y, const float* W2,
+                      const float* bias2, float* C, int32_t M, int32_t N, int32_t epi, float alpha,
+                      float eps, int32_t reps, void* stream) {
+  WN_CHECK(A && W && M > 0 && gemm_x6r512_supported(M, N, epi), "gemm_x6r512: shape");
+  WN_CHECK(epi != 3 || (W2 && C), "gemm_x6r512: the chained epilogue needs W2 and C");
+  hipStream_t s = (hipStream_t)stream;
+  static thread_local DevBuf w3, w3b;
+  WN_TRY(w3.ensure(x6_bytes(N, 512)));
+  WN_TRY(x6_split(W, N, 512, 512, w3.as<char>(), s));
+  X6RArgs a;
+  a.A = A; a.lda = 512; a.K = 512; a.W3 = w3.as<char>(); a.bias = bias; a.M = M; a.N = N;
+  a.epi = epi; a.C = C; a.ldc = epi == 3 ? 512 : N; a.resid = x_inout; a.ldr = N; a.alpha = alpha;
+  a.x_out = x_inout; a.ldx = N; a.ln_w = ln_w; a.ln_b = ln_b; a.eps = eps; a.y = y; a.ldy = N;
+  if (epi == 3) {
+    WN_TRY(w3b.ensure(x6_bytes(1024, 512)));
+    WN_TRY(x6_split(W2, 1024, 512, 512, w3b.as<char>(), s));
+    a.W3b = w3b.as<char>(); a.bias2 = bias2;
+  }
+  for (int r = 0; r < (reps > 0 ? reps : 1); ++r) WN_TRY(gemm_x6r(a, s));
+  return 0;
+}
+
 int wn_op_log_add(const double* a_dev, const double* b_dev, double* out_dev,
                   int32_t n, void* stream) {
   return log_add_pairs(a_dev, b_dev, out_dev, n, (hipStream_t)stream);

@@ -459,6 +459,7 @@ int g_x6r_chain = 1; // wn_tune_set("x6r_chain"): 0 = out-projection + LayerNorm
 int g_x6r_pro = 1;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of the QKV projection (A/B, tests)
 
 bool gemm_x6r_supported(int M, int N, int K, int epi) {
+  if (K == 512) return gemm_x6r512_supported(M, N, epi);
   if (K != RK || M <= 0) return false;
   if (epi == 1 || epi == 3) return N == 256;
   if (epi == 2) return N == 512;
@@ -466,6 +467,8 @@ bool gemm_x6r_supported(int M, int N, int K, int epi) {
 }
 
 int gemm_x6r(const X6RArgs& a, hipStream_t s) {
+  if (a.K == 512) return gemm_x6r512(a, s);
+  WN_CHECK(a.K == RK, "gemm_x6r: K must be 256 or 512");
   if (a.pro_P) {
     WN_CHECK(a.epi == 0 && a.N == 768 && a.W3 && a.M > 0 && a.pro_S >= 1 && a.pro_b2 && a.pro_x &&
                  a.ln_w && a.ln_b && a.C && a.ldc % 4 == 0,

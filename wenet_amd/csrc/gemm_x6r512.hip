@@ -1,0 +1,506 @@
+// Row-block fp32 GEMM on the bf16 matrix cores (six plane products) for the encoder's small
+// projections at d_model = 512 -- K = 512, N = 512 .. 1536: the d = 512 counterpart of
+// gemm_x6r.hip (round 4).  Same launches per Conformer layer as at d = 256:
+//   * QKV projection (attention.py:109-131), optionally forming its own input
+//     LN_mha(x + 0.5 FFN_macaron) from the slice partials of the feed-forward GEMM pair
+//     (encoder_layer.py:220-232; ffn_reduce_ln's mode 0, same operations in the same order);
+//   * attention output projection + residual + LN_conv chained with pointwise_conv1 + GLU
+//     (attention.py:176, encoder_layer.py:238-240, convolution.py:115-118);
+//   * pointwise_conv2 + residual + LN_ff (convolution.py:148, encoder_layer.py:251-255).
+// Before (profiles/r06b_kernel_stats_config4_streams1.md, per layer at config 4): QKV 76 us on
+// the tile GEMM + 7 us plane-split pass + 18 us ffn_reduce_ln; out-projection and
+// pointwise_conv2 49 us each on v_mfma_f32 + 7 us LayerNorm each; pointwise_conv1 + GLU 84 us on
+// v_mfma_f32 -- 298 us of a 1.1-ms layer for 14 % of its FLOPs.
+//
+// What differs from the K = 256 kernel: 32 rows x 512 k x three planes are 96 KB -- 384 registers
+// per lane, too many next to the accumulators and the W fragments.  The block splits its rows
+// ONCE into an X3-format image in LDS ([k block][plane][lane x 16 B]: exactly the fragment a
+// lane needs, conflict-free ds_read_b128), each wave splitting a quarter of the k blocks, and
+// every wave reads its "B" operand fragments from there (3 x 16 B per k block, one k block
+// ahead).  Everything else is gemm_x6r.hip: one wave per SIMD, wave w owns the columns
+// [128 w, 128 w + 128) of a 512-column pass (N = 1536: three passes over the same X image), W
+// fragments straight from the weight plane image in L2 (PF k blocks ahead), lane = row in the
+// accumulators, LayerNorm statistics across the four waves through LDS, every global access as
+// contiguous row segments through wave-private LDS patches.
+// LDS: 96 KB X image + 36 KB (fp32 half rows of the prologue / GLU patches); the epilogue's
+// wave patches (4 x 16.5 KB) reuse the X image once the MFMA loop is done.
+#include "common.h"
+#include "kernels.h"
+#include "x6.h"
+
+namespace wn {
+
+namespace {
+
+constexpr int K5 = 512;
+constexpr int KB5 = K5 / 16;            // 32 k blocks
+constexpr int XIMG = KB5 * X3_TILE;     // 96 KB
+constexpr int HPATCH = 36 * 1024;       // fp32 half rows [32][1040 B] / GLU wave patches
+constexpr int NT5 = 4;                  // 32-column tiles per wave and pass
+constexpr int PF5 = 2;                  // W fragment prefetch distance (k blocks)
+
+// EPI 0: C = acc + bias (N = 512 passes); EPI 1: x_out = resid + alpha (acc + bias),
+// y = LayerNorm(x_out) (N = 512); EPI 3: EPI 1, then C = GLU(y W3b^T + bias2) with W3b the image
+// of a 1024 x 512 weight whose rows are permuted per 64 as [32 values | 32 gates] (y itself is
+// stored only if p.y is set).  PRO: the A rows are formed from feed-forward slice partials
+// (X6RArgs::pro_*), EPI 0 only.
+template <int EPI, bool PRO>
+__global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem5[];
+  __shared__ float red[2][4][32];
+  char* ximg = smem5;
+  char* hpatch = smem5 + XIMG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 4);
+  const int hi = lane >> 5, li = lane & 31;
+  const int m0 = blockIdx.x * 32;
+  const int Tn = (p.N + 31) >> 5;
+  const int64_t kstride = (int64_t)Tn * X3_TILE;
+
+  // W fragments of pass ps: records [k block][tile][plane], this wave's tiles 16 ps + 4 w ..
+  bf16x8 wf[PF5 + 1][NT5][3];
+  auto w_base = [&](const void* W3, int ps) {
+    return reinterpret_cast<const char*>(W3) + ((int64_t)(ps * 16 + wave * NT5) * 3) * X3_REC +
+           lane * 16;
+  };
+  auto load_w = [&](const char* wb, int64_t kst, int ks) {
+    const char* q = wb + ks * kst;
+#pragma unroll
+    for (int t = 0; t < NT5; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        wf[ks % (PF5 + 1)][t][pl] = *reinterpret_cast<const bf16x8*>(q + (t * 3 + pl) * X3_REC);
+  };
+
+  // ---- prologue: the block's 32 rows -> X image in LDS ---------------------------------------
+  // rows as fp32, whole rows per instruction (wave w: rows 8 w .. 8 w + 7, two 1-KB halves)
+  f32x4 rowv[2][8];
+  if constexpr (PRO) {
+    // x_new = x + alpha (sum_s P[s] + b2), written back; A = LayerNorm(x_new): ffn_reduce_ln's
+    // mode 0 per row -- the slice sum left to right from b2, the residual add, mean, then the
+    // centred squares (lane: columns 4 lane .. + 3 of each half; the wave butterfly over 64 lanes)
+    int r8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r8[j] = min(m0 + wave * 8 + j, p.M - 1);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = hh * 256 + lane * 4;
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.pro_b2 + c);
+      f32x4 acc8[8], xo8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc8[j] = b2;
+        xo8[j] = *reinterpret_cast<const f32x4*>(p.pro_x + (int64_t)r8[j] * K5 + c);
+      }
+      int sl = 0;
+      for (; sl + 4 <= p.pro_S; sl += 4) {
+        f32x4 v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            v[u][j] = *reinterpret_cast<const f32x4*>(
+                p.pro_P + ((int64_t)(sl + u) * p.M + r8[j]) * K5 + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc8[j] += v[u][j];
+      }
+      for (; sl < p.pro_S; ++sl) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = *reinterpret_cast<const f32x4*>(p.pro_P + ((int64_t)sl * p.M + r8[j]) * K5 + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc8[j] += v[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rowv[hh][j][e] = xo8[j][e] + p.pro_alpha * acc8[j][e];
+        if (m0 + wave * 8 + j < p.M)     // (rows past M are copies of row M - 1: never stored)
+          *reinterpret_cast<f32x4*>(p.pro_x + (int64_t)(m0 + wave * 8 + j) * K5 + c) = rowv[hh][j];
+      }
+    }
+    // LayerNorm of the 8 rows (ffn_reduce_ln_kernel<8>'s norm(): per lane the two quads summed
+    // quad 0 first, then the butterfly)
+    float sm[8], sq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t += rowv[hh][j][e];
+      sm[j] = t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sm[j] += __shfl_xor(sm[j], o, 64);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sm[j] *= (1.0f / K5);
+      float q = 0.f;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dd = rowv[hh][j][e] - sm[j];
+          q = __builtin_fmaf(dd, dd, q);
+        }
+      sq[j] = q;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sq[j] += __shfl_xor(sq[j], o, 64);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = hh * 256 + lane * 4;
+      const f32x4 gw = *reinterpret_cast<const f32x4*>(p.ln_w + c);
+      const f32x4 gb = *reinterpret_cast<const f32x4*>(p.ln_b + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float rstd = 1.0f / sqrtf(sq[j] * (1.0f / K5) + p.eps);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          rowv[hh][j][e] = (rowv[hh][j][e] - sm[j]) * rstd * gw[e] + gb[e];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = min(m0 + wave * 8 + j, p.M - 1);
+        rowv[hh][j] =
+            *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + hh * 256 + lane * 4);
+      }
+  }
+  const char* wb = w_base(p.W3, 0);
+#pragma unroll
+  for (int s = 0; s < PF5; ++s) load_w(wb, kstride, s);
+
+  // fp32 half rows -> LDS (row stride 1040 B: conflict-free for the lane = row reads) -> this
+  // wave's quarter of the half's k blocks in the fragment layout (lane = row li, k half hi) ->
+  // exact three-way split -> X image.  `src`: half hh of row 8 w + j for lane.
+  auto image_half = [&](int hh, const f32x4 (&src)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      *reinterpret_cast<f32x4*>(hpatch + (wave * 8 + j) * 1040 + lane * 16) = src[j];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ks = wave * 4 + u;              // k block of this half
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(hpatch + li * 1040 + ks * 64 + hi * 32);
+      const f32x4 xb =
+          *reinterpret_cast<const f32x4*>(hpatch + li * 1040 + ks * 64 + hi * 32 + 16);
+      bf16x8 x0, x1, x2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const Split3 sa = split3(xa[e]), sb = split3(xb[e]);
+        x0[e] = sa.h0; x1[e] = sa.h1; x2[e] = sa.h2;
+        x0[4 + e] = sb.h0; x1[4 + e] = sb.h1; x2[4 + e] = sb.h2;
+      }
+      char* o = ximg + (int64_t)((hh * 16 + ks) * 3) * X3_REC + lane * 16;
+      *reinterpret_cast<bf16x8*>(o) = x0;
+      *reinterpret_cast<bf16x8*>(o + X3_REC) = x1;
+      *reinterpret_cast<bf16x8*>(o + 2 * X3_REC) = x2;
+    }
+    __syncthreads();                            // half patch reusable, image half visible
+  };
+  image_half(0, rowv[0]);
+  image_half(1, rowv[1]);
+
+  // ---- one 512-column pass: acc[t] = W tile (16 ps + 4 w + t) x X^T ---------------------------
+  // plane products, the small ones first: (W plane, activation plane); the tiles alternate so
+  // that no MFMA waits for its predecessor's accumulator
+  constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+  f32x16 acc[NT5];
+  auto gemm_pass = [&](const char* wbp, int64_t kst) {   // (the first PF5 W loads are issued)
+#pragma unroll
+    for (int t = 0; t < NT5; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    bf16x8 xf[2][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      xf[0][pl] = *reinterpret_cast<const bf16x8*>(ximg + pl * X3_REC + lane * 16);
+#pragma unroll
+    for (int ks = 0; ks < KB5; ++ks) {
+      if (ks + PF5 < KB5) load_w(wbp, kst, ks + PF5);
+      if (ks + 1 < KB5) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          xf[(ks + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(
+              ximg + (int64_t)((ks + 1) * 3 + pl) * X3_REC + lane * 16);
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int t = 0; t < NT5; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks % (PF5 + 1)][t][PW[q]],
+                                                           xf[ks & 1][PX[q]], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- epilogue helpers: lane = row, registers = columns col0 + 32 t + 8 g + 4 hi + e ----------
+  // every tile of C / x_out / y and of the residual goes through a wave-private LDS patch (32
+  // rows x 512 B, row stride + 16 B) and crosses the memory pipe as 512-B row segments
+  constexpr int SEG = NT5 * 128, PST = SEG + 16, LPR = SEG / 16, NIT = 32 * LPR / 64;
+  char* wp = ximg + wave * (32 * PST);          // (only once the X image is dead)
+  auto put = [&](const f32x4 (&v)[NT5][4]) {
+#pragma unroll
+    for (int t = 0; t < NT5; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(wp + li * PST + (t * 32 + 8 * g + 4 * hi) * 4) = v[t][g];
+  };
+  auto get = [&](f32x4 (&v)[NT5][4]) {
+#pragma unroll
+    for (int t = 0; t < NT5; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        v[t][g] = *reinterpret_cast<const f32x4*>(wp + li * PST + (t * 32 + 8 * g + 4 * hi) * 4);
+  };
+  auto store_rows = [&](float* base, int ld, int col0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 64 + lane, r = q / LPR, pc = q - r * LPR;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wp + r * PST + pc * 16);
+      if (m0 + r < p.M && col0 + pc * 4 < p.N)
+        *reinterpret_cast<f32x4*>(base + (int64_t)(m0 + r) * ld + col0 + pc * 4) = v;
+    }
+  };
+
+  if constexpr (EPI == 0) {
+    // N / 512 passes over the same X image, which therefore stays alive: the C tiles leave
+    // through the half-row area instead (36 KB: 4 x 8.5 KB), two tiles of a wave at a time
+    constexpr int HSEG = 2 * 128, HPST = HSEG + 16, HLPR = HSEG / 16, HNIT = 32 * HLPR / 64;
+    char* hp = hpatch + wave * (32 * HPST);     // 4 x 8.5 KB = 34 KB
+    const int npass = p.N / 512;
+    for (int ps = 0; ps < npass; ++ps) {
+      const char* wbp = w_base(p.W3, ps);
+      if (ps > 0) {
+#pragma unroll
+        for (int s = 0; s < PF5; ++s) load_w(wbp, kstride, s);
+      }
+      gemm_pass(wbp, kstride);
+      const int col0 = ps * 512 + wave * SEG;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {             // tiles 2 u, 2 u + 1
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int t = 2 * u + tt;
+            const int c = col0 + t * 32 + 8 * g + 4 * hi;
+            f32x4 v = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c);
+            *reinterpret_cast<f32x4*>(hp + li * HPST + (tt * 32 + 8 * g + 4 * hi) * 4) = v;
+          }
+#pragma unroll
+        for (int it = 0; it < HNIT; ++it) {
+          const int q = it * 64 + lane, r = q / HLPR, pc = q - r * HLPR;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(hp + r * HPST + pc * 16);
+          if (m0 + r < p.M)
+            *reinterpret_cast<f32x4*>(p.C + (int64_t)(m0 + r) * p.ldc + col0 + u * 64 + pc * 4) = v;
+        }
+      }
+    }
+  } else {
+    gemm_pass(wb, kstride);
+    const int col0 = wave * SEG;
+    __syncthreads();                            // the X image is dead: wave patches
+    f32x4 v[NT5][4], rs[NT5][4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 64 + lane, r = q / LPR, pc = q - r * LPR;
+      const int rc = min(m0 + r, p.M - 1);
+      *reinterpret_cast<f32x4*>(wp + r * PST + pc * 16) =
+          *reinterpret_cast<const f32x4*>(p.resid + (int64_t)rc * p.ldr + col0 + pc * 4);
+    }
+    get(rs);
+    float s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT5; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = col0 + t * 32 + 8 * g + 4 * hi;
+        f32x4 a = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+        if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c);
+        v[t][g] = rs[t][g] + p.alpha * a;
+        s1 += (v[t][g][0] + v[t][g][1]) + (v[t][g][2] + v[t][g][3]);
+      }
+    put(v);
+    store_rows(p.x_out, p.ldx, col0);
+    // mean over the row's 512 columns: lane pair, then the four waves
+    s1 += __shfl_xor(s1, 32, 64);
+    if (hi == 0) red[0][wave][li] = s1;
+    __syncthreads();
+    const float mean =
+        ((red[0][0][li] + red[0][1][li]) + (red[0][2][li] + red[0][3][li])) * (1.0f / K5);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT5; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[t][g][e] - mean;
+          s2 += d * d;
+        }
+    s2 += __shfl_xor(s2, 32, 64);
+    if (hi == 0) red[1][wave][li] = s2;
+    __syncthreads();
+    const float var =
+        ((red[1][0][li] + red[1][1][li]) + (red[1][2][li] + red[1][3][li])) * (1.0f / K5);
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+#pragma unroll
+    for (int t = 0; t < NT5; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = col0 + t * 32 + 8 * g + 4 * hi;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p.ln_w + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.ln_b + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[t][g][e] = (v[t][g][e] - mean) * rstd * w[e] + b[e];
+      }
+    if (EPI == 1 || p.y != nullptr) {
+      put(v);
+      store_rows(p.y, p.ldy, col0);
+    }
+    if constexpr (EPI == 3) {
+      // ---- chained: C = GLU(y W3b^T + bias2), N2 = 1024: the LayerNorm rows never leave the CU.
+      // Half by half (waves 2 hh, 2 hh + 1 own the columns of k half hh): fp32 half rows into
+      // the half patch, every wave splits its quarter of the half's k blocks into the X image
+      const char* wb2 = w_base(p.W3b, 0);
+      const int64_t kst2 = (int64_t)32 * X3_TILE;        // 1024 / 32 tiles per k block
+#pragma unroll
+      for (int s = 0; s < PF5; ++s) load_w(wb2, kst2, s);
+      __syncthreads();                          // the wave patches (in the image area) are dead
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        if ((wave >> 1) == hh) {
+#pragma unroll
+          for (int t = 0; t < NT5; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<f32x4*>(hpatch + li * 1040 +
+                                        ((wave & 1) * SEG / 4 + t * 32 + 8 * g + 4 * hi) * 4) =
+                  v[t][g];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ks = wave * 4 + u;
+          const f32x4 xa = *reinterpret_cast<const f32x4*>(hpatch + li * 1040 + ks * 64 + hi * 32);
+          const f32x4 xb =
+              *reinterpret_cast<const f32x4*>(hpatch + li * 1040 + ks * 64 + hi * 32 + 16);
+          bf16x8 x0, x1, x2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const Split3 sa = split3(xa[e]), sb = split3(xb[e]);
+            x0[e] = sa.h0; x1[e] = sa.h1; x2[e] = sa.h2;
+            x0[4 + e] = sb.h0; x1[4 + e] = sb.h1; x2[4 + e] = sb.h2;
+          }
+          char* o = ximg + (int64_t)((hh * 16 + ks) * 3) * X3_REC + lane * 16;
+          *reinterpret_cast<bf16x8*>(o) = x0;
+          *reinterpret_cast<bf16x8*>(o + X3_REC) = x1;
+          *reinterpret_cast<bf16x8*>(o + 2 * X3_REC) = x2;
+        }
+        __syncthreads();
+      }
+      // two passes of 512 image columns = 256 GLU columns each; wave w: value / gate tile pairs
+      // (4 w, 4 w + 1), (4 w + 2, 4 w + 3) of the pass
+      char* wp2 = hpatch + wave * (32 * 272);   // 32 rows x (2 x 128 B + 16): 4 x 8.5 KB
+      for (int ps = 0; ps < 2; ++ps) {
+        const char* wbp = w_base(p.W3b, ps);
+        if (ps > 0) {
+#pragma unroll
+          for (int s = 0; s < PF5; ++s) load_w(wbp, kst2, s);
+        }
+        gemm_pass(wbp, kst2);
+        const int c2 = ps * 512 + wave * SEG;   // first column of the wave's tiles in the image
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c = c2 + 2 * u * 32 + 8 * g + 4 * hi;
+            f32x4 a = f32x4{acc[2 * u][4 * g], acc[2 * u][4 * g + 1], acc[2 * u][4 * g + 2],
+                            acc[2 * u][4 * g + 3]};
+            f32x4 gt = f32x4{acc[2 * u + 1][4 * g], acc[2 * u + 1][4 * g + 1],
+                             acc[2 * u + 1][4 * g + 2], acc[2 * u + 1][4 * g + 3]};
+            if (p.bias2) {
+              a += *reinterpret_cast<const f32x4*>(p.bias2 + c);
+              gt += *reinterpret_cast<const f32x4*>(p.bias2 + c + 32);
+            }
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
+            *reinterpret_cast<f32x4*>(wp2 + li * 272 + (u * 32 + 8 * g + 4 * hi) * 4) = o;
+          }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {          // 32 rows x 16 pieces of 16 bytes
+          const int q = it * 64 + lane, r = q >> 4, pc = q & 15;
+          const f32x4 o = *reinterpret_cast<const f32x4*>(wp2 + r * 272 + pc * 16);
+          if (m0 + r < p.M)
+            *reinterpret_cast<f32x4*>(p.C + (int64_t)(m0 + r) * p.ldc + c2 / 2 + pc * 4) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, bool PRO>
+int launch_x6r512(const X6RArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)XIMG + HPATCH;
+  auto kern = x6r512_kernel<EPI, PRO>;
+  static bool done = false;                     // per instantiation
+  if (!done) {
+    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 32)), dim3(256), lds, s, a);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+bool gemm_x6r512_supported(int M, int N, int epi) {
+  if (M <= 0) return false;
+  if (epi == 1 || epi == 3) return N == 512;
+  if (epi == 0) return N % 512 == 0 && N >= 512 && N <= 2048;
+  return false;                                 // (GLU alone: the chain covers it)
+}
+
+int gemm_x6r512(const X6RArgs& a, hipStream_t s) {
+  if (a.pro_P) {
+    WN_CHECK(a.epi == 0 && gemm_x6r512_supported(a.M, a.N, 0) && a.W3 && a.pro_S >= 1 &&
+                 a.pro_b2 && a.pro_x && a.ln_w && a.ln_b && a.C && a.ldc % 4 == 0,
+             "gemm_x6r512: prologue fold arguments");
+    return launch_x6r512<0, true>(a, s);
+  }
+  WN_CHECK(a.A && a.W3 && a.lda % 4 == 0 && gemm_x6r512_supported(a.M, a.N, a.epi),
+           "gemm_x6r512: shape");
+  if (a.epi == 1) {
+    WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && a.y && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
+                 a.ldy % 4 == 0, "gemm_x6r512: row-LN epilogue arguments");
+    return launch_x6r512<1, false>(a, s);
+  }
+  if (a.epi == 3) {
+    WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
+                 (a.y == nullptr || a.ldy % 4 == 0) && a.W3b && a.C && a.ldc % 4 == 0,
+             "gemm_x6r512: chained row-LN + GLU arguments");
+    return launch_x6r512<3, false>(a, s);
+  }
+  WN_CHECK(a.C && a.ldc % 4 == 0, "gemm_x6r512: no output");
+  return launch_x6r512<0, false>(a, s);
+}
+
+}  // namespace wn

@@ -200,7 +200,8 @@ struct RowLnArgs {
 // Row-block six-product GEMM, K = 256, A rows in registers (gemm_x6r.hip)
 struct X6RArgs {
   const float* A = nullptr; int lda = 0;     // [M][lda] fp32
-  const void* W3 = nullptr;                  // X3 image of W (N x 256)
+  int K = 256;                               // 256 (gemm_x6r.hip) or 512 (gemm_x6r512.hip)
+  const void* W3 = nullptr;                  // X3 image of W (N x K)
   const float* bias = nullptr;               // [N] or null
   int M = 0, N = 0;
   int epi = 0;          // 0: C = acc + bias; 1: x_out = resid + alpha (acc + bias), y = LN(x_out);
@@ -210,13 +211,13 @@ struct X6RArgs {
   float* x_out = nullptr; int ldx = 0;
   const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
   float* y = nullptr; int ldy = 0;           // may alias A (a block reads its rows first)
-  // epi 3 = epi 1 chained with C = GLU(y W3b^T + bias2): W3b = X3 image of a 512 x 256 weight
-  // (rows [32 values | 32 gates] per 64), C [M][256]; y is stored only if set
+  // epi 3 = epi 1 chained with C = GLU(y W3b^T + bias2): W3b = X3 image of a 2 K x K weight
+  // (rows [32 values | 32 gates] per 64), C [M][K]; y is stored only if set
   const void* W3b = nullptr; const float* bias2 = nullptr;
-  // prologue fold (epi 0, N = 768 -- the QKV projection behind a fused feed-forward module): the
+  // prologue fold (epi 0, N = 3 K -- the QKV projection behind a fused feed-forward module): the
   // A rows are NOT read from `A` but formed as ffn_reduce_ln (mode 0) forms them,
   //   x_new = pro_x + pro_alpha (sum_s pro_P[s] + pro_b2),  A = LayerNorm(x_new; ln_w, ln_b, eps),
-  // x_new written back to pro_x ([M][256]); pro_P = [pro_S][M][256] slice partials
+  // x_new written back to pro_x ([M][K]); pro_P = [pro_S][M][K] slice partials
   const float* pro_P = nullptr; int pro_S = 0; const float* pro_b2 = nullptr;
   float pro_alpha = 0.f; float* pro_x = nullptr;
 };
@@ -226,7 +227,9 @@ extern int g_x6r_pro;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its o
 extern int g_x6r;     // wn_tune_set("x6r")
 extern int g_x6r_chain;   // wn_tune_set("x6r_chain")
 bool gemm_x6r_supported(int M, int N, int K, int epi);
-int gemm_x6r(const X6RArgs& a, hipStream_t s);
+int gemm_x6r(const X6RArgs& a, hipStream_t s);          // dispatches on a.K
+bool gemm_x6r512_supported(int M, int N, int epi);
+int gemm_x6r512(const X6RArgs& a, hipStream_t s);
 extern int g_gemm_rowln;
 bool gemm_rowln_supported(int M, int N, int K);
 int gemm_rowln(const RowLnArgs& a, hipStream_t s);

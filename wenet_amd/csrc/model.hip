@@ -653,14 +653,14 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       if (fS < 0) return -2;
     }
     // the QKV projection on the row-block kernel: it can form LN(x + 0.5 FFN) itself from the
-    // slice partials (gemm_x6r.hip, PRO 1) -- no ffn_reduce_ln launch, no t1 round trip
+    // slice partials (gemm_x6r.hip / gemm_x6r512.hip, PRO) -- no ffn_reduce_ln launch, no t1 round trip
     const void* qkv_w6 = nullptr;
     if (!h16 && t_gemm_prec == PREC_F32 && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
         gemm_x6r_supported(M, 3 * d, L.qkv.in, 0)) {
       auto it = t_x6->find(L.qkv.w);
       if (it != t_x6->end()) qkv_w6 = it->second;
     }
-    const bool pro = fS > 0 && qkv_w6 && g_x6r_pro != 0 && d == 256 && 3 * d == 768;
+    const bool pro = fS > 0 && qkv_w6 && g_x6r_pro != 0 && (d == 256 || d == 512);
     if (fS > 0) {
       if (!pro)
         WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ffm2.b, 0.5f, L.norm_mha.w,
@@ -677,7 +677,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     bool qkv_done = false;
     if (qkv_w6) {
       X6RArgs g;
-      g.A = t1; g.lda = d; g.W3 = qkv_w6; g.bias = L.qkv.b; g.M = M; g.N = 3 * d;
+      g.A = t1; g.lda = d; g.K = d; g.W3 = qkv_w6; g.bias = L.qkv.b; g.M = M; g.N = 3 * d;
       g.epi = 0; g.C = qkv; g.ldc = 3 * d;
       if (pro) {
         g.pro_P = m->ffn_part.as<float>(); g.pro_S = fS; g.pro_b2 = L.ffm2.b; g.pro_alpha = 0.5f;
@@ -716,15 +716,18 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     WN_TRY(attention(a, s));
     // x += out_proj(context); t1 = LN_conv(x)       encoder_layer.py:236-240
     const bool rowln = !h16 && t_gemm_prec == PREC_F32 && gemm_rowln_supported(M, d, d);
-    // the same fusion as six bf16 plane products with the A rows in registers (gemm_x6r.hip)
+    // the same fusion as six bf16 plane products on the row-block kernels (gemm_x6r.hip: A rows
+    // in registers, d = 256; gemm_x6r512.hip: A image in LDS, d = 512 -- no v_mfma_f32 row-LN
+    // kernel exists at that width)
+    const bool rowx = rowln || (!h16 && t_gemm_prec == PREC_F32 && d == 512);
     auto x6r_rowln = [&](const Linear& l, const float* A, const Norm& nrm) -> int {
-      if (!(rowln && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+      if (!(rowx && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
             gemm_x6r_supported(M, d, l.in, 1)))
         return 1;
       auto it = t_x6->find(l.w);
       if (it == t_x6->end()) return 1;
       X6RArgs g;
-      g.A = A; g.lda = d; g.W3 = it->second; g.bias = l.b; g.M = M; g.N = d; g.epi = 1;
+      g.A = A; g.lda = d; g.K = d; g.W3 = it->second; g.bias = l.b; g.M = M; g.N = d; g.epi = 1;
       g.resid = x; g.ldr = d; g.alpha = 1.0f; g.x_out = x; g.ldx = d;
       g.ln_w = nrm.w; g.ln_b = nrm.b; g.eps = eps; g.y = t1; g.ldy = d;
       return gemm_x6r(g, s) == 0 ? 0 : -1;
@@ -733,12 +736,13 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     // (gemm_x6r.hip epi 3): LN_conv(x) never reaches HBM
     bool pw1_done = false;
     int xr = 1;
-    if (rowln && g_x6r >= 1 && g_x6r_chain != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
-        gemm_x6r_supported(M, d, L.out.in, 3) && gemm_x6r_supported(M, 2 * d, L.pw1.in, 2)) {
+    if (rowx && g_x6r >= 1 && g_x6r_chain != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+        gemm_x6r_supported(M, d, L.out.in, 3) &&
+        (d == 512 || gemm_x6r_supported(M, 2 * d, L.pw1.in, 2))) {
       auto io = t_x6->find(L.out.w), ip = t_x6->find(L.pw1.w);
       if (io != t_x6->end() && ip != t_x6->end()) {
         X6RArgs g;
-        g.A = t2; g.lda = d; g.W3 = io->second; g.bias = L.out.b; g.M = M; g.N = d; g.epi = 3;
+        g.A = t2; g.lda = d; g.K = d; g.W3 = io->second; g.bias = L.out.b; g.M = M; g.N = d; g.epi = 3;
         g.resid = x; g.ldr = d; g.alpha = 1.0f; g.x_out = x; g.ldx = d;
         g.ln_w = L.norm_conv.w; g.ln_b = L.norm_conv.b; g.eps = eps; g.y = nullptr; g.ldy = d;
         g.W3b = ip->second; g.bias2 = L.pw1.b; g.C = t2; g.ldc = d;   // (C aliases A: a block reads its rows first)
@@ -761,12 +765,12 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       WN_TRY(ln(L.norm_conv, x, t1, M, d, eps, s, h16));
     }
     // pointwise_conv1 + GLU                        convolution.py:115-118
-    if (!pw1_done && rowln && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+    if (!pw1_done && rowx && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
         gemm_x6r_supported(M, 2 * d, L.pw1.in, 2)) {
       auto it = t_x6->find(L.pw1.w);
       if (it != t_x6->end()) {
         X6RArgs g;
-        g.A = t1; g.lda = d; g.W3 = it->second; g.bias = L.pw1.b; g.M = M; g.N = 2 * d;
+        g.A = t1; g.lda = d; g.K = d; g.W3 = it->second; g.bias = L.pw1.b; g.M = M; g.N = 2 * d;
         g.epi = 2; g.C = t2; g.ldc = d;
         WN_TRY(gemm_x6r(g, s));
         pw1_done = true;
@@ -786,6 +790,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     // x += pointwise_conv2(.); t1 = LN_ff(x)        encoder_layer.py:251-255
     xr = x6r_rowln(L.pw2, t1, L.norm_ff);
     if (xr < 0) return -2;
+    const bool ln_ff_done = xr == 0 || rowln;       // t1 = LN_ff(x) came out of the GEMM's epilogue
     if (xr == 0) {
     } else if (rowln) {
       RowLnArgs g;
@@ -799,7 +804,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     // x += 0.5 * FFN(LN(x)); x = LN(x)              encoder_layer.py:253-263
     fS = 0;
     if (!h16 && t_gemm_prec == PREC_F32) {
-      if (!rowln) WN_TRY(ln(L.norm_ff, x, t1, M, d, eps, s));
+      if (!ln_ff_done) WN_TRY(ln(L.norm_ff, x, t1, M, d, eps, s));
       fS = ffn_fused_try(m, L.ff1, L.ff2, ACT_SILU, s);
       if (fS < 0) return -2;
     }
