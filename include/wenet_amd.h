@@ -290,6 +290,17 @@ int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host
                            float reverse_weight, float* l2r_logp_host,
                            float* r2l_logp_host, void* stream);
 
+/* Optional, in front of wn_ctc_prefix_beam_search when wn_rescore follows on the same batch: the
+ * part of attention_rescoring that does not depend on the hypotheses -- the cross-attention K / V
+ * projections of the encoder output for every decoder layer (decoder_layer.py:123-138; the
+ * reference recomputes them per utterance inside forward_attention_decoder) -- is queued on a
+ * second stream of the handle, ordered behind `stream`'s work so far, and overlaps the search
+ * (T' dependent steps on B workgroups while most CUs idle).  wn_rescore waits for it and skips
+ * those projections; results are the same bits.  use_right_decoder: also for the right-to-left
+ * decoder (reverse_weight > 0).  A new batch or layout (wn_encode, wn_set_encoder_out,
+ * wn_filter_blank_embedding) voids the prefetch. */
+int wn_rescore_prefetch(wn_model* m, int32_t use_right_decoder, void* stream);
+
 /* attention_rescoring COMPLETE on the device (search.py:374-458; SURVEY.md 8b `wn_rescore`):
  * the decoder pass of wn_attention_rescoring, then one kernel does what search.py:424-457 does
  * in Python -- per hypothesis the fp32 left-to-right sum of the gathered log-probs + <eos>

@@ -96,3 +96,36 @@ def test_rescore_needs_a_prefix_beam_result():
                                _lib.f32p(score), nd, nd, nf, _stream_ptr(model.device))
     assert rc != 0
     assert b'prefix beam' in _lib.lib().wn_last_error()
+
+
+@pytest.mark.parametrize('config,B,frames', [('tiny_causal', 4, (90, 330)),
+                                             ('librispeech_bidecoder_large', 12, (500, 900))])
+def test_rescore_prefetch_on_the_side_stream_changes_nothing(config, B, frames):
+    """wn_rescore_prefetch (cross-attention K / V of every decoder layer projected on a second
+    stream while the prefix beam search runs) against the projections inside the rescoring pass:
+    the same GEMMs on the same operands -- identical records, also when a prefetch is abandoned
+    (a decode without rescoring in between) and over repeated decodes (ordering of the two
+    streams)."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=31)
+    kw = dict(beam_size=6, ctc_weight=0.5, reverse_weight=0.3)
+    M = ['attention_rescoring']
+    try:
+        _lib.check(L.wn_tune_set(b'rescore_prefetch', 0), 'tune')
+        ref = model.decode(M, feats.cuda(), lens, **kw)[M[0]]
+        _lib.check(L.wn_tune_set(b'rescore_prefetch', 1), 'tune')
+        runs = [model.decode(M, feats.cuda(), lens, **kw)[M[0]] for _ in range(3)]
+        # an abandoned prefetch: prefetch by hand, then a new batch without rescoring
+        model._forward_encoder(feats.cuda(), lens)
+        _lib.check(L.wn_rescore_prefetch(model._h, 1, torch.cuda.current_stream().cuda_stream),
+                   'prefetch')
+        model.decode(['ctc_greedy_search'], feats[:2].cuda(), lens[:2])
+        runs.append(model.decode(M, feats.cuda(), lens, **kw)[M[0]])
+    finally:
+        L.wn_tune_set(b'rescore_prefetch', 1)
+    for got in runs:
+        for a, b in zip(ref, got):
+            assert a.tokens == b.tokens and a.score == b.score
+            assert a.all_scores == b.all_scores and a.tokens_confidence == b.tokens_confidence

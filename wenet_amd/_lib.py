@@ -35,7 +35,7 @@ EXPORTS = [
     'wn_attention_beam_search', 'wn_encode_chunk_batch', 'wn_op_gemm_lowp', 'wn_op_mx_quantize', 'wn_op_ffn_fused', 'wn_op_gemm_x6', 'wn_op_ffn_x6', 'wn_op_gemm_x6r', 'wn_op_gemm_x6r512', 'wn_profile_kernel_name', 'wn_profile_ffn_split', 'wn_profile_ffn_clocks', 'wn_profile_gemm_clocks', 'wn_filter_blank_embedding',
     'wn_workspace_create', 'wn_resample_length', 'wn_resample', 'wn_fbank', 'wn_log_mel', 'wn_encode', 'wn_encode_chunk', 'wn_set_encoder_out',
     'wn_ctc_logprobs', 'wn_set_ctc_probs', 'wn_ctc_greedy_search',
-    'wn_set_context_graph', 'wn_ctc_prefix_beam_search', 'wn_attention_rescoring', 'wn_rescore', 'wn_decoder_forward', 'wn_decoder_next_topk', 'wn_op_gemm',
+    'wn_set_context_graph', 'wn_ctc_prefix_beam_search', 'wn_attention_rescoring', 'wn_rescore', 'wn_rescore_prefetch', 'wn_decoder_forward', 'wn_decoder_next_topk', 'wn_op_gemm',
     'wn_op_layernorm', 'wn_op_log_add', 'wn_debug_set', 'wn_profile_enable',
     'wn_profile_collect', 'wn_tune_set',
 ]
@@ -95,6 +95,7 @@ def lib():
                                          POINTER(f32), POINTER(f32), vp]
     L.wn_rescore.argtypes = [vp, i32, pi32, pi32, pi32, pf64, i32, c_double, c_double, pi32,
                              POINTER(f32), pf64, pf64, POINTER(f32), vp]
+    L.wn_rescore_prefetch.argtypes = [vp, i32, vp]
     L.wn_decoder_forward.argtypes = [vp, i32, i32, i32, pi32, pi32, i32, vp, vp]
     L.wn_decoder_next_topk.argtypes = [vp, i32, pi32, pi32, pi32, i32, i32,
                                        POINTER(f32), pi32, vp]

@@ -5,7 +5,7 @@
 #include "model_state.h"
 
 namespace {
-int g_beam_cu_mask = 0;   // wn_tune_set("beam_cu_mask"), see wn_ctc_prefix_beam_search
+int g_rescore_prefetch = 1;   // wn_tune_set("rescore_prefetch"): 0 = wn_rescore_prefetch does nothing (A/B)
 
 // ---------------------------------------------------------------------------
 // weight ingestion
@@ -650,8 +650,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_linear") g_x6_linear = value;
   else if (k == "x6_linear_min") g_x6_linear_min = value;
   else if (k == "x6_af32") g_x6_af32 = value;
-  else if (k == "beam_cu_mask") g_beam_cu_mask = value;
-  else if (k == "x6_conv_cus") g_x6_conv_cus = value;
+  else if (k == "rescore_prefetch") g_rescore_prefetch = value;
   else if (k == "beam_weak_hash") g_beam_weak_hash = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "gemm_rowln") g_gemm_rowln = value;
@@ -1096,52 +1095,6 @@ int wn_set_context_graph(wn_model* m, int32_t n_nodes, const int32_t* fail,
   return 0;
 }
 
-// wn_tune_set("beam_cu_mask", n * 1000 + stride) (0 = off, the default; prepared at the end of
-// round 3, not yet run): the prefix beam search kernel -- T' dependent frames on B workgroups,
-// 1.13 ms at config 2 -- goes to a stream whose CU mask has n bits set, `stride` bits apart
-// (8001: bits 0..7, 8032: every 32nd bit).  With two decodes in flight the search of batch i
-// runs under the subsampling of batch i + 1, its 32 workgroups on 32 different CUs, and conv2's
-// one-block-per-CU tiles then need three rounds instead of two: 862 us against 663 us
-// (tools/timeline_two_streams.py).  On 8 CUs the search shares SIMDs with
-// itself; x6_conv_cus = 248 lets conv2 cut its rounds for the rest.  Which CUs the mask bits
-// name (one XCD or one CU of each) is for the measurement to find out: hence the stride.
-// (g_beam_cu_mask: top of this file.)
-namespace {
-int beam_stream_begin(wn_model* m, hipStream_t s, hipStream_t* out) {
-  *out = s;
-  if (g_beam_cu_mask <= 0) return 0;
-  MaskedStream& ms = m->pb_ms;
-  if (ms.cfg != g_beam_cu_mask) {
-    ms.reset();
-    int ncu = 0;
-    WN_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, m->device));
-    WN_CHECK(ncu > 0, "beam_cu_mask: no CU count");
-    const int n = std::min(std::max(g_beam_cu_mask / 1000, 1), ncu);
-    const int stride = std::max(g_beam_cu_mask % 1000, 1);
-    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-    for (int i = 0, bit = 0; i < n; ++i, bit += stride) {
-      int b = bit % ncu;
-      while (mask[b >> 5] & (1u << (b & 31))) b = (b + 1) % ncu;   // (wrapped onto a set bit)
-      mask[b >> 5] |= 1u << (b & 31);
-    }
-    WN_HIP(hipExtStreamCreateWithCUMask(&ms.st, (uint32_t)mask.size(), mask.data()));
-    WN_HIP(hipEventCreateWithFlags(&ms.e0, hipEventDisableTiming));
-    WN_HIP(hipEventCreateWithFlags(&ms.e1, hipEventDisableTiming));
-    ms.cfg = g_beam_cu_mask;
-  }
-  WN_HIP(hipEventRecord(ms.e0, s));
-  WN_HIP(hipStreamWaitEvent(ms.st, ms.e0, 0));
-  *out = ms.st;
-  return 0;
-}
-int beam_stream_end(wn_model* m, hipStream_t s, hipStream_t bs) {
-  if (bs == s) return 0;
-  WN_HIP(hipEventRecord(m->pb_ms.e1, bs));
-  WN_HIP(hipStreamWaitEvent(s, m->pb_ms.e1, 0));
-  return 0;
-}
-}  // namespace
-
 int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
                               int32_t* n_hyps_host, int32_t* hyp_lens_host,
                               int32_t* hyp_tlens_host, int32_t* hyp_tokens_host,
@@ -1186,10 +1139,7 @@ int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
     WN_TRY(m->pb_dbg.ensure(8 * sizeof(long long)));
     a.dbg_cycles = m->pb_dbg.as<long long>();
   }
-  hipStream_t bs = s;
-  WN_TRY(beam_stream_begin(m, s, &bs));
-  WN_TRY(ctc_prefix_beam(a, bs));
-  WN_TRY(beam_stream_end(m, s, bs));
+  WN_TRY(ctc_prefix_beam(a, s));
   if (pb_dbg) {
     long long h[5];
     WN_HIP(hipMemcpyAsync(h, a.dbg_cycles, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -1229,7 +1179,7 @@ namespace {
 // and reused by later calls (the autoregressive search calls this per step).
 int decoder_layers(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
                    const int* d_tok, bool mem_cache, hipStream_t s,
-                   const int* self_kvlen = nullptr) {
+                   const int* self_kvlen = nullptr, const float* kv_base = nullptr) {
   const wn_config& c = m->cfg;
   const int d = c.d_model, Menc = m->rows;
   float* x = m->r_x.as<float>();
@@ -1268,10 +1218,12 @@ int decoder_layers(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
     // (K/V projected once per utterance, not once per hypothesis)
     WN_TRY(ln(L.n2, x, t1, R, d, eps, s));
     WN_TRY(linear(L.src_q, t1, d, t2, d, R, s));
-    float* mem = mem_cache ? m->r_mem_all.as<float>() + (size_t)li * mem_layer
-                           : m->r_mem.as<float>();
-    if (!mem_cache || fill_cache)
-      WN_TRY(linear(L.src_kv, m->enc.as<float>(), d, mem, 2 * d, Menc, s));
+    // kv_base: projected ahead of this pass (wn_rescore_prefetch)
+    const float* mem = kv_base ? kv_base + (size_t)li * mem_layer
+                       : mem_cache ? m->r_mem_all.as<float>() + (size_t)li * mem_layer
+                                   : m->r_mem.as<float>();
+    if (!kv_base && (!mem_cache || fill_cache))
+      WN_TRY(linear(L.src_kv, m->enc.as<float>(), d, const_cast<float*>(mem), 2 * d, Menc, s));
     AttnArgs cx;
     cx.Q = t2; cx.ldq = d; cx.K = mem; cx.V = mem + d; cx.ldk = cx.ldv = 2 * d;
     cx.O = t1; cx.ldo = d;
@@ -1293,10 +1245,10 @@ int decoder_layers(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
 
 int run_decoder(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
                 const int* d_tok, const int* d_tgt, float* out_dev,
-                hipStream_t s) {
+                hipStream_t s, const float* kv_base = nullptr) {
   const wn_config& c = m->cfg;
   const int d = c.d_model, V = c.vocab;
-  WN_TRY(decoder_layers(m, D, R, n_seq, max_q, d_tok, false, s));
+  WN_TRY(decoder_layers(m, D, R, n_seq, max_q, d_tok, false, s, nullptr, kv_base));
   float* t1 = m->r_t1.as<float>();
   WN_TRY(ln(D.after, m->r_x.as<float>(), t1, R, d, c.norm_eps, s));
   // (the caller sized r_logits for a pitch of V rounded up to 4)
@@ -1790,6 +1742,57 @@ __global__ __launch_bounds__(64) void rescore_reduce_kernel(RescoreArgs a) {
 }
 }  // namespace
 
+int wn_rescore_prefetch(wn_model* m, int32_t use_right_decoder, void* stream) {
+  WN_CHECK(m && m->B > 0 && m->enc.p, "wn_rescore_prefetch: no current batch");
+  WN_ENTER(m);
+  PrecisionScope prec_scope(m);
+  hipStream_t s = (hipStream_t)stream;
+  if (m->kv_ready) {       // an earlier prefetch of this batch: ordered behind it
+    WN_HIP(hipStreamWaitEvent(s, m->side.e1, 0));
+    m->kv_ready = false;
+  }
+  if (g_rescore_prefetch == 0 || m->left.layers.empty() || m->rows <= 0) return 0;
+  WN_HIP(hipSetDevice(m->device));
+  const int d = m->cfg.d_model, Menc = m->rows;
+  const bool r2l = use_right_decoder != 0 && !m->right.layers.empty();
+  std::vector<const Linear*> kv;
+  for (const DecLayer& L : m->left.layers) kv.push_back(&L.src_kv);
+  if (r2l) for (const DecLayer& L : m->right.layers) kv.push_back(&L.src_kv);
+  const size_t mem_layer = (size_t)Menc * 2 * d;
+  WN_TRY(m->r_kv_all.ensure(kv.size() * mem_layer * sizeof(float)));
+  WN_TRY(m->side.ensure());
+  WN_HIP(hipEventRecord(m->side.e0, s));            // the encoder output is complete
+  WN_HIP(hipStreamWaitEvent(m->side.st, m->side.e0, 0));
+  hipStream_t ss = m->side.st;
+  // all layers project the SAME rows: split the encoder output into planes once and run the
+  // six-product GEMM per layer (linear() would split it once per layer) -- where linear()
+  // would take that route at all
+  bool x6ok = t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_linear != 0 && t_x6 &&
+              Menc >= 512 && d % 16 == 0 &&
+              2.0 * Menc * (2.0 * d) * d >= 1e8 * g_x6_linear_min;
+  if (x6ok)
+    for (const Linear* l : kv) x6ok = x6ok && t_x6->count(l->w) != 0;
+  if (x6ok) {
+    WN_TRY(m->r_enc3.ensure(x6_bytes(Menc, d)));
+    WN_TRY(x6_split(m->enc.as<float>(), Menc, d, d, m->r_enc3.as<char>(), ss));
+  }
+  for (size_t i = 0; i < kv.size(); ++i) {
+    float* dst = m->r_kv_all.as<float>() + i * mem_layer;
+    if (x6ok) {
+      X6Args x;
+      x.A3 = m->r_enc3.as<char>(); x.B3 = t_x6->find(kv[i]->w)->second; x.M = Menc;
+      x.N = 2 * d; x.K = d; x.epi = 0; x.bias = kv[i]->b; x.C = dst; x.ldc = 2 * d;
+      WN_TRY(gemm_x6(x, ss));
+    } else {
+      WN_TRY(linear(*kv[i], m->enc.as<float>(), d, dst, 2 * d, Menc, ss));
+    }
+  }
+  WN_HIP(hipEventRecord(m->side.e1, ss));
+  m->kv_ready = true; m->kv_rows = Menc;
+  m->kv_nl = (int)m->left.layers.size(); m->kv_nr = r2l ? (int)m->right.layers.size() : 0;
+  return 0;
+}
+
 int wn_rescore(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
                const int32_t* hyp_lens_host, const int32_t* hyp_tokens_host,
                const double* ctc_scores_host, int32_t max_len, double ctc_weight,
@@ -1900,11 +1903,20 @@ int wn_rescore(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
     WN_TRY(m->r_h.ensure((size_t)R * c.dec_ffn_dim * sizeof(float)));
     WN_TRY(m->r_mem.ensure((size_t)m->rows * 2 * d * sizeof(float)));
     WN_TRY(m->r_logits.ensure((size_t)R * ((V + 3) / 4 * 4) * sizeof(float)));
+    // cross-attention K | V projected while the prefix beam search ran (wn_rescore_prefetch)?
+    const float* kv_l = nullptr;
+    const float* kv_r = nullptr;
+    if (m->kv_ready && m->kv_rows == m->rows && m->kv_nl == (int)m->left.layers.size() &&
+        (!use_r2l || m->kv_nr == (int)m->right.layers.size())) {
+      WN_HIP(hipStreamWaitEvent(s, m->side.e1, 0));
+      kv_l = m->r_kv_all.as<float>();
+      kv_r = kv_l + (size_t)m->kv_nl * m->rows * 2 * d;
+    }
     WN_TRY(run_decoder(m, m->left, R, n_seq, max_q, m->r_tok.as<int>(), m->r_tgt.as<int>(), o_l,
-                       s));
+                       s, kv_l));
     if (use_r2l)
       WN_TRY(run_decoder(m, m->right, R, n_seq, max_q, m->r_rtok.as<int>(),
-                         m->r_rtgt.as<int>(), o_r, s));
+                         m->r_rtgt.as<int>(), o_r, s, kv_r));
   }
   char* rb = m->r_res.as<char>();
   RescoreArgs a;

@@ -511,7 +511,6 @@ int g_gemm_x6 = 1;
 int g_x6_conv = 1;
 int g_x6_sub = 1;
 int g_x6_conv_tail = 1;
-int g_x6_conv_cus = 256;   // wn_tune_set("x6_conv_cus"): CUs per round of conv2's 256-row tiles (see gemm_x6())
 int g_x6_linear = 1;
 // 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in
 // registers.  Measured (r02ag): the split costs more than the plane bytes it saves -- FFN w_1
@@ -588,9 +587,10 @@ int gemm_x6(const X6Args& args, hipStream_t s) {
     // One 256-row tile per CU and round: when the last round would be less than half
     // full, its rows go to a second launch of 128-row tiles (half as long) instead --
     // 589 tiles at config 2 = 2.3 rounds become 2 rounds + 154 half tiles.
-    // (g_x6_conv_cus: the CUs a round may use -- 256; fewer when the prefix beam search of the
-    // batch in front keeps some for itself, wn_tune_set("beam_cu_mask"))
-    const int ncu = std::min(std::max(g_x6_conv_cus, 64), 256);
+    // (rounds cut for fewer CUs, with the prefix beam search of the batch in front confined to
+    // its own few CUs by a CU-masked stream, were measured in round 4: 39-44 k against 44 k
+    // audio-s/s on the same box, profiles/r06b_cu_mask.txt -- removed)
+    const int ncu = 256;
     const int t256 = cdiv(a.M, 256), full = t256 / ncu * ncu;
     auto run = [&](const X6Args& x, int rows) {
       if (af32) return rows == 256 ? launch_x6<256, 0, ACT_RELU, true, true>(x, s)

@@ -221,7 +221,6 @@ struct X6RArgs {
   const float* pro_P = nullptr; int pro_S = 0; const float* pro_b2 = nullptr;
   float pro_alpha = 0.f; float* pro_x = nullptr;
 };
-extern int g_x6_conv_cus;  // wn_tune_set("x6_conv_cus"): CUs per round of conv2's tiles (256)
 extern int g_dwconv_tiled; // wn_tune_set("dwconv_tiled"): 1 = depthwise convolution with four rows per wave
 extern int g_x6r_pro;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of QKV
 extern int g_x6r;     // wn_tune_set("x6r")

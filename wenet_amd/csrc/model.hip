@@ -422,6 +422,10 @@ int set_layout(wn_model* m, int B, int Tp, const std::vector<int>& off,
                const std::vector<int>& len, int rows, hipStream_t s) {
   m->B = B; m->Tp = Tp; m->off = off; m->len = len; m->rows = rows;
   m->mem_cache_valid = false;
+  if (m->kv_ready) {     // a prefetch nobody consumed may still be reading m->enc
+    (void)hipStreamWaitEvent(s, m->side.e1, 0);
+    m->kv_ready = false;
+  }
   std::vector<int> row_utt(std::max(rows, 1), -1);
   for (int b = 0; b < B; ++b)
     for (int t = 0; t < len[b]; ++t) row_utt[off[b] + t] = b;
@@ -566,7 +570,7 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
       g.a_pix = pix; g.a_tiles = tiles; g.conv_kbc = d / 16;
       g.conv_taps = 9;
       {   // scratch for the K-slice partials of the last, partial round of tiles (gemm_x6.hip)
-        const int ncu = std::min(std::max(g_x6_conv_cus, 64), 256);   // (as in gemm_x6())
+        const int ncu = 256;   // (as in gemm_x6())
         const int t256 = cdiv(M * F2, 256), rem = t256 - t256 / ncu * ncu;
         if (d <= 256 && t256 >= ncu && rem > 0 && rem <= ncu / 2) {
           const size_t need = (size_t)4 * ((size_t)M * F2 - (size_t)(t256 - rem) * 256) * d *
@@ -1043,6 +1047,10 @@ int encode_transformer(wn_model* m, const float* feats_dev,
   m->B = B; m->Tp = Tp; m->off = off2; m->len = len2; m->rows = M;
   m->ctc_valid = false;
   m->mem_cache_valid = false;
+  if (m->kv_ready) {     // a prefetch nobody consumed may still be reading m->enc
+    (void)hipStreamWaitEvent(s, m->side.e1, 0);
+    m->kv_ready = false;
+  }
   if (M == 0) {
     WN_TRY(m->stage.begin((size_t)B * 16 + 1024));
     WN_TRY(upload_desc(m, m->d_off, off2, s));

@@ -117,22 +117,27 @@ struct PinnedBuf {
   }
 };
 
-// A stream restricted to a few CUs (hipExtStreamCreateWithCUMask) + the two events that order
-// it with the caller's stream: see wn_tune_set("beam_cu_mask") in cabi.hip.
-struct MaskedStream {
+// A second stream of the handle + the two events that order it with the caller's stream: work
+// that does not depend on the search result runs there while the (latency-bound, few-CU) prefix
+// beam search runs on the caller's stream -- wn_rescore_prefetch in cabi.hip.
+struct SideStream {
   hipStream_t st = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  int cfg = 0;
-  MaskedStream() = default;
-  MaskedStream(const MaskedStream&) = delete;
-  MaskedStream& operator=(const MaskedStream&) = delete;
-  void reset() {
+  SideStream() = default;
+  SideStream(const SideStream&) = delete;
+  SideStream& operator=(const SideStream&) = delete;
+  int ensure() {
+    if (st) return 0;
+    WN_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    WN_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    WN_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    return 0;
+  }
+  ~SideStream() {
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (st) (void)hipStreamDestroy(st);
-    st = nullptr; e0 = e1 = nullptr; cfg = 0;
   }
-  ~MaskedStream() { reset(); }
 };
 
 struct Linear { const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0; };
@@ -378,7 +383,13 @@ struct wn_model {
   DevBuf ab_cache, ab_state;   // `attention` mode: self-attention K|V cache, beam state
   bool mem_cache_valid = false;
 
-  MaskedStream pb_ms;          // prefix beam search on its own few CUs (beam_cu_mask)
+  SideStream side;             // wn_rescore_prefetch
+  // cross-attention K | V of the current batch for every decoder layer (left, then right),
+  // projected ahead of the rescoring pass (wn_rescore_prefetch), and the plane image of the
+  // encoder output they were projected from
+  DevBuf r_kv_all, r_enc3;
+  bool kv_ready = false;
+  int kv_rows = 0, kv_nl = 0, kv_nr = 0;
   Stager stage;
   // optional HIP-event bracket around the FFN w_1 GEMM launches (the kernel
   // the roofline is quoted on); see wn_profile_*.

@@ -733,6 +733,14 @@ class ASRModel:
                                                    blank_id, self.device)
         prefix = None
         if st['need_beam']:
+            if ('attention_rescoring' in methods and self._cfg.dec_layers > 0
+                    and not self.apply_non_blank_embedding):
+                # the hypothesis-independent part of rescoring runs on a second stream under the
+                # prefix beam search (with the non-blank filter the decoder's memory is not
+                # known yet)
+                _lib.check(self._L.wn_rescore_prefetch(
+                    self._h, 1 if reverse_weight > 0 else 0, _stream_ptr(self.device)),
+                    'wn_rescore_prefetch')
             prefix, self._last_prefix_raw = _prefix_beam(
                 self._h, B, max_len, beam_size, blank_id, self.device)
             if 'ctc_prefix_beam_search' in methods:
