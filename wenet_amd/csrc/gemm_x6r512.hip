@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
   // ---- epilogue helpers: lane = row, registers = columns col0 + 32 t + 8 g + 4 hi + e ----------
   // every tile of C / x_out / y and of the residual goes through a wave-private LDS patch (32
   // rows x 512 B, row stride + 16 B) and crosses the memory pipe as 512-B row segments
-  constexpr int SEG = NT5 * 128, PST = SEG + 16, LPR = SEG / 16, NIT = 32 * LPR / 64;
+  constexpr int WCOLS = NT5 * 32;                  // columns a wave owns in a pass
+  constexpr int SEG = NT5 * 128, PST = SEG + 16, LPR = SEG / 16, NIT = 32 * LPR / 64;   // (bytes)
   char* wp = ximg + wave * (32 * PST);          // (only once the X image is dead)
   auto put = [&](const f32x4 (&v)[NT5][4]) {
 #pragma unroll
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
         for (int s = 0; s < PF5; ++s) load_w(wbp, kstride, s);
       }
       gemm_pass(wbp, kstride);
-      const int col0 = ps * 512 + wave * SEG;
+      const int col0 = ps * 512 + wave * WCOLS;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {             // tiles 2 u, 2 u + 1
 #pragma unroll
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
     }
   } else {
     gemm_pass(wb, kstride);
-    const int col0 = wave * SEG;
+    const int col0 = wave * WCOLS;
     __syncthreads();                            // the X image is dead: wave patches
     f32x4 v[NT5][4], rs[NT5][4];
 #pragma unroll
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
               *reinterpret_cast<f32x4*>(hpatch + li * 1040 +
-                                        ((wave & 1) * SEG / 4 + t * 32 + 8 * g + 4 * hi) * 4) =
+                                        ((wave & 1) * WCOLS + t * 32 + 8 * g + 4 * hi) * 4) =
                   v[t][g];
         }
         __syncthreads();
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
           for (int s = 0; s < PF5; ++s) load_w(wbp, kst2, s);
         }
         gemm_pass(wbp, kst2);
-        const int c2 = ps * 512 + wave * SEG;   // first column of the wave's tiles in the image
+        const int c2 = ps * 512 + wave * WCOLS; // first column of the wave's tiles in the image
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
