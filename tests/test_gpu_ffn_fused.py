@@ -303,14 +303,27 @@ def test_qkv_prologue_fold_is_bit_identical_to_the_reduce_launch(B, frames, chun
 
 
 # ---- d_model = 512: the row-block kernels with the A image in LDS (csrc/gemm_x6r512.hip) ----------
+@pytest.mark.parametrize('rows', [32, 64])
 @pytest.mark.parametrize('M,N,epi', [(7932, 512, 1), (7932, 1536, 0), (16231, 512, 0), (33, 512, 1),
                                      (1000, 1024, 0), (31, 1536, 0), (4097, 512, 1),
-                                     (7932, 512, 3), (45, 512, 3), (16231, 512, 3)])
-def test_gemm_x6r512_vs_fp64(M, N, epi):
+                                     (7932, 512, 3), (45, 512, 3), (16231, 512, 3), (16231, 1536, 0),
+                                     (65, 512, 3), (16231, 512, 1)])
+def test_gemm_x6r512_vs_fp64(M, N, epi, rows):
     """K = 512: epi 0 plain projection (one to three 512-column passes over the same A image),
     epi 1 residual + LayerNorm over complete rows, epi 3 the same chained with pointwise_conv1 +
     GLU (weight rows permuted per 64 as [32 values | 32 gates]) from the LayerNorm rows in LDS;
-    ragged row counts; deterministic."""
+    ragged row counts; deterministic.  Both block heights: 32 rows (A as a plane image in LDS)
+    and 64 rows (fp32 rows in LDS, split per k block in registers; picked from M = 12288 on)."""
+    from wenet_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.wn_tune_set(b'x6r512_rows', rows), 'tune')
+    try:
+        _x6r512_case(M, N, epi)
+    finally:
+        L.wn_tune_set(b'x6r512_rows', 0)
+
+
+def _x6r512_case(M, N, epi):
     from wenet_amd import _lib
     L = _lib.lib()
     d = 512

@@ -645,6 +645,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_sub") g_x6_sub = value;
   else if (k == "x6_conv_tail") g_x6_conv_tail = value;
   else if (k == "x6r_pro") g_x6r_pro = value;
+  else if (k == "x6r512_rows") g_x6r512_rows = value;
   else if (k == "dwconv_tiled") g_dwconv_tiled = value;
   else if (k == "attn_fold") g_attn_fold = value;
   else if (k == "x6_linear") g_x6_linear = value;

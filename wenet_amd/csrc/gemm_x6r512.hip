@@ -1,9 +1,8 @@
 // Row-block fp32 GEMM on the bf16 matrix cores (six plane products) for the encoder's small
 // projections at d_model = 512 -- K = 512, N = 512 .. 1536: the d = 512 counterpart of
 // gemm_x6r.hip (round 4).  Same launches per Conformer layer as at d = 256:
-//   * QKV projection (attention.py:109-131), optionally forming its own input
-//     LN_mha(x + 0.5 FFN_macaron) from the slice partials of the feed-forward GEMM pair
-//     (encoder_layer.py:220-232; ffn_reduce_ln's mode 0, same operations in the same order);
+//   * QKV projection (attention.py:109-131; its input LN_mha(x + 0.5 FFN_macaron) still comes
+//     from ffn_reduce_ln);
 //   * attention output projection + residual + LN_conv chained with pointwise_conv1 + GLU
 //     (attention.py:176, encoder_layer.py:238-240, convolution.py:115-118);
 //   * pointwise_conv2 + residual + LN_ff (convolution.py:148, encoder_layer.py:251-255).
@@ -42,9 +41,10 @@ constexpr int PF5 = 2;                  // W fragment prefetch distance (k block
 // EPI 0: C = acc + bias (N = 512 passes); EPI 1: x_out = resid + alpha (acc + bias),
 // y = LayerNorm(x_out) (N = 512); EPI 3: EPI 1, then C = GLU(y W3b^T + bias2) with W3b the image
 // of a 1024 x 512 weight whose rows are permuted per 64 as [32 values | 32 gates] (y itself is
-// stored only if p.y is set).  PRO: the A rows are formed from feed-forward slice partials
-// (X6RArgs::pro_*), EPI 0 only.
-template <int EPI, bool PRO>
+// stored only if p.y is set).  (A prologue that formed the rows from the feed-forward slice
+// partials, like gemm_x6r.hip's PRO, was built and measured in round 4: 107 us against 79 us +
+// 20 us for the separate ffn_reduce_ln launch at config 4 -- removed.)
+template <int EPI>
 __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem5[];
   __shared__ float red[2][4][32];
@@ -76,109 +76,14 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
   // ---- prologue: the block's 32 rows -> X image in LDS ---------------------------------------
   // rows as fp32, whole rows per instruction (wave w: rows 8 w .. 8 w + 7, two 1-KB halves)
   f32x4 rowv[2][8];
-  if constexpr (PRO) {
-    // x_new = x + alpha (sum_s P[s] + b2), written back; A = LayerNorm(x_new): ffn_reduce_ln's
-    // mode 0 per row -- the slice sum left to right from b2, the residual add, mean, then the
-    // centred squares (lane: columns 4 lane .. + 3 of each half; the wave butterfly over 64 lanes)
-    int r8[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r8[j] = min(m0 + wave * 8 + j, p.M - 1);
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int c = hh * 256 + lane * 4;
-      const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.pro_b2 + c);
-      f32x4 acc8[8], xo8[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        acc8[j] = b2;
-        xo8[j] = *reinterpret_cast<const f32x4*>(p.pro_x + (int64_t)r8[j] * K5 + c);
-      }
-      int sl = 0;
-      for (; sl + 4 <= p.pro_S; sl += 4) {
-        f32x4 v[4][8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            v[u][j] = *reinterpret_cast<const f32x4*>(
-                p.pro_P + ((int64_t)(sl + u) * p.M + r8[j]) * K5 + c);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc8[j] += v[u][j];
-      }
-      for (; sl < p.pro_S; ++sl) {
-        f32x4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          v[j] = *reinterpret_cast<const f32x4*>(p.pro_P + ((int64_t)sl * p.M + r8[j]) * K5 + c);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc8[j] += v[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rowv[hh][j][e] = xo8[j][e] + p.pro_alpha * acc8[j][e];
-        if (m0 + wave * 8 + j < p.M)     // (rows past M are copies of row M - 1: never stored)
-          *reinterpret_cast<f32x4*>(p.pro_x + (int64_t)(m0 + wave * 8 + j) * K5 + c) = rowv[hh][j];
-      }
-    }
-    // LayerNorm of the 8 rows (ffn_reduce_ln_kernel<8>'s norm(): per lane the two quads summed
-    // quad 0 first, then the butterfly)
-    float sm[8], sq[8];
+  for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float t = 0.f;
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t += rowv[hh][j][e];
-      sm[j] = t;
+      const int r = min(m0 + wave * 8 + j, p.M - 1);
+      rowv[hh][j] =
+          *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + hh * 256 + lane * 4);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sm[j] += __shfl_xor(sm[j], o, 64);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      sm[j] *= (1.0f / K5);
-      float q = 0.f;
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float dd = rowv[hh][j][e] - sm[j];
-          q = __builtin_fmaf(dd, dd, q);
-        }
-      sq[j] = q;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sq[j] += __shfl_xor(sq[j], o, 64);
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int c = hh * 256 + lane * 4;
-      const f32x4 gw = *reinterpret_cast<const f32x4*>(p.ln_w + c);
-      const f32x4 gb = *reinterpret_cast<const f32x4*>(p.ln_b + c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float rstd = 1.0f / sqrtf(sq[j] * (1.0f / K5) + p.eps);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          rowv[hh][j][e] = (rowv[hh][j][e] - sm[j]) * rstd * gw[e] + gb[e];
-      }
-    }
-  } else {
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = min(m0 + wave * 8 + j, p.M - 1);
-        rowv[hh][j] =
-            *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + hh * 256 + lane * 4);
-      }
-  }
   const char* wb = w_base(p.W3, 0);
 #pragma unroll
   for (int s = 0; s < PF5; ++s) load_w(wb, kstride, s);
@@ -456,10 +361,324 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
   }
 }
 
-template <int EPI, bool PRO>
+// ---------------------------------------------------------------------------------------------
+// 64-row blocks (round 4, second form).  With 32 rows per block every CU streams the WHOLE weight
+// image from L2 for 32 rows of work: 1.6 MB per 512-column pass against 11.7 us of MFMA work --
+// 64 B / clk / CU, the L1 fill rate, and 248 CUs x 64 B = the aggregate L2 rate; measured 24.4 us
+// per pass (tools/bench_x6r.py, profiles/r06f_bench_x6r.txt), i.e. both limits at ~50 %.  Twice
+// the rows per block halve the weight bytes per MFMA.  M = 7932 gives only 124 such blocks (no
+// gain: half the CUs, twice the work each), M >= ~12 k fills the chip once -- config 3's 16231
+// rows ran TWO rounds of 32-row blocks.
+// 64 rows x 512 k as planes would be 192 KB: the rows stay fp32 in LDS (132 KB, row stride
+// 2064 B: conflict-free lane = row reads) and a wave splits the two fragments of a k block in
+// registers right before it multiplies them (per k block 16 values -> 48 bf16 against 48 MFMAs:
+// the VALU work rides under the matrix pipe).  Wave w: columns [128 w, 128 w + 128) of a pass for
+// BOTH 32-row tiles (8 accumulator tiles).  C / x_out / y / residual tiles cross the memory pipe
+// as 128-byte row segments through a 4.5-KB wave patch.  The chained GEMM (EPI 3) needs no
+// second image: the LayerNorm rows go back into the row area as fp32.
+constexpr int WROWS = 64;
+constexpr int RSTR = 2064;                    // bytes per fp32 row in LDS (516 floats)
+constexpr int XROWS = WROWS * RSTR;           // 132,096 B
+constexpr int QPST = 144;                     // quarter patch: 32 rows x (128 B + 16)
+constexpr int QPATCH = 4 * 32 * QPST;         // 18,432 B
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem5w[];
+  __shared__ float red[2][4][WROWS];
+  char* xrows = smem5w;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 4);
+  char* qp = smem5w + XROWS + wave * (32 * QPST);
+  const int hi = lane >> 5, li = lane & 31;
+  const int m0 = blockIdx.x * WROWS;
+  const int Tn = (p.N + 31) >> 5;
+  const int64_t kstride = (int64_t)Tn * X3_TILE;
+
+  bf16x8 wf[PF5 + 1][NT5][3];
+  auto w_base = [&](const void* W3, int ps) {
+    return reinterpret_cast<const char*>(W3) + ((int64_t)(ps * 16 + wave * NT5) * 3) * X3_REC +
+           lane * 16;
+  };
+  auto load_w = [&](const char* wb, int64_t kst, int ks) __attribute__((always_inline)) {
+    const char* q = wb + ks * kst;
+#pragma unroll
+    for (int t = 0; t < NT5; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        wf[ks % (PF5 + 1)][t][pl] = *reinterpret_cast<const bf16x8*>(q + (t * 3 + pl) * X3_REC);
+  };
+  const char* wb = w_base(p.W3, 0);
+#pragma unroll
+  for (int s = 0; s < PF5; ++s) load_w(wb, kstride, s);
+
+  // ---- the block's 64 rows -> LDS, fp32, whole rows per instruction (wave w: rows 16 w ..) ----
+#pragma unroll
+  for (int b8 = 0; b8 < 2; ++b8) {
+    f32x4 rv[8][2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = min(m0 + wave * 16 + b8 * 8 + j, p.M - 1);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+        rv[j][hh] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + hh * 256 + lane * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+        *reinterpret_cast<f32x4*>(xrows + (wave * 16 + b8 * 8 + j) * RSTR + hh * 1024 + lane * 16) =
+            rv[j][hh];
+  }
+  __syncthreads();
+
+  constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+  f32x16 acc[2][NT5];
+  // one 512-column pass over both row tiles; the fp32 fragments of k block ks + 1 are read from
+  // LDS while the products of k block ks run, and split when their turn comes
+  auto gemm_pass = [&](const char* wbp, int64_t kst) __attribute__((always_inline)) {   // (the first PF5 W loads are issued)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int t = 0; t < NT5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
+    f32x4 raw[2][2][2];                                  // [buffer][row tile][k quad]
+    auto read_x = [&](int buf, int ks) __attribute__((always_inline)) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const char* q = xrows + (rt * 32 + li) * RSTR + ks * 64 + hi * 32;
+        raw[buf][rt][0] = *reinterpret_cast<const f32x4*>(q);
+        raw[buf][rt][1] = *reinterpret_cast<const f32x4*>(q + 16);
+      }
+    };
+    read_x(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KB5; ++ks) {
+      if (ks + PF5 < KB5) load_w(wbp, kst, ks + PF5);
+      bf16x8 X[2][3];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const Split3 sa = split3(raw[ks & 1][rt][0][e]), sb = split3(raw[ks & 1][rt][1][e]);
+          X[rt][0][e] = sa.h0; X[rt][1][e] = sa.h1; X[rt][2][e] = sa.h2;
+          X[rt][0][4 + e] = sb.h0; X[rt][1][4 + e] = sb.h1; X[rt][2][4 + e] = sb.h2;
+        }
+      if (ks + 1 < KB5) read_x((ks + 1) & 1, ks + 1);
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int t = 0; t < NT5; ++t)
+            acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks % (PF5 + 1)][t][PW[q]],
+                                                                 X[rt][PX[q]], acc[rt][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- tile traffic through the wave's quarter patch: lane = row <-> 128-byte row segments -----
+  // v[g] = columns 8 g + 4 hi .. + 3 of the tile for row li
+  auto tile_out = [&](const f32x4 (&v)[4], float* base, int ld, int row0, int col)
+      __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4*>(qp + li * QPST + (8 * g + 4 * hi) * 4) = v[g];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = it * 64 + lane, r = q >> 3, pc = q & 7;
+      const f32x4 o = *reinterpret_cast<const f32x4*>(qp + r * QPST + pc * 16);
+      if (row0 + r < p.M)
+        *reinterpret_cast<f32x4*>(base + (int64_t)(row0 + r) * ld + col + pc * 4) = o;
+    }
+  };
+  auto tile_in = [&](f32x4 (&v)[4], const float* base, int ld, int row0, int col)
+      __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = it * 64 + lane, r = q >> 3, pc = q & 7;
+      const int rc = min(row0 + r, p.M - 1);
+      *reinterpret_cast<f32x4*>(qp + r * QPST + pc * 16) =
+          *reinterpret_cast<const f32x4*>(base + (int64_t)rc * ld + col + pc * 4);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      v[g] = *reinterpret_cast<const f32x4*>(qp + li * QPST + (8 * g + 4 * hi) * 4);
+  };
+  constexpr int WCOLS = NT5 * 32;
+
+  if constexpr (EPI == 0) {
+    const int npass = p.N / 512;
+    for (int ps = 0; ps < npass; ++ps) {
+      const char* wbp = w_base(p.W3, ps);
+      if (ps > 0) {
+#pragma unroll
+        for (int s = 0; s < PF5; ++s) load_w(wbp, kstride, s);
+      }
+      gemm_pass(wbp, kstride);
+      const int col0 = ps * 512 + wave * WCOLS;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < NT5; ++t) {
+          f32x4 v[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            v[g] = f32x4{acc[rt][t][4 * g], acc[rt][t][4 * g + 1], acc[rt][t][4 * g + 2],
+                         acc[rt][t][4 * g + 3]};
+            if (p.bias)
+              v[g] += *reinterpret_cast<const f32x4*>(p.bias + col0 + t * 32 + 8 * g + 4 * hi);
+          }
+          tile_out(v, p.C, p.ldc, m0 + rt * 32, col0 + t * 32);
+        }
+    }
+  } else {
+    gemm_pass(wb, kstride);
+    const int col0 = wave * WCOLS;
+    f32x4 v[2][NT5][4];
+    float s1[2] = {0.f, 0.f};
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int t = 0; t < NT5; ++t) {
+        f32x4 rs[4];
+        tile_in(rs, p.resid, p.ldr, m0 + rt * 32, col0 + t * 32);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = col0 + t * 32 + 8 * g + 4 * hi;
+          f32x4 a = f32x4{acc[rt][t][4 * g], acc[rt][t][4 * g + 1], acc[rt][t][4 * g + 2],
+                          acc[rt][t][4 * g + 3]};
+          if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c);
+          v[rt][t][g] = rs[g] + p.alpha * a;
+          s1[rt] += (v[rt][t][g][0] + v[rt][t][g][1]) + (v[rt][t][g][2] + v[rt][t][g][3]);
+        }
+        tile_out(v[rt][t], p.x_out, p.ldx, m0 + rt * 32, col0 + t * 32);
+      }
+    // LayerNorm statistics of the 64 rows: lane pair, then the four waves (mean, then the centred
+    // squares)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      s1[rt] += __shfl_xor(s1[rt], 32, 64);
+      if (hi == 0) red[0][wave][rt * 32 + li] = s1[rt];
+    }
+    __syncthreads();                            // (also: every wave is done with the row area)
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int r = rt * 32 + li;
+      mean[rt] = ((red[0][0][r] + red[0][1][r]) + (red[0][2][r] + red[0][3][r])) * (1.0f / K5);
+      float s2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT5; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = v[rt][t][g][e] - mean[rt];
+            s2 += d * d;
+          }
+      s2 += __shfl_xor(s2, 32, 64);
+      if (hi == 0) red[1][wave][r] = s2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int r = rt * 32 + li;
+      const float var = ((red[1][0][r] + red[1][1][r]) + (red[1][2][r] + red[1][3][r])) * (1.0f / K5);
+      rstd[rt] = 1.0f / sqrtf(var + p.eps);
+    }
+#pragma unroll
+    for (int t = 0; t < NT5; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = col0 + t * 32 + 8 * g + 4 * hi;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p.ln_w + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.ln_b + c);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[rt][t][g][e] = (v[rt][t][g][e] - mean[rt]) * rstd[rt] * w[e] + b[e];
+      }
+    if (EPI == 1 || p.y != nullptr) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < NT5; ++t) tile_out(v[rt][t], p.y, p.ldy, m0 + rt * 32, col0 + t * 32);
+    }
+    if constexpr (EPI == 3) {
+      // ---- chained: C = GLU(y W3b^T + bias2), N2 = 1024: the LayerNorm rows go back into the
+      // row area (every wave left it at the barriers above) and the second GEMM reads them like
+      // the first
+      const char* wb2 = w_base(p.W3b, 0);
+      const int64_t kst2 = (int64_t)32 * X3_TILE;
+#pragma unroll
+      for (int s = 0; s < PF5; ++s) load_w(wb2, kst2, s);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < NT5; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(xrows + (rt * 32 + li) * RSTR +
+                                      (col0 + t * 32 + 8 * g + 4 * hi) * 4) = v[rt][t][g];
+      __syncthreads();
+      for (int ps = 0; ps < 2; ++ps) {
+        const char* wbp = w_base(p.W3b, ps);
+        if (ps > 0) {
+#pragma unroll
+          for (int s = 0; s < PF5; ++s) load_w(wbp, kst2, s);
+        }
+        gemm_pass(wbp, kst2);
+        const int c2 = ps * 512 + wave * WCOLS;   // first column of the wave's tiles in the image
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            f32x4 o[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int c = c2 + 2 * u * 32 + 8 * g + 4 * hi;
+              f32x4 a = f32x4{acc[rt][2 * u][4 * g], acc[rt][2 * u][4 * g + 1],
+                              acc[rt][2 * u][4 * g + 2], acc[rt][2 * u][4 * g + 3]};
+              f32x4 gt = f32x4{acc[rt][2 * u + 1][4 * g], acc[rt][2 * u + 1][4 * g + 1],
+                               acc[rt][2 * u + 1][4 * g + 2], acc[rt][2 * u + 1][4 * g + 3]};
+              if (p.bias2) {
+                a += *reinterpret_cast<const f32x4*>(p.bias2 + c);
+                gt += *reinterpret_cast<const f32x4*>(p.bias2 + c + 32);
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                o[g][e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
+            }
+            tile_out(o, p.C, p.ldc, m0 + rt * 32, c2 / 2 + u * 32);
+          }
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch_x6r512w(const X6RArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)XROWS + QPATCH;
+  auto kern = x6r512w_kernel<EPI>;
+  static bool done = false;                     // per instantiation
+  if (!done) {
+    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(cdiv(a.M, WROWS)), dim3(256), lds, s, a);
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int EPI>
 int launch_x6r512(const X6RArgs& a, hipStream_t s) {
   const size_t lds = (size_t)XIMG + HPATCH;
-  auto kern = x6r512_kernel<EPI, PRO>;
+  auto kern = x6r512_kernel<EPI>;
   static bool done = false;                     // per instantiation
   if (!done) {
     WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -480,28 +699,33 @@ bool gemm_x6r512_supported(int M, int N, int epi) {
   return false;                                 // (GLU alone: the chain covers it)
 }
 
+int g_x6r512_rows = 0;   // wn_tune_set("x6r512_rows"): 0 auto, 32 / 64 force the block height (A/B, tests)
+
+// 64-row blocks once they cover at least three quarters of the 256 CUs (M >= 12288)
+static bool x6r512_wide(const X6RArgs& a) {
+  if (g_x6r512_rows == 64) return true;
+  if (g_x6r512_rows == 32) return false;
+  return cdiv(a.M, WROWS) >= 192;
+}
+
 int gemm_x6r512(const X6RArgs& a, hipStream_t s) {
-  if (a.pro_P) {
-    WN_CHECK(a.epi == 0 && gemm_x6r512_supported(a.M, a.N, 0) && a.W3 && a.pro_S >= 1 &&
-                 a.pro_b2 && a.pro_x && a.ln_w && a.ln_b && a.C && a.ldc % 4 == 0,
-             "gemm_x6r512: prologue fold arguments");
-    return launch_x6r512<0, true>(a, s);
-  }
+  WN_CHECK(!a.pro_P, "gemm_x6r512: no prologue fold at K = 512 (measured slower than ffn_reduce_ln)");
   WN_CHECK(a.A && a.W3 && a.lda % 4 == 0 && gemm_x6r512_supported(a.M, a.N, a.epi),
            "gemm_x6r512: shape");
+  const bool wide = x6r512_wide(a);
   if (a.epi == 1) {
     WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && a.y && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
                  a.ldy % 4 == 0, "gemm_x6r512: row-LN epilogue arguments");
-    return launch_x6r512<1, false>(a, s);
+    return wide ? launch_x6r512w<1>(a, s) : launch_x6r512<1>(a, s);
   }
   if (a.epi == 3) {
     WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
                  (a.y == nullptr || a.ldy % 4 == 0) && a.W3b && a.C && a.ldc % 4 == 0,
              "gemm_x6r512: chained row-LN + GLU arguments");
-    return launch_x6r512<3, false>(a, s);
+    return wide ? launch_x6r512w<3>(a, s) : launch_x6r512<3>(a, s);
   }
   WN_CHECK(a.C && a.ldc % 4 == 0, "gemm_x6r512: no output");
-  return launch_x6r512<0, false>(a, s);
+  return wide ? launch_x6r512w<0>(a, s) : launch_x6r512<0>(a, s);
 }
 
 }  // namespace wn

@@ -229,6 +229,7 @@ bool gemm_x6r_supported(int M, int N, int K, int epi);
 int gemm_x6r(const X6RArgs& a, hipStream_t s);          // dispatches on a.K
 bool gemm_x6r512_supported(int M, int N, int epi);
 int gemm_x6r512(const X6RArgs& a, hipStream_t s);
+extern int g_x6r512_rows;   // wn_tune_set("x6r512_rows")
 extern int g_gemm_rowln;
 bool gemm_rowln_supported(int M, int N, int K);
 int gemm_rowln(const RowLnArgs& a, hipStream_t s);

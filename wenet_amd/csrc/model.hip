@@ -664,7 +664,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       auto it = t_x6->find(L.qkv.w);
       if (it != t_x6->end()) qkv_w6 = it->second;
     }
-    const bool pro = fS > 0 && qkv_w6 && g_x6r_pro != 0 && (d == 256 || d == 512);
+    const bool pro = fS > 0 && qkv_w6 && g_x6r_pro != 0 && d == 256;   // (d = 512: measured slower)
     if (fS > 0) {
       if (!pro)
         WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ffm2.b, 0.5f, L.norm_mha.w,
