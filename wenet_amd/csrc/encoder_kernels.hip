@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs a) {
   acc.store(a.y + (int64_t)row * a.ldy, lane);
 }
 
-// dwconv_tiled = 1 (end of round 3; bit-identical on the GPU; not the default yet): a wave
+// dwconv_tiled = 1 (the default since round 4; bit-identical to the kernel above): a wave
 // computes R = 4 consecutive packed rows.  The kernel above reads K neighbour rows per output
 // row -- 8 x 1 KB from L2 per row at config 2, 65 MB per launch for an 8-MB tensor; a tile of 4
 // rows shares its R + 7 window rows per group of 8 taps (11 row loads instead of 32, the taps
@@ -907,7 +907,7 @@ int layernorm(const float* x, int ldx, const float* w, const float* b, float* y,
     WN_HIP(hipGetLastError());
     return 0;
   }
-  // (two rows per wave measured no gain, DESIGN.md section 6: one row per wave only)
+  // (two rows per wave measured no gain, docs/LOG_rounds1-3.md section 6: one row per wave only)
   dim3 g(cdiv(M, 4)), t(256);
 #define WN_LN(E)                                                                 \
   case E * 64:                                                                   \
@@ -980,7 +980,7 @@ int cmvn_conv1_relu(const Conv1Args& a, hipStream_t s) {
   return 0;
 }
 
-int g_dwconv_tiled = 1;   // wn_tune_set("dwconv_tiled"): 1 = four rows per wave
+int g_dwconv_tiled = 1;   // wn_tune_set("dwconv_tiled"): 1 = four rows per wave (default; 0 = one row per wave, A/B and tests)
 
 int dwconv_ln_silu(const DwConvArgs& a, hipStream_t s) {
   if (g_dwconv_tiled == 1 && (a.D == 256 || a.D == 512)) {

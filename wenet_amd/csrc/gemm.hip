@@ -277,7 +277,7 @@ int gemm_f32(const GemmArgs& a, hipStream_t stream) {
   //   3: 64x128, 2x4 waves    4: 64x128, 2x2 waves (GLU)   5: 64x64, 2x2 waves
   //   6: 128x128, 2x2 waves (conv)
   // (a 256x256 one-block-per-CU tile was +3.5 % on the isolated FFN-w1 shape and -14 % inside
-  // the decode pipeline, where the other stream's search kernel holds CUs: removed)
+  // the decode pipeline, where the other stream's search kernel holds CUs: removed, docs/LOG_rounds1-3.md section 6)
   const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
   const int64_t t64x128 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 128);
   if (a.glu)

@@ -26,7 +26,7 @@
 //    (gemm_epilogue.h).
 // With fp32 operands in HBM / L2 the kernel is bound by the global -> LDS stream
 // (8 B per bf16 MAC pair), not by the matrix cores; bf16 activation storage is
-// the next step.
+// the next step (docs/LOG_rounds1-3.md section 7).
 #include "common.h"
 #include "gemm_epilogue.h"
 

@@ -9,7 +9,7 @@
 //  * a K tile is 16 + 16 staging VGPRs per thread (256x256 block) instead of 64,
 //    so the global loads run TWO tiles ahead (two named register sets, as the
 //    fp32 kernel's PF = 2 path) -- the exposed L2 / Infinity-Cache latency was what
-//    bounded gemm_bf16_kernel;
+//    bounded gemm_bf16_kernel (docs/LOG_rounds1-3.md section 3);
 //  * 16-byte loads and 16-byte LDS stores on both operands.
 // Same block shapes, LDS image (row stride K tile + 8 elements), fragment reads,
 // XCD order and epilogue as gemm_bf16.hip.

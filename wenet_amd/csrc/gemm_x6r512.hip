@@ -190,11 +190,14 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
     const int npass = p.N / 512;
     for (int ps = 0; ps < npass; ++ps) {
       const char* wbp = w_base(p.W3, ps);
-      if (ps > 0) {
-#pragma unroll
-        for (int s = 0; s < PF5; ++s) load_w(wbp, kstride, s);
-      }
       gemm_pass(wbp, kstride);
+      // the next pass's first W fragments go out BEFORE this pass's stores (vmcnt retires in
+      // order: loads queued behind the stores would wait for the whole burst to drain)
+      if (ps + 1 < npass) {
+        const char* wbn = w_base(p.W3, ps + 1);
+#pragma unroll
+        for (int s = 0; s < PF5; ++s) load_w(wbn, kstride, s);
+      }
       const int col0 = ps * 512 + wave * WCOLS;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {             // tiles 2 u, 2 u + 1
@@ -325,11 +328,12 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
       char* wp2 = hpatch + wave * (32 * 272);   // 32 rows x (2 x 128 B + 16): 4 x 8.5 KB
       for (int ps = 0; ps < 2; ++ps) {
         const char* wbp = w_base(p.W3b, ps);
-        if (ps > 0) {
-#pragma unroll
-          for (int s = 0; s < PF5; ++s) load_w(wbp, kst2, s);
-        }
         gemm_pass(wbp, kst2);
+        if (ps == 0) {                          // (ahead of the stores, see EPI 0)
+          const char* wbn = w_base(p.W3b, 1);
+#pragma unroll
+          for (int s = 0; s < PF5; ++s) load_w(wbn, kst2, s);
+        }
         const int c2 = ps * 512 + wave * WCOLS; // first column of the wave's tiles in the image
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -453,28 +457,48 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
         raw[buf][rt][1] = *reinterpret_cast<const f32x4*>(q + 16);
       }
     };
+    // one quad (4 values) of row tile rt -> elements 4 h .. 4 h + 3 of the three planes
+    auto split_quad = [&](bf16x8 (&X)[2][3], const f32x4& v, int rt, int h)
+        __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const Split3 sp = split3(v[e]);
+        X[rt][0][4 * h + e] = sp.h0; X[rt][1][4 * h + e] = sp.h1; X[rt][2][4 * h + e] = sp.h2;
+      }
+    };
+    // software pipeline: the products of k block ks run on fragments split one iteration
+    // earlier; the four quads of k block ks + 1 are split BETWEEN the product groups of ks (one
+    // wave per SIMD: VALU work in front of the MFMAs would leave the matrix pipe idle), and the
+    // fp32 values of k block ks + 2 are on their way from LDS
+    bf16x8 X[2][3], Xn[2][3];
     read_x(0, 0);
+    read_x(1, 1);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      split_quad(X, raw[0][rt][0], rt, 0);
+      split_quad(X, raw[0][rt][1], rt, 1);
+    }
 #pragma unroll
     for (int ks = 0; ks < KB5; ++ks) {
       if (ks + PF5 < KB5) load_w(wbp, kst, ks + PF5);
-      bf16x8 X[2][3];
+      f32x4 nx[2][2];
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < 2; ++rt) { nx[rt][0] = raw[(ks + 1) & 1][rt][0]; nx[rt][1] = raw[(ks + 1) & 1][rt][1]; }
+      if (ks + 2 < KB5) read_x(ks & 1, ks + 2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const Split3 sa = split3(raw[ks & 1][rt][0][e]), sb = split3(raw[ks & 1][rt][1][e]);
-          X[rt][0][e] = sa.h0; X[rt][1][e] = sa.h1; X[rt][2][e] = sa.h2;
-          X[rt][0][4 + e] = sb.h0; X[rt][1][4 + e] = sb.h1; X[rt][2][4 + e] = sb.h2;
-        }
-      if (ks + 1 < KB5) read_x((ks + 1) & 1, ks + 1);
-#pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = 0; q < 6; ++q) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
           for (int t = 0; t < NT5; ++t)
             acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks % (PF5 + 1)][t][PW[q]],
                                                                  X[rt][PX[q]], acc[rt][t], 0, 0, 0);
+        if (ks + 1 < KB5 && q < 4) split_quad(Xn, nx[q >> 1][q & 1], q >> 1, q & 1);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) X[rt][pl] = Xn[rt][pl];
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -513,11 +537,15 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
     const int npass = p.N / 512;
     for (int ps = 0; ps < npass; ++ps) {
       const char* wbp = w_base(p.W3, ps);
-      if (ps > 0) {
-#pragma unroll
-        for (int s = 0; s < PF5; ++s) load_w(wbp, kstride, s);
-      }
       gemm_pass(wbp, kstride);
+      // the next pass's first W fragments go out BEFORE this pass's stores: vmcnt retires in
+      // order, so loads queued behind 128 KB of stores would hold the next pass's first MFMAs
+      // until the store burst of all blocks has drained
+      if (ps + 1 < npass) {
+        const char* wbn = w_base(p.W3, ps + 1);
+#pragma unroll
+        for (int s = 0; s < PF5; ++s) load_w(wbn, kstride, s);
+      }
       const int col0 = ps * 512 + wave * WCOLS;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
@@ -627,11 +655,12 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
       __syncthreads();
       for (int ps = 0; ps < 2; ++ps) {
         const char* wbp = w_base(p.W3b, ps);
-        if (ps > 0) {
-#pragma unroll
-          for (int s = 0; s < PF5; ++s) load_w(wbp, kst2, s);
-        }
         gemm_pass(wbp, kst2);
+        if (ps == 0) {                            // (ahead of the stores, see EPI 0)
+          const char* wbn = w_base(p.W3b, 1);
+#pragma unroll
+          for (int s = 0; s < PF5; ++s) load_w(wbn, kst2, s);
+        }
         const int c2 = ps * 512 + wave * WCOLS;   // first column of the wave's tiles in the image
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)

@@ -44,7 +44,7 @@ def freeze_host_heap() -> int:
     collections stop re-walking it while the decode threads wait.  The collector stays
     enabled for everything allocated afterwards.  Measured with two decodes in flight at
     BASELINE configs[1]: without it about one round in seven of 20 decodes runs 25 % slower
-    and the median is 2-4 % lower.  Returns the number of frozen
+    and the median is 2-4 % lower (docs/LOG_rounds1-3.md section 4).  Returns the number of frozen
     objects; `gc.unfreeze()` undoes it."""
     gc.collect()
     gc.freeze()
