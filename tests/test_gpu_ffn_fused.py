@@ -411,3 +411,32 @@ def test_d512_row_block_kernels_match_the_other_forms(config, B, frames, chunk):
     e1, e2 = (got - nochain).abs().max().item(), (got - ref).abs().max().item()
     print(f'\n[{config} B={B}] d512 row-block kernels: vs two launches {e1:.2e}, vs tile GEMMs {e2:.2e}')
     assert e1 < 1e-4 and 0 < e2 < 2e-4
+
+
+@pytest.mark.parametrize('config,B,frames,chunk', [('aishell_u2pp', 32, (800, 1200), -1),
+                                                   ('aishell_u2pp', 7, (30, 900), 16),
+                                                   ('aishell_conformer', 6, (300, 700), -1)])
+def test_depthwise_conv_prologue_is_bit_identical_to_the_separate_launch(config, B, frames, chunk):
+    """gemm_x6r.hip DWC (the pointwise_conv2 row-block GEMM forms depthwise conv + LayerNorm /
+    eval-BatchNorm + SiLU of the GLU output itself, convolution.py:119-148) does
+    dwconv_tiled_kernel's arithmetic in the same order per output row: the encoder output is the
+    same bits as with the separate launch -- causal (K = 8, left pad frames) and symmetric
+    (K = 15, BatchNorm affine) kernels, ragged utterances whose rows share 8-row groups, very short
+    utterances, chunk masks."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=91)
+    try:
+        _lib.check(L.wn_tune_set(b'x6r_dwc', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        ref = ref.cpu()
+        _lib.check(L.wn_tune_set(b'x6r_dwc', 1), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got = got.cpu()
+    finally:
+        L.wn_tune_set(b'x6r_dwc', 1)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, got2.cpu())
+    assert torch.equal(got, ref), (got - ref).abs().max().item()

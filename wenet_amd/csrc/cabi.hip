@@ -645,6 +645,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_sub") g_x6_sub = value;
   else if (k == "x6_conv_tail") g_x6_conv_tail = value;
   else if (k == "x6r_pro") g_x6r_pro = value;
+  else if (k == "x6r_dwc") g_x6r_dwc = value;
   else if (k == "x6r512_rows") g_x6r512_rows = value;
   else if (k == "dwconv_tiled") g_dwconv_tiled = value;
   else if (k == "attn_fold") g_attn_fold = value;
@@ -1198,9 +1199,11 @@ int decoder_layers(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
                      m->r_pos.as<int>(), D.embed, D.pe, sqrtf((float)d), d / 4, x);
   WN_HIP(hipGetLastError());
   int li = 0;
+  bool ln1_done = false;      // t1 already holds this layer's norm1(x) (the previous FFN's reduce)
   for (const DecLayer& L : D.layers) {
     // causal self attention                             decoder_layer.py:100-121
-    WN_TRY(ln(L.n1, x, t1, R, d, eps, s));
+    if (!ln1_done) WN_TRY(ln(L.n1, x, t1, R, d, eps, s));
+    ln1_done = false;
     WN_TRY(linear(L.self_qkv, t1, d, qkv, 3 * d, R, s));
     AttnArgs a;
     a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
@@ -1236,8 +1239,22 @@ int decoder_layers(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
     WN_TRY(linear(L.src_out, t1, d, x, d, R, s, ACT_NONE, x, d));
     // FFN (ReLU)                                         decoder_layer.py:140-147
     WN_TRY(ln(L.n3, x, t1, R, d, eps, s));
-    WN_TRY(linear(L.ff1, t1, d, hb, c.dec_ffn_dim, R, s, ACT_RELU));
-    WN_TRY(linear(L.ff2, hb, c.dec_ffn_dim, x, d, R, s, ACT_NONE, x, d));
+    // large batches (a rescoring pass): the six-product GEMM pair with the hidden tensor as a
+    // plane image; its reduce adds b_2 and the residual and applies the NEXT LayerNorm (the
+    // next layer's norm1, or after_norm behind the last layer: the callers' own after_norm
+    // call then recomputes the same rows)
+    const int fS = ffn_x6_pair(m, L.ff1, L.ff2, ACT_RELU, t1, R, s);
+    if (fS < 0) return -2;
+    if (fS > 0) {
+      const bool last = (size_t)li + 1 == D.layers.size();
+      const Norm& nx = last ? D.after : D.layers[li + 1].n1;
+      WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ff2.b, 1.0f, nx.w, nx.b, nullptr,
+                           nullptr, t1, R, d, eps, 0, s));
+      ln1_done = !last;
+    } else {
+      WN_TRY(linear(L.ff1, t1, d, hb, c.dec_ffn_dim, R, s, ACT_RELU));
+      WN_TRY(linear(L.ff2, hb, c.dec_ffn_dim, x, d, R, s, ACT_NONE, x, d));
+    }
     ++li;
   }
   if (fill_cache) m->mem_cache_valid = true;

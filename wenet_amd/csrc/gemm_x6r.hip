@@ -28,6 +28,7 @@
 // Grid = ceil(M / 32) blocks (248 at M = 7932: the 256 CUs once).
 #include "common.h"
 #include "kernels.h"
+#include "rowregs.h"
 #include "x6.h"
 
 namespace wn {
@@ -40,7 +41,7 @@ constexpr int RKB = RK / 16;         // 16 k blocks
 // EPI 0: C = acc + bias; EPI 1: x_out = resid + alpha (acc + bias), y = LayerNorm(x_out);
 // EPI 2: C = GLU(acc + bias) (N / 2 columns); EPI 3: EPI 1, then C = GLU(y W3b^T + bias2) from
 // the rows in LDS (y itself is stored only if p.y is set)
-// PRO: the block forms its A rows itself from the slice partials of the fused feed-forward module
+// PRO 1: the block forms its A rows itself from the slice partials of the fused feed-forward module
 // in front of it (X6RArgs::pro_*): the sum, the residual add and the LayerNorm of ffn_reduce_ln's
 // mode 0 -- same operations in the same order, a wave per row, 4 consecutive columns per lane --
 // on the rows the prologue holds as whole rows anyway (round 3: one launch and one round trip of
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   f32x4 xa[RKB], xb[RKB];
   {
     f32x4 rowv[8];
-    if constexpr (PRO != 0) {
+    if constexpr (PRO == 1) {
       const int c = lane * 4;
       const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.pro_b2 + c);
       // the slice loads of a row block IN FLIGHT together: four slices x eight rows per round;
@@ -146,6 +147,84 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
         const float rstd = 1.0f / sqrtf(sq[j] * (1.0f / RK) + p.eps);
 #pragma unroll
         for (int e = 0; e < 4; ++e) rowv[j][e] = (rowv[j][e] - sm[j]) * rstd * gw[e] + gb[e];
+      }
+    } else if constexpr (PRO == 2) {
+      // DWC (round 4): the A rows are the middle of the convolution module -- depthwise conv over
+      // time + LayerNorm / eval-BatchNorm affine + SiLU of the GLU output p.dw.x
+      // (convolution.py:119-146) -- formed here instead of by dwconv_tiled_kernel: the same
+      // operations per output row in the same order (bias, the taps in ascending order with the
+      // pad rule evaluated against the output row's own utterance, norm, SiLU; lane = 4
+      // consecutive channels = RowRegs<4>), so the same bits; one launch and one round trip of
+      // the 8-MB tensor less per layer.  Wave w: rows 8 w .. 8 w + 7 of the block; a group of 8
+      // taps shares its 15 window rows.
+      const DwConvArgs& a = p.dw;
+      constexpr int R = 8, TG = 8, NWIN = R + TG - 1;
+      const int row0 = m0 + wave * R;
+      const int lpad = a.causal ? a.K - 1 : (a.K - 1) / 2;
+      int u_l = -1, off_l = 0, len_l = 0;
+      if (lane < R && row0 + lane < a.M) u_l = a.row_utt[row0 + lane];
+      if (u_l >= 0) {
+        off_l = a.off[u_l];
+        len_l = a.len[u_l];
+      }
+      int t_r[R], len_r[R];
+      bool on[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int u = __builtin_amdgcn_readlane(u_l, r);
+        t_r[r] = row0 + r - __builtin_amdgcn_readlane(off_l, r);
+        len_r[r] = __builtin_amdgcn_readlane(len_l, r);
+        on[r] = u >= 0 && t_r[r] < len_r[r];
+      }
+      RowRegs<4> acc[R], cp;
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r].load(a.bias, lane);
+      cp.load(a.cpad, lane);
+      for (int k0 = 0; k0 < a.K; k0 += TG) {
+        RowRegs<4> wk[TG], xw[NWIN];
+#pragma unroll
+        for (int i = 0; i < NWIN; ++i) {
+          const int q = min(max(row0 + k0 - lpad + i, 0), a.M - 1);
+          xw[i].load(a.x + (int64_t)q * a.ldx, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < TG; ++i)
+          if (k0 + i < a.K) wk[i].load(a.wt + (int64_t)(k0 + i) * 256, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+          for (int j = 0; j < TG; ++j) {
+            const int k = k0 + j, tt = t_r[r] + k - lpad;
+            if (on[r] && k < a.K) {
+              if (tt >= 0 && tt < len_r[r]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  acc[r].v[e] = fmaf(wk[j].v[e], xw[r + j].v[e], acc[r].v[e]);
+              } else if ((tt < 0 && a.causal) || (tt >= len_r[r] && tt < a.t_max)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[r].v[e] = fmaf(wk[j].v[e], cp.v[e], acc[r].v[e]);
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (on[r]) {
+          if (a.norm_mode == 0) {
+            ln_inplace<4>(acc[r], a.ln_w, a.ln_b, lane, a.eps);
+          } else {
+            RowRegs<4> sc, sh;
+            sc.load(a.ln_w, lane);
+            sh.load(a.ln_b, lane);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[r].v[e] = fmaf(acc[r].v[e], sc.v[e], sh.v[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[r].v[e] = silu_f(acc[r].v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rowv[r][e] = on[r] ? acc[r].v[e] : 0.f;
       }
     } else {
 #pragma unroll
@@ -456,6 +535,7 @@ int launch_x6r(const X6RArgs& a, hipStream_t s) {
 
 int g_x6r = 1;       // wn_tune_set("x6r"): 0 = the v_mfma_f32 row-LN GEMM / tile GEMMs (A/B, tests)
 int g_x6r_chain = 1; // wn_tune_set("x6r_chain"): 0 = out-projection + LayerNorm and pointwise_conv1 + GLU as two launches
+int g_x6r_dwc = 1;   // wn_tune_set("x6r_dwc"): 0 = dwconv_ln_silu stays its own launch in front of pointwise_conv2 (A/B, tests)
 int g_x6r_pro = 1;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of the QKV projection (A/B, tests)
 
 bool gemm_x6r_supported(int M, int N, int K, int epi) {
@@ -475,8 +555,16 @@ int gemm_x6r(const X6RArgs& a, hipStream_t s) {
              "gemm_x6r: prologue fold arguments");
     return launch_x6r<6, 0, 1, 1>(a, s);
   }
-  WN_CHECK(a.A && a.W3 && a.lda % 4 == 0 && gemm_x6r_supported(a.M, a.N, RK, a.epi),
+  WN_CHECK((a.A || a.dw_on) && a.W3 && a.lda % 4 == 0 && gemm_x6r_supported(a.M, a.N, RK, a.epi),
            "gemm_x6r: shape");
+  if (a.dw_on) {
+    WN_CHECK(a.epi == 1 && a.N == 256 && a.W3 && a.M > 0 && a.dw.D == 256 && a.dw.M == a.M &&
+                 a.dw.x && a.dw.ldx % 4 == 0 && a.dw.wt && a.dw.bias && a.dw.cpad && a.dw.ln_w &&
+                 a.dw.ln_b && a.dw.row_utt && a.dw.off && a.dw.len && a.dw.K >= 1 &&
+                 a.resid && a.x_out && a.ln_w && a.ln_b && a.y && a.ldr % 4 == 0 &&
+                 a.ldx % 4 == 0 && a.ldy % 4 == 0, "gemm_x6r: depthwise-conv prologue arguments");
+    return launch_x6r<2, 1, 3, 2>(a, s);
+  }
   if (a.epi == 1) {
     WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && a.y && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
                  a.ldy % 4 == 0, "gemm_x6r: row-LN epilogue arguments");

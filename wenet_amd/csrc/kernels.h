@@ -220,8 +220,14 @@ struct X6RArgs {
   // x_new written back to pro_x ([M][K]); pro_P = [pro_S][M][K] slice partials
   const float* pro_P = nullptr; int pro_S = 0; const float* pro_b2 = nullptr;
   float pro_alpha = 0.f; float* pro_x = nullptr;
+  // depthwise-conv prologue (epi 1, K = N = 256 -- pointwise_conv2 behind the middle of the
+  // convolution module): the A rows are NOT read from `A` but formed as dwconv_ln_silu forms
+  // them from dw.x (dw.y is ignored: the rows never reach HBM)
+  int dw_on = 0;
+  DwConvArgs dw;
 };
 extern int g_dwconv_tiled; // wn_tune_set("dwconv_tiled"): 1 = depthwise convolution with four rows per wave
+extern int g_x6r_dwc;   // wn_tune_set("x6r_dwc")
 extern int g_x6r_pro;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of QKV
 extern int g_x6r;     // wn_tune_set("x6r")
 extern int g_x6r_chain;   // wn_tune_set("x6r_chain")

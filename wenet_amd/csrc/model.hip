@@ -381,6 +381,37 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
   return S;
 }
 
+// The six-product GEMM pair of a feed-forward module on ANY rows (the decoders' ReLU modules over
+// the R hypothesis rows of a rescoring pass, decoder_layer.py:140-147): A = LN(x) [M][d] is split
+// into planes, w_1 + activation writes the plane image of the hidden tensor from its epilogue
+// (no fp32 hidden tensor, no separate split pass over it: 10 B per hidden element of HBM traffic
+// less than linear() + linear()), w_2 leaves K-slice partials in m->ffn_part for ffn_reduce_ln.
+// Returns the slice count, 0 if the shape stays on linear(), < 0 on error.
+int ffn_x6_pair(wn_model* m, const Linear& w1, const Linear& w2, int act, const float* A, int M,
+                hipStream_t s) {
+  const int d = w1.in, F = w1.out;
+  if (t_gemm_prec != PREC_F32 || g_gemm_x6 == 0 || g_x6_linear == 0 || !m->x6_at ||
+      w1.out != w2.in || w2.out != d || !(d == 256 || d == 512) || F % 16 != 0 || M < 512 ||
+      2.0 * M * (double)F * d < 1e8 * g_x6_linear_min)
+    return 0;
+  auto i1 = m->x6_at->find(w1.w), i2 = m->x6_at->find(w2.w);
+  if (i1 == m->x6_at->end() || i2 == m->x6_at->end()) return 0;
+  const int S = ffn_x6_split(M, F);
+  if (m->ffn_part.ensure((size_t)S * M * d * sizeof(float)) != 0 ||
+      m->x6_a.ensure(x6_bytes(M, d)) != 0 || m->x6_h.ensure(x6_bytes(M, F)) != 0)
+    return -1;
+  if (x6_split(A, M, d, d, m->x6_a.as<char>(), s) != 0) return -1;
+  X6Args g1;
+  g1.A3 = m->x6_a.as<char>(); g1.B3 = i1->second; g1.M = M; g1.N = F; g1.K = d; g1.bias = w1.b;
+  g1.act = act; g1.epi = 2; g1.C3 = m->x6_h.as<char>();
+  if (gemm_x6(g1, s) != 0) return -1;
+  X6Args g2;
+  g2.A3 = m->x6_h.as<char>(); g2.B3 = i2->second; g2.M = M; g2.N = d; g2.K = F;
+  g2.epi = 1; g2.ksplit = S; g2.C = m->ffn_part.as<float>();
+  if (gemm_x6(g2, s) != 0) return -1;
+  return S;
+}
+
 // fp32 fused feed-forward module (ffn_fused.hip): t1 = LN(x) is in place; leaves the
 // hidden-slice partials in m->ffn_part and returns S (0: shape not taken, caller runs
 // the two-GEMM path).  Every 6th launch is bracketed for the roofline (wn_profile_*).
@@ -724,13 +755,15 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     // in registers, d = 256; gemm_x6r512.hip: A image in LDS, d = 512 -- no v_mfma_f32 row-LN
     // kernel exists at that width)
     const bool rowx = rowln || (!h16 && t_gemm_prec == PREC_F32 && d == 512);
-    auto x6r_rowln = [&](const Linear& l, const float* A, const Norm& nrm) -> int {
+    auto x6r_rowln = [&](const Linear& l, const float* A, const Norm& nrm,
+                         const DwConvArgs* dwc = nullptr) -> int {
       if (!(rowx && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
             gemm_x6r_supported(M, d, l.in, 1)))
         return 1;
       auto it = t_x6->find(l.w);
       if (it == t_x6->end()) return 1;
       X6RArgs g;
+      if (dwc) { g.dw = *dwc; g.dw_on = 1; }
       g.A = A; g.lda = d; g.K = d; g.W3 = it->second; g.bias = l.b; g.M = M; g.N = d; g.epi = 1;
       g.resid = x; g.ldr = d; g.alpha = 1.0f; g.x_out = x; g.ldx = d;
       g.ln_w = nrm.w; g.ln_b = nrm.b; g.eps = eps; g.y = t1; g.ldy = d;
@@ -790,9 +823,13 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     dw.len = m->d_len.as<int>();
     dw.M = M; dw.D = d; dw.K = c.cnn_kernel; dw.causal = c.causal;
     dw.t_max = m->Tp; dw.eps = 1e-5f;
-    WN_TRY(dwconv_ln_silu(dw, s));
     // x += pointwise_conv2(.); t1 = LN_ff(x)        encoder_layer.py:251-255
-    xr = x6r_rowln(L.pw2, t1, L.norm_ff);
+    // d = 256 on the row-block kernel: the depthwise conv + norm + SiLU is its prologue
+    // (gemm_x6r.hip DWC) -- no launch, no round trip of the conv module's middle tensor
+    const bool dwc = g_x6r_dwc != 0 && d == 256 && rowx && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 &&
+                     M >= 512 && t_x6->count(L.pw2.w) != 0 && gemm_x6r_supported(M, d, L.pw2.in, 1);
+    if (!dwc) WN_TRY(dwconv_ln_silu(dw, s));
+    xr = x6r_rowln(L.pw2, t1, L.norm_ff, dwc ? &dw : nullptr);
     if (xr < 0) return -2;
     const bool ln_ff_done = xr == 0 || rowln;       // t1 = LN_ff(x) came out of the GEMM's epilogue
     if (xr == 0) {

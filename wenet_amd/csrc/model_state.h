@@ -491,6 +491,8 @@ int build_x6_images(wn_model* m);
 int vocab_linear(wn_model* m, const Linear& l, const float* A, int lda, float* C, int M,
                  hipStream_t s);
 int ffn_x6_split(int M, int F);
+int ffn_x6_pair(wn_model* m, const Linear& w1, const Linear& w2, int act, const float* A, int M,
+                hipStream_t s);
 int set_layout(wn_model* m, int B, int Tp, const std::vector<int>& off,
                const std::vector<int>& len, int rows, hipStream_t s);
 int subsample_conv2d4(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host, int B,
