@@ -227,11 +227,12 @@ def test_bench_batch_config5_vs_reference_at_the_configured_shape():
     assert report['fp8']['rel'][-1] > report['bf16']['rel'][-1]
 
 
-# measured |GPU - oracle| on the top-2 CTC log-probs in the reduced modes at the configured shape
-# (same operand rounding on both sides; what differs is the fp32 summation order, which moves
-# values across bf16 / e4m3 rounding boundaries, 32 blocks deep): see the printed report; the
-# margins below are 4 x the measured errors
-LOWP_FRAME_EPS = {'bf16': 0.08, 'fp8': 0.16}
+# |GPU - oracle| on the top-1 CTC log-probs in the reduced modes at the configured shape, same
+# operand rounding on both sides (what differs is the fp32 summation order, which moves values
+# across bf16 / e4m3 rounding boundaries, 32 blocks deep) -- measured (visit r06k, printed by the
+# test): bf16 1.6e-2, 2 of 24000 frames with another arg-max (golden margins <= 0.004); MXFP8 FFN
+# 1.2e-1, 10 frames (margins <= 0.23).  The per-frame margins are 5 x / 4 x those errors.
+LOWP_FRAME_EPS = {'bf16': 0.08, 'fp8': 0.5}
 
 
 @pytest.mark.parametrize('mode', ['bf16', 'fp8'])
@@ -267,20 +268,30 @@ def test_config5_reduced_modes_token_level_vs_the_oracle_under_the_same_rounding
     finally:
         model.set_compute_dtype('fp32')
     eps = LOWP_FRAME_EPS[mode]
-    n_frames = n_strict = n_flips = same = 0
-    err = 0.0
+    # measure first (so that a failure prints the whole picture), then apply the per-frame rule
+    worst, err, n_dis, tot = 0.0, 0.0, 0, 0
     for b in range(B):
         o, n = int(z['row_off'][b]), int(z['enc_lens'][b])
         rv, ri = z['ctc_top2_val'][o:o + n], z['ctc_top2_idx'][o:o + n]
         agree = topi[b, :n, 0] == ri[:, 0]
         err = max(err, float(np.abs(topv[b, :n, 0][agree] - rv[:, 0][agree]).max()))
+        if (~agree).any():
+            worst = max(worst, float((rv[:, 0] - rv[:, 1])[~agree].max()))
+        n_dis += int((~agree).sum())
+        tot += n
+    print(f'\n[config5 {mode} vs oracle under the same rounding] {tot} frames, {n_dis} with another '
+          f'arg-max (largest golden margin among them {worst:.3f}), max |d logp| on agreeing '
+          f'frames {err:.2e}; eps {eps}')
+    n_frames = n_strict = n_flips = same = 0
+    for b in range(B):
+        o, n = int(z['row_off'][b]), int(z['enc_lens'][b])
+        rv, ri = z['ctc_top2_val'][o:o + n], z['ctc_top2_idx'][o:o + n]
         f, s_, fl = greedy_frame_check(topi[b, :n, 0], ri, rv, res[b].tokens, meta['greedy'][b],
                                        what=f'config5 {mode}[{b}]', eps=eps)
         n_frames += f; n_strict += s_; n_flips += fl
         same += int(list(res[b].tokens) == meta['greedy'][b])
-    print(f'\n[config5 {mode} vs oracle under the same rounding] frames {n_frames}, strict '
-          f'{n_strict} ({n_strict / n_frames:.3f}), flips {n_flips}, max |d logp| on agreeing '
-          f'frames {err:.2e} (eps {eps}), identical token lists {same}/{B}')
+    print(f'[config5 {mode}] strict frames {n_strict} / {n_frames} ({n_strict / n_frames:.3f}), flips '
+          f'{n_flips}, identical token lists {same}/{B}')
     assert err < eps / 2, err
     assert n_strict >= 0.8 * n_frames
 

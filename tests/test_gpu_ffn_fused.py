@@ -416,13 +416,16 @@ def test_d512_row_block_kernels_match_the_other_forms(config, B, frames, chunk):
 @pytest.mark.parametrize('config,B,frames,chunk', [('aishell_u2pp', 32, (800, 1200), -1),
                                                    ('aishell_u2pp', 7, (30, 900), 16),
                                                    ('aishell_conformer', 6, (300, 700), -1)])
-def test_depthwise_conv_prologue_is_bit_identical_to_the_separate_launch(config, B, frames, chunk):
+def test_depthwise_conv_prologue_matches_the_separate_launch(config, B, frames, chunk):
     """gemm_x6r.hip DWC (the pointwise_conv2 row-block GEMM forms depthwise conv + LayerNorm /
     eval-BatchNorm + SiLU of the GLU output itself, convolution.py:119-148) does
-    dwconv_tiled_kernel's arithmetic in the same order per output row: the encoder output is the
-    same bits as with the separate launch -- causal (K = 8, left pad frames) and symmetric
-    (K = 15, BatchNorm affine) kernels, ragged utterances whose rows share 8-row groups, very short
-    utterances, chunk masks."""
+    dwconv_tiled_kernel's operations in the same order per output row -- causal (K = 8, left pad
+    frames) and symmetric (K = 15, BatchNorm affine) kernels, ragged utterances whose rows share
+    8-row groups, very short utterances, chunk masks.  Not the same BITS: the two translation
+    units compile the shared LayerNorm / SiLU source under different vectoriser settings and
+    contract a multiply-add differently (measured 2.9e-6 on unit-scale encoder outputs, r06k;
+    making the fma explicit moved every LayerNorm of the path by an ulp and one utterance in 256
+    across a pruning tie, so the source stays as it was); deterministic, and within 2e-5."""
     from wenet_amd import _lib, synthetic as S
     L = _lib.lib()
     configs, sd, model = cached_model(config, 0)
@@ -439,4 +442,6 @@ def test_depthwise_conv_prologue_is_bit_identical_to_the_separate_launch(config,
         L.wn_tune_set(b'x6r_dwc', 1)
     assert torch.isfinite(got).all()
     assert torch.equal(got, got2.cpu())
-    assert torch.equal(got, ref), (got - ref).abs().max().item()
+    err = (got - ref).abs().max().item()
+    print(f'\n[{config} B={B}] depthwise-conv prologue vs separate launch: max |d enc| {err:.2e}')
+    assert err < 2e-5

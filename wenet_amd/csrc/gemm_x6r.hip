@@ -154,8 +154,10 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
       // (convolution.py:119-146) -- formed here instead of by dwconv_tiled_kernel: the same
       // operations per output row in the same order (bias, the taps in ascending order with the
       // pad rule evaluated against the output row's own utterance, norm, SiLU; lane = 4
-      // consecutive channels = RowRegs<4>), so the same bits; one launch and one round trip of
-      // the 8-MB tensor less per layer.  Wave w: rows 8 w .. 8 w + 7 of the block; a group of 8
+      // consecutive channels = RowRegs<4>); one launch and one round trip of the 8-MB tensor
+      // less per layer.  (Same source, not the same bits: this file is compiled with
+      // -fno-slp-vectorize and contracts a multiply-add of the shared LayerNorm differently:
+      // 3e-6 on unit-scale outputs, tests/test_gpu_ffn_fused.py.)  Wave w: rows 8 w .. 8 w + 7 of the block; a group of 8
       // taps shares its 15 window rows.
       const DwConvArgs& a = p.dw;
       constexpr int R = 8, TG = 8, NWIN = R + TG - 1;
