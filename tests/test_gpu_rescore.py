@@ -129,3 +129,27 @@ def test_rescore_prefetch_on_the_side_stream_changes_nothing(config, B, frames):
         for a, b in zip(ref, got):
             assert a.tokens == b.tokens and a.score == b.score
             assert a.all_scores == b.all_scores and a.tokens_confidence == b.tokens_confidence
+
+
+@pytest.mark.parametrize('config,B,frames', [('tiny_causal', 5, (90, 330)),
+                                             ('librispeech_bidecoder_large', 12, (500, 900))])
+def test_cross_attention_per_utterance_group_changes_nothing(config, B, frames):
+    """The rescoring decoder's cross attention with all hypothesis rows of an utterance as ONE
+    attention sequence (they share the utterance's encoder frames) against one sequence per
+    hypothesis: per query row the same keys in the same tile order -- identical records."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=37)
+    kw = dict(beam_size=7, ctc_weight=0.5, reverse_weight=0.3)
+    M = ['attention_rescoring']
+    try:
+        _lib.check(L.wn_tune_set(b'rescore_groups', 0), 'tune')
+        ref = model.decode(M, feats.cuda(), lens, **kw)[M[0]]
+        _lib.check(L.wn_tune_set(b'rescore_groups', 1), 'tune')
+        got = model.decode(M, feats.cuda(), lens, **kw)[M[0]]
+    finally:
+        L.wn_tune_set(b'rescore_groups', 1)
+    for a, b in zip(ref, got):
+        assert a.tokens == b.tokens and a.score == b.score
+        assert a.all_scores == b.all_scores and a.tokens_confidence == b.tokens_confidence

@@ -5,6 +5,7 @@
 #include "model_state.h"
 
 namespace {
+int g_rescore_groups = 1;     // wn_tune_set("rescore_groups"): 0 = cross attention per hypothesis (A/B, tests)
 int g_rescore_prefetch = 1;   // wn_tune_set("rescore_prefetch"): 0 = wn_rescore_prefetch does nothing (A/B)
 
 // ---------------------------------------------------------------------------
@@ -653,6 +654,7 @@ int wn_tune_set(const char* key, int32_t value) {
   else if (k == "x6_linear_min") g_x6_linear_min = value;
   else if (k == "x6_af32") g_x6_af32 = value;
   else if (k == "rescore_prefetch") g_rescore_prefetch = value;
+  else if (k == "rescore_groups") g_rescore_groups = value;
   else if (k == "beam_weak_hash") g_beam_weak_hash = value;
   else if (k == "ctc_wave") g_ctc_wave = value;
   else if (k == "gemm_rowln") g_gemm_rowln = value;
@@ -1179,9 +1181,20 @@ namespace {
 // sequences); the result stays in m->r_x.  With `mem_cache` the cross-attention
 // K/V projections of the encoder output are computed once per batch and layer
 // and reused by later calls (the autoregressive search calls this per step).
+// Cross attention over GROUPS of sequences that share their keys (the hypotheses of one
+// utterance in a rescoring pass: consecutive rows, the same encoder frames): one attention
+// "sequence" per group instead of one per hypothesis -- full 64-query tiles and the K / V rows
+// staged once per 64 queries instead of once per hypothesis.  Per query row the same keys in the
+// same tile order: the same bits.
+struct CrossGroups {
+  const int* q_off; const int* q_len; const int* kv_off; const int* kv_len;
+  int n_seq, max_q;
+};
+
 int decoder_layers(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
                    const int* d_tok, bool mem_cache, hipStream_t s,
-                   const int* self_kvlen = nullptr, const float* kv_base = nullptr) {
+                   const int* self_kvlen = nullptr, const float* kv_base = nullptr,
+                   const CrossGroups* cg = nullptr) {
   const wn_config& c = m->cfg;
   const int d = c.d_model, Menc = m->rows;
   float* x = m->r_x.as<float>();
@@ -1234,6 +1247,10 @@ int decoder_layers(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
     cx.q_off = m->r_qoff.as<int>(); cx.q_len = m->r_qlen.as<int>();
     cx.kv_off = m->r_kvoff.as<int>(); cx.kv_len = m->r_kvlen.as<int>();
     cx.n_seq = n_seq; cx.n_heads = c.dec_heads; cx.max_q_len = max_q;
+    if (cg) {
+      cx.q_off = cg->q_off; cx.q_len = cg->q_len; cx.kv_off = cg->kv_off; cx.kv_len = cg->kv_len;
+      cx.n_seq = cg->n_seq; cx.max_q_len = cg->max_q;
+    }
     cx.mask_mode = 0; cx.scale = 0.125f;
     WN_TRY(attention(cx, s));
     WN_TRY(linear(L.src_out, t1, d, x, d, R, s, ACT_NONE, x, d));
@@ -1263,10 +1280,10 @@ int decoder_layers(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
 
 int run_decoder(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
                 const int* d_tok, const int* d_tgt, float* out_dev,
-                hipStream_t s, const float* kv_base = nullptr) {
+                hipStream_t s, const float* kv_base = nullptr, const CrossGroups* cg = nullptr) {
   const wn_config& c = m->cfg;
   const int d = c.d_model, V = c.vocab;
-  WN_TRY(decoder_layers(m, D, R, n_seq, max_q, d_tok, false, s, nullptr, kv_base));
+  WN_TRY(decoder_layers(m, D, R, n_seq, max_q, d_tok, false, s, nullptr, kv_base, cg));
   float* t1 = m->r_t1.as<float>();
   WN_TRY(ln(D.after, m->r_x.as<float>(), t1, R, d, c.norm_eps, s));
   // (the caller sized r_logits for a pitch of V rounded up to 4)
@@ -1875,8 +1892,19 @@ int wn_rescore(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
   }
   const int n_seq = (int)seq_src.size();
   seq_first[B] = n_seq;
+  // cross-attention groups: all hypothesis rows of an utterance against its encoder frames
+  std::vector<int> gq_off, gq_len, gkv_off, gkv_len;
+  int g_max_q = 0;
+  for (int b = 0; b < B; ++b) {
+    const int q0 = seq_first[b], q1 = seq_first[b + 1];
+    if (q1 <= q0) continue;
+    const int rows = qoff[q1 - 1] + qlen[q1 - 1] - qoff[q0];
+    gq_off.push_back(qoff[q0]); gq_len.push_back(rows);
+    gkv_off.push_back(m->off[b]); gkv_len.push_back(m->len[b]);
+    g_max_q = std::max(g_max_q, rows);
+  }
   const size_t nb = (size_t)B * beam;
-  WN_TRY(m->stage.begin((size_t)(5 * n_seq + B + 64) * sizeof(int) + 4096 +
+  WN_TRY(m->stage.begin((size_t)(5 * n_seq + 5 * B + 64) * sizeof(int) + 8192 +
                         (from_beam ? 0 : nb * max_len * sizeof(int) + nb * sizeof(double) + 256)));
   if (!from_beam) {
     // tokens | scores in one device block, the prefix beam search's own row pitch
@@ -1894,7 +1922,16 @@ int wn_rescore(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
   WN_TRY(upload_desc(m, m->r_qlen, qlen, s));
   WN_TRY(upload_desc(m, m->r_kvoff, kvoff, s));
   WN_TRY(upload_desc(m, m->r_kvlen, kvlen, s));
+  WN_TRY(upload_desc(m, m->r_gqoff, gq_off, s));
+  WN_TRY(upload_desc(m, m->r_gqlen, gq_len, s));
+  WN_TRY(upload_desc(m, m->r_gkvoff, gkv_off, s));
+  WN_TRY(upload_desc(m, m->r_gkvlen, gkv_len, s));
   WN_TRY(m->stage.end(s));
+  CrossGroups cgrp;
+  cgrp.q_off = m->r_gqoff.as<int>(); cgrp.q_len = m->r_gqlen.as<int>();
+  cgrp.kv_off = m->r_gkvoff.as<int>(); cgrp.kv_len = m->r_gkvlen.as<int>();
+  cgrp.n_seq = (int)gq_off.size(); cgrp.max_q = g_max_q;
+  const CrossGroups* cg = g_rescore_groups != 0 && !gq_off.empty() ? &cgrp : nullptr;
   // results, one block: tok_conf | conf | best_score | best_idx | all_scores
   const size_t o_tc = 0, o_cf = o_tc + (size_t)B * max_len * sizeof(double),
                o_bs = o_cf + (size_t)B * sizeof(double), o_bi = o_bs + (size_t)B * sizeof(float),
@@ -1931,10 +1968,10 @@ int wn_rescore(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
       kv_r = kv_l + (size_t)m->kv_nl * m->rows * 2 * d;
     }
     WN_TRY(run_decoder(m, m->left, R, n_seq, max_q, m->r_tok.as<int>(), m->r_tgt.as<int>(), o_l,
-                       s, kv_l));
+                       s, kv_l, cg));
     if (use_r2l)
       WN_TRY(run_decoder(m, m->right, R, n_seq, max_q, m->r_rtok.as<int>(),
-                         m->r_rtgt.as<int>(), o_r, s, kv_r));
+                         m->r_rtgt.as<int>(), o_r, s, kv_r, cg));
   }
   char* rb = m->r_res.as<char>();
   RescoreArgs a;

@@ -377,6 +377,7 @@ struct wn_model {
   DevBuf r_x, r_t1, r_t2, r_qkv, r_h, r_mem, r_logits, r_out;
   DevBuf r_mem_all;            // per-layer cross-attention K/V of the current batch
   DevBuf r_seqsrc, r_seqfirst; // wn_rescore: sequence -> (utt, hyp) slot, first sequence per utterance
+  DevBuf r_gqoff, r_gqlen, r_gkvoff, r_gkvlen;   // wn_rescore: cross-attention groups (one per utterance)
   DevBuf r_hyp;                // wn_rescore: host-given n-best (tokens | ctc scores) on the device
   DevBuf r_res;                // wn_rescore: results, one block
   PinnedBuf r_host;            // ... and where they land on the host
