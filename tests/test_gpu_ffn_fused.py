@@ -413,14 +413,10 @@ def test_d512_row_block_kernels_match_the_other_forms(config, B, frames, chunk):
     assert e1 < 1e-4 and 0 < e2 < 2e-4
 
 
-@pytest.mark.parametrize('config,B,frames,chunk,rows', [
-    ('aishell_u2pp', 32, (800, 1200), -1, 0), ('aishell_u2pp', 7, (30, 900), 16, 0),
-    ('aishell_conformer', 6, (300, 700), -1, 0),
-    ('wenetspeech_u2pp', 8, (30, 900), 16, 32),             # d = 512, causal K = 15, 32-row blocks
-    ('wenetspeech_u2pp', 8, (30, 900), 16, 64),             # ... 64-row blocks
-    ('librispeech_bidecoder_large', 5, (300, 800), -1, 64),  # d = 512, symmetric K = 31
-])
-def test_depthwise_conv_prologue_matches_the_separate_launch(config, B, frames, chunk, rows):
+@pytest.mark.parametrize('config,B,frames,chunk', [('aishell_u2pp', 32, (800, 1200), -1),
+                                                   ('aishell_u2pp', 7, (30, 900), 16),
+                                                   ('aishell_conformer', 6, (300, 700), -1)])
+def test_depthwise_conv_prologue_matches_the_separate_launch(config, B, frames, chunk):
     """gemm_x6r.hip DWC (the pointwise_conv2 row-block GEMM forms depthwise conv + LayerNorm /
     eval-BatchNorm + SiLU of the GLU output itself, convolution.py:119-148) does
     dwconv_tiled_kernel's operations in the same order per output row -- causal (K = 8, left pad
@@ -435,7 +431,6 @@ def test_depthwise_conv_prologue_matches_the_separate_launch(config, B, frames, 
     configs, sd, model = cached_model(config, 0)
     feats, lens = S.make_features(B, frames, seed=91)
     try:
-        _lib.check(L.wn_tune_set(b'x6r512_rows', rows), 'tune')
         _lib.check(L.wn_tune_set(b'x6r_dwc', 0), 'tune')
         ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
         ref = ref.cpu()
@@ -445,9 +440,8 @@ def test_depthwise_conv_prologue_matches_the_separate_launch(config, B, frames, 
         got = got.cpu()
     finally:
         L.wn_tune_set(b'x6r_dwc', 1)
-        L.wn_tune_set(b'x6r512_rows', 0)
     assert torch.isfinite(got).all()
     assert torch.equal(got, got2.cpu())
     err = (got - ref).abs().max().item()
-    print(f'\n[{config} B={B} rows {rows}] depthwise-conv prologue vs separate launch: max |d enc| {err:.2e}')
+    print(f'\n[{config} B={B}] depthwise-conv prologue vs separate launch: max |d enc| {err:.2e}')
     assert err < 2e-5

@@ -159,13 +159,75 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
       // -fno-slp-vectorize and contracts a multiply-add of the shared LayerNorm differently:
       // 3e-6 on unit-scale outputs, tests/test_gpu_ffn_fused.py.)  Wave w: rows 8 w .. 8 w + 7 of the block; a group of 8
       // taps shares its 15 window rows.
-      RowRegs<4> acc[8];
-      bool on[8];
-      dwconv_rows8<4>(p.dw, m0 + wave * 8, lane, acc, on);
+      const DwConvArgs& a = p.dw;
+      constexpr int R = 8, TG = 8, NWIN = R + TG - 1;
+      const int row0 = m0 + wave * R;
+      const int lpad = a.causal ? a.K - 1 : (a.K - 1) / 2;
+      int u_l = -1, off_l = 0, len_l = 0;
+      if (lane < R && row0 + lane < a.M) u_l = a.row_utt[row0 + lane];
+      if (u_l >= 0) {
+        off_l = a.off[u_l];
+        len_l = a.len[u_l];
+      }
+      int t_r[R], len_r[R];
+      bool on[R];
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
+      for (int r = 0; r < R; ++r) {
+        const int u = __builtin_amdgcn_readlane(u_l, r);
+        t_r[r] = row0 + r - __builtin_amdgcn_readlane(off_l, r);
+        len_r[r] = __builtin_amdgcn_readlane(len_l, r);
+        on[r] = u >= 0 && t_r[r] < len_r[r];
+      }
+      RowRegs<4> acc[R], cp;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rowv[r][e] = acc[r].v[e];
+      for (int r = 0; r < R; ++r) acc[r].load(a.bias, lane);
+      cp.load(a.cpad, lane);
+      for (int k0 = 0; k0 < a.K; k0 += TG) {
+        RowRegs<4> wk[TG], xw[NWIN];
+#pragma unroll
+        for (int i = 0; i < NWIN; ++i) {
+          const int q = min(max(row0 + k0 - lpad + i, 0), a.M - 1);
+          xw[i].load(a.x + (int64_t)q * a.ldx, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < TG; ++i)
+          if (k0 + i < a.K) wk[i].load(a.wt + (int64_t)(k0 + i) * 256, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+          for (int j = 0; j < TG; ++j) {
+            const int k = k0 + j, tt = t_r[r] + k - lpad;
+            if (on[r] && k < a.K) {
+              if (tt >= 0 && tt < len_r[r]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  acc[r].v[e] = fmaf(wk[j].v[e], xw[r + j].v[e], acc[r].v[e]);
+              } else if ((tt < 0 && a.causal) || (tt >= len_r[r] && tt < a.t_max)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[r].v[e] = fmaf(wk[j].v[e], cp.v[e], acc[r].v[e]);
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (on[r]) {
+          if (a.norm_mode == 0) {
+            ln_inplace<4>(acc[r], a.ln_w, a.ln_b, lane, a.eps);
+          } else {
+            RowRegs<4> sc, sh;
+            sc.load(a.ln_w, lane);
+            sh.load(a.ln_b, lane);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[r].v[e] = fmaf(acc[r].v[e], sc.v[e], sh.v[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[r].v[e] = silu_f(acc[r].v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rowv[r][e] = on[r] ? acc[r].v[e] : 0.f;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {

@@ -25,7 +25,6 @@
 // wave patches (4 x 16.5 KB) reuse the X image once the MFMA loop is done.
 #include "common.h"
 #include "kernels.h"
-#include "rowregs.h"
 #include "x6.h"
 
 namespace wn {
@@ -45,7 +44,7 @@ constexpr int PF5 = 2;                  // W fragment prefetch distance (k block
 // stored only if p.y is set).  (A prologue that formed the rows from the feed-forward slice
 // partials, like gemm_x6r.hip's PRO, was built and measured in round 4: 107 us against 79 us +
 // 20 us for the separate ffn_reduce_ln launch at config 4 -- removed.)
-template <int EPI, bool DWC = false>
+template <int EPI>
 __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem5[];
   __shared__ float red[2][4][32];
@@ -77,29 +76,14 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
   // ---- prologue: the block's 32 rows -> X image in LDS ---------------------------------------
   // rows as fp32, whole rows per instruction (wave w: rows 8 w .. 8 w + 7, two 1-KB halves)
   f32x4 rowv[2][8];
-  if constexpr (DWC) {
-    // the A rows are the middle of the convolution module, formed from the GLU output p.dw.x
-    // (rowregs.h dwconv_rows8: dwconv_tiled_kernel's operations in its order; lane = 4
-    // consecutive channels of each 256-channel half = RowRegs<8>)
-    RowRegs<8> acc[8];
-    bool on[8];
-    dwconv_rows8<8>(p.dw, m0 + wave * 8, lane, acc, on);
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
+  for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rowv[hh][j][e] = acc[j].v[4 * hh + e];
-  } else {
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = min(m0 + wave * 8 + j, p.M - 1);
-        rowv[hh][j] =
-            *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + hh * 256 + lane * 4);
-      }
-  }
+    for (int j = 0; j < 8; ++j) {
+      const int r = min(m0 + wave * 8 + j, p.M - 1);
+      rowv[hh][j] =
+          *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + hh * 256 + lane * 4);
+    }
   const char* wb = w_base(p.W3, 0);
 #pragma unroll
   for (int s = 0; s < PF5; ++s) load_w(wb, kstride, s);
@@ -402,7 +386,7 @@ constexpr int XROWS = WROWS * RSTR;           // 132,096 B
 constexpr int QPST = 144;                     // quarter patch: 32 rows x (128 B + 16)
 constexpr int QPATCH = 4 * 32 * QPST;         // 18,432 B
 
-template <int EPI, bool DWC = false>
+template <int EPI>
 __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem5w[];
   __shared__ float red[2][4][WROWS];
@@ -437,25 +421,12 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
 #pragma unroll
   for (int b8 = 0; b8 < 2; ++b8) {
     f32x4 rv[8][2];
-    if constexpr (DWC) {           // (see x6r512_kernel)
-      RowRegs<8> dacc[8];
-      bool on[8];
-      dwconv_rows8<8>(p.dw, m0 + wave * 16 + b8 * 8, lane, dacc, on);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < 8; ++j) {
+      const int r = min(m0 + wave * 16 + b8 * 8 + j, p.M - 1);
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) rv[j][hh][e] = dacc[j].v[4 * hh + e];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = min(m0 + wave * 16 + b8 * 8 + j, p.M - 1);
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-          rv[j][hh] =
-              *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + hh * 256 + lane * 4);
-      }
+      for (int hh = 0; hh < 2; ++hh)
+        rv[j][hh] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + hh * 256 + lane * 4);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -718,10 +689,10 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
   }
 }
 
-template <int EPI, bool DWC = false>
+template <int EPI>
 int launch_x6r512w(const X6RArgs& a, hipStream_t s) {
   const size_t lds = (size_t)XROWS + QPATCH;
-  auto kern = x6r512w_kernel<EPI, DWC>;
+  auto kern = x6r512w_kernel<EPI>;
   static bool done = false;                     // per instantiation
   if (!done) {
     WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -733,10 +704,10 @@ int launch_x6r512w(const X6RArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int EPI, bool DWC = false>
+template <int EPI>
 int launch_x6r512(const X6RArgs& a, hipStream_t s) {
   const size_t lds = (size_t)XIMG + HPATCH;
-  auto kern = x6r512_kernel<EPI, DWC>;
+  auto kern = x6r512_kernel<EPI>;
   static bool done = false;                     // per instantiation
   if (!done) {
     WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -768,17 +739,9 @@ static bool x6r512_wide(const X6RArgs& a) {
 
 int gemm_x6r512(const X6RArgs& a, hipStream_t s) {
   WN_CHECK(!a.pro_P, "gemm_x6r512: no prologue fold at K = 512 (measured slower than ffn_reduce_ln)");
-  WN_CHECK((a.A || a.dw_on) && a.W3 && a.lda % 4 == 0 && gemm_x6r512_supported(a.M, a.N, a.epi),
+  WN_CHECK(a.A && a.W3 && a.lda % 4 == 0 && gemm_x6r512_supported(a.M, a.N, a.epi),
            "gemm_x6r512: shape");
   const bool wide = x6r512_wide(a);
-  if (a.dw_on) {
-    WN_CHECK(a.epi == 1 && a.dw.D == 512 && a.dw.M == a.M && a.dw.x && a.dw.ldx % 4 == 0 &&
-                 a.dw.wt && a.dw.bias && a.dw.cpad && a.dw.ln_w && a.dw.ln_b && a.dw.row_utt &&
-                 a.dw.off && a.dw.len && a.dw.K >= 1 && a.resid && a.x_out && a.ln_w && a.ln_b &&
-                 a.y && a.ldr % 4 == 0 && a.ldx % 4 == 0 && a.ldy % 4 == 0,
-             "gemm_x6r512: depthwise-conv prologue arguments");
-    return wide ? launch_x6r512w<1, true>(a, s) : launch_x6r512<1, true>(a, s);
-  }
   if (a.epi == 1) {
     WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && a.y && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
                  a.ldy % 4 == 0, "gemm_x6r512: row-LN epilogue arguments");

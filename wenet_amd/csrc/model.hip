@@ -824,10 +824,9 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     dw.M = M; dw.D = d; dw.K = c.cnn_kernel; dw.causal = c.causal;
     dw.t_max = m->Tp; dw.eps = 1e-5f;
     // x += pointwise_conv2(.); t1 = LN_ff(x)        encoder_layer.py:251-255
-    // on the row-block kernels the depthwise conv + norm + SiLU is the GEMM's prologue
-    // (gemm_x6r.hip / gemm_x6r512.hip DWC) -- no launch, no round trip of the conv module's middle tensor
-    const bool dwc = g_x6r_dwc != 0 && (d == 256 || d == 512) && rowx && g_x6r != 0 &&
-                     g_gemm_x6 != 0 && t_x6 &&
+    // d = 256 on the row-block kernel: the depthwise conv + norm + SiLU is its prologue
+    // (gemm_x6r.hip DWC) -- no launch, no round trip of the conv module's middle tensor
+    const bool dwc = g_x6r_dwc != 0 && d == 256 && rowx && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 &&
                      M >= 512 && t_x6->count(L.pw2.w) != 0 && gemm_x6r_supported(M, d, L.pw2.in, 1);
     if (!dwc) WN_TRY(dwconv_ln_silu(dw, s));
     xr = x6r_rowln(L.pw2, t1, L.norm_ff, dwc ? &dw : nullptr);
