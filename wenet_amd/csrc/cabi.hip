@@ -642,16 +642,12 @@ int wn_tune_set(const char* key, int32_t value) {
 #endif
     g_x6_probe = value;
   }
-  else if (k == "x6_conv") g_x6_conv = value;
-  else if (k == "x6_sub") g_x6_sub = value;
-  else if (k == "x6_conv_tail") g_x6_conv_tail = value;
   else if (k == "x6r_pro") g_x6r_pro = value;
   else if (k == "x6r_dwc") g_x6r_dwc = value;
   else if (k == "x6r512_rows") g_x6r512_rows = value;
   else if (k == "dwconv_tiled") g_dwconv_tiled = value;
   else if (k == "attn_fold") g_attn_fold = value;
   else if (k == "x6_linear") g_x6_linear = value;
-  else if (k == "x6_linear_min") g_x6_linear_min = value;
   else if (k == "x6_af32") g_x6_af32 = value;
   else if (k == "rescore_prefetch") g_rescore_prefetch = value;
   else if (k == "rescore_groups") g_rescore_groups = value;
@@ -1804,7 +1800,7 @@ int wn_rescore_prefetch(wn_model* m, int32_t use_right_decoder, void* stream) {
   // would take that route at all
   bool x6ok = t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_linear != 0 && t_x6 &&
               Menc >= 512 && d % 16 == 0 &&
-              2.0 * Menc * (2.0 * d) * d >= 1e8 * g_x6_linear_min;
+              2.0 * Menc * (2.0 * d) * d >= 1e8 * 60;
   if (x6ok)
     for (const Linear* l : kv) x6ok = x6ok && t_x6->count(l->w) != 0;
   if (x6ok) {

@@ -508,9 +508,6 @@ int launch_x6_act(const X6Args& a, hipStream_t s) {
 }  // namespace
 
 int g_gemm_x6 = 1;
-int g_x6_conv = 1;
-int g_x6_sub = 1;
-int g_x6_conv_tail = 1;
 int g_x6_linear = 1;
 // 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in
 // registers.  Measured (r02ag): the split costs more than the plane bytes it saves -- FFN w_1
@@ -612,7 +609,7 @@ int gemm_x6(const X6Args& args, hipStream_t s) {
       for (int t = std::min(4, ncu / rem); t >= 2; --t)
         if (nkb % t == 0) { S = t; break; }
       const int rows = a.M - full * 256;
-      if (g_x6_conv_tail != 0 && !af32 && S >= 2 && a.part &&
+      if (!af32 && S >= 2 && a.part &&
           a.part_bytes >= (size_t)S * rows * a.N * sizeof(float) && a.N % 4 == 0) {
         X6Args r = a;
         r.a_pix = a.a_pix + (size_t)full * 256;

@@ -152,12 +152,9 @@ struct X6Args {
   // (part_bytes >= slices x rows x N x 4); null: the remainder runs as 128-row tiles
   float* part = nullptr; size_t part_bytes = 0;
 };
-extern int g_x6_conv_tail;  // wn_tune_set("x6_conv_tail"): 0 = the remainder of conv2's tiles as 128-row tiles
 extern int g_x6_probe;
 int gemm_x6_clocks(unsigned long long* out);   // probe & 4 stamps [8 waves][8]
 extern int g_x6_linear;    // wn_tune_set("x6_linear"): 0 = linear() never routes to the six-product GEMM
-extern int g_x6_conv;      // wn_tune_set("x6_conv"): 0 = conv2 stays on v_mfma_f32
-extern int g_x6_sub;       // wn_tune_set("x6_sub"): 0 = the subsampling's output Linear stays on v_mfma_f32, 1 K slices of 256-row tiles, 2 of 128-row tiles
 extern int g_x6_af32;      // wn_tune_set("x6_af32"): 0 plane images (default), 1 fp32 A rows split in registers
 extern int g_gemm_x6;     // wn_tune_set("gemm_x6"): 0 = the v_mfma_f32 kernels (A/B, tests)
 size_t x6_bytes(int R, int K);

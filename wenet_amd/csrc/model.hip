@@ -41,7 +41,7 @@ int upload_desc(wn_model* m, DevBuf& buf, const std::vector<int>& v,
 // a_bf16 / c_bf16: A / C are bf16 matrices in the same buffers (lda / ldc stay the
 // element counts) -- only under bf16_store_active().
 // linear(): GEMMs from this many 0.1 GFLOP on go to the six-product kernel through a split pass
-int g_x6_linear_min = 60;   // wn_tune_set("x6_linear_min")
+constexpr int g_x6_linear_min = 60;   // (40 / 20 measured slower at configs 3 / 4, r05l)
 
 int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M,
            hipStream_t s, int act, const float* resid, int ldr, float alpha, bool glu, bool a_bf16,
@@ -479,13 +479,13 @@ int set_layout(wn_model* m, int B, int Tp, const std::vector<int>& off,
 int sub_out_linear(wn_model* m, int M, int F2, hipStream_t s) {
   const wn_config& c = m->cfg;
   const int d = c.d_model, K = F2 * d;
-  if (t_gemm_prec != PREC_F32 || g_gemm_x6 == 0 || g_x6_sub == 0 || !m->x6_at || m->layers.empty() ||
+  if (t_gemm_prec != PREC_F32 || g_gemm_x6 == 0 || !m->x6_at || m->layers.empty() ||
       (d != 256 && d != 512) || K % 16 != 0 || M < 512 || (int64_t)M * K * 4 >= ((int64_t)1 << 31) ||
       bf16_store_active())
     return 0;
   auto it = m->x6_at->find(m->sub_out.w);
   if (it == m->x6_at->end()) return 0;
-  const int bm = g_x6_sub == 2 ? 128 : 256;
+  const int bm = 256;
   const int tiles = cdiv(M, bm) * cdiv(d, 256), nkb = K / 16;
   int S = 0;
   for (int t = std::min(16, 256 / std::max(tiles, 1)); t >= 2; --t)
@@ -547,7 +547,7 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
     // fp32 on the bf16 matrix cores (gemm_x6.hip): conv1 writes the plane image of its
     // output, conv2 gathers its rows from it
     const void* w6 = nullptr;
-    if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_conv != 0 && m->x6_at && d % 32 == 0 &&
+    if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && m->x6_at && d % 32 == 0 &&
         F1 <= 64 &&
         (M * F2 >= 4096 || g_gemm_x6 == 2)) {
       auto it = m->x6_at->find(m->conv2.w);

@@ -480,7 +480,7 @@ struct PrecisionScope {
 };
 
 // ---- engine (model.hip) -------------------------------------------------------------------
-extern int g_x6_linear_min;
+
 bool bf16_store_active();
 int upload_desc(wn_model* m, DevBuf& buf, const std::vector<int>& v, hipStream_t s);
 int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M, hipStream_t s,
