@@ -300,6 +300,45 @@ def test_prefix_beam_known_answer_gpu():
     assert r.nbest_times == [[0, 2], [0, 2], [2]]
 
 
+def test_maximum_length_utterance_and_one_frame_beyond():
+    """The longest utterance the positional table allows (T' = 5000 encoder frames = 200 s of
+    audio: RelPositionalEncoding max_len 5000, embedding.py:38-56,134-147) next to a short one,
+    against the oracle: encoder output, greedy tokens, prefix-beam n-best (attention over 5000
+    keys, 157 key tiles; the prefix beam search over 5000 dependent frames).  One encoder frame
+    more must be refused like the reference's `assert offset + size <= self.max_len`
+    (embedding.py:94), not read past the table."""
+    from wenet_amd import synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model('tiny_causal', 0)
+    T = 4 * 5000 + 3                       # T' = ((T - 1) // 2 - 1) // 2 = 5000
+    feats, _ = S.make_features(2, (T, T), seed=8)
+    lens = torch.tensor([T, 431], dtype=torch.int32)
+    feats[1, 431:] = 0.0
+    with torch.no_grad():
+        enc_ref, mask = O.encoder_forward(configs, sd, feats, lens)
+    enc, gmask = model._forward_encoder(feats.cuda(), lens)
+    ref_lens = mask.squeeze(1).sum(1).tolist()
+    assert gmask.squeeze(1).sum(1).tolist() == ref_lens == [5000, 107]
+    for b in range(2):
+        n = ref_lens[b]
+        err = (enc[b, :n].cpu() - enc_ref[b, :n]).abs().max().item()
+        assert err < 2e-3, (b, err)
+    ref = O.decode(configs, sd, METHODS[:2], feats, lens, beam_size=4)
+    got = model.decode(METHODS[:2], feats.cuda(), lens, beam_size=4)
+    logp = O.ctc_logprobs(sd, enc_ref)
+    for b in range(2):
+        n = ref_lens[b]
+        top = logp[b, :n].topk(2, dim=-1)
+        greedy_frame_check(model.ctc_logprobs(enc)[b, :n].argmax(-1).cpu().numpy(),
+                           top.indices.numpy(), top.values.numpy(),
+                           got['ctc_greedy_search'][b].tokens, ref['ctc_greedy_search'][b].tokens,
+                           what=f'max length[{b}]')
+    assert len(got['ctc_prefix_beam_search'][0].nbest) == len(ref['ctc_prefix_beam_search'][0].nbest)
+    too_long = torch.zeros((1, T + 4, 80))
+    with pytest.raises(RuntimeError, match='positional table'):
+        model._forward_encoder(too_long.cuda(), torch.tensor([T + 4], dtype=torch.int32))
+
+
 def test_zero_length_and_short_utterances():
     from wenet_amd import synthetic as S
     O = _oracle()

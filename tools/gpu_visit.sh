@@ -8,8 +8,8 @@
 #   tests:<pytest args>         e.g. tests:tests/test_gpu_rescore.py+-k+bit
 #   smoke                       __graft_entry__.smoke()
 #   bench:<workload>[:<args>]   bench.py --workload <workload> <args> -> bench_<workload>[_n].json
-#   stats:<workload>[:<args>]   rocprofv3 --kernel-trace --stats of a short bench run
-#                               -> kernel_stats_<workload>.md
+#   stats:<workload>[:<args>]   rocprofv3 --kernel-trace --stats of a short bench run, one decode in
+#                               flight (stats2: two) -> kernel_stats_<workload>_streams<n>.md
 #   pmc:<workload>[:<args>]     the three PMC passes + kernel trace (tools/pmc_table.py)
 #                               -> pmc_table_<workload>.md
 #   py:<script>[:<args>]        python <script> <args> -> <script>.txt
@@ -50,10 +50,11 @@ print('bench', sys.argv[2], '| value', d['value'], 'ms', d['ms_per_step'], 'plai
       d.get('cpu_baseline', {}).get('value'))
 PY
       ;;
-    stats)
-      timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_$a1 -o prof -- \
-        python bench.py --workload $a1 $SHORT --streams 1 $a2 > $OUT/stats_$a1.json 2> $OUT/stats_$a1.err
-      python tools/rocpd_stats.py $OUT/kt_$a1/prof_results.db $OUT/kernel_stats_$a1.md | head -34 | cut -c1-220
+    stats|stats2)
+      st=1; [ $kind = stats2 ] && st=2      # decodes in flight (stats2: the headline's pipeline)
+      timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt${st}_$a1 -o prof -- \
+        python bench.py --workload $a1 $SHORT --streams $st $a2 > $OUT/stats${st}_$a1.json 2> $OUT/stats${st}_$a1.err
+      python tools/rocpd_stats.py $OUT/kt${st}_$a1/prof_results.db $OUT/kernel_stats_${a1}_streams$st.md | head -34 | cut -c1-220
       find $OUT -name "*.db" -size +20M -delete ;;
     pmc)
       CMD="python bench.py --workload $a1 --steps 2 --warmup 1 --no-cpu-baseline --no-clock-sample --no-f32-mfma-leg --no-plain-leg --no-nbest-leg --streams 1 --min-seconds 0.1 $a2"
