@@ -12,6 +12,7 @@
 #                               flight (stats2: two) -> kernel_stats_<workload>_streams<n>.md
 #   pmc:<workload>[:<args>]     the three PMC passes + kernel trace (tools/pmc_table.py)
 #                               -> pmc_table_<workload>.md
+#   probe                       launch-cost probe (one-wave-per-SIMD kernels on slow boxes)
 #   py:<script>[:<args>]        python <script> <args> -> <script>.txt
 # env WN_TUNE / WN_EXPERIMENTAL pass through.  Everything lands in gpurun_out/TAG/.
 TAG=${1:?tag}; shift
@@ -65,6 +66,10 @@ PY
       timeout 600 rocprofv3 --kernel-trace --stats -d $P/kt -o prof -- $CMD > $P/kt.log 2>&1; echo "kt $?"
       python tools/pmc_table.py $P > $OUT/pmc_table_$a1.md; head -30 $OUT/pmc_table_$a1.md | cut -c1-220
       find $OUT -name "*.db" -size +20M -delete; find $OUT -name "*.csv" -size +8M -delete ;;
+    probe)
+      # launch-cost probe (tools/probes/launch_probe.hip): which resource shape pays on a slow box
+      hipcc --offload-arch=gfx950 -O2 tools/probes/launch_probe.hip -o /tmp/launch_probe 2> /dev/null
+      timeout 120 /tmp/launch_probe > $OUT/launch_probe_$n.txt 2>&1; tail -10 $OUT/launch_probe_$n.txt ;;
     py)
       timeout 900 python $a1 $a2 > $OUT/$(basename $a1 .py)_$n.txt 2>&1
       echo "[$n] $a1 exit $?"; tail -12 $OUT/$(basename $a1 .py)_$n.txt | cut -c1-300 ;;
