@@ -69,7 +69,10 @@ PY
     probe)
       # launch-cost probe (tools/probes/launch_probe.hip): which resource shape pays on a slow box
       hipcc --offload-arch=gfx950 -O2 tools/probes/launch_probe.hip -o /tmp/launch_probe 2> /dev/null
-      timeout 120 /tmp/launch_probe > $OUT/launch_probe_$n.txt 2>&1; tail -10 $OUT/launch_probe_$n.txt ;;
+      timeout 120 /tmp/launch_probe > $OUT/launch_probe_$n.txt 2>&1; tail -10 $OUT/launch_probe_$n.txt
+      # what the box says about itself (slow boxes vs normal ones: clocks, power cap, partitions)
+      { rocm-smi --showperflevel --showclocks --showpower --showmaxpower --showcomputepartition \
+          --showmemorypartition --showfwinfo 2>&1; rocminfo 2>/dev/null | grep -i -E "name:|compute unit|max clock|wavefront|xnack" | head -40; } > $OUT/box_info_$n.txt 2>&1 ;;
     py)
       timeout 900 python $a1 $a2 > $OUT/$(basename $a1 .py)_$n.txt 2>&1
       echo "[$n] $a1 exit $?"; tail -12 $OUT/$(basename $a1 .py)_$n.txt | cut -c1-300 ;;
