@@ -41,6 +41,7 @@ int upload_desc(wn_model* m, DevBuf& buf, const std::vector<int>& v,
 // a_bf16 / c_bf16: A / C are bf16 matrices in the same buffers (lda / ldc stay the
 // element counts) -- only under bf16_store_active().
 // linear(): GEMMs from this many 0.1 GFLOP on go to the six-product kernel through a split pass
+static thread_local bool t_linear_took_x6 = false;   // what the last linear() of this thread ran on
 constexpr int g_x6_linear_min = 60;   // (40 / 20 measured slower at configs 3 / 4, r05l)
 
 int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M,
@@ -55,6 +56,7 @@ int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M,
       2.0 * M * (double)l.out * l.in >= 1e8 * g_x6_linear_min) {
     auto it = t_x6->find(l.w);
     if (it != t_x6->end()) {
+      t_linear_took_x6 = true;
       WN_TRY(t_x6_a->ensure(x6_bytes(M, l.in)));
       WN_TRY(x6_split(A, M, l.in, lda, t_x6_a->as<char>(), s));
       X6Args x;
@@ -64,6 +66,7 @@ int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M,
       return gemm_x6(x, s);
     }
   }
+  t_linear_took_x6 = false;
   GemmArgs g;
   g.A = A; g.W = l.w; g.bias = l.b; g.C = C; g.resid = resid;
   g.M = M; g.N = l.out; g.K = l.in; g.lda = lda; g.ldc = ldc; g.ldr = ldr;
@@ -92,6 +95,10 @@ int ffn_w1(wn_model* m, const Linear& l, const float* A, float* C, int M,
   WN_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], s));
   m->prof_used += 2;
   m->prof_flops += 2.0 * M * (double)l.out * l.in;
+  // (the bracket also holds the plane-split pass of A when linear() took the six-product route)
+  m->prof_kernel = t_linear_took_x6
+                       ? "x6_split + gemm_x6_kernel (FFN w_1 + act through linear(), six bf16 plane products)"
+                       : "gemm (FFN w_1)";
   return 0;
 }
 
