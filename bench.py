@@ -11,8 +11,9 @@ features that are already resident in HBM: BASELINE.json configs[1]
 (AIShell u2++ Conformer 12L/4h/256d, batch 32 x ~10 s, ctc_prefix_beam_search,
 beam 10) on every GPU (weak scaling: 32 utterances per GPU -- group g of the
 global batch is `synthetic.make_bench_group(workload, g)` -- sorted by length and
-dealt in snake order; results are gathered with one RCCL all_gather inside the
-timed region).  Weights are random-init (sharpened CTC head,
+dealt in snake order; results are gathered with one RCCL all_gather per step on a
+worker thread + side stream, drained inside the timed region:
+wenet_amd/dist.py ResultGatherer).  Weights are random-init (sharpened CTC head,
 wenet_amd/synthetic.py), inputs synthetic.
 
 Timing: W warm-up steps, then ROUNDS of exactly K steps, each round bracketed by a
@@ -27,10 +28,14 @@ the opt-in reduced-precision modes as extra data points; the default line
 (config2, fp32 = the reference's dtype) is the headline.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     : the FFN w_1 GEMM (MFMA), achieved = algorithmic FLOP of its
-                 launches / their HIP-event durations inside the timed rounds,
-                 peak from MI355X_MICROARCH.md; `whole_decode_frac` = all encoder +
-                 CTC-head contraction FLOPs of the batch / step time / peak;
+  roofline     : the feed-forward kernel (d_model 256: both contractions fused in
+                 ffn_x6f_kernel; 512: the w_1 GEMM), achieved = algorithmic FLOP of its
+                 launches / their HIP-event durations inside the timed rounds, peak =
+                 the six-product ceiling (dense bf16 peak / 6, MI355X_MICROARCH.md);
+                 `whole_decode_frac` = all encoder + CTC-head contraction FLOPs of the
+                 batch / step time / the same ceiling;
+  plain_decode, f32_mfma_only, nbest_materialised, end_to_end : transparency legs
+                 (one extra round each, never `value`);
   cpu_baseline : the oracle (torch-CPU restatement of the reference decode,
                  kind "port") timed on this box's host cores on the whole batch;
                  profiles/cpu_port_vs_reference.json calibrates the port against
