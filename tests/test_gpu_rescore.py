@@ -153,3 +153,42 @@ def test_cross_attention_per_utterance_group_changes_nothing(config, B, frames):
     for a, b in zip(ref, got):
         assert a.tokens == b.tokens and a.score == b.score
         assert a.all_scores == b.all_scores and a.tokens_confidence == b.tokens_confidence
+
+
+@pytest.mark.parametrize('beam', [1, 3, 64])
+def test_rescore_edge_shapes_vs_oracle(beam):
+    """Rescoring at the edges of its shape range against the oracle's attention_rescoring
+    (search.py:374-458 restated): beam 1 (one hypothesis: the arg-max is trivial, the score is
+    not), the widest beam the search supports (64: one lane per hypothesis in the reduce kernel),
+    utterances of a single encoder frame next to long ones (their n-best holds the EMPTY
+    hypothesis: only <eos> is scored), results of the free search function (another handle's
+    prefix beam: the lists are uploaded, not read from this model's device block)."""
+    from wenet_amd import search as SR, synthetic as S
+    from oracle import wenet_oracle as O
+    configs, sd, model = cached_model('tiny_causal', 0)
+    feats, _ = S.make_features(4, (300, 300), seed=53)
+    lens = torch.tensor([300, 7, 11, 163], dtype=torch.int32)     # 7 frames -> T' = 1
+    for b in range(4):
+        feats[b, int(lens[b]):] = 0.0
+    kw = dict(beam_size=beam, ctc_weight=0.3, reverse_weight=0.5)
+    M = ['ctc_prefix_beam_search', 'attention_rescoring']
+    got = model.decode(M, feats.cuda(), lens, **kw)
+    ref = O.decode(configs, sd, M, feats, lens, **kw)
+    assert any(len(h) == 0 for r in got[M[0]] for h in r.nbest)
+    for b in range(4):
+        g, r = got[M[1]][b], ref[M[1]][b]
+        assert [list(x) for x in got[M[0]][b].nbest] == [list(x) for x in ref[M[0]][b].nbest], b
+        np.testing.assert_allclose(g.all_scores, r.all_scores, rtol=0, atol=1e-3)
+        assert list(g.tokens) == list(r.tokens) and abs(g.score - r.score) < 1e-3
+        assert abs(g.confidence - r.confidence) < 1e-4
+        np.testing.assert_allclose(g.tokens_confidence, r.tokens_confidence, atol=1e-4)
+        assert list(g.times) == list(r.times)
+    # the free functions: prefix beam on another (workspace) handle, then rescoring by the model
+    enc, mask = model._forward_encoder(feats.cuda(), lens)
+    enc_lens = mask.squeeze(1).sum(1)
+    logp = model.ctc_logprobs(enc, encoder_lens=enc_lens.cpu())
+    pre = SR.ctc_prefix_beam_search(logp, enc_lens, beam)
+    free = SR.attention_rescoring(model, pre, enc, enc_lens, 0.3, 0.5)
+    for b in range(4):
+        assert free[b].tokens == got[M[1]][b].tokens and free[b].score == got[M[1]][b].score
+        assert free[b].all_scores == got[M[1]][b].all_scores
