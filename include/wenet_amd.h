@@ -512,34 +512,22 @@ int wn_profile_gemm_clocks(uint64_t* out64);
  * compare every ConformerEncoderLayer output with the oracle. */
 int wn_debug_set(wn_model* m, const char* key, int32_t value);
 
-/* Process-wide kernel tuning knob for A/B measurements (tools/bench_gemm.py, tools/bench_x6.py,
- * bench.py --tune, the WN_TUNE variable of the test session): "gemm_variant" (bit mask of
- * experimental code paths), "gemm_tile" / "gemm_tile_bf16" (force a block tile); fp32 mode:
- * "gemm_x6" (1 default: feed-forward, conv2, the vocabulary layers and every large linear as
- * six bf16 plane products of exactly split fp32 operands; 0: every GEMM on
- * v_mfma_f32_32x32x2_f32; 2: also for small batches), "x6_conv" / "x6_linear" (0: leave conv2 /
- * the linear() route on v_mfma_f32), "x6_af32" (1: fp32 A rows split in registers), "ffn_fused",
- * "gemm_rowln", "attn_fold" (1 default: rel-pos term folded into the keys inside the attention
- * kernel; 0: two contractions per score; 2: folded by a separate pass), "ctc_wave" (1 default: a wave per row for the
- * top-k; 0: a block per row; 2: the wave kernel with two-level maxima -- bit-identical,
- * measured at the end of round 3, not the default yet), "x6_sub"
- * (1 default: the subsampling's output Linear as K slices of the six-product GEMM; 0:
- * v_mfma_f32), "x6_conv_tail" (1 default: conv2's last partial round of tiles as K slices),
- * "x6r_pro" (1 default: the QKV row-block GEMM forms LN(x + 0.5 FFN) itself from the fused FFN's
- * slice partials; 2: the same with the slice loads in flight together -- bit-identical,
- * measured at the end of round 3, not the default yet), "attn_gload" (1: fp32 folded attention with the staging loads of all chunks issued
- * together -- bit-identical, not the default yet; 0 default), "dwconv_tiled" (1: depthwise convolution
- * with four rows per wave -- bit-identical, not the default yet; 0 default); bf16 / fp8 modes: "attn_bf16_dma" (self attention over bf16 Q | K | V: 0
- * register-staged, 1 / 2 LDS-DMA staged from K rows and a V^T image, 4 default: V rows by DMA +
- * ds_read_b64_tr_b16, 5 the same with the transpose reads as inline asm -- a measurement form,
- * see csrc/attention_bf16.hip TRA), "attn_bf16_defer" (deferred-rescale threshold x 10 in log2 units, 80
- * default, 0 off), "attn_bf16_nw" (query groups per block, 0 auto); measurement: "lp_probe",
- * "x6_probe", "ffn_x6f_var" (clock stamps / ablations, see wn_profile_*_clocks); "beam_cu_mask"
- * (n * 1000 + stride, 0 default = off: the prefix beam search kernel on a stream whose CU mask
- * has n bits set -- prepared for decodes in flight, not yet run) and "x6_conv_cus" (256 default:
- * the CUs a round of conv2's tiles may use; 248 with an 8-CU search mask), ...
- * Unknown keys are an error.  The defaults are the shipped configuration. */
+/* Tuning knobs: A/B switches between kernel forms, measurement probes and test hooks.  The key
+ * list, what every value selects and the defaults (= the shipped configuration) are ONE table,
+ * WN_TUNE_KEYS in wenet_amd/csrc/tune.h; unknown keys are an error.  Values that are wrong by
+ * design (ablations) are refused unless the library was built with WN_ABLATION=1.
+ *
+ * wn_tune_set writes the PROCESS DEFAULT: what handle-less operators (wn_op_*) and every handle
+ * without an override of its own see (tools/bench_*.py, bench.py --tune, most tests).
+ * wn_model_tune_set writes ONE HANDLE's override (INT32_MIN = drop the override, follow the process
+ * default again); a handle's entry points run on its effective set, resolved when the call enters
+ * and current only for the calling thread, so two handles driven by two host threads can run
+ * different kernel forms side by side.  wn_model_clone copies the overrides.  wn_tune_get reads
+ * the effective value for a handle (NULL: the process default).
+ * No counterpart in the reference: its kernels are chosen by torch's dispatcher. */
 int wn_tune_set(const char* key, int32_t value);
+int wn_model_tune_set(wn_model* m, const char* key, int32_t value);
+int wn_tune_get(const wn_model* m, const char* key, int32_t* value);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,29 @@ def test_argument_validation_without_a_device():
         assert L.wn_tune_set(b'ffn_x6f_var', 0) == 0 and L.wn_tune_set(b'x6_probe', 0) == 0
 
 
+def test_tune_table_defaults_and_process_default_round_trip():
+    """wn_tune_set writes the process default, wn_tune_get(NULL, ...) reads it; every key of
+    csrc/tune.h's table is reachable and starts at its documented default."""
+    import ctypes
+    import re
+    from wenet_amd import _lib
+    L = _lib.lib()
+    table = open(os.path.join(ROOT, 'wenet_amd', 'csrc', 'tune.h')).read()
+    keys = re.findall(r'^\s*X\((\w+), (-?\d+)\)', table, re.M)
+    assert len(keys) >= 25 and ('ffn_x6f', '1') in keys
+    v = ctypes.c_int32(0)
+    for name, dflt in keys:
+        assert L.wn_tune_get(None, name.encode(), ctypes.byref(v)) == 0, name
+        assert v.value == int(dflt), (name, v.value, dflt)
+    assert L.wn_tune_get(None, b'no_such_knob', ctypes.byref(v)) == -1
+    assert L.wn_tune_set(b'attn_bf16_nw', 4) == 0
+    assert L.wn_tune_get(None, b'attn_bf16_nw', ctypes.byref(v)) == 0 and v.value == 4
+    assert L.wn_tune_set(b'attn_bf16_nw', 0) == 0
+    # INT32_MIN is the per-handle "inherit" marker, not a process default
+    assert L.wn_tune_set(b'attn_bf16_nw', -2 ** 31) == -1
+    assert L.wn_model_tune_set(None, b'attn_bf16_nw', 1) == -1
+
+
 def test_product_path_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under wenet_amd/ may import,
     call or link it."""

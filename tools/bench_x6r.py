@@ -2,7 +2,7 @@
 shapes (K = 256: out-projection / pointwise_conv2 + residual + LayerNorm, QKV) and
 csrc/gemm_x6r512.hip at the config-3 / config-4 shapes (K = 512: projections of one to three
 512-column passes, + residual + LayerNorm, + the pointwise_conv1 + GLU chain).
-GPU only:  python tools/bench_x6r.py
+GPU only:  python tools/bench_x6r.py [knob=value ...]   (knobs go to wn_tune_set first)
 """
 import os
 import sys
@@ -26,6 +26,10 @@ def timed(fn):
 
 def main():
     L = _lib.lib()
+    for kv in sys.argv[1:]:
+        k, v = kv.split('=')
+        _lib.check(L.wn_tune_set(k.encode(), int(v)), 'wn_tune_set ' + kv)
+        print('knob', kv, flush=True)
     st = torch.cuda.current_stream().cuda_stream
     reps = 50
     for n, epi, what in ((256, 1, 'proj + residual + LayerNorm'), (256, 0, 'proj'),

@@ -37,7 +37,7 @@ EXPORTS = [
     'wn_ctc_logprobs', 'wn_set_ctc_probs', 'wn_ctc_greedy_search',
     'wn_set_context_graph', 'wn_ctc_prefix_beam_search', 'wn_attention_rescoring', 'wn_rescore', 'wn_rescore_prefetch', 'wn_decoder_forward', 'wn_decoder_next_topk', 'wn_op_gemm',
     'wn_op_layernorm', 'wn_op_log_add', 'wn_debug_set', 'wn_profile_enable',
-    'wn_profile_collect', 'wn_tune_set',
+    'wn_profile_collect', 'wn_tune_set', 'wn_model_tune_set', 'wn_tune_get',
 ]
 
 _lib = None
@@ -121,6 +121,8 @@ def lib():
     L.wn_op_log_add.argtypes = [vp, vp, vp, i32, vp]
     L.wn_debug_set.argtypes = [vp, c_char_p, i32]
     L.wn_tune_set.argtypes = [c_char_p, i32]
+    L.wn_model_tune_set.argtypes = [vp, c_char_p, i32]
+    L.wn_tune_get.argtypes = [vp, c_char_p, pi32]
     L.wn_profile_enable.argtypes = [vp, i32]
     L.wn_profile_collect.argtypes = [vp, pi32, pf64, pf64]
     for n in EXPORTS:

@@ -32,8 +32,6 @@
 
 namespace wn {
 
-extern int g_attn_bf16_dma;
-extern int g_attn_bf16_defer;
 
 namespace {
 
@@ -830,30 +828,27 @@ int launch(const AttnArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int g_attn_bf16_nw = 0;  // wn_tune_set("attn_bf16_nw"): 0 auto, else 2 / 4 / 8
-int g_attn_bf16_defer = 80;  // wn_tune_set("attn_bf16_defer"): deferred-rescale threshold x 10 in log2 units (0 = rescale whenever a maximum moves)
-int g_attn_bf16_dma = 1; // bf16 Q | K | V self attention: 0 = register-staged kernel (A/B, tests), else K / V rows by LDS-DMA + asm transpose reads
 
 int attention_bf16(const AttnArgs& a, hipStream_t s) {
   // argument checks are attention()'s (the only caller)
   WN_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldp % 4 == 0,
            "attention(bf16): strides must be multiples of 4 elements");
   WN_CHECK(!(a.qkv_bf16 && a.P), "attention(bf16): bf16 Q/K/V only without the rel-pos term");
-  int nw = g_attn_bf16_nw;
+  int nw = tune().attn_bf16_nw;
   if (nw != 2 && nw != 4 && nw != 8)
     nw = a.max_q_len >= 1024 ? 8 : a.max_q_len >= 384 ? 4 : 2;
   // self attention over bf16 Q | K | V without masks: K and V rows by LDS-DMA, the PV fragments
   // through transpose reads
-  if (g_attn_bf16_dma != 0 && a.qkv_bf16 && !a.P && a.mask_mode == 0 && nw >= 4 &&
+  if (tune().attn_bf16_dma != 0 && a.qkv_bf16 && !a.P && a.mask_mode == 0 && nw >= 4 &&
       a.q_len == a.kv_len && a.q_off == a.kv_off && a.ldk % 8 == 0 && a.ldv == a.ldk &&
       (int64_t)a.max_q_len * a.ldk * 2 < (int64_t(1) << 31))
   {
     // 4-wave blocks (128 queries) also for long sequences: twice the K / V stream from L2, but
     // barrier groups of four waves lose less to skew than groups of eight (config 5 fp8: 14.81 k
     // vs 14.62 k, r05v); attn_bf16_nw = 8 forces the 256-query blocks
-    if (g_attn_bf16_nw != 8) nw = 4;
+    if (tune().attn_bf16_nw != 8) nw = 4;
     AttnArgs d = a;
-    d.defer_thr = 0.1f * (float)g_attn_bf16_defer;
+    d.defer_thr = 0.1f * (float)tune().attn_bf16_defer;
     return nw == 8 ? launch_dma_tra<8>(d, s) : launch_dma_tra<4>(d, s);
   }
   switch (nw) {

@@ -5,8 +5,6 @@
 #include "model_state.h"
 
 namespace {
-int g_rescore_groups = 1;     // wn_tune_set("rescore_groups"): 0 = cross attention per hypothesis (A/B, tests)
-int g_rescore_prefetch = 1;   // wn_tune_set("rescore_prefetch"): 0 = wn_rescore_prefetch does nothing (A/B)
 
 // ---------------------------------------------------------------------------
 // weight ingestion
@@ -481,6 +479,7 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->cfg = src->cfg;
   m->device = src->device;
   m->prec = src->prec;
+  m->tune_ovr = src->tune_ovr;
   // weights, projected position tables and fbank tables are read-only: share
   m->weights = src->weights;
   m->n_weight_elems = src->n_weight_elems;
@@ -583,7 +582,7 @@ int32_t wn_profile_ffn_split(const wn_model* m) { return m ? m->prof_split : 0; 
 
 int wn_profile_gemm_clocks(uint64_t* out64) {
   WN_CHECK(out64, "wn_profile_gemm_clocks: null output");
-  if (wn::g_lp_probe & 4)   // the pipelined bf16 / MXFP8 kernel stamped last (tools/lp_clocks.py)
+  if (wn::tune().lp_probe & 4)   // the pipelined bf16 / MXFP8 kernel stamped last (tools/lp_clocks.py)
     return wn::gemm_lp_clocks(reinterpret_cast<unsigned long long*>(out64));
   return wn::gemm_x6_clocks(reinterpret_cast<unsigned long long*>(out64));
 }
@@ -623,51 +622,33 @@ int wn_debug_set(wn_model* m, const char* key, int32_t value) {
 int wn_tune_set(const char* key, int32_t value) {
   WN_CHECK(key, "wn_tune_set: null key");
   const std::string k(key);
-  if (k == "gemm_tile_bf16") g_gemm_tile_bf16 = value;
-  else if (k == "attn_split") g_attn_split = value;
-  else if (k == "attn_bf16") g_attn_bf16 = value;
-  else if (k == "bf16_store") g_bf16_store = value;
-  else if (k == "attn_bf16_nw") g_attn_bf16_nw = value;
-  else if (k == "attn_bf16_dma") g_attn_bf16_dma = value;
-  else if (k == "attn_bf16_defer") g_attn_bf16_defer = value;
-  else if (k == "lp_probe") g_lp_probe = value;
-  else if (k == "qkv_bf16") g_qkv_bf16 = value;
-  else if (k == "fp8_min_tiles") g_fp8_min_tiles = value;
-  else if (k == "ffn_fused") g_ffn_fused = value;
-  else if (k == "gemm_x6") g_gemm_x6 = value;
-  else if (k == "x6_probe") {
-#ifndef WN_ABLATION
-    WN_CHECK((value & ~4) == 0, "wn_tune_set: x6_probe 1 / 2 (no MFMAs / no DMA) need a "
-             "WN_ABLATION build");
-#endif
-    g_x6_probe = value;
-  }
-  else if (k == "x6r_pro") g_x6r_pro = value;
-  else if (k == "x6r_dwc") g_x6r_dwc = value;
-  else if (k == "x6r512_rows") g_x6r512_rows = value;
-  else if (k == "dwconv_tiled") g_dwconv_tiled = value;
-  else if (k == "attn_fold") g_attn_fold = value;
-  else if (k == "x6_linear") g_x6_linear = value;
-  else if (k == "x6_af32") g_x6_af32 = value;
-  else if (k == "rescore_prefetch") g_rescore_prefetch = value;
-  else if (k == "rescore_groups") g_rescore_groups = value;
-  else if (k == "beam_weak_hash") g_beam_weak_hash = value;
-  else if (k == "ctc_wave") g_ctc_wave = value;
-  else if (k == "gemm_rowln") g_gemm_rowln = value;
-  else if (k == "x6r") g_x6r = value;
-  else if (k == "ffn_x6f") g_ffn_x6f = value;
-#ifdef WN_ABLATION
-  else if (k == "ffn_x6f_ring") g_ffn_x6f_ring = value;
-#endif
-  else if (k == "x6r_chain") g_x6r_chain = value;
-  else if (k == "ffn_x6f_var") {
-#ifndef WN_ABLATION
-    WN_CHECK(value == 0 || value == 25088, "wn_tune_set: ffn_x6f_var variants other than the "
-             "clock-stamp form (25088) need a WN_ABLATION build");
-#endif
-    g_ffn_x6f_var = value;
-  }
-  else { set_error("wn_tune_set: unknown key " + k); return -1; }
+  int* f = tune_field(g_tune_default, k);
+  if (!f) { set_error("wn_tune_set: unknown key " + k); return -1; }
+  WN_CHECK(value != TUNE_INHERIT, "wn_tune_set: INT32_MIN is the per-handle 'inherit' marker");
+  if (tune_check(k, value, "wn_tune_set") != 0) return -1;
+  *f = value;
+  return 0;
+}
+
+int wn_model_tune_set(wn_model* m, const char* key, int32_t value) {
+  WN_CHECK(m && key, "wn_model_tune_set: null argument");
+  WN_ENTER(m);
+  const std::string k(key);
+  int* f = tune_field(m->tune_ovr, k);
+  if (!f) { set_error("wn_model_tune_set: unknown key " + k); return -1; }
+  if (tune_check(k, value, "wn_model_tune_set") != 0) return -1;
+  *f = value;
+  return 0;
+}
+
+int wn_tune_get(const wn_model* m, const char* key, int32_t* value) {
+  WN_CHECK(key && value, "wn_tune_get: null argument");
+  const std::string k(key);
+  Tune eff = g_tune_default;
+  if (m) tune_resolve(m->tune_ovr, &eff);
+  const int* f = tune_field(eff, k);
+  if (!f) { set_error("wn_tune_get: unknown key " + k); return -1; }
+  *value = *f;
   return 0;
 }
 
@@ -1782,7 +1763,7 @@ int wn_rescore_prefetch(wn_model* m, int32_t use_right_decoder, void* stream) {
     WN_HIP(hipStreamWaitEvent(s, m->side.e1, 0));
     m->kv_ready = false;
   }
-  if (g_rescore_prefetch == 0 || m->left.layers.empty() || m->rows <= 0) return 0;
+  if (tune().rescore_prefetch == 0 || m->left.layers.empty() || m->rows <= 0) return 0;
   WN_HIP(hipSetDevice(m->device));
   const int d = m->cfg.d_model, Menc = m->rows;
   const bool r2l = use_right_decoder != 0 && !m->right.layers.empty();
@@ -1798,7 +1779,7 @@ int wn_rescore_prefetch(wn_model* m, int32_t use_right_decoder, void* stream) {
   // all layers project the SAME rows: split the encoder output into planes once and run the
   // six-product GEMM per layer (linear() would split it once per layer) -- where linear()
   // would take that route at all
-  bool x6ok = t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_linear != 0 && t_x6 &&
+  bool x6ok = t_gemm_prec == PREC_F32 && tune().gemm_x6 != 0 && tune().x6_linear != 0 && t_x6 &&
               Menc >= 512 && d % 16 == 0 &&
               2.0 * Menc * (2.0 * d) * d >= 1e8 * 60;
   if (x6ok)
@@ -1927,7 +1908,7 @@ int wn_rescore(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
   cgrp.q_off = m->r_gqoff.as<int>(); cgrp.q_len = m->r_gqlen.as<int>();
   cgrp.kv_off = m->r_gkvoff.as<int>(); cgrp.kv_len = m->r_gkvlen.as<int>();
   cgrp.n_seq = (int)gq_off.size(); cgrp.max_q = g_max_q;
-  const CrossGroups* cg = g_rescore_groups != 0 && !gq_off.empty() ? &cgrp : nullptr;
+  const CrossGroups* cg = tune().rescore_groups != 0 && !gq_off.empty() ? &cgrp : nullptr;
   // results, one block: tok_conf | conf | best_score | best_idx | all_scores
   const size_t o_tc = 0, o_cf = o_tc + (size_t)B * max_len * sizeof(double),
                o_bs = o_cf + (size_t)B * sizeof(double), o_bi = o_bs + (size_t)B * sizeof(float),
@@ -2102,7 +2083,7 @@ int wn_op_gemm_x6(const float* A, const float* W, const float* bias, const float
   WN_TRY(w3.ensure(x6_bytes(N, K)));
   WN_TRY(x6_split(W, N, K, K, w3.as<char>(), s));
   X6Args a;
-  if (g_x6_af32 != 0 && (int64_t)M * K * 4 < ((int64_t)1 << 31)) {
+  if (tune().x6_af32 != 0 && (int64_t)M * K * 4 < ((int64_t)1 << 31)) {
     a.A = A; a.lda = K; a.a_bytes = (int64_t)M * K * 4;      // split in registers
   } else {
     WN_TRY(a3.ensure(x6_bytes(M, K)));
@@ -2125,7 +2106,7 @@ int wn_op_ffn_x6(const float* X, const float* W1, const float* b1, const float* 
   WN_CHECK(M > 0 && (D == 256 || D == 512) && F > 0 && F % 64 == 0, "ffn_x6: shape");
   hipStream_t s = (hipStream_t)stream;
   static thread_local DevBuf x3, w13, w23, h3, part;
-  if (g_ffn_x6f != 0 && g_x6_af32 == 0 && ffn_x6f_supported(M, D, F, act)) {
+  if (tune().ffn_x6f != 0 && tune().x6_af32 == 0 && ffn_x6f_supported(M, D, F, act)) {
     // hidden tensor on chip (ffn_x6f.hip)
     FfnX6Args a;
     a.S = ffn_x6f_split(M, F);
@@ -2148,7 +2129,7 @@ int wn_op_ffn_x6(const float* X, const float* W1, const float* b1, const float* 
   WN_TRY(part.ensure((size_t)S * M * D * sizeof(float)));
   WN_TRY(x6_split(W1, F, D, D, w13.as<char>(), s));
   WN_TRY(x6_split(W2, D, F, F, w23.as<char>(), s));
-  const bool af32 = g_x6_af32 != 0 && (int64_t)M * F * 4 < ((int64_t)1 << 31);
+  const bool af32 = tune().x6_af32 != 0 && (int64_t)M * F * 4 < ((int64_t)1 << 31);
   static thread_local DevBuf hf;
   if (af32) WN_TRY(hf.ensure((size_t)M * F * sizeof(float)));
   for (int r = 0; r < (reps > 0 ? reps : 1); ++r) {

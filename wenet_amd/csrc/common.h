@@ -5,6 +5,8 @@
 
 #include <string>
 
+#include "tune.h"
+
 namespace wn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -123,21 +125,11 @@ int gemm_bf16_stored(const GemmArgs& a, const void* Wh, hipStream_t stream);
 bool gemm_bf16p_supported(const GemmArgs& a);
 int gemm_bf16_pipelined(const GemmArgs& a, const void* Wh, hipStream_t stream);
 int gemm_mxfp8(const GemmArgs& a, const void* Wq, hipStream_t stream);
-extern int g_lp_probe;                         // wn_tune_set("lp_probe")
 int gemm_lp_clocks(unsigned long long* out);   // [8 waves][8] stamps of the pipelined kernel
 // fp32 [rows][ld] -> e4m3 [rows][K] + block scales [K/128][pitch] dwords
 int mx_quantize(const float* x, int ld, int rows, int K, void* q, unsigned* scale, int pitch,
                 hipStream_t s);
 enum { PREC_FP8 = 2 };  // bf16 mode with MXFP8 FFN GEMMs (wn_model_set_precision)
 int convert_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t s);
-// 1 (default): in the bf16 mode the GEMM-only tensors (LayerNorm output, FFN
-// hidden, attention context) are stored as bf16; 0: every tensor stays fp32 and
-// the GEMMs convert on the fly (wn_tune_set("bf16_store"), A/B and tests)
-extern int g_bf16_store;
-
-// Tuning knobs (wn_tune_set): experiments / A-B runs only, defaults are the
-// shipped configuration.
-extern int g_gemm_tile_bf16;  // tests: 1 = the 128-row tiles of gemm_bf16{,s}.hip only, 8 = force the
-                              // pipelined 256 x 256 kernel (gemm_bf16p.hip); 0 = the shape rule
 
 }  // namespace wn

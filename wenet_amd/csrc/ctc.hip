@@ -1096,12 +1096,11 @@ __global__ __launch_bounds__(BIG_THREADS) void prefix_beam_big_kernel(PrefixBeam
 
 }  // namespace
 
-int g_ctc_wave = 1;   // wn_tune_set("ctc_wave"): 0 = always the block-per-row kernel (A/B, tests)
 
 int ctc_logsoftmax_topk(const CtcRowArgs& a, hipStream_t s) {
   WN_CHECK(a.M > 0 && a.V > 0, "ctc: empty");
   WN_CHECK(a.k >= 1 && a.k <= a.V, "ctc: top-k must be in [1, vocab]");
-  if (a.logp == nullptr && g_ctc_wave != 0 && a.V <= 96 * 64 && a.k <= 16) {
+  if (a.logp == nullptr && tune().ctc_wave != 0 && a.V <= 96 * 64 && a.k <= 16) {
     dim3 g(cdiv(a.M, 4)), t(256);
     if (a.V <= 8 * 64) hipLaunchKernelGGL(ctc_row_wave2_kernel<8>, g, t, 0, s, a);
     else if (a.V <= 72 * 64) hipLaunchKernelGGL(ctc_row_wave2_kernel<72>, g, t, 0, s, a);
@@ -1193,11 +1192,10 @@ int64_t prefix_beam_pool_ints(int max_len, int beam) {
   return 4 * ((int64_t)max_len * beam + 1);
 }
 
-int g_beam_weak_hash = 0;   // tests: 2-bit prefix hash (exercises the exact sequence test)
 
 int ctc_prefix_beam(const PrefixBeamArgs& a_in, hipStream_t s) {
   PrefixBeamArgs a = a_in;
-  a.weak_hash = g_beam_weak_hash;
+  a.weak_hash = tune().beam_weak_hash;
   WN_CHECK(a.B > 0, "prefix beam: empty batch");
   WN_CHECK(a.beam >= 1 && a.beam <= BIGB,
            "prefix beam: beam_size must be in [1, 64]");

@@ -921,10 +921,9 @@ int cmvn_conv1_relu(const Conv1Args& a, hipStream_t s) {
   return 0;
 }
 
-int g_dwconv_tiled = 1;   // wn_tune_set("dwconv_tiled"): 1 = four rows per wave (default; 0 = one row per wave, A/B and tests)
 
 int dwconv_ln_silu(const DwConvArgs& a, hipStream_t s) {
-  if (g_dwconv_tiled == 1 && (a.D == 256 || a.D == 512)) {
+  if (tune().dwconv_tiled == 1 && (a.D == 256 || a.D == 512)) {
     dim3 gt(cdiv(cdiv(a.M, 4), 4)), tt(256);
     if (a.D == 256) hipLaunchKernelGGL(dwconv_tiled_kernel<4>, gt, tt, 0, s, a);
     else hipLaunchKernelGGL(dwconv_tiled_kernel<8>, gt, tt, 0, s, a);
@@ -947,7 +946,6 @@ int dwconv_ln_silu(const DwConvArgs& a, hipStream_t s) {
   return 0;
 }
 
-int g_attn_fold = 1;   // wn_tune_set("attn_fold"): 0 = two contractions per score (A/B)
 
 int relpos_fold(float* K, int ldk, const float* P, int ldp, const float* bias_u,
                 const float* bias_v, const int* row_utt, const int* off, const int* p_off,
@@ -965,21 +963,19 @@ int relpos_fold(float* K, int ldk, const float* P, int ldp, const float* bias_u,
   return 0;
 }
 
-int g_attn_split = 0;  // wn_tune_set("attn_split")
-int g_attn_bf16 = 1;   // wn_tune_set("attn_bf16")
 
 int attention(const AttnArgs& a, hipStream_t s) {
   WN_CHECK(a.n_seq > 0 && a.n_heads > 0 && a.max_q_len > 0, "attention: empty");
   WN_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0,
            "attention: strides must be multiples of 4 floats");
   WN_CHECK(a.mask_mode != 2 || a.chunk_size > 0, "attention: chunk size");
-  if (t_gemm_prec == PREC_BF16 && g_attn_bf16 != 0) return attention_bf16(a, s);
+  if (t_gemm_prec == PREC_BF16 && tune().attn_bf16 != 0) return attention_bf16(a, s);
   constexpr int NW = 2;
   dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 64);
   // key split for the encoder's self attention over long sequences: twice the
-  // waves for the same tiles (g_attn_split: 0 auto, 1 off, 2 on)
-  const bool split = g_attn_split == 2 ||
-                     (g_attn_split == 0 && (a.P != nullptr || a.kbias != nullptr) &&
+  // waves for the same tiles (tune().attn_split: 0 auto, 1 off, 2 on)
+  const bool split = tune().attn_split == 2 ||
+                     (tune().attn_split == 0 && (a.P != nullptr || a.kbias != nullptr) &&
                       a.max_q_len >= 128);
   const bool fold = a.P != nullptr && a.fold && a.bias_u && a.bias_v;
   if (split) {

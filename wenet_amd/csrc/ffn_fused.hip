@@ -361,7 +361,6 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(
 
 }  // namespace
 
-int g_ffn_fused = 1;     // wn_tune_set("ffn_fused"): 0 = the two-GEMM path (A/B, tests)
 
 // hidden split: the largest S in {1, 2, 4, 8, 16} with tiles_m * S blocks filling the CUs
 // once (128-row blocks, one per CU), at least one
@@ -384,8 +383,8 @@ bool ffn_fused_supported(int M, int D, int F, int act) {
     return false;
   const int S = ffn_fused_split(M, D, F);
   if (S <= 0) return false;
-  // fewer blocks: the GEMM pair fills the chip better (g_ffn_fused == 2: tests force it)
-  return g_ffn_fused == 2 || cdiv(M, FBM) * S >= 128;
+  // fewer blocks: the GEMM pair fills the chip better (tune().ffn_fused == 2: tests force it)
+  return tune().ffn_fused == 2 || cdiv(M, FBM) * S >= 128;
 }
 
 template <int ND, int ACT>

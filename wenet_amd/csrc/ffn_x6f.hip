@@ -628,9 +628,6 @@ int launch_x6f(const FfnX6Args& a, hipStream_t s) {
 
 }  // namespace
 
-int g_ffn_x6f = 1;        // wn_tune_set("ffn_x6f"): 0 = the two six-product GEMMs (A/B, tests)
-int g_ffn_x6f_ring = 3;   // WN_ABLATION builds: 4..6 = the older stages of 24 records
-int g_ffn_x6f_var = 0;    // wn_tune_set("ffn_x6f_var"): 25088 = clock stamps; WN_ABLATION builds: the VAR variants
 
 int ffn_x6f_clocks(unsigned long long* out) {
   WN_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x6f_clk), sizeof(g_x6f_clk)));
@@ -662,7 +659,7 @@ bool ffn_x6f_supported(int M, int D, int F, int act) {
   if (F % (S * 64) != 0 || F / S > 2048) return false;
   if ((int64_t)cdiv(M, 32) * X3_TILE * XKB >= ((int64_t)1 << 40)) return false;
   // (fewer blocks than half the CUs: the GEMM pair fills the chip better; 2 = tests force it)
-  return g_ffn_x6f == 2 || cdiv(M, 128) * S >= 128;
+  return tune().ffn_x6f == 2 || cdiv(M, 128) * S >= 128;
 }
 
 int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
@@ -677,12 +674,12 @@ int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
   }
   // the default kernel with shader-clock stamps (same results; bench.py samples the clock the
   // kernel ran at through it, tools/ffn_clocks.py)
-  if (g_ffn_x6f_var == 25088 && a.act == ACT_SILU) return launch_x6f<ACT_SILU, 3, 25088>(a, s);
+  if (tune().ffn_x6f_var == 25088 && a.act == ACT_SILU) return launch_x6f<ACT_SILU, 3, 25088>(a, s);
 #ifdef WN_ABLATION
   // measurement builds only (python -m wenet_amd.build with WN_ABLATION=1): variants that leave
   // out a part of the kernel -- WRONG RESULTS BY DESIGN -- and the older stage shapes
-  if (g_ffn_x6f_var != 0 && a.act == ACT_SILU) {
-    switch (g_ffn_x6f_var) {
+  if (tune().ffn_x6f_var != 0 && a.act == ACT_SILU) {
+    switch (tune().ffn_x6f_var) {
       case 1: return launch_x6f<ACT_SILU, 6, 1>(a, s);
       case 2: return launch_x6f<ACT_SILU, 6, 2>(a, s);
       case 4: return launch_x6f<ACT_SILU, 6, 4>(a, s);
@@ -710,9 +707,9 @@ int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
       default: break;
     }
   }
-  if (g_ffn_x6f_ring == 4) { WN_X6F(4, 0) }
-  else if (g_ffn_x6f_ring == 5) { WN_X6F(5, 0) }
-  else if (g_ffn_x6f_ring >= 6) { WN_X6F(6, 0) }
+  if (tune().ffn_x6f_ring == 4) { WN_X6F(4, 0) }
+  else if (tune().ffn_x6f_ring == 5) { WN_X6F(5, 0) }
+  else if (tune().ffn_x6f_ring >= 6) { WN_X6F(6, 0) }
 #endif
   // three stages of 48 records
   WN_X6F(3, 16896)

@@ -254,7 +254,7 @@ int dispatch_tile(const GemmArgs& a, bool conv, hipStream_t stream) {
     return t128 >= 224 ? dispatch_epi<128, 128, 2, 4, true, BKT>(a, stream)
                        : dispatch_epi<64, 128, 2, 2, true, BKT>(a, stream);
   if constexpr (BKT == 64) {
-    if (g_gemm_tile_bf16 != 1 && t256 >= 256 && (t256 >= 1024 || a.K >= 2048))
+    if (tune().gemm_tile_bf16 != 1 && t256 >= 256 && (t256 >= 1024 || a.K >= 2048))
       return dispatch_epi<256, 256, 4, 2, false, 64>(a, stream);
   }
   return t128 >= 224 ? dispatch_epi<128, 128, 2, 4, false, BKT>(a, stream)
@@ -263,8 +263,6 @@ int dispatch_tile(const GemmArgs& a, bool conv, hipStream_t stream) {
 
 }  // namespace
 
-int g_gemm_tile_bf16 = 0;
-int g_bf16_store = 1;  // measured r01h: config 5 73.0 -> 58.5 ms, identical arithmetic
 thread_local const float* t_wslab_f32 = nullptr;
 thread_local const void* t_wslab_bf16 = nullptr;
 thread_local int64_t t_wslab_elems = 0;

@@ -590,7 +590,7 @@ int launch_p(const GemmArgs& a, const void* Wq, hipStream_t stream) {
 template <int ET>
 int dispatch_p(const GemmArgs& args, const void* W, hipStream_t stream) {
   GemmArgs a = args;
-  if (g_lp_probe) a.probe = g_lp_probe;
+  if (tune().lp_probe) a.probe = tune().lp_probe;
   const bool resid = a.resid != nullptr;
   if (a.c_mx) {
     if constexpr (ET == 1) {
@@ -660,7 +660,6 @@ __global__ __launch_bounds__(256) void mx_quantize_kernel(
 
 }  // namespace
 
-int g_lp_probe = 0;
 int gemm_lp_clocks(unsigned long long* out) {
   WN_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lp_clk), sizeof(g_lp_clk)));
   return 0;

@@ -220,7 +220,7 @@ int dispatch_tile(const GemmArgs& a, const __bf16* Wh, bool ch, hipStream_t stre
     return t128 >= 224 ? dispatch_epi<128, 128, 4, 2, BKT, true>(a, Wh, ch, stream)
                        : dispatch_epi<64, 128, 2, 2, BKT, true>(a, Wh, ch, stream);
   if constexpr (BKT == 64) {
-    if (g_gemm_tile_bf16 != 1 && t256 >= 256 && (t256 >= 1024 || a.K >= 2048))
+    if (tune().gemm_tile_bf16 != 1 && t256 >= 256 && (t256 >= 1024 || a.K >= 2048))
       return dispatch_epi<256, 256, 4, 2, 64>(a, Wh, ch, stream);
   }
   return t128 >= 224 ? dispatch_epi<128, 128, 2, 4, BKT>(a, Wh, ch, stream)
@@ -267,7 +267,7 @@ int gemm_bf16_stored(const GemmArgs& a, const void* Wh, hipStream_t stream) {
   // gemm_tile_bf16 = 8 forces it, any other forced tile keeps this file's kernels
   {
     const int64_t t256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
-    const bool want = g_gemm_tile_bf16 == 8 || (g_gemm_tile_bf16 == 0 && t256 >= 192);
+    const bool want = tune().gemm_tile_bf16 == 8 || (tune().gemm_tile_bf16 == 0 && t256 >= 192);
     if (want && gemm_bf16p_supported(a)) return gemm_bf16_pipelined(a, Wh, stream);
   }
   return a.K % 64 == 0 ? dispatch_tile<64>(a, W, a.c_bf16, stream)

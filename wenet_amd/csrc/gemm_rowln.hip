@@ -173,10 +173,9 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(RowLnArgs p) {
 
 }  // namespace
 
-int g_gemm_rowln = 1;   // wn_tune_set("gemm_rowln"): 0 = GEMM + LayerNorm launches (A/B)
 
 bool gemm_rowln_supported(int M, int N, int K) {
-  return g_gemm_rowln != 0 && N == RN && K % 32 == 0 && K >= 96 && M > 0 &&
+  return tune().gemm_rowln != 0 && N == RN && K % 32 == 0 && K >= 96 && M > 0 &&
          (int64_t)M * K * 4 < (int64_t(1) << 31);
 }
 

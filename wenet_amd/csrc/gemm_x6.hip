@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void x6_split_kernel(const float* __restrict__
 // channels-last tensor whose X3 image has one row per input pixel): GEMM row r reads pixel
 // a_pix[r] + tap_delta[tap] for the k blocks of tap = kb / conv_kbc -- the DMA addresses
 // are per lane instead of linear, the LDS side is unchanged.
-// AF32 (opt-in, g_x6_af32: measured slower than plane images, see below): the A operand is
+// AF32 (opt-in, tune().x6_af32: measured slower than plane images, see below): the A operand is
 // a plain row-major fp32 matrix (p.A, p.lda) -- or, with CONV, the
 // channels-last fp32 tensor itself -- and is split into its three planes IN REGISTERS after
 // the fragment read: no plane image of an activation ever exists (none is written by a
@@ -507,14 +507,10 @@ int launch_x6_act(const X6Args& a, hipStream_t s) {
 
 }  // namespace
 
-int g_gemm_x6 = 1;
-int g_x6_linear = 1;
 // 0 (default): activations reach the kernel as plane images; 1: as plain fp32 rows split in
 // registers.  Measured (r02ag): the split costs more than the plane bytes it saves -- FFN w_1
 // 53.8 -> 63.7 us, w_2 54.6 -> 60.7, conv2 921 -> 1055 (+ conv1 185 -> 125), 8192 x 4096 x
 // 4096 1124 -> 1312 us, decode step 7.28 -> 7.4-7.7 ms.
-int g_x6_af32 = 0;
-int g_x6_probe = 0;     // wn_tune_set("x6_probe"): 4 = clock stamps; WN_ABLATION builds: 1 no MFMAs, 2 no DMA
 
 namespace {
 // C[r][c] = relu(sum_s P[s][r][c] + bias[c]): the K-slice partials of conv2's last tiles
@@ -562,7 +558,7 @@ int gemm_x6_bm(int M, int N, int ksplit) {
 
 int gemm_x6(const X6Args& args, hipStream_t s) {
   X6Args a = args;
-  if (g_x6_probe) a.probe = g_x6_probe;      // ablation knob (tools/bench_x6.py --probe)
+  if (tune().x6_probe) a.probe = tune().x6_probe;      // ablation knob (tools/bench_x6.py --probe)
   const bool af32 = a.A != nullptr;
   WN_CHECK((a.A3 || af32) && a.B3 && a.M > 0 && a.N > 0 && a.K > 0 && a.K % 16 == 0,
            "gemm_x6: shape");

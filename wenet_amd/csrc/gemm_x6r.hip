@@ -535,10 +535,6 @@ int launch_x6r(const X6RArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int g_x6r = 1;       // wn_tune_set("x6r"): 0 = the v_mfma_f32 row-LN GEMM / tile GEMMs (A/B, tests)
-int g_x6r_chain = 1; // wn_tune_set("x6r_chain"): 0 = out-projection + LayerNorm and pointwise_conv1 + GLU as two launches
-int g_x6r_dwc = 1;   // wn_tune_set("x6r_dwc"): 0 = dwconv_ln_silu stays its own launch in front of pointwise_conv2 (A/B, tests)
-int g_x6r_pro = 1;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of the QKV projection (A/B, tests)
 
 bool gemm_x6r_supported(int M, int N, int K, int epi) {
   if (K == 512) return gemm_x6r512_supported(M, N, epi);

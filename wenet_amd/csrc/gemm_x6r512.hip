@@ -728,12 +728,11 @@ bool gemm_x6r512_supported(int M, int N, int epi) {
   return false;                                 // (GLU alone: the chain covers it)
 }
 
-int g_x6r512_rows = 0;   // wn_tune_set("x6r512_rows"): 0 auto, 32 / 64 force the block height (A/B, tests)
 
 // 64-row blocks once they cover at least three quarters of the 256 CUs (M >= 12288)
 static bool x6r512_wide(const X6RArgs& a) {
-  if (g_x6r512_rows == 64) return true;
-  if (g_x6r512_rows == 32) return false;
+  if (tune().x6r512_rows == 64) return true;
+  if (tune().x6r512_rows == 32) return false;
   return cdiv(a.M, WROWS) >= 192;
 }
 

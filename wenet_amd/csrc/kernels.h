@@ -16,7 +16,6 @@ int layernorm_mx(const float* x, int ldx, const float* w, const float* b, void* 
 
 // y1 = LN(x; w1,b1), y2 = LN(y1; w2,b2) in one pass over contiguous [M][D] rows
 // (y1 may alias x).
-extern int g_attn_split;
 int layernorm2(const float* x, const float* w1, const float* b1, const float* w2,
                const float* b2, float* y1, float* y2, int M, int D, float eps,
                hipStream_t s, bool y2_bf16 = false);
@@ -85,17 +84,12 @@ struct AttnArgs {
   float scale = 0.125f;
 };
 int attention(const AttnArgs& a, hipStream_t s);
-extern int g_attn_fold;
 int relpos_fold(float* K, int ldk, const float* P, int ldp, const float* bias_u,
                 const float* bias_v, const int* row_utt, const int* off, const int* p_off,
                 float* kbias, int n_heads, int M, int D, hipStream_t s);
 // The same with bf16 MFMA operands (attention_bf16.hip); attention() routes here
-// when the calling thread's precision is PREC_BF16 (and g_attn_bf16 != 0).
+// when the calling thread's precision is PREC_BF16 (and tune().attn_bf16 != 0).
 int attention_bf16(const AttnArgs& a, hipStream_t s);
-extern int g_attn_bf16;      // 1 (default): bf16 mode uses the bf16 attention kernel
-extern int g_attn_bf16_nw;   // 0 auto, else waves (32-query groups) per block
-extern int g_attn_bf16_defer;  // wn_tune_set("attn_bf16_defer"): threshold x 10 of the deferred rescale (0 = off)
-extern int g_attn_bf16_dma;  // 0 = register-staged kernel only (A/B, tests), else the LDS-DMA staged kernel where it applies
 
 // Fused feed-forward module, fp32 (ffn_fused.hip): P[s] (S, M, D) = partial
 // act(X W1^T + b1) W2^T over hidden slice s; ffn_reduce_ln then forms
@@ -108,9 +102,6 @@ struct FfnArgs {
   float* P;           // [S][M][D]
   int M, D, F, S, act;
 };
-extern int g_ffn_fused;
-extern int g_beam_weak_hash;   // wn_tune_set("beam_weak_hash")
-extern int g_ctc_wave;    // wn_tune_set("ctc_wave")
 int ffn_fused_split(int M, int D, int F);
 bool ffn_fused_supported(int M, int D, int F, int act);
 int ffn_fused(const FfnArgs& a, hipStream_t s);
@@ -147,16 +138,12 @@ struct X6Args {
   int a_tiles = 0, conv_kbc = 0;
   int conv_taps = 0;          // > 0: K order (channel block, tap) instead of (tap, channel block)
   int tap_delta[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  int probe = 0;              // ablation bits (g_x6_probe)
+  int probe = 0;              // ablation bits (tune().x6_probe)
   // gathered A (conv2): scratch for the K-slice partials of the last, partial round of tiles
   // (part_bytes >= slices x rows x N x 4); null: the remainder runs as 128-row tiles
   float* part = nullptr; size_t part_bytes = 0;
 };
-extern int g_x6_probe;
 int gemm_x6_clocks(unsigned long long* out);   // probe & 4 stamps [8 waves][8]
-extern int g_x6_linear;    // wn_tune_set("x6_linear"): 0 = linear() never routes to the six-product GEMM
-extern int g_x6_af32;      // wn_tune_set("x6_af32"): 0 plane images (default), 1 fp32 A rows split in registers
-extern int g_gemm_x6;     // wn_tune_set("gemm_x6"): 0 = the v_mfma_f32 kernels (A/B, tests)
 size_t x6_bytes(int R, int K);
 int x6_split(const float* src, int R, int K, int ld, void* dst, hipStream_t s);
 int gemm_x6_bm(int M, int N, int ksplit);
@@ -171,9 +158,6 @@ struct FfnX6Args {
   float* P = nullptr;          // [S][M][256] hidden-slice partials
   int M = 0, D = 0, F = 0, S = 0, act = 0;
 };
-extern int g_ffn_x6f;        // wn_tune_set("ffn_x6f"): 0 = two six-product GEMMs, 2 = force (tests)
-extern int g_ffn_x6f_var;    // wn_tune_set("ffn_x6f_var"): measurement variants (ffn_x6f.hip VAR)
-extern int g_ffn_x6f_ring;   // wn_tune_set("ffn_x6f_ring"): DMA ring depth 4..6
 int ffn_x6f_clocks(unsigned long long* out);   // VAR & 8192 stamps [4 waves][24]
 int x6_split_perm(const float* src, int R, int K, int ld, void* dst, hipStream_t s);
 int ffn_x6f_split(int M, int F);
@@ -223,17 +207,10 @@ struct X6RArgs {
   int dw_on = 0;
   DwConvArgs dw;
 };
-extern int g_dwconv_tiled; // wn_tune_set("dwconv_tiled"): 1 = depthwise convolution with four rows per wave
-extern int g_x6r_dwc;   // wn_tune_set("x6r_dwc")
-extern int g_x6r_pro;   // wn_tune_set("x6r_pro"): 0 = ffn_reduce_ln stays its own launch in front of QKV
-extern int g_x6r;     // wn_tune_set("x6r")
-extern int g_x6r_chain;   // wn_tune_set("x6r_chain")
 bool gemm_x6r_supported(int M, int N, int K, int epi);
 int gemm_x6r(const X6RArgs& a, hipStream_t s);          // dispatches on a.K
 bool gemm_x6r512_supported(int M, int N, int epi);
 int gemm_x6r512(const X6RArgs& a, hipStream_t s);
-extern int g_x6r512_rows;   // wn_tune_set("x6r512_rows")
-extern int g_gemm_rowln;
 bool gemm_rowln_supported(int M, int N, int K);
 int gemm_rowln(const RowLnArgs& a, hipStream_t s);
 

@@ -17,19 +17,60 @@ thread_local const std::map<const float*, wn_model::MxW>* t_mx = nullptr;
 // routes the large fp32 GEMMs to the six-product kernel through them (gemm_x6.hip)
 thread_local const std::map<const float*, const void*>* t_x6 = nullptr;
 thread_local DevBuf* t_x6_a = nullptr;
-// fp8 mode: smallest number of 256 x 256 tiles of an FFN GEMM pair for which the MXFP8
-// kernels are used (below it the bf16 kernels fill the chip better); tests set 0
-int g_fp8_min_tiles = 192;
-// bf16-storage form, encoders without the rel-pos term: the QKV GEMM writes bf16 and the
-// attention kernel reads it (1, default); 0 keeps fp32 Q / K / V (A/B, tests)
-int g_qkv_bf16 = 1;
+
+// ---- tuning knobs (tune.h) --------------------------------------------------------------------
+namespace wn {
+Tune g_tune_default;
+thread_local const Tune* t_tune = nullptr;
+
+int* tune_field(Tune& t, const std::string& key) {
+#define X(name, dflt) if (key == #name) return &t.name;
+  WN_TUNE_KEYS(X)
+#undef X
+  return nullptr;
+}
+
+int tune_check(const std::string& key, int32_t value, const char* who) {
+  if (value == TUNE_INHERIT) return 0;
+#ifndef WN_ABLATION
+  if (key == "x6_probe" && (value & ~4) != 0) {
+    set_error(std::string(who) + ": x6_probe 1 / 2 (no MFMAs / no DMA) need a WN_ABLATION build");
+    return -1;
+  }
+  if (key == "ffn_x6f_var" && value != 0 && value != 25088) {
+    set_error(std::string(who) + ": ffn_x6f_var variants other than the clock-stamp form "
+              "(25088) need a WN_ABLATION build");
+    return -1;
+  }
+  if (key == "ffn_x6f_ring" && value != 3) {
+    set_error(std::string(who) + ": ffn_x6f_ring needs a WN_ABLATION build");
+    return -1;
+  }
+#endif
+  return 0;
+}
+
+void tune_resolve(const Tune& ovr, Tune* eff) {
+#define X(name, dflt) eff->name = ovr.name != TUNE_INHERIT ? ovr.name : g_tune_default.name;
+  WN_TUNE_KEYS(X)
+#undef X
+}
+
+Tune tune_all_inherit() {
+  Tune t;
+#define X(name, dflt) t.name = TUNE_INHERIT;
+  WN_TUNE_KEYS(X)
+#undef X
+  return t;
+}
+}  // namespace wn
 
 
 // bf16-storage form of the bf16 mode: LayerNorm output, FFN hidden and attention
 // context are written as bf16 (their only consumers are GEMMs that round them to
 // bf16 first thing), the GEMMs read the bf16 image of the weight slab.
 bool bf16_store_active() {
-  return t_gemm_prec == PREC_BF16 && g_bf16_store != 0 && g_attn_bf16 != 0 &&
+  return t_gemm_prec == PREC_BF16 && tune().bf16_store != 0 && tune().attn_bf16 != 0 &&
          t_wslab_bf16 != nullptr;
 }
 
@@ -50,7 +91,7 @@ int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M,
   // Large fp32 GEMMs (the d = 512 encoders' projections, the decoders' GEMMs over B x N x L
   // rows): split A into planes (one pass, 4 B in / 6 B out) and run the six-product kernel
   // -- worth it from ~6 GFLOP on, where the split is a few per cent of the GEMM it halves.
-  if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_linear != 0 && t_x6 && t_x6_a && !glu &&
+  if (t_gemm_prec == PREC_F32 && tune().gemm_x6 != 0 && tune().x6_linear != 0 && t_x6 && t_x6_a && !glu &&
       !a_bf16 && !c_bf16 && l.in % 16 == 0 && l.out % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 &&
       (resid == nullptr || ldr % 4 == 0) && M >= 512 &&
       2.0 * M * (double)l.out * l.in >= 1e8 * g_x6_linear_min) {
@@ -132,7 +173,7 @@ int ffn_module(wn_model* m, const Norm& nrm, const Linear& w1, const Linear& w2,
     p1.fp8 = p2.fp8 = true; p1.c_mx = true;
     p2.N = d; p2.K = w1.out; p2.lda = w1.out; p2.ldc = d; p2.resid = x; p2.ldr = d;
     if (i1 != t_mx->end() && i2 != t_mx->end() && d % 256 == 0 && w1.out % 128 == 0 &&
-        t256 >= g_fp8_min_tiles && gemm_bf16p_supported(p1) && gemm_bf16p_supported(p2)) {
+        t256 >= tune().fp8_min_tiles && gemm_bf16p_supported(p1) && gemm_bf16p_supported(p2)) {
       mx = true; q1 = &i1->second; q2 = &i2->second;
     }
   }
@@ -273,7 +314,7 @@ int vocab_linear(wn_model* m, const Linear& l, const float* A, int lda, float* C
   const int V = l.out, V4 = (V + 3) / 4 * 4;
   const void* w6 = nullptr;
   const float* bias = l.b;
-  if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && g_x6_linear != 0 && m->x6_at &&
+  if (t_gemm_prec == PREC_F32 && tune().gemm_x6 != 0 && tune().x6_linear != 0 && m->x6_at &&
       l.in % 16 == 0 && lda % 4 == 0 && M >= 512) {
     auto it = m->x6_at->find(l.w);
     if (it != m->x6_at->end()) w6 = it->second;
@@ -309,13 +350,13 @@ int ffn_x6_split(int M, int F) {
 int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStream_t s) {
   const int d = m->cfg.d_model, M = m->rows, F = w1.out;
   // (d: the widths ffn_reduce_ln takes)
-  if (t_gemm_prec != PREC_F32 || g_gemm_x6 == 0 || !m->x6_at || w1.out != w2.in ||
-      !(d == 256 || d == 512) || F % 16 != 0 || (M < 512 && g_gemm_x6 != 2))
+  if (t_gemm_prec != PREC_F32 || tune().gemm_x6 == 0 || !m->x6_at || w1.out != w2.in ||
+      !(d == 256 || d == 512) || F % 16 != 0 || (M < 512 && tune().gemm_x6 != 2))
     return 0;
   auto i1 = m->x6_at->find(w1.w), i2 = m->x6_at->find(w2.w);
   if (i1 == m->x6_at->end() || i2 == m->x6_at->end()) return 0;
   static thread_local int tick = 0;
-  if (g_ffn_x6f != 0 && g_x6_af32 == 0 && m->x6p_at && ffn_x6f_supported(M, d, F, act)) {
+  if (tune().ffn_x6f != 0 && tune().x6_af32 == 0 && m->x6p_at && ffn_x6f_supported(M, d, F, act)) {
     // hidden tensor on chip (ffn_x6f.hip)
     auto ip = m->x6p_at->find(w2.w);
     if (ip != m->x6p_at->end()) {
@@ -347,9 +388,9 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
   }
   const int S = ffn_x6_split(M, F);
   if (m->ffn_part.ensure((size_t)S * M * d * sizeof(float)) != 0) return -1;
-  // plane images (x6_split of t1, w_1 writes the hidden planes); g_x6_af32 (A/B knob): the A
+  // plane images (x6_split of t1, w_1 writes the hidden planes); tune().x6_af32 (A/B knob): the A
   // operands stay plain fp32 (t1, the hidden tensor in hbuf) and are split in registers
-  const bool af32 = g_x6_af32 != 0 && (int64_t)M * F * 4 < ((int64_t)1 << 31);
+  const bool af32 = tune().x6_af32 != 0 && (int64_t)M * F * 4 < ((int64_t)1 << 31);
   X6Args g1;
   g1.B3 = i1->second; g1.M = M; g1.N = F; g1.K = d; g1.bias = w1.b; g1.act = act;
   if (af32) {
@@ -397,7 +438,7 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
 int ffn_x6_pair(wn_model* m, const Linear& w1, const Linear& w2, int act, const float* A, int M,
                 hipStream_t s) {
   const int d = w1.in, F = w1.out;
-  if (t_gemm_prec != PREC_F32 || g_gemm_x6 == 0 || g_x6_linear == 0 || !m->x6_at ||
+  if (t_gemm_prec != PREC_F32 || tune().gemm_x6 == 0 || tune().x6_linear == 0 || !m->x6_at ||
       w1.out != w2.in || w2.out != d || !(d == 256 || d == 512) || F % 16 != 0 || M < 512 ||
       2.0 * M * (double)F * d < 1e8 * g_x6_linear_min)
     return 0;
@@ -426,7 +467,7 @@ int ffn_fused_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipS
   const wn_config& c = m->cfg;
   const int d = c.d_model, M = m->rows;
   if (const int s6 = ffn_x6_try(m, w1, w2, act, s)) return s6;
-  if (t_gemm_prec != PREC_F32 || g_ffn_fused == 0 || w1.out != w2.in ||
+  if (t_gemm_prec != PREC_F32 || tune().ffn_fused == 0 || w1.out != w2.in ||
       !ffn_fused_supported(M, d, w1.out, act))
     return 0;
   FfnArgs a;
@@ -486,7 +527,7 @@ int set_layout(wn_model* m, int B, int Tp, const std::vector<int>& off,
 int sub_out_linear(wn_model* m, int M, int F2, hipStream_t s) {
   const wn_config& c = m->cfg;
   const int d = c.d_model, K = F2 * d;
-  if (t_gemm_prec != PREC_F32 || g_gemm_x6 == 0 || !m->x6_at || m->layers.empty() ||
+  if (t_gemm_prec != PREC_F32 || tune().gemm_x6 == 0 || !m->x6_at || m->layers.empty() ||
       (d != 256 && d != 512) || K % 16 != 0 || M < 512 || (int64_t)M * K * 4 >= ((int64_t)1 << 31) ||
       bf16_store_active())
     return 0;
@@ -554,13 +595,13 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
     // fp32 on the bf16 matrix cores (gemm_x6.hip): conv1 writes the plane image of its
     // output, conv2 gathers its rows from it
     const void* w6 = nullptr;
-    if (t_gemm_prec == PREC_F32 && g_gemm_x6 != 0 && m->x6_at && d % 32 == 0 &&
+    if (t_gemm_prec == PREC_F32 && tune().gemm_x6 != 0 && m->x6_at && d % 32 == 0 &&
         F1 <= 64 &&
-        (M * F2 >= 4096 || g_gemm_x6 == 2)) {
+        (M * F2 >= 4096 || tune().gemm_x6 == 2)) {
       auto it = m->x6_at->find(m->conv2.w);
       if (it != m->x6_at->end()) w6 = it->second;
     }
-    if (w6 && g_x6_af32 != 0 && (int64_t)M1 * F1 * d * 4 < ((int64_t)1 << 31)) {
+    if (w6 && tune().x6_af32 != 0 && (int64_t)M1 * F1 * d * 4 < ((int64_t)1 << 31)) {
       // conv1 as always (fp32, channels last); conv2 gathers its A rows from it, 64 B per
       // pixel and k block, and splits them in registers
       WN_TRY(m->c1.ensure((size_t)M1 * F1 * d * sizeof(float)));
@@ -697,12 +738,12 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     // the QKV projection on the row-block kernel: it can form LN(x + 0.5 FFN) itself from the
     // slice partials (gemm_x6r.hip / gemm_x6r512.hip, PRO) -- no ffn_reduce_ln launch, no t1 round trip
     const void* qkv_w6 = nullptr;
-    if (!h16 && t_gemm_prec == PREC_F32 && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+    if (!h16 && t_gemm_prec == PREC_F32 && tune().x6r != 0 && tune().gemm_x6 != 0 && t_x6 && M >= 512 &&
         gemm_x6r_supported(M, 3 * d, L.qkv.in, 0)) {
       auto it = t_x6->find(L.qkv.w);
       if (it != t_x6->end()) qkv_w6 = it->second;
     }
-    const bool pro = fS > 0 && qkv_w6 && g_x6r_pro != 0 && d == 256;   // (d = 512: measured slower)
+    const bool pro = fS > 0 && qkv_w6 && tune().x6r_pro != 0 && d == 256;   // (d = 512: measured slower)
     if (fS > 0) {
       if (!pro)
         WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ffm2.b, 0.5f, L.norm_mha.w,
@@ -735,7 +776,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     a.Q = qkv; a.K = qkv + d; a.V = qkv + 2 * d;
     a.ldq = a.ldk = a.ldv = 3 * d;
     a.P = L.pos_tab; a.ldp = d; a.bias_u = L.bias_u; a.bias_v = L.bias_v;
-    if (!h16 && t_gemm_prec == PREC_F32 && g_attn_fold == 2 && (d == 256 || d == 512) &&
+    if (!h16 && t_gemm_prec == PREC_F32 && tune().attn_fold == 2 && (d == 256 || d == 512) &&
         d == c.n_heads * 64) {
       // A/B form: the folding as a separate pass (k <- k + p in place, scalars in HBM)
       WN_TRY(m->attn_kbias.ensure((size_t)M * c.n_heads * sizeof(float)));
@@ -744,7 +785,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
                          m->attn_kbias.as<float>(), c.n_heads, M, d, s));
       a.kbias = m->attn_kbias.as<float>();
       a.P = nullptr; a.bias_u = a.bias_v = nullptr;
-    } else if (!h16 && t_gemm_prec == PREC_F32 && g_attn_fold != 0) {
+    } else if (!h16 && t_gemm_prec == PREC_F32 && tune().attn_fold != 0) {
       // rel-pos folded into the keys as the attention kernel stages them: ONE score
       // contraction (encoder_kernels.hip, attention_kernel FOLD / relpos_fold_kernel)
       a.fold = true;
@@ -764,7 +805,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     const bool rowx = rowln || (!h16 && t_gemm_prec == PREC_F32 && d == 512);
     auto x6r_rowln = [&](const Linear& l, const float* A, const Norm& nrm,
                          const DwConvArgs* dwc = nullptr) -> int {
-      if (!(rowx && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+      if (!(rowx && tune().x6r != 0 && tune().gemm_x6 != 0 && t_x6 && M >= 512 &&
             gemm_x6r_supported(M, d, l.in, 1)))
         return 1;
       auto it = t_x6->find(l.w);
@@ -780,7 +821,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     // (gemm_x6r.hip epi 3): LN_conv(x) never reaches HBM
     bool pw1_done = false;
     int xr = 1;
-    if (rowx && g_x6r >= 1 && g_x6r_chain != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+    if (rowx && tune().x6r >= 1 && tune().x6r_chain != 0 && tune().gemm_x6 != 0 && t_x6 && M >= 512 &&
         gemm_x6r_supported(M, d, L.out.in, 3) &&
         (d == 512 || gemm_x6r_supported(M, 2 * d, L.pw1.in, 2))) {
       auto io = t_x6->find(L.out.w), ip = t_x6->find(L.pw1.w);
@@ -809,7 +850,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       WN_TRY(ln(L.norm_conv, x, t1, M, d, eps, s, h16));
     }
     // pointwise_conv1 + GLU                        convolution.py:115-118
-    if (!pw1_done && rowx && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 && M >= 512 &&
+    if (!pw1_done && rowx && tune().x6r != 0 && tune().gemm_x6 != 0 && t_x6 && M >= 512 &&
         gemm_x6r_supported(M, 2 * d, L.pw1.in, 2)) {
       auto it = t_x6->find(L.pw1.w);
       if (it != t_x6->end()) {
@@ -833,7 +874,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     // x += pointwise_conv2(.); t1 = LN_ff(x)        encoder_layer.py:251-255
     // d = 256 on the row-block kernel: the depthwise conv + norm + SiLU is its prologue
     // (gemm_x6r.hip DWC) -- no launch, no round trip of the conv module's middle tensor
-    const bool dwc = g_x6r_dwc != 0 && d == 256 && rowx && g_x6r != 0 && g_gemm_x6 != 0 && t_x6 &&
+    const bool dwc = tune().x6r_dwc != 0 && d == 256 && rowx && tune().x6r != 0 && tune().gemm_x6 != 0 && t_x6 &&
                      M >= 512 && t_x6->count(L.pw2.w) != 0 && gemm_x6r_supported(M, d, L.pw2.in, 1);
     if (!dwc) WN_TRY(dwconv_ln_silu(dw, s));
     xr = x6r_rowln(L.pw2, t1, L.norm_ff, dwc ? &dw : nullptr);
@@ -1023,7 +1064,7 @@ int transformer_layers(wn_model* m, hipStream_t s) {
     WN_TRY(ln(L.n1, x, t1, M, d, eps, s, h16));
     // bf16-storage form: Q | K | V leave the GEMM as bf16 (the attention kernel rounds
     // them to bf16 first thing anyway): half the GEMM's store and the attention's stream
-    const bool q16 = h16 && g_qkv_bf16 != 0;
+    const bool q16 = h16 && tune().qkv_bf16 != 0;
     WN_TRY(linear(L.qkv, t1, d, qkv, 3 * d, M, s, ACT_NONE, nullptr, 0, 1.0f, false,
                   h16, q16));
     AttnArgs a;

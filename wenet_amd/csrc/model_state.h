@@ -407,6 +407,10 @@ struct wn_model {
   // loudly (status -4) instead of corrupting the staging buffer when a second
   // thread enters the same handle (use wn_model_clone for a second thread).
   std::atomic<bool> busy{false};
+  // tuning knobs (tune.h): this handle's overrides (wn_model_tune_set; TUNE_INHERIT = follow
+  // the process default) and the effective set WN_ENTER resolves for the call in flight
+  Tune tune_ovr = tune_all_inherit();
+  Tune tune_eff;
   int dbg_layers = -1;       // run only the first n encoder layers
   int dbg_skip_after_norm = 0;
   // fbank tables
@@ -423,16 +427,27 @@ struct wn_model {
 };
 
 
-// Makes the handle's GEMM operand precision current for the calling thread for
-// the duration of one C-ABI call (every GEMM launch reads t_gemm_prec).
+// One host thread per handle at a time; for the duration of the C-ABI call the handle's
+// effective tuning set (tune.h: its overrides over the process defaults) is the calling
+// thread's tune().
 struct HandleGuard {
   wn_model* m;
   bool ok;
-  explicit HandleGuard(wn_model* m_) : m(m_), ok(false) {
+  const Tune* saved_tune;
+  explicit HandleGuard(wn_model* m_) : m(m_), ok(false), saved_tune(t_tune) {
     bool expected = false;
     ok = m->busy.compare_exchange_strong(expected, true, std::memory_order_acquire);
+    if (ok) {
+      tune_resolve(m->tune_ovr, &m->tune_eff);
+      t_tune = &m->tune_eff;
+    }
   }
-  ~HandleGuard() { if (ok) m->busy.store(false, std::memory_order_release); }
+  ~HandleGuard() {
+    if (ok) {
+      t_tune = saved_tune;
+      m->busy.store(false, std::memory_order_release);
+    }
+  }
 };
 #define WN_ENTER(m)                                                              \
   HandleGuard handle_guard(m);                                                   \
@@ -447,12 +462,6 @@ extern thread_local const std::map<const float*, wn_model::MxW>* t_mx;
 // routes the large fp32 GEMMs to the six-product kernel through them (gemm_x6.hip)
 extern thread_local const std::map<const float*, const void*>* t_x6;
 extern thread_local DevBuf* t_x6_a;
-// fp8 mode: smallest number of 256 x 256 tiles of an FFN GEMM pair for which the MXFP8
-// kernels are used (below it the bf16 kernels fill the chip better); tests set 0
-extern int g_fp8_min_tiles;
-// bf16-storage form, encoders without the rel-pos term: the QKV GEMM writes bf16 and the
-// attention kernel reads it (1, default); 0 keeps fp32 Q / K / V (A/B, tests)
-extern int g_qkv_bf16;
 
 struct PrecisionScope {
   int saved;

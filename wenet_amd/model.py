@@ -313,6 +313,17 @@ class ASRModel:
                    'wn_model_set_precision')
         return self
 
+    def tune(self, key: str, value=None) -> int:
+        """This handle's tuning knob `key` (csrc/tune.h): with `value`, override it for this
+        handle only (wn_model_tune_set; 'inherit' drops the override); returns the effective
+        value.  Process-wide defaults: wn_tune_set.  No counterpart in the reference."""
+        if value is not None:
+            v = -2 ** 31 if value == 'inherit' else int(value)
+            _lib.check(self._L.wn_model_tune_set(self._h, key.encode(), v), 'wn_model_tune_set')
+        out = ctypes.c_int32(0)
+        _lib.check(self._L.wn_tune_get(self._h, key.encode(), ctypes.byref(out)), 'wn_tune_get')
+        return out.value
+
     @property
     def compute_dtype(self) -> str:
         return {1: 'bf16', 2: 'fp8'}.get(self._L.wn_model_get_precision(self._h), 'fp32')
