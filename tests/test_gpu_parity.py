@@ -260,13 +260,15 @@ def test_prefix_beam_small_vocab_stress(V, T, beam):
 @pytest.mark.parametrize('V,T,beam,ctx', [(4, 50, 3, False), (7, 60, 6, True), (6, 120, 5, False),
                                           (8, 33, 8, True), (300, 40, 32, False),
                                           (20, 60, 20, True)])
-def test_prefix_identity_is_exact_behind_a_2_bit_hash(V, T, beam, ctx):
+@pytest.mark.parametrize('lds_pool', [1, 0])
+def test_prefix_identity_is_exact_behind_a_2_bit_hash(V, T, beam, ctx, lds_pool):
     """Prefix identity = token sequence, exactly: with wn_tune_set("beam_weak_hash", 1) the
     64-bit prefix hash is replaced by a 2-bit one, so nearly every pair of prefixes passes the
     hash filter and the search is right only if the exact test behind it -- same node, else
     the token-by-token walk through the node pool -- is.  Both kernels (beam <= 16 and the
     general one), with and without a context graph: n-best lists, order, time stamps and
-    fp64 scores identical to the oracle's."""
+    fp64 scores identical to the oracle's.  lds_pool: the node pool in LDS (default where it
+    fits) or in global scratch (what utterances past ~32 s get, wn_tune_set("beam_lds_pool", 0))."""
     from wenet_amd import _lib, search as S, synthetic
     from wenet_amd.context_graph import ContextGraph
     O = _oracle()
@@ -281,9 +283,11 @@ def test_prefix_identity_is_exact_behind_a_2_bit_hash(V, T, beam, ctx):
     L = _lib.lib()
     try:
         _lib.check(L.wn_tune_set(b'beam_weak_hash', 1), 'tune')
+        _lib.check(L.wn_tune_set(b'beam_lds_pool', lds_pool), 'tune')
         got = S.ctc_prefix_beam_search(logp.cuda(), lens, beam, gg, 0)
     finally:
         L.wn_tune_set(b'beam_weak_hash', 0)
+        L.wn_tune_set(b'beam_lds_pool', 1)
     for b in range(32):
         _same_nbest(got[b], ref[b].nbest, ref[b].nbest_scores, ref[b].nbest_times, f'utt {b}')
 

@@ -271,6 +271,19 @@ __device__ __noinline__ bool same_prefix_nodes(const int* n_parent, const int* n
   return true;
 }
 
+// The same walk with the node pool in LDS (prefix_beam_kernel<.., LPOOL = true>): plain reads,
+// ordered by the frame loop's barriers; inlined so that the accesses stay ds_read.
+__device__ __forceinline__ bool same_prefix_nodes_lds(const int* n_parent, const int* n_token,
+                                                      int x, int y) {
+  while (x != y) {
+    if (x <= 0 || y <= 0) return false;
+    if (n_token[x] != n_token[y]) return false;
+    x = n_parent[x];
+    y = n_parent[y];
+  }
+  return true;
+}
+
 // Latency design (the search is T' dependent steps per utterance; nothing
 // here is bandwidth- or FLOP-bound):
 //  * one workgroup per utterance with one THREAD per entry (beam + beam^2 <=
@@ -416,13 +429,20 @@ constexpr int PB_CHUNK = 32;  // frames of top-k staged per LDS buffer
 constexpr int PB_THREADS = 512;
 constexpr int PB_WAVES = PB_THREADS / 64;
 constexpr int PB_CHUNKS = (MAXE + 63) / 64;  // 5: beam up to 16
+constexpr size_t PB_LPOOL_BYTES = 128 * 1024;   // dynamic LDS the node pool may take (static: ~16 KB)
 
 // NCH = 64-entry chunks the rank pass scans: compile-time so that the pass has
 // no per-chunk branches (2 covers beam <= 10, the default of every recipe).
 // CTX: context biasing compiled in (a.cg set); the plain search keeps its own
 // instantiation so that its frame loop carries none of this.
-template <int NCH, bool CTX>
+// LPOOL: the utterance's node pool (4 x (max_len * beam + 1) ints) lives in dynamic LDS instead
+// of the global scratch: the pool stores of the frame loop, the rare sequence walks and above all
+// the n-best emission (one DEPENDENT load per token and hypothesis: 113 us of the 1.17 ms search
+// at config 2 through L2, r06x) run at LDS latency.  The launcher takes it whenever the pool fits
+// (PB_LPOOL_BYTES), i.e. up to ~32 s of audio at beam 10.
+template <int NCH, bool CTX, bool LPOOL>
 __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int lds_pool[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63;
   // wave-uniform values must be PROVABLY uniform (SGPRs) or every loop on
@@ -441,11 +461,15 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
   __shared__ float lp[2][PB_CHUNK][MAXB];
 
   const int cap = a.max_len * beam + 1;
-  int* pool = a.pool + (int64_t)b * a.pool_stride;
+  int* pool = LPOOL ? lds_pool : a.pool + (int64_t)b * a.pool_stride;
   int* n_parent = pool;            // prefix nodes
   int* n_token = pool + cap;
   int* t_prev = pool + 2 * cap;    // time nodes
   int* t_val = pool + 3 * cap;
+  auto same_nodes = [&](int x, int y) __attribute__((always_inline)) {
+    if constexpr (LPOOL) return same_prefix_nodes_lds(n_parent, n_token, x, y);
+    else return same_prefix_nodes(n_parent, n_token, x, y);
+  };
 
   if (tid == 0) {
     n_parent[0] = -1; n_token[0] = -1;
@@ -538,7 +562,7 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
         for (unsigned mk = rp_hits; mk; mk &= mk - 1) {
           const int j = __ffs(mk) - 1;
           const int nj = H.node[j];
-          if (nj == Kpar || same_prefix_nodes(n_parent, n_token, nj, Kpar)) rp = j;
+          if (nj == Kpar || same_nodes(nj, Kpar)) rp = j;
         }
       }
       if (qb >= 0 || ql >= 0) {
@@ -621,7 +645,7 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
           const int j = __ffs(mk) - 1;
           const int pj = H.par[j];
           merged |= H.last[j] == u &&
-                    (pj == Pn || same_prefix_nodes(n_parent, n_token, pj, Pn));
+                    (pj == Pn || same_nodes(pj, Pn));
         }
       }
       if (u != a.blank && !merged) {
@@ -1193,6 +1217,21 @@ int64_t prefix_beam_pool_ints(int max_len, int beam) {
 }
 
 
+template <int NCH, bool CTX, bool LPOOL>
+static int launch_pb(const PrefixBeamArgs& a, size_t pool_bytes, hipStream_t s) {
+  auto kern = prefix_beam_kernel<NCH, CTX, LPOOL>;
+  if (LPOOL) {
+    static bool done = false;
+    if (!done) {
+      WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)PB_LPOOL_BYTES));
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(PB_THREADS), pool_bytes, s, a);
+  return 0;
+}
+
 int ctc_prefix_beam(const PrefixBeamArgs& a_in, hipStream_t s) {
   PrefixBeamArgs a = a_in;
   a.weak_hash = tune().beam_weak_hash;
@@ -1211,17 +1250,17 @@ int ctc_prefix_beam(const PrefixBeamArgs& a_in, hipStream_t s) {
   static_assert(64 + MAXB * MAXB <= PB_THREADS, "one thread per entry");
   static_assert(PB_CHUNK * MAXB <= PB_THREADS, "one thread per staged top-k pair");
   const bool small = MAXB + a.beam * a.beam <= 128;
+  const size_t pool_bytes = (size_t)prefix_beam_pool_ints(a.max_len, a.beam) * sizeof(int);
+  const bool lpool = pool_bytes <= PB_LPOOL_BYTES && tune().beam_lds_pool != 0;
+  int rc;
   if (a.cg.keys == nullptr) {
-    if (small)
-      hipLaunchKernelGGL((prefix_beam_kernel<2, false>), dim3(a.B), dim3(PB_THREADS), 0, s, a);
-    else
-      hipLaunchKernelGGL((prefix_beam_kernel<PB_CHUNKS, false>), dim3(a.B), dim3(PB_THREADS), 0, s, a);
+    if (small) rc = lpool ? launch_pb<2, false, true>(a, pool_bytes, s) : launch_pb<2, false, false>(a, 0, s);
+    else rc = lpool ? launch_pb<PB_CHUNKS, false, true>(a, pool_bytes, s) : launch_pb<PB_CHUNKS, false, false>(a, 0, s);
   } else {
-    if (small)
-      hipLaunchKernelGGL((prefix_beam_kernel<2, true>), dim3(a.B), dim3(PB_THREADS), 0, s, a);
-    else
-      hipLaunchKernelGGL((prefix_beam_kernel<PB_CHUNKS, true>), dim3(a.B), dim3(PB_THREADS), 0, s, a);
+    if (small) rc = lpool ? launch_pb<2, true, true>(a, pool_bytes, s) : launch_pb<2, true, false>(a, 0, s);
+    else rc = lpool ? launch_pb<PB_CHUNKS, true, true>(a, pool_bytes, s) : launch_pb<PB_CHUNKS, true, false>(a, 0, s);
   }
+  if (rc != 0) return rc;
   WN_HIP(hipGetLastError());
   return 0;
 }

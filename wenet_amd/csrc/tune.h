@@ -87,6 +87,9 @@ namespace wn {
   X(rescore_prefetch, 1)                                                                        \
   /* tests: 2-bit prefix hash in the prefix beam search (exercises the exact sequence test) */  \
   X(beam_weak_hash, 0)                                                                          \
+  /* prefix beam search: 0 = the node pool stays in global scratch even where it fits LDS      \
+     (A/B, tests) */                                                                            \
+  X(beam_lds_pool, 1)                                                                           \
   /* CTC log-softmax: 0 = always the block-per-row kernel (A/B, tests) */                       \
   X(ctc_wave, 1)
 
