@@ -443,6 +443,8 @@ constexpr size_t PB_LPOOL_BYTES = 128 * 1024;   // dynamic LDS the node pool may
 template <int NCH, bool CTX, bool LPOOL>
 __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs a) {
   extern __shared__ __attribute__((aligned(16))) int lds_pool[];
+  // NCH = 2 <=> MAXB + beam^2 <= 128 <=> beam <= 10: the scans over the beam stop there
+  constexpr int BMAX = NCH == 2 ? 10 : MAXB;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63;
   // wave-uniform values must be PROVABLY uniform (SGPRs) or every loop on
@@ -533,54 +535,67 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
     int Ecs = 0;       // contribution in the reference's loop order (has_context)
     if (tid < nb) {
       // ---- unchanged prefix K = H[r] ------------------------------------------
+      // Every LDS read whose address is known up front is issued here, unconditionally (slots
+      // >= beam / nb hold stale values and are masked in the compares): ONE round trip for the
+      // scans and for K's own fields instead of one per use; the only dependent reads left are
+      // the parent's fields (index rp), again one batch.
       const int r = tid;
       const int Klast = H.last[r];
       Ehash = H.hash[r]; Eparh = H.par_hash[r];
-      // all LDS reads first and unconditional (slots >= beam / nb hold stale
-      // values and are masked in the compares): one LDS round trip for the
-      // whole scan instead of one per iteration
-      int qb = -1, ql = -1, rp = -1;
-      int tq[MAXB];
-      u64 hh[MAXB];
+      const int Knode = H.node[r], Kpar = H.par[r], Kdepth = H.depth[r];
+      const double Kscore = H.score[r], Kvit = H.vit[r], Kns = H.ns[r], Kvns = H.vns[r];
+      const int Ktim = H.tim[r], Ktns = H.tns[r], Ktnsp = H.tnsp[r];
+      int tq[BMAX], nd[BMAX];
+      float lv[BMAX];
+      u64 hh[BMAX];
 #pragma unroll
-      for (int q = 0; q < MAXB; ++q) tq[q] = tk[q];
+      for (int q = 0; q < BMAX; ++q) { tq[q] = tk[q]; lv[q] = lq[q]; }
 #pragma unroll
-      for (int j = 0; j < MAXB; ++j) hh[j] = H.hash[j];
+      for (int j = 0; j < BMAX; ++j) { hh[j] = H.hash[j]; nd[j] = H.node[j]; }
+      int qb = -1, ql = -1;
+      float pb = 0.f, pl = 0.f;
 #pragma unroll
-      for (int q = 0; q < MAXB; ++q) {
+      for (int q = 0; q < BMAX; ++q) {
         const bool inb = q < beam;
-        qb = (inb & (tq[q] == a.blank)) ? q : qb;
-        ql = (inb & (Klast >= 0) & (tq[q] == Klast)) ? q : ql;
+        const bool mb = inb & (tq[q] == a.blank);
+        const bool ml = inb & (Klast >= 0) & (tq[q] == Klast);
+        qb = mb ? q : qb; pb = mb ? lv[q] : pb;
+        ql = ml ? q : ql; pl = ml ? lv[q] : pl;
       }
-      // parent of K inside the beam: hash filter, then the exact test (same node, else walk)
-      unsigned rp_hits = 0;
+      // parent of K inside the beam: hash filter, then the exact test -- the same node (the
+      // usual case, decided in the scan), else the walk
+      unsigned rp_hits = 0, rp_same = 0;
 #pragma unroll
-      for (int j = 0; j < MAXB; ++j)
-        rp_hits |= ((j < nb) & (hh[j] == Eparh)) ? (1u << j) : 0u;
-      if (rp_hits) {
-        const int Kpar = H.par[r];
-        for (unsigned mk = rp_hits; mk; mk &= mk - 1) {
-          const int j = __ffs(mk) - 1;
-          const int nj = H.node[j];
-          if (nj == Kpar || same_nodes(nj, Kpar)) rp = j;
-        }
+      for (int j = 0; j < BMAX; ++j) {
+        const bool hm = (j < nb) & (hh[j] == Eparh);
+        rp_hits |= hm ? (1u << j) : 0u;
+        rp_same |= (hm & (nd[j] == Kpar)) ? (1u << j) : 0u;
       }
+      unsigned rp_set = rp_same;
+      for (unsigned mk = rp_hits & ~rp_same; mk; mk &= mk - 1) {   // rare: a re-created prefix
+        const int j = __ffs(mk) - 1;
+        if (same_nodes(H.node[j], Kpar)) rp_set |= 1u << j;
+      }
+      const int rp = rp_set ? 31 - __clz(rp_set) : -1;   // (the last match in beam order)
+      // the parent's fields, one batch (slot 0 when there is none: never used then)
+      const int rpc = max(rp, 0);
+      const int Plast = H.last[rpc], Pts = H.ts[rpc], Ptim = H.tim[rpc];
+      const double Ps = H.s[rpc], Pvs = H.vs[rpc], Pscore = H.score[rpc], Pvit = H.vit[rpc];
       if (qb >= 0 || ql >= 0) {
         valid = 1;
-        Ekey = H.node[r]; Epar = H.par[r]; Etoken = Klast; Edepth = H.depth[r];
+        Ekey = Knode; Epar = Kpar; Etoken = Klast; Edepth = Kdepth;
         if (qb >= 0) {
-          const double p = (double)lq[qb];
-          Es = H.score[r] + p;       // log_add(-inf, x) == x
-          Evs = H.vit[r] + p;
-          Ets = H.tim[r];
+          const double p = (double)pb;
+          Es = Kscore + p;       // log_add(-inf, x) == x
+          Evs = Kvit + p;
+          Ets = Ktim;
           seq = min(seq, (qb * nb + r) * 2);
         }
         if (ql >= 0) {
-          const double p = (double)lq[ql];
+          const double p = (double)pl;
           const int u = Klast;
-          const double xa = H.ns[r] + p, va = H.vns[r] + p;
-          const int Ktns = H.tns[r];
-          Etnsp = H.tnsp[r];
+          const double xa = Kns + p, va = Kvns + p;
+          Etnsp = Ktnsp;
           seq = min(seq, (ql * nb + r) * 2);
           double v = NEG_INF, ctp = NEG_INF;
           int tsrc = 0, top = 0;
@@ -588,9 +603,9 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
             Ens = xa;
             if (v < va) { v = va; tsrc = Ktns; top = 2; }
           } else {
-            double xb, vb; int tb, sub;
-            if (H.last[rp] == u) { xb = H.s[rp] + p; vb = H.vs[rp] + p; tb = H.ts[rp]; sub = 1; }
-            else { xb = H.score[rp] + p; vb = H.vit[rp] + p; tb = H.tim[rp]; sub = 0; }
+            const bool rep = Plast == u;
+            const double xb = (rep ? Ps : Pscore) + p, vb = (rep ? Pvs : Pvit) + p;
+            const int tb = rep ? Pts : Ptim, sub = rep ? 1 : 0;
             seq = min(seq, (ql * nb + rp) * 2 + sub);
             Ens = log_add2_fast(xa, xb);
             if (r < rp) {          // hyp K is visited before its parent
@@ -626,37 +641,45 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
       }
     } else if (tid >= 64 && x_r < nb) {
       // ---- extension P + u ----------------------------------------------------
+      // the same rule: P's fields, the token, the beam's hashes / last tokens / parents in one
+      // batch of unconditional reads
       const int r = x_r, q = x_q;
       const int u = tk[q];
+      const float lpq = lq[q];
       const u64 Ph = H.hash[r];
+      const int Pn = H.node[r], Plast = H.last[r], Pdepth = H.depth[r];
+      const int Pts = H.ts[r], Ptim = H.tim[r];
+      const double Ps = H.s[r], Pvs = H.vs[r], Pscore = H.score[r], Pvit = H.vit[r];
+      u64 hh[BMAX];
+      int lj[BMAX], pj[BMAX];
+#pragma unroll
+      for (int j = 0; j < BMAX; ++j) { hh[j] = H.hash[j]; lj[j] = H.last[j]; pj[j] = H.par[j]; }
       const u64 ch = prefix_hash(Ph, u, a.weak_hash);
-      u64 hh[MAXB];
-#pragma unroll
-      for (int j = 0; j < MAXB; ++j) hh[j] = H.hash[j];  // unconditional, see above
       // does P + u land on a beam member?  hash filter, then exact: same last token and the
-      // member's parent IS P (same node, else walk)
-      unsigned mg_hits = 0;
-#pragma unroll
-      for (int j = 0; j < MAXB; ++j) mg_hits |= ((j < nb) & (hh[j] == ch)) ? (1u << j) : 0u;
+      // member's parent IS P (same node -- decided in the scan -- else the walk)
+      unsigned mg_walk = 0;
       bool merged = false;
-      if (mg_hits) {
-        const int Pn = H.node[r];
-        for (unsigned mk = mg_hits; mk; mk &= mk - 1) {
+#pragma unroll
+      for (int j = 0; j < BMAX; ++j) {
+        const bool hm = (j < nb) & (hh[j] == ch) & (lj[j] == u);
+        merged |= hm & (pj[j] == Pn);
+        mg_walk |= (hm & (pj[j] != Pn)) ? (1u << j) : 0u;
+      }
+      if (!merged) {
+        for (unsigned mk = mg_walk; mk; mk &= mk - 1) {     // rare: a re-created prefix
           const int j = __ffs(mk) - 1;
-          const int pj = H.par[j];
-          merged |= H.last[j] == u &&
-                    (pj == Pn || same_nodes(pj, Pn));
+          merged |= same_nodes(H.par[j], Pn);
         }
       }
       if (u != a.blank && !merged) {
-        const double p = (double)lq[q];
-        double x, v; int tb, sub;
-        if (u == H.last[r]) { x = H.s[r] + p; v = H.vs[r] + p; tb = H.ts[r]; sub = 1; }
-        else { x = H.score[r] + p; v = H.vit[r] + p; tb = H.tim[r]; sub = 0; }
+        const double p = (double)lpq;
+        const bool rep = u == Plast;
+        const double x = (rep ? Ps : Pscore) + p, v = (rep ? Pvs : Pvit) + p;
+        const int tb = rep ? Pts : Ptim, sub = rep ? 1 : 0;
         valid = 1;
         Ens = x;
         if (v > NEG_INF) { Evns = v; Etns_src = tb; Etns_op = 1; }
-        Ekey = -1; Epar = H.node[r]; Etoken = u; Edepth = H.depth[r] + 1;
+        Ekey = -1; Epar = Pn; Etoken = u; Edepth = Pdepth + 1;
         Ehash = ch; Eparh = Ph;
         seq = (q * nb + r) * 2 + sub;
         if (CTX) Ecx = H.cscore[r] + ctx_step(a.cg, H.cstate[r], u, &Ecs);
@@ -700,13 +723,8 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
       const double se_v = e_in ? e_score[e_l] : NEG_INF;
       const int qe_v = e_in ? e_seq[e_l] : 0x7fffffff;
       const int se_lo = __double2loint(se_v), se_hi = __double2hiint(se_v);
-      const int n_it = (n_ent - wave + PB_WAVES - 1) / PB_WAVES;
       int my_r = 0;
-#pragma unroll 4
-      for (int it = 0; it < n_it; ++it) {
-        const double se = __hiloint2double(__builtin_amdgcn_readlane(se_hi, it),
-                                           __builtin_amdgcn_readlane(se_lo, it));
-        const int qe = __builtin_amdgcn_readlane(qe_v, it);
+      auto rank_of = [&](const double se, const int qe) __attribute__((always_inline)) {
         int r = 0;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -718,7 +736,32 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
             r += __popcll(__ballot(sj[c] > se));
           }
         }
-        if (lane == it) my_r = r;
+        return r;
+      };
+      if constexpr (NCH == 2) {
+        // <= 128 slots = 16 per wave: fully unrolled with constant lane indices (v_readlane with
+        // an immediate, v_writelane of the count into lane `it`): 16 independent chains instead
+        // of a rolled loop whose every step waits on VALU -> SGPR -> SALU -> VALU hazards
+        // (2550 -> ~1500 cycles of the frame's 8400, r06z).  Slots past n_ent carry -inf keys:
+        // their counts are computed and never stored.
+#pragma unroll
+        for (int it = 0; it < (NCH * 64) / PB_WAVES; ++it) {
+          const double se = __hiloint2double(__builtin_amdgcn_readlane(se_hi, it),
+                                             __builtin_amdgcn_readlane(se_lo, it));
+          const int qe = __builtin_amdgcn_readlane(qe_v, it);
+          const int r = __builtin_amdgcn_readfirstlane(rank_of(se, qe));   // (uniform: an SGPR)
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(my_r) : "s"(r), "n"(it));
+        }
+      } else {
+        const int n_it = (n_ent - wave + PB_WAVES - 1) / PB_WAVES;
+#pragma unroll 4
+        for (int it = 0; it < n_it; ++it) {
+          const double se = __hiloint2double(__builtin_amdgcn_readlane(se_hi, it),
+                                             __builtin_amdgcn_readlane(se_lo, it));
+          const int qe = __builtin_amdgcn_readlane(qe_v, it);
+          const int r = rank_of(se, qe);
+          if (lane == it) my_r = r;
+        }
       }
       if (e_in) {
         e_rank[e_l] = my_r;
