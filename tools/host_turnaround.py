@@ -7,7 +7,7 @@ Wraps every C-ABI call of the decode path with a wall-clock timer and prints, pe
 spent inside the library (for the synchronous searches that includes waiting for the GPU) and, for
 the whole decode, the Python time outside the library.
 
-    python tools/host_turnaround.py [config2|config3|config4] [n_decodes]
+    python tools/host_turnaround.py [config2|config3|config4] [n_decodes] [knob=value ...]
 """
 import collections
 import os
@@ -24,6 +24,10 @@ from wenet_amd.model import ASRModel  # noqa: E402
 wlname = sys.argv[1] if len(sys.argv) > 1 else 'config2'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 wl = S.BENCH_WORKLOADS[wlname]
+for kv in sys.argv[3:]:
+    k, v = kv.split('=')
+    _lib.check(_lib.lib().wn_tune_set(k.encode(), int(v)), 'wn_tune_set ' + kv)
+    print('knob', kv)
 configs = S.make_configs(wl['config'])
 model = ASRModel(configs, S.make_state_dict(configs, 0), device='cuda:0')
 feats, lens = S.make_bench_batch(wlname, 1)

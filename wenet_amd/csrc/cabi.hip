@@ -933,7 +933,7 @@ int wn_ctc_greedy_search(wn_model* m, int32_t blank_id, int32_t* tokens_host,
                         hipMemcpyDeviceToHost, s));
   WN_HIP(hipMemcpyAsync(tok_lens_host, m->g_len.p, (size_t)B * sizeof(int),
                         hipMemcpyDeviceToHost, s));
-  WN_HIP(hipStreamSynchronize(s));
+  WN_HIP(stream_wait(s));
   return 0;
 }
 
@@ -954,7 +954,7 @@ int wn_filter_blank_embedding(wn_model* m, float* padded_out_dev, int32_t* n_kee
   std::vector<int> keep(B);
   WN_HIP(hipMemcpyAsync(keep.data(), m->nb_keep.p, (size_t)B * sizeof(int),
                         hipMemcpyDeviceToHost, s));
-  WN_HIP(hipStreamSynchronize(s));
+  WN_HIP(stream_wait(s));
   int T = 0;
   for (int b = 0; b < B; ++b) { n_keep_host[b] = keep[b]; T = std::max(T, keep[b]); }
   *t_out = T;
@@ -1131,7 +1131,7 @@ int wn_ctc_prefix_beam_search(wn_model* m, int32_t beam, int32_t blank_id,
   }
   m->pb_valid = false;
   WN_HIP(hipMemcpyAsync(m->pb_host.p, ob, o_end, hipMemcpyDeviceToHost, s));
-  WN_HIP(hipStreamSynchronize(s));
+  WN_HIP(stream_wait(s));
   m->pb_valid = true; m->pb_B = B; m->pb_beam = beam; m->pb_max_len = max_len;
   m->pb_o_sc = o_sc; m->pb_o_nh = o_nh; m->pb_o_len = o_len; m->pb_o_tok = o_tok;
   const char* hb = m->pb_host.p;
@@ -1493,7 +1493,7 @@ int wn_attention_beam_search(wn_model* m, int32_t beam, int32_t maxlen, float le
   std::vector<int> ot((size_t)B * W), ol(B);
   WN_HIP(hipMemcpyAsync(ot.data(), out_tok, ot.size() * sizeof(int), hipMemcpyDeviceToHost, s));
   WN_HIP(hipMemcpyAsync(ol.data(), out_len, ol.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-  WN_HIP(hipStreamSynchronize(s));
+  WN_HIP(stream_wait(s));
   for (int b = 0; b < B; ++b) {
     lens_host[b] = std::min(ol[b], maxlen);
     for (int j = 0; j < lens_host[b]; ++j) tokens_host[(size_t)b * maxlen + j] = ot[(size_t)b * W + j];
@@ -1648,7 +1648,7 @@ int wn_attention_rescoring(wn_model* m, int32_t beam, const int32_t* n_hyps_host
   WN_HIP(hipMemcpyAsync(hl.data(), o_l, R * sizeof(float), hipMemcpyDeviceToHost, s));
   if (use_r2l)
     WN_HIP(hipMemcpyAsync(hr.data(), o_r, R * sizeof(float), hipMemcpyDeviceToHost, s));
-  WN_HIP(hipStreamSynchronize(s));
+  WN_HIP(stream_wait(s));
   for (int r = 0; r < R; ++r) {
     l2r_logp_host[out_index[r]] = hl[r];
     r2l_logp_host[out_index[r]] = hr[r];
@@ -1966,7 +1966,7 @@ int wn_rescore(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
   hipLaunchKernelGGL(rescore_reduce_kernel, dim3(B), dim3(64), 0, s, a);
   WN_HIP(hipGetLastError());
   WN_HIP(hipMemcpyAsync(m->r_host.p, rb, o_end, hipMemcpyDeviceToHost, s));
-  WN_HIP(hipStreamSynchronize(s));
+  WN_HIP(stream_wait(s));
   const char* hb = m->r_host.p;
   memcpy(best_idx_host, hb + o_bi, (size_t)B * sizeof(int));
   memcpy(best_score_host, hb + o_bs, (size_t)B * sizeof(float));

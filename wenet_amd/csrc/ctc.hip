@@ -499,11 +499,12 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
   // Entry slots are fixed for the whole search so that no index arithmetic
   // (integer division by `beam`) sits in the frame loop, and the two kinds of
   // entries never share a wave (no divergent double pass):
-  //   slot r           (wave 0, lanes < MAXB) : unchanged prefix H[r]
-  //   slot MAXB + r*beam + q  (waves 1..)     : extension H[r] + topk[q]
+  //   slot r           (wave 0, lanes < BMAX) : unchanged prefix H[r]
+  //   slot BMAX + r*beam + q  (waves 1..)     : extension H[r] + topk[q]
+  // (BMAX = 10 for beam <= 10: 110 slots, 14 per wave in the rank pass)
   const int x_r = tid >= 64 ? (tid - 64) / beam : 0;
   const int x_q = tid >= 64 ? (tid - 64) - x_r * beam : 0;
-  const int my_slot = tid < MAXB ? tid : (tid >= 64 ? MAXB + (tid - 64) : 0x7fffffff);
+  const int my_slot = tid < BMAX ? tid : (tid >= 64 ? BMAX + (tid - 64) : 0x7fffffff);
   const int nx_f = tid / beam, nx_q = tid - nx_f * beam;
 
   const bool dbg = a.dbg_cycles != nullptr && b == 0 && tid == 0;
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
       nx_tok = a.topk_idx[(int64_t)(off + nx_t) * a.k + nx_q];
       nx_lp = a.topk_val[(int64_t)(off + nx_t) * a.k + nx_q];
     }
-    const int n_ent = MAXB + nb * beam;  // slots in use (with holes)
+    const int n_ent = BMAX + nb * beam;  // slots in use (with holes)
     // ---- this thread's entry ----------------------------------------------
     int valid = 0;
     double Es = NEG_INF, Ens = NEG_INF, Evs = NEG_INF, Evns = NEG_INF;
@@ -739,13 +740,13 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PrefixBeamArgs 
         return r;
       };
       if constexpr (NCH == 2) {
-        // <= 128 slots = 16 per wave: fully unrolled with constant lane indices (v_readlane with
+        // <= 110 slots = 14 per wave: fully unrolled with constant lane indices (v_readlane with
         // an immediate, v_writelane of the count into lane `it`): 16 independent chains instead
         // of a rolled loop whose every step waits on VALU -> SGPR -> SALU -> VALU hazards
         // (2550 -> ~1500 cycles of the frame's 8400, r06z).  Slots past n_ent carry -inf keys:
         // their counts are computed and never stored.
 #pragma unroll
-        for (int it = 0; it < (NCH * 64) / PB_WAVES; ++it) {
+        for (int it = 0; it < (BMAX + BMAX * BMAX + PB_WAVES - 1) / PB_WAVES; ++it) {
           const double se = __hiloint2double(__builtin_amdgcn_readlane(se_hi, it),
                                              __builtin_amdgcn_readlane(se_lo, it));
           const int qe = __builtin_amdgcn_readlane(qe_v, it);

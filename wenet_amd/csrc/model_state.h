@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <string>
@@ -426,6 +427,22 @@ struct wn_model {
   int F2() const { return (F1() - 1) / 2; }
 };
 
+
+// Wait for a stream whose last work item is milliseconds long and whose result the caller needs
+// NOW (the searches' result copies): poll instead of sleeping on the completion interrupt, whose
+// wake-up costs tens of microseconds per decode; after 50 ms (a stuck or very long queue) fall
+// back to the blocking wait.  wn_tune_set("sync_spin", 0) = always the blocking wait (A/B).
+inline hipError_t stream_wait(hipStream_t s) {
+  if (tune().sync_spin != 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0;; ++i) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e != hipErrorNotReady) return e;
+      if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+    }
+  }
+  return hipStreamSynchronize(s);
+}
 
 // One host thread per handle at a time; for the duration of the C-ABI call the handle's
 // effective tuning set (tune.h: its overrides over the process defaults) is the calling

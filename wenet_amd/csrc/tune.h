@@ -90,6 +90,8 @@ namespace wn {
   /* prefix beam search: 0 = the node pool stays in global scratch even where it fits LDS      \
      (A/B, tests) */                                                                            \
   X(beam_lds_pool, 1)                                                                           \
+  /* result waits of the searches / rescoring: 1 = poll the stream, 0 = blocking wait (A/B) */  \
+  X(sync_spin, 1)                                                                               \
   /* CTC log-softmax: 0 = always the block-per-row kernel (A/B, tests) */                       \
   X(ctc_wave, 1)
 
