@@ -552,8 +552,18 @@ int x6_split(const float* src, int R, int K, int ld, void* dst, hipStream_t s) {
 // co-resident blocks drift apart and overlap each other's prologue / store burst (FFN w_1:
 // 51.9 vs 57.9 us, r02ao).  (The 8-wave form of the 128-row tile -- 63.9 us, 1400 us -- is
 // kept only for the fp32-A variant.)
+// From two rounds on the choice follows the LAST round: 256-row tiles cost ceil(t256 / 256)
+// rounds; 128-row tiles fill a round with 512 (two per CU, together as long as one 256-row
+// tile) and a remainder of up to 256 of them runs one per CU in half a round.  The CTC head of
+// config 2 (31 x 17 = 527 tiles = 2 rounds + 15 tiles) pays 3 rounds as 256-row tiles, 2.5 as
+// 128-row ones (144 -> ~120 us).  Ties keep the 256-row tile.
 int gemm_x6_bm(int M, int N, int ksplit) {
-  return cdiv(M, 256) * cdiv(N, XBN) * ksplit >= 512 ? 256 : 128;
+  const int tn = cdiv(N, XBN) * ksplit;
+  const int t256 = cdiv(M, 256) * tn, t128 = cdiv(M, 128) * tn;
+  if (t256 < 512) return 128;
+  const int rem = t128 % 512;
+  const int half_rounds_128 = 2 * (t128 / 512) + (rem == 0 ? 0 : rem <= 256 ? 1 : 2);
+  return half_rounds_128 < 2 * cdiv(t256, 256) ? 128 : 256;
 }
 
 int gemm_x6(const X6Args& args, hipStream_t s) {
