@@ -31,9 +31,8 @@ if os.environ.get('WN_ABLATION') == '1':
 # beside MFMAs)
 EXTRA_FLAGS = {'ffn_x6f.hip': ['-fno-slp-vectorize'], 'gemm_x6r.hip': ['-fno-slp-vectorize'], 'gemm_x6r512.hip': ['-fno-slp-vectorize'],
                # the softmax of the bf16 attention kernels is VALU-bound: no v_pk_add + v_mov
-               # packing of the row sums, no canonicalising v_max x, x in front of every fmaxf
-               # on an MFMA result (scores are finite; the masks use -1e30, not inf)
-               'attention_bf16.hip': ['-fno-slp-vectorize', '-fno-honor-nans']}
+               # packing of the row sums
+               'attention_bf16.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():

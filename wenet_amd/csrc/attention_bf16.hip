@@ -35,6 +35,27 @@ namespace wn {
 
 namespace {
 
+// Maxima of the online softmax as the bare v_max_f32 / v_max3_f32 (IEEE maxNum: a NaN operand
+// yields the other one; the NaN still reaches the output through exp2 and the row sum).  Plain
+// fmaxf on an MFMA result makes the compiler put a canonicalising v_max x, x in front of every
+// use unless the whole file is built with -fno-honor-nans (rounds 2-3; dropped in round 4).
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+template <typename V16>
+__device__ __forceinline__ float vmax16(const V16& v) {
+  const float a = vmax3(v[0], v[1], v[2]), b = vmax3(v[3], v[4], v[5]), c = vmax3(v[6], v[7], v[8]);
+  const float d = vmax3(v[9], v[10], v[11]), e = vmax3(v[12], v[13], v[14]);
+  return vmax(vmax3(a, b, c), vmax3(d, e, v[15]));
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -278,13 +299,9 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
       const bool full = a.mask_mode == 0 && j0 + KT <= kvlen;
       float psum = 0.f, alpha;
       if (full) {
-        float t0 = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-        float t1 = fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]));
-        float t2 = fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11]));
-        float t3 = fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]));
-        float tmax = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
+        float tmax = vmax16(sc);
+        tmax = vmax(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = vmax(m_run, tmax);
         alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
         const float mc = -m_new * cs;
 #pragma unroll
@@ -299,10 +316,10 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
         for (int r = 0; r < 16; ++r) {
           const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           ok[r] = (j >= jmin) && (j < jmax);
-          if (ok[r]) tmax = fmaxf(tmax, sc[r]);
+          if (ok[r]) tmax = vmax(tmax, sc[r]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
+        tmax = vmax(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = vmax(m_run, tmax);
         alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
         const float mc = -m_new * cs;
 #pragma unroll
@@ -390,7 +407,7 @@ constexpr int DSTAGE = 2 * DTILE;       // K tile | V^T tile
 __device__ __forceinline__ float pair_max(float v) {   // max over lanes l, l ^ 32
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v),
                                                   false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  return vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float pair_sum(float v) {   // sum over lanes l, l ^ 32
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v),
@@ -548,12 +565,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
     auto softmax_tile = [&](f32x16& sc, int j0, float& alpha) {
       float psum;
       if (j0 + KT <= kvlen) {
-        float t0 = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-        float t1 = fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]));
-        float t2 = fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11]));
-        float t3 = fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]));
-        const float tmax = pair_max(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
-        float m_new = fmaxf(m_run, tmax);
+        const float tmax = pair_max(vmax16(sc));
+        float m_new = vmax(m_run, tmax);
         // Deferred rescale (defer_thr > 0): with 64 queries per wave SOME lane's running maximum
         // moves in almost every tile (probability 1 - (1 - 1/t)^64 at tile t), so the wave-uniform
         // branch below rescaled the 32 output registers nearly always.  The reference maximum of a
@@ -575,10 +588,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           ok[r] = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi < kvlen;
-          if (ok[r]) tmax = fmaxf(tmax, sc[r]);
+          if (ok[r]) tmax = vmax(tmax, sc[r]);
         }
         tmax = pair_max(tmax);
-        const float m_new = fmaxf(m_run, tmax);
+        const float m_new = vmax(m_run, tmax);
         alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
         const float mc = -m_new * cs;
         psum = 0.f;
@@ -718,12 +731,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
       // ---- online softmax on this lane's query (see the register-staged kernel) ----------
       float psum, alpha;
       if (j0 + KT <= kvlen) {
-        float t0 = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-        float t1 = fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]));
-        float t2 = fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11]));
-        float t3 = fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]));
-        const float tmax = pair_max(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
-        const float m_new = fmaxf(m_run, tmax);
+        const float tmax = pair_max(vmax16(sc));
+        const float m_new = vmax(m_run, tmax);
         alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
         const float mc = -m_new * cs;
 #pragma unroll
@@ -737,10 +746,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           ok[r] = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi < kvlen;
-          if (ok[r]) tmax = fmaxf(tmax, sc[r]);
+          if (ok[r]) tmax = vmax(tmax, sc[r]);
         }
         tmax = pair_max(tmax);
-        const float m_new = fmaxf(m_run, tmax);
+        const float m_new = vmax(m_run, tmax);
         alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
         const float mc = -m_new * cs;
         psum = 0.f;
