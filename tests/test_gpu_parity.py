@@ -292,6 +292,22 @@ def test_prefix_identity_is_exact_behind_a_2_bit_hash(V, T, beam, ctx, lds_pool)
         _same_nbest(got[b], ref[b].nbest, ref[b].nbest_scores, ref[b].nbest_times, f'utt {b}')
 
 
+@pytest.mark.parametrize('T,beam', [(819, 10), (820, 10), (2047, 4), (2048, 4)])
+def test_prefix_beam_at_the_lds_pool_boundary(T, beam):
+    """The node pool (4 x (T * beam + 1) ints) moves from dynamic LDS to global scratch when it
+    passes 128 KB (csrc/ctc.hip PB_LPOOL_BYTES): the last length that fits and the first that
+    does not, for two beams, against the oracle (search.py:127-249) -- n-best, order, times, fp64
+    scores."""
+    from wenet_amd import search as S, synthetic
+    O = _oracle()
+    assert (4 * (T * beam + 1) * 4 <= 128 * 1024) == (T in (819, 2047))
+    logp, lens = synthetic.peaky_logprobs(3, (T // 3, T), 12, 2.0, T + beam)
+    ref = O.ctc_prefix_beam_search(logp, lens, beam)
+    got = S.ctc_prefix_beam_search(logp.cuda(), lens, beam)
+    for b in range(3):
+        _same_nbest(got[b], ref[b].nbest, ref[b].nbest_scores, ref[b].nbest_times, f'utt {b}')
+
+
 def test_prefix_beam_known_answer_gpu():
     """runtime/core/test/ctc_prefix_beam_search_test.cc:29-72 on the GPU."""
     from wenet_amd import search as S
