@@ -504,7 +504,9 @@ int wn_profile_ffn_clocks(uint64_t* out64);
  * start, loop end, kernel end (shader clock), 100-MHz real time at entry / end, k blocks.  While
  * wn_tune_set("lp_probe", 4 [| 8 first block | 16 last block]) is set, the stamps of the pipelined
  * bf16 / MXFP8 GEMM instead: entry, first tile landed, K loop end, last store issued, stores
- * drained, real time at entry / end, K tiles (tools/lp_clocks.py). */
+ * drained, real time at entry / end, K tiles (tools/lp_clocks.py).  With "x6_probe" = 8: the
+ * five phase stamps block 0 of the last row-block GEMM launch (csrc/gemm_x6r.hip) left: entry,
+ * rows in LDS, planes in LDS, main loop done, stores drained (tools/x6r_clocks.py). */
 int wn_profile_gemm_clocks(uint64_t* out64);
 
 /* Test hook: "n_layers" = run only the first n encoder layers (-1: all),

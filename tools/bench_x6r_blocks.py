@@ -1,3 +1,7 @@
+"""Row-block six-product GEMM (csrc/gemm_x6r.hip) as a function of the NUMBER OF BLOCKS (M = 32 ..
+7932 rows): is a launch bound by what one block does or by what all of them share?
+GPU only:  python tools/bench_x6r_blocks.py
+"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.getcwd())

@@ -582,6 +582,8 @@ int32_t wn_profile_ffn_split(const wn_model* m) { return m ? m->prof_split : 0; 
 
 int wn_profile_gemm_clocks(uint64_t* out64) {
   WN_CHECK(out64, "wn_profile_gemm_clocks: null output");
+  if (wn::tune().x6_probe == 8)   // the row-block kernel's phase stamps (tools/x6r_clocks.py)
+    return wn::gemm_x6r_clocks(reinterpret_cast<unsigned long long*>(out64));
   if (wn::tune().lp_probe & 4)   // the pipelined bf16 / MXFP8 kernel stamped last (tools/lp_clocks.py)
     return wn::gemm_lp_clocks(reinterpret_cast<unsigned long long*>(out64));
   return wn::gemm_x6_clocks(reinterpret_cast<unsigned long long*>(out64));

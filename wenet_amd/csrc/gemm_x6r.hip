@@ -46,11 +46,20 @@ constexpr int RKB = RK / 16;         // 16 k blocks
 // mode 0 -- same operations in the same order, a wave per row, 4 consecutive columns per lane --
 // on the rows the prologue holds as whole rows anyway (round 3: one launch and one round trip of
 // LN(x) through HBM less per layer).
+// shader-clock stamps of block 0, wave 0 of the last launch: entry, rows in LDS + first W loads +
+// barrier, planes in LDS, main loop done, stores drained (wn_tune_set("x6_probe", 8) makes
+// wn_profile_gemm_clocks return them; tools/x6r_clocks.py)
+__device__ unsigned long long g_x6r_clk[8];
 template <int NT, int EPI, int PF, int PRO = 0>
 __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
+  const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long k0 = __builtin_readcyclecounter(), k1 = 0, k2 = 0, k3 = 0, k4 = 0;
   __shared__ float red[2][4][32];
   constexpr int PATCH = 4 * 32 * (NT * 128 + 16) > 32 * 1040 ? 4 * 32 * (NT * 128 + 16) : 32 * 1040;
   __shared__ __attribute__((aligned(16))) char patch[PATCH];
+  // the three bf16 planes of the block's 32 rows, fragment layout: record (k block, plane) =
+  // lane x 16 B (round 4: were 192 registers of EVERY wave, split four times over)
+  __shared__ __attribute__((aligned(16))) char ximg[RKB * 3 * 1024];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < 4);
@@ -64,7 +73,6 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   // per instruction, and every wave needs all 32 rows.  The block loads the rows ONCE, whole rows
   // per instruction (wave w: rows 8 w .. 8 w + 7), and turns them through LDS: row stride 1040
   // bytes = 260 dwords, conflict-free for the lane = row reads.
-  f32x4 xa[RKB], xb[RKB];
   {
     f32x4 rowv[8];
     if constexpr (PRO == 1) {
@@ -253,45 +261,101 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
       for (int pl = 0; pl < 3; ++pl)
         wf[ks % (PF + 1)][t][pl] = *reinterpret_cast<const bf16x8*>(q + (t * 3 + pl) * X3_REC);
   };
+  // PF == 1 (six column tiles: two buffers of 18 records are all the register file leaves): the
+  // RELOAD form -- both buffers are filled up front and every record is reloaded (k block ks + 2)
+  // right behind its last MFMA of k block ks (plane 2 after the first product, plane 1 after the
+  // fourth, plane 0 after the sixth), so that loads are in flight all the time instead of one
+  // burst of 18 per k block waited for one k block later: the weight stream of a block ran at
+  // 33 B/clk that way against the ~55 B/clk a CU can pull (tools/probes/stream_probe.hip) --
+  // 2150 cycles per k block for 1152 cycles of MFMAs (r07v).
+  constexpr bool RELOAD = PF == 1;
+  auto load_rec = [&](int ks, int t, int pl) {
+    wf[ks % (PF + 1)][t][pl] =
+        *reinterpret_cast<const bf16x8*>(wb + ks * kstride + (t * 3 + pl) * X3_REC);
+  };
+  // (behind the row loads and their LDS stores: loads return in order, a W record issued in
+  // front of the rows would be waited for with them)
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int s = 0; s < PF; ++s) load_w(s);
+  for (int s = 0; s < (RELOAD ? 2 : PF); ++s) load_w(s);
   __syncthreads();
+  k1 = __builtin_readcyclecounter();
+  // exact three-way bf16 split (x6.h) of the rows in the fp32 patch: wave w splits k blocks
+  // 4 w .. 4 w + 3 and parks the fragments in ximg; every wave reads all of them back, one
+  // k block ahead of its MFMAs
+  auto split_quarter = [&]() {
 #pragma unroll
-  for (int ks = 0; ks < RKB; ++ks) {
-    xa[ks] = *reinterpret_cast<const f32x4*>(patch + li * 1040 + ks * 64 + hi * 32);
-    xb[ks] = *reinterpret_cast<const f32x4*>(patch + li * 1040 + ks * 64 + hi * 32 + 16);
-  }
-
-  // exact three-way bf16 split of the rows in registers (x6.h)
-  bf16x8 X[RKB][3];
+    for (int j = 0; j < RKB / 4; ++j) {
+      const int ks = wave * (RKB / 4) + j;
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(patch + li * 1040 + ks * 64 + hi * 32);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(patch + li * 1040 + ks * 64 + hi * 32 + 16);
+      bf16x8 x3[3];
 #pragma unroll
-  for (int ks = 0; ks < RKB; ++ks) {
+      for (int e = 0; e < 4; ++e) {
+        const Split3 sa = split3(a4[e]), sb = split3(b4[e]);
+        x3[0][e] = sa.h0; x3[1][e] = sa.h1; x3[2][e] = sa.h2;
+        x3[0][4 + e] = sb.h0; x3[1][4 + e] = sb.h1; x3[2][4 + e] = sb.h2;
+      }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const Split3 sa = split3(xa[ks][e]), sb = split3(xb[ks][e]);
-      X[ks][0][e] = sa.h0; X[ks][1][e] = sa.h1; X[ks][2][e] = sa.h2;
-      X[ks][0][4 + e] = sb.h0; X[ks][1][4 + e] = sb.h1; X[ks][2][4 + e] = sb.h2;
+      for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<bf16x8*>(ximg + (ks * 3 + pl) * 1024 + lane * 16) = x3[pl];
     }
-  }
+  };
+  bf16x8 xf[2][3];
+  auto load_x = [&](int ks) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      xf[ks & 1][pl] = *reinterpret_cast<const bf16x8*>(ximg + (ks * 3 + pl) * 1024 + lane * 16);
+  };
+  split_quarter();
+  __syncthreads();
+  load_x(0);
 
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // the epilogue's per-column vectors (bias, LayerNorm weight / bias), one batch of loads in
+  // flight under the GEMM: as `if (bias) v += bias[c]` inside the epilogue's loops every one of
+  // the 24 loads of a six-tile wave was waited for on its own (11 k of the QKV kernel's 54 k
+  // cycles, r07v)
+  const int ecol = wave * NT * 32 + 4 * hi;
+  f32x4 ebias[NT][4], elw[(EPI == 1 || EPI == 3) ? NT : 1][4], elb[(EPI == 1 || EPI == 3) ? NT : 1][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = min(ecol + t * 32 + 8 * g, p.N - 4);
+      ebias[t][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) ebias[t][g] = *reinterpret_cast<const f32x4*>(p.bias + c);   // (uniform)
+      if constexpr (EPI == 1 || EPI == 3) {
+        elw[t][g] = *reinterpret_cast<const f32x4*>(p.ln_w + c);
+        elb[t][g] = *reinterpret_cast<const f32x4*>(p.ln_b + c);
+      }
+    }
+  k2 = __builtin_readcyclecounter();
 
   // plane products, the small ones first: (W plane, activation plane); the tiles alternate so
   // that no MFMA waits for its predecessor's accumulator
   constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
   for (int ks = 0; ks < RKB; ++ks) {
-    if (ks + PF < RKB) load_w(ks + PF);
+    if (!RELOAD && ks + PF < RKB) load_w(ks + PF);
+    if (ks + 1 < RKB) load_x(ks + 1);
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = 0; q < 6; ++q) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks % (PF + 1)][t][PW[q]],
-                                                         X[ks][PX[q]], acc[t], 0, 0, 0);
+                                                         xf[ks & 1][PX[q]], acc[t], 0, 0, 0);
+      if (RELOAD && ks + 2 < RKB && (q == 0 || q == 3 || q == 5)) {
+        // the plane whose last product this was (PW = {2, 0, 1, 1, 0, 0})
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) load_rec(ks + 2, t, q == 0 ? 2 : q == 3 ? 1 : 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -300,6 +364,8 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   // tile of C / x_out / y and of the residual goes through a wave-private LDS patch instead (32
   // rows x NT * 128 bytes, row stride + 16 bytes: conflict-free for the lane = row side) and
   // crosses the memory pipe as row segments of NT * 128 contiguous bytes.
+  asm volatile("" : "+v"(acc[0]), "+v"(acc[NT - 1]));
+  k3 = __builtin_readcyclecounter();
   const int col0 = wave * NT * 32;
   constexpr int SEG = NT * 128;                 // bytes of a row this wave owns
   constexpr int PST = SEG + 16;                 // patch row stride
@@ -337,9 +403,8 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int c = col0 + t * 32 + 8 * g + 4 * hi;
-        v[t][g] = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-        if (p.bias && c < p.N) v[t][g] += *reinterpret_cast<const f32x4*>(p.bias + c);
+        v[t][g] = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]} +
+                  ebias[t][g];
       }
     put(v);
     store_rows(p.C, p.ldc);
@@ -358,10 +423,8 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
                         acc[2 * u][4 * g + 3]};
         f32x4 gt = f32x4{acc[2 * u + 1][4 * g], acc[2 * u + 1][4 * g + 1],
                          acc[2 * u + 1][4 * g + 2], acc[2 * u + 1][4 * g + 3]};
-        if (p.bias) {
-          a += *reinterpret_cast<const f32x4*>(p.bias + c);
-          gt += *reinterpret_cast<const f32x4*>(p.bias + c + 32);
-        }
+        a += ebias[2 * u][g];
+        gt += ebias[2 * u + 1][g];
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
@@ -390,9 +453,8 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int c = col0 + t * 32 + 8 * g + 4 * hi;
-        f32x4 a = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-        if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c);
+        const f32x4 a = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2],
+                              acc[t][4 * g + 3]} + ebias[t][g];
         v[t][g] = rs[t][g] + p.alpha * a;
         s1 += (v[t][g][0] + v[t][g][1]) + (v[t][g][2] + v[t][g][3]);
       }
@@ -424,9 +486,7 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int c = col0 + t * 32 + 8 * g + 4 * hi;
-        const f32x4 w = *reinterpret_cast<const f32x4*>(p.ln_w + c);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.ln_b + c);
+        const f32x4 w = elw[t][g], b = elb[t][g];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[t][g][e] = (v[t][g][e] - mean) * rstd * w[e] + b[e];
       }
@@ -464,34 +524,34 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
 #pragma unroll
       for (int s2i = 0; s2i < PF2; ++s2i) load_w2(s2i);
       __syncthreads();
-#pragma unroll
-      for (int ks = 0; ks < RKB; ++ks) {
-        xa[ks] = *reinterpret_cast<const f32x4*>(patch + li * 1040 + ks * 64 + hi * 32);
-        xb[ks] = *reinterpret_cast<const f32x4*>(patch + li * 1040 + ks * 64 + hi * 32 + 16);
-      }
-#pragma unroll
-      for (int ks = 0; ks < RKB; ++ks) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const Split3 sa = split3(xa[ks][e]), sb = split3(xb[ks][e]);
-          X[ks][0][e] = sa.h0; X[ks][1][e] = sa.h1; X[ks][2][e] = sa.h2;
-          X[ks][0][4 + e] = sb.h0; X[ks][1][4 + e] = sb.h1; X[ks][2][4 + e] = sb.h2;
-        }
-      }
+      split_quarter();                            // (ximg: the first GEMM is done with it)
+      __syncthreads();
+      load_x(0);
       f32x16 acc2[NT2];
 #pragma unroll
       for (int t = 0; t < NT2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+      f32x4 ebias2[NT2][4];                        // (one batch, under the GEMM: see ebias)
+#pragma unroll
+      for (int t = 0; t < NT2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          ebias2[t][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.bias2)
+            ebias2[t][g] = *reinterpret_cast<const f32x4*>(p.bias2 + wave * NT2 * 32 + t * 32 +
+                                                           8 * g + 4 * hi);
+        }
 #pragma unroll
       for (int ks = 0; ks < RKB; ++ks) {
         if (ks + PF2 < RKB) load_w2(ks + PF2);
+        if (ks + 1 < RKB) load_x(ks + 1);
 #pragma unroll
         for (int q = 0; q < 6; ++q)
 #pragma unroll
           for (int t = 0; t < NT2; ++t)
             acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[ks % (PF2 + 1)][t][PW[q]],
-                                                              X[ks][PX[q]], acc2[t], 0, 0, 0);
+                                                              xf[ks & 1][PX[q]], acc2[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();                            // the A patch is dead
@@ -506,10 +566,8 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
                           acc2[2 * u][4 * g + 3]};
           f32x4 gt = f32x4{acc2[2 * u + 1][4 * g], acc2[2 * u + 1][4 * g + 1],
                            acc2[2 * u + 1][4 * g + 2], acc2[2 * u + 1][4 * g + 3]};
-          if (p.bias2) {
-            a += *reinterpret_cast<const f32x4*>(p.bias2 + c);
-            gt += *reinterpret_cast<const f32x4*>(p.bias2 + c + 32);
-          }
+          a += ebias2[2 * u][g];
+          gt += ebias2[2 * u + 1][g];
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
@@ -524,6 +582,9 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  k4 = __builtin_readcyclecounter();
+  if (stamp) { g_x6r_clk[0] = k0; g_x6r_clk[1] = k1; g_x6r_clk[2] = k2; g_x6r_clk[3] = k3; g_x6r_clk[4] = k4; }
 }
 
 template <int NT, int EPI, int PF, int PRO = 0>
@@ -535,6 +596,11 @@ int launch_x6r(const X6RArgs& a, hipStream_t s) {
 
 }  // namespace
 
+int gemm_x6r_clocks(unsigned long long* out) {
+  WN_HIP(hipDeviceSynchronize());
+  WN_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x6r_clk), sizeof(g_x6r_clk)));
+  return 0;
+}
 
 bool gemm_x6r_supported(int M, int N, int K, int epi) {
   if (K == 512) return gemm_x6r512_supported(M, N, epi);

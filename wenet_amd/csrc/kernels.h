@@ -207,6 +207,7 @@ struct X6RArgs {
   int dw_on = 0;
   DwConvArgs dw;
 };
+int gemm_x6r_clocks(unsigned long long* out);   // phase stamps of the last x6r_kernel launch (gemm_x6r.hip)
 bool gemm_x6r_supported(int M, int N, int K, int epi);
 int gemm_x6r(const X6RArgs& a, hipStream_t s);          // dispatches on a.K
 bool gemm_x6r512_supported(int M, int N, int epi);

@@ -33,7 +33,7 @@ int* tune_field(Tune& t, const std::string& key) {
 int tune_check(const std::string& key, int32_t value, const char* who) {
   if (value == TUNE_INHERIT) return 0;
 #ifndef WN_ABLATION
-  if (key == "x6_probe" && (value & ~4) != 0) {
+  if (key == "x6_probe" && (value & ~12) != 0) {
     set_error(std::string(who) + ": x6_probe 1 / 2 (no MFMAs / no DMA) need a WN_ABLATION build");
     return -1;
   }

@@ -55,7 +55,8 @@ namespace wn {
   /* 0 = activations reach gemm_x6 as plane images; 1 = as fp32 rows split in registers.       \
      Measured (r02ag): the split costs more than the plane bytes it saves */                    \
   X(x6_af32, 0)                                                                                 \
-  /* gemm_x6: 4 = clock stamps; WN_ABLATION builds: 1 no MFMAs, 2 no DMA */                     \
+  /* gemm_x6: 4 = clock stamps; 8 = wn_profile_gemm_clocks returns the row-block kernel's      \
+     phase stamps (gemm_x6r.hip); WN_ABLATION builds: 1 no MFMAs, 2 no DMA */                  \
   X(x6_probe, 0)                                                                                \
   /* fused six-product FFN (ffn_x6f.hip, d_model 256): 0 = the two six-product GEMMs (A/B,     \
      tests), 2 = force */                                                                       \
