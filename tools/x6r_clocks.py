@@ -23,6 +23,25 @@ for n, epi in ((768, 0), (256, 1), (256, 0)):
         torch.cuda.synchronize()
         out = (ctypes.c_uint64 * 64)()
         _lib.check(L.wn_profile_gemm_clocks(out), 'clk')
-        k = list(out)[:5]
-        print(f'x6r N={n} epi {epi} M={M}: prologue (rows -> LDS, first W loads, barrier) {k[1]-k[0]}, '
-              f'LDS -> split3 {k[2]-k[1]}, main loop {k[3]-k[2]}, epilogue {k[4]-k[3]}, total {k[4]-k[0]} cycles', flush=True)
+        k = list(out)[8 * epi:8 * epi + 8]
+        print(f'x6r N={n} epi {epi} M={M}: rows in registers {k[5]-k[0]}, -> LDS + first W loads + barrier '
+              f'{k[1]-k[5]}, split3 -> planes {k[2]-k[1]}, main loop {k[3]-k[2]}, epilogue {k[4]-k[3]}, '
+              f'total {k[4]-k[0]} cycles in {(k[7]-k[6]) * 10} ns', flush=True)
+if len(sys.argv) > 1 and sys.argv[1] == 'encoder':
+    # the kernels as the encoder launches them (config 2's batch): row [epi + 4 (prologue form)]
+    from wenet_amd import synthetic as S
+    from wenet_amd.model import ASRModel
+    configs = S.make_configs('aishell_u2pp')
+    model = ASRModel(configs, S.make_state_dict(configs, 0), device='cuda:0')
+    feats, lens = S.make_bench_batch('config2', 1)
+    for _ in range(2):
+        model._forward_encoder(feats.cuda(), lens, -1, -1)
+    torch.cuda.synchronize()
+    out = (ctypes.c_uint64 * 64)()
+    _lib.check(L.wn_profile_gemm_clocks(out), 'clk')
+    names = {4: 'QKV with the FFN-partials prologue (epi 0, PRO 1)', 3: 'out-proj + LN + pw1 + GLU chain (epi 3)',
+             5: 'dwconv prologue + pointwise_conv2 + LN (epi 1, PRO 2)'}
+    for row, what in names.items():
+        k = list(out)[8 * row:8 * row + 8]
+        print(f'{what}: rows in registers {k[5]-k[0]}, -> LDS + first W loads + barrier {k[1]-k[5]}, '
+              f'split3 -> planes {k[2]-k[1]}, main loop {k[3]-k[2]}, epilogue {k[4]-k[3]}, total {k[4]-k[0]} cycles in {(k[7]-k[6]) * 10} ns')

@@ -46,14 +46,15 @@ constexpr int RKB = RK / 16;         // 16 k blocks
 // mode 0 -- same operations in the same order, a wave per row, 4 consecutive columns per lane --
 // on the rows the prologue holds as whole rows anyway (round 3: one launch and one round trip of
 // LN(x) through HBM less per layer).
-// shader-clock stamps of block 0, wave 0 of the last launch: entry, rows in LDS + first W loads +
+// shader-clock stamps of the middle block's wave 0 of the last launch, per kernel form: entry, rows in LDS + first W loads +
 // barrier, planes in LDS, main loop done, stores drained (wn_tune_set("x6_probe", 8) makes
 // wn_profile_gemm_clocks return them; tools/x6r_clocks.py)
-__device__ unsigned long long g_x6r_clk[8];
+__device__ unsigned long long g_x6r_clk[8][8];   // [EPI + 4 (PRO != 0)][stamp]
 template <int NT, int EPI, int PF, int PRO = 0>
 __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
-  const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
-  unsigned long long k0 = __builtin_readcyclecounter(), k1 = 0, k2 = 0, k3 = 0, k4 = 0;
+  const bool stamp = blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;   // (a block inside an utterance)
+  unsigned long long k0 = __builtin_readcyclecounter(), k1 = 0, k2 = 0, k3 = 0, k4 = 0, kp = 0;
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
   __shared__ float red[2][4][32];
   constexpr int PATCH = 4 * 32 * (NT * 128 + 16) > 32 * 1040 ? 4 * 32 * (NT * 128 + 16) : 32 * 1040;
   __shared__ __attribute__((aligned(16))) char patch[PATCH];
@@ -190,6 +191,11 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[r].load(a.bias, lane);
       cp.load(a.cpad, lane);
+      // Branch-free (round 4, second form): the pad rule picks the x operand of ONE fma per (row,
+      // tap) -- the window row, the pad row, or 0 (acc + w * 0 = acc: the tap is skipped) --
+      // instead of two wave-uniform branches per (row, tap): 128 taken-or-not branches cost more
+      // than the 256 fmas they guarded (15.6 k of the prologue's 33 k cycles, r08g).  Same
+      // operations on every contributing tap, in the same order.
       for (int k0 = 0; k0 < a.K; k0 += TG) {
         RowRegs<4> wk[TG], xw[NWIN];
 #pragma unroll
@@ -198,44 +204,99 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
           xw[i].load(a.x + (int64_t)q * a.ldx, lane);
         }
 #pragma unroll
-        for (int i = 0; i < TG; ++i)
-          if (k0 + i < a.K) wk[i].load(a.wt + (int64_t)(k0 + i) * 256, lane);
+        for (int i = 0; i < TG; ++i) {
+          const int kq = min(k0 + i, a.K - 1);      // (a tap past K: loaded, never used)
+          wk[i].load(a.wt + (int64_t)kq * 256, lane);
+        }
+        // interior waves (every tap of every row inside its own utterance: all but the ~3 % of
+        // waves that touch an utterance boundary) skip the selects altogether
+        bool interior = k0 + TG <= a.K;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < R; ++r)
+          interior = interior && on[r] && t_r[r] + k0 - lpad >= 0 &&
+                     t_r[r] + k0 + TG - 1 - lpad < len_r[r];
+        if (interior) {
 #pragma unroll
-          for (int j = 0; j < TG; ++j) {
-            const int k = k0 + j, tt = t_r[r] + k - lpad;
-            if (on[r] && k < a.K) {
-              if (tt >= 0 && tt < len_r[r]) {
+          for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  acc[r].v[e] = fmaf(wk[j].v[e], xw[r + j].v[e], acc[r].v[e]);
-              } else if ((tt < 0 && a.causal) || (tt >= len_r[r] && tt < a.t_max)) {
+            for (int j = 0; j < TG; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[r].v[e] = fmaf(wk[j].v[e], cp.v[e], acc[r].v[e]);
+              for (int e = 0; e < 4; ++e)
+                acc[r].v[e] = fmaf(wk[j].v[e], xw[r + j].v[e], acc[r].v[e]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int j = 0; j < TG; ++j) {
+              const int k = k0 + j, tt = t_r[r] + k - lpad;
+              const bool live = on[r] && k < a.K;
+              const bool in = live && tt >= 0 && tt < len_r[r];
+              const bool pad =
+                  live && !in && ((tt < 0 && a.causal) || (tt >= len_r[r] && tt < a.t_max));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float x = in ? xw[r + j].v[e] : (pad ? cp.v[e] : 0.f);
+                acc[r].v[e] = fmaf(wk[j].v[e], x, acc[r].v[e]);
               }
             }
           }
         }
       }
+      // norm + SiLU of the eight rows SIDE BY SIDE: ln_inplace's operations per row (rowregs.h),
+      // every butterfly stage issued for all rows before the next one -- eight independent chains
+      // instead of eight dependent ones of 12 cross-lane steps each (15.4 k cycles, r08g)
+      if (a.norm_mode == 0) {
+        float sm[R], sq[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (on[r]) {
-          if (a.norm_mode == 0) {
-            ln_inplace<4>(acc[r], a.ln_w, a.ln_b, lane, a.eps);
-          } else {
-            RowRegs<4> sc, sh;
-            sc.load(a.ln_w, lane);
-            sh.load(a.ln_b, lane);
+        for (int r = 0; r < R; ++r) {
+          float t = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[r].v[e] = fmaf(acc[r].v[e], sc.v[e], sh.v[e]);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[r].v[e] = silu_f(acc[r].v[e]);
+          for (int e = 0; e < 4; ++e) t += acc[r].v[e];
+          sm[r] = t;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rowv[r][e] = on[r] ? acc[r].v[e] : 0.f;
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+          for (int r = 0; r < R; ++r) sm[r] += __shfl_xor(sm[r], o, 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          sm[r] *= 1.0f / RK;
+          float t = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = acc[r].v[e] - sm[r];
+            t += d * d;
+          }
+          sq[r] = t;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+          for (int r = 0; r < R; ++r) sq[r] += __shfl_xor(sq[r], o, 64);
+        RowRegs<4> ww, bb;
+        ww.load(a.ln_w, lane);
+        bb.load(a.ln_b, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float var = sq[r] * (1.0f / RK);
+          const float rstd = 1.0f / sqrtf(var + a.eps);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[r].v[e] = (acc[r].v[e] - sm[r]) * rstd * ww.v[e] + bb.v[e];
+        }
+      } else {
+        RowRegs<4> sc, sh;
+        sc.load(a.ln_w, lane);
+        sh.load(a.ln_b, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[r].v[e] = fmaf(acc[r].v[e], sc.v[e], sh.v[e]);
       }
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rowv[r][e] = on[r] ? silu_f(acc[r].v[e]) : 0.f;
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -243,6 +304,8 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
         rowv[j] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)r * p.lda + lane * 4);
       }
     }
+    asm volatile("" : "+v"(rowv[0]), "+v"(rowv[7]));
+    kp = __builtin_readcyclecounter();             // (the A rows are in registers)
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       *reinterpret_cast<f32x4*>(patch + (wave * 8 + j) * 1040 + lane * 16) = rowv[j];
@@ -584,7 +647,11 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   k4 = __builtin_readcyclecounter();
-  if (stamp) { g_x6r_clk[0] = k0; g_x6r_clk[1] = k1; g_x6r_clk[2] = k2; g_x6r_clk[3] = k3; g_x6r_clk[4] = k4; }
+  if (stamp) {
+    unsigned long long* o = g_x6r_clk[EPI + (PRO != 0 ? 4 : 0)];
+    o[0] = k0; o[1] = k1; o[2] = k2; o[3] = k3; o[4] = k4; o[5] = kp;
+    o[6] = rt0; o[7] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 template <int NT, int EPI, int PF, int PRO = 0>
