@@ -189,6 +189,16 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
     char* hp = hpatch + wave * (32 * HPST);     // 4 x 8.5 KB = 34 KB
     const int npass = p.N / 512;
     for (int ps = 0; ps < npass; ++ps) {
+      // the pass's bias vectors as ONE batch of loads under the GEMM (inside the store loops,
+      // behind `if (bias)`, every load was waited for on its own: gemm_x6r.hip, r07v)
+      f32x4 eb[NT5][4];
+#pragma unroll
+      for (int t = 0; t < NT5; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          eb[t][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.bias) eb[t][g] = *reinterpret_cast<const f32x4*>(p.bias + ps * 512 + wave * WCOLS + t * 32 + 8 * g + 4 * hi);
+        }
       const char* wbp = w_base(p.W3, ps);
       gemm_pass(wbp, kstride);
       // the next pass's first W fragments go out BEFORE this pass's stores (vmcnt retires in
@@ -206,9 +216,8 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int t = 2 * u + tt;
-            const int c = col0 + t * 32 + 8 * g + 4 * hi;
-            f32x4 v = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c);
+            const f32x4 v = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2],
+                                  acc[t][4 * g + 3]} + eb[t][g];
             *reinterpret_cast<f32x4*>(hp + li * HPST + (tt * 32 + 8 * g + 4 * hi) * 4) = v;
           }
 #pragma unroll
@@ -221,6 +230,16 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
       }
     }
   } else {
+    // the pass's bias vectors as ONE batch of loads under the GEMM (inside the store loops,
+    // behind `if (bias)`, every load was waited for on its own: gemm_x6r.hip, r07v)
+    f32x4 eb[NT5][4];
+#pragma unroll
+    for (int t = 0; t < NT5; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        eb[t][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) eb[t][g] = *reinterpret_cast<const f32x4*>(p.bias + wave * WCOLS + t * 32 + 8 * g + 4 * hi);
+      }
     gemm_pass(wb, kstride);
     const int col0 = wave * WCOLS;
     __syncthreads();                            // the X image is dead: wave patches
@@ -238,9 +257,8 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
     for (int t = 0; t < NT5; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int c = col0 + t * 32 + 8 * g + 4 * hi;
-        f32x4 a = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-        if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c);
+        const f32x4 a = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2],
+                              acc[t][4 * g + 3]} + eb[t][g];
         v[t][g] = rs[t][g] + p.alpha * a;
         s1 += (v[t][g][0] + v[t][g][1]) + (v[t][g][2] + v[t][g][3]);
       }
@@ -327,6 +345,16 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
       // (4 w, 4 w + 1), (4 w + 2, 4 w + 3) of the pass
       char* wp2 = hpatch + wave * (32 * 272);   // 32 rows x (2 x 128 B + 16): 4 x 8.5 KB
       for (int ps = 0; ps < 2; ++ps) {
+        // the pass's bias vectors as ONE batch of loads under the GEMM (inside the store loops,
+        // behind `if (bias)`, every load was waited for on its own: gemm_x6r.hip, r07v)
+        f32x4 eb2[NT5][4];
+#pragma unroll
+        for (int t = 0; t < NT5; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            eb2[t][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias2) eb2[t][g] = *reinterpret_cast<const f32x4*>(p.bias2 + ps * 512 + wave * WCOLS + t * 32 + 8 * g + 4 * hi);
+          }
         const char* wbp = w_base(p.W3b, ps);
         gemm_pass(wbp, kst2);
         if (ps == 0) {                          // (ahead of the stores, see EPI 0)
@@ -344,10 +372,8 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
                             acc[2 * u][4 * g + 3]};
             f32x4 gt = f32x4{acc[2 * u + 1][4 * g], acc[2 * u + 1][4 * g + 1],
                              acc[2 * u + 1][4 * g + 2], acc[2 * u + 1][4 * g + 3]};
-            if (p.bias2) {
-              a += *reinterpret_cast<const f32x4*>(p.bias2 + c);
-              gt += *reinterpret_cast<const f32x4*>(p.bias2 + c + 32);
-            }
+            a += eb2[2 * u][g];
+            gt += eb2[2 * u + 1][g];
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
@@ -536,6 +562,14 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
   if constexpr (EPI == 0) {
     const int npass = p.N / 512;
     for (int ps = 0; ps < npass; ++ps) {
+      f32x4 ebw[NT5][4];     // (one batch under the GEMM, see x6r512_kernel)
+#pragma unroll
+      for (int t = 0; t < NT5; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          ebw[t][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.bias) ebw[t][g] = *reinterpret_cast<const f32x4*>(p.bias + ps * 512 + wave * WCOLS + t * 32 + 8 * g + 4 * hi);
+        }
       const char* wbp = w_base(p.W3, ps);
       gemm_pass(wbp, kstride);
       // the next pass's first W fragments go out BEFORE this pass's stores: vmcnt retires in
@@ -556,13 +590,20 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
           for (int g = 0; g < 4; ++g) {
             v[g] = f32x4{acc[rt][t][4 * g], acc[rt][t][4 * g + 1], acc[rt][t][4 * g + 2],
                          acc[rt][t][4 * g + 3]};
-            if (p.bias)
-              v[g] += *reinterpret_cast<const f32x4*>(p.bias + col0 + t * 32 + 8 * g + 4 * hi);
+            v[g] += ebw[t][g];
           }
           tile_out(v, p.C, p.ldc, m0 + rt * 32, col0 + t * 32);
         }
     }
   } else {
+    f32x4 ebw[NT5][4];     // (one batch under the GEMM, see x6r512_kernel)
+#pragma unroll
+    for (int t = 0; t < NT5; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        ebw[t][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) ebw[t][g] = *reinterpret_cast<const f32x4*>(p.bias + wave * WCOLS + t * 32 + 8 * g + 4 * hi);
+      }
     gemm_pass(wb, kstride);
     const int col0 = wave * WCOLS;
     f32x4 v[2][NT5][4];
@@ -578,7 +619,7 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
           const int c = col0 + t * 32 + 8 * g + 4 * hi;
           f32x4 a = f32x4{acc[rt][t][4 * g], acc[rt][t][4 * g + 1], acc[rt][t][4 * g + 2],
                           acc[rt][t][4 * g + 3]};
-          if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c);
+          a += ebw[t][g];
           v[rt][t][g] = rs[g] + p.alpha * a;
           s1[rt] += (v[rt][t][g][0] + v[rt][t][g][1]) + (v[rt][t][g][2] + v[rt][t][g][3]);
         }
@@ -654,6 +695,14 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
                                       (col0 + t * 32 + 8 * g + 4 * hi) * 4) = v[rt][t][g];
       __syncthreads();
       for (int ps = 0; ps < 2; ++ps) {
+        f32x4 ebw2[NT5][4];     // (one batch under the GEMM, see x6r512_kernel)
+#pragma unroll
+        for (int t = 0; t < NT5; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            ebw2[t][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias2) ebw2[t][g] = *reinterpret_cast<const f32x4*>(p.bias2 + ps * 512 + wave * WCOLS + t * 32 + 8 * g + 4 * hi);
+          }
         const char* wbp = w_base(p.W3b, ps);
         gemm_pass(wbp, kst2);
         if (ps == 0) {                            // (ahead of the stores, see EPI 0)
@@ -674,10 +723,8 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
                               acc[rt][2 * u][4 * g + 2], acc[rt][2 * u][4 * g + 3]};
               f32x4 gt = f32x4{acc[rt][2 * u + 1][4 * g], acc[rt][2 * u + 1][4 * g + 1],
                                acc[rt][2 * u + 1][4 * g + 2], acc[rt][2 * u + 1][4 * g + 3]};
-              if (p.bias2) {
-                a += *reinterpret_cast<const f32x4*>(p.bias2 + c);
-                gt += *reinterpret_cast<const f32x4*>(p.bias2 + c + 32);
-              }
+              a += ebw2[2 * u][g];
+              gt += ebw2[2 * u + 1][g];
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 o[g][e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
