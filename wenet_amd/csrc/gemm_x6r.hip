@@ -10,12 +10,16 @@
 // plane image of A.  Here the structure of ffn_x6f.hip is reused instead:
 //   * a block = 4 waves = ONE wave per SIMD owns 32 rows of A; the block loads those rows once
 //     as fp32 (whole rows per instruction) and turns them through LDS into the fragment layout
-//     (lane = row, its k half); every wave splits them into the three bf16 planes in registers
-//     -- the "B" operand fragments of all 16 k blocks, 192 registers, no plane image of A;
+//     (lane = row, its k half); wave w splits k blocks 4 w .. 4 w + 3 into the three bf16 planes
+//     and parks the fragments in LDS (48 KB), from where every wave reads the "B" operand of a
+//     k block one step ahead of its MFMAs -- no plane image of A in HBM (round 4: the planes
+//     were 192 registers of EVERY wave before, split four times over);
 //   * the waves split N: wave w computes columns [w N / 4, (w + 1) N / 4) = NT tiles of 32, so
 //     each W fragment is read by exactly one wave -- straight from the weight plane image in
-//     L2 into registers (16 B per lane, one 1-KB record per instruction, PF k blocks ahead):
-//     no LDS, no DMA ring, no barrier in the main loop; 248 blocks re-read the same 0.4-1.2 MB
+//     L2 into registers (16 B per lane, one 1-KB record per instruction, PF k blocks ahead; the
+//     six-tile kernels reload a record right behind its last MFMA instead, RELOAD below): no
+//     DMA ring, no barrier in the main loop; a CU pulls such a stream at ~52 of the ~55 B/clk
+//     it can (tools/probes/stream_probe.hip); 248 blocks re-read the same 0.4-1.2 MB
 //     image, which stays in every XCD's L2;
 //   * W fragment = the instruction's "A" operand, so a lane ends up with ONE row and the columns
 //     8 g + 4 (lane / 32) + q of every tile: a row's LayerNorm statistics are 32 NT values per
