@@ -383,12 +383,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int cb = n0 + (wn * 2 + j) * 32;               // first column of the 32-col tile
-    f32x4 bias4[4];
+    // (clamped addresses under ONE uniform test: `c < N ? load : 0` per vector made every one of
+    // these loads a branch with its own wait, gemm_x6r.hip r07v)
+    f32x4 bias4[4] = {};
+    if (EPI != 1 && p.bias) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c = cb + 8 * g + 4 * hi;
-      bias4[g] = (EPI != 1 && p.bias && c < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + c)
-                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; ++g)
+        bias4[g] = *reinterpret_cast<const f32x4*>(p.bias + min(cb + 8 * g + 4 * hi, p.N - 4));
     }
 #pragma unroll
     for (int i = 0; i < TA; ++i) {
@@ -448,6 +449,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
         if (row >= p.M) continue;
         float* crow = EPI == 1 ? p.C + ((int64_t)slice * p.M + row) * p.N
                                : p.C + (int64_t)row * p.ldc;
+        f32x4 rs[4] = {};
+        if (EPI == 0 && p.resid) {                 // (the row's residual quads as one batch)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            rs[g] = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)row * p.ldr +
+                                                    min(cb + 8 * g + 4 * hi, p.N - 4));
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = cb + 8 * g + 4 * hi;
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_x6_kernel(X6Args p, int tiles
           f32x4 o = v[g];
           if constexpr (EPI == 0) {
             o *= p.alpha;
-            if (p.resid) o += *reinterpret_cast<const f32x4*>(p.resid + (int64_t)row * p.ldr + c);
+            if (p.resid) o += rs[g];    // (its own block: never contracted with the multiply)
           }
           *reinterpret_cast<f32x4*>(crow + c) = o;
         }
