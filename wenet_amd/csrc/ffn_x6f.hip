@@ -255,10 +255,10 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
   // the bias slice: loaded behind the X rows and the first stages (the counter that orders
   // them retires in issue order -- a wait for these values in front of the DMA issue would hold
   // the DMA back until every X row has arrived), stored to LDS after the split
+  // (clamped, unconditional: `i < n ? b1[i] : 0` made each of them a branch with its own wait)
   float b1v[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    b1v[i] = tid + 256 * i < NC * 64 ? p.b1[cg0 * 64 + tid + 256 * i] : 0.f;
+  for (int i = 0; i < 8; ++i) b1v[i] = p.b1[cg0 * 64 + min(tid + 256 * i, NC * 64 - 1)];
   if constexpr ((VAR & 8192) != 0) { __builtin_amdgcn_sched_barrier(0); clk[15] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
   // exact three-way bf16 split of the rows in registers (x6.h): the operand fragments of
   // phase A for the whole launch; no plane image of LN(x) is ever written
