@@ -188,7 +188,10 @@ def end_to_end_leg(model, lens, device, total_audio, ms_per_step):
         'unit': 'audio_s/s',
         'fbank_ms_per_batch': round(fb_ms, 3),
         'note': 'PCM resident in HBM -> wn_fbank -> decode; fbank timed separately '
-                f'({reps} reps, HIP events) and added to ms_per_step',
+                f'({reps} reps, HIP events) and added to ms_per_step.  16-kHz PCM: no '
+                'resampling in this leg -- wn_resample (other sample rates) is pinned to an '
+                'fp64 evaluation of torchaudio\'s published definition only: PARITY '
+                'UNPINNED (torchaudio absent from the image, oracle/gen_golden_resample.py)',
     }
 
 
@@ -306,6 +309,8 @@ def main():
             assert r.nbest_times is not None
         finish(res)
 
+    t_decoded = [0.0]
+
     def run_steps(n, fin=None):
         """n decode passes over the batch, `--streams` of them in flight; the
         per-step result gather (one all_gather) stays on the main thread, in
@@ -315,6 +320,7 @@ def main():
                 for _ in range(n)]
         for f in futs:
             fin(f.result()[method])
+        t_decoded[0] = time.perf_counter()   # this rank's last result is on the host
         return gatherer.drain()
 
     def barrier():
@@ -350,13 +356,18 @@ def main():
         else:
             from wenet_amd.pipeline import freeze_host_heap
             freeze_host_heap()
-    round_s = []
+    round_s, local_decode_s, local_drain_s = [], [], []
     while True:
         barrier()
         t0 = time.perf_counter()
         out = run_steps(args.steps)   # EXACTLY --steps steps per timed round
+        t_drained = time.perf_counter()
         barrier()
         round_s.append(max_over_ranks(time.perf_counter() - t0))
+        # this rank's own share of the round (diagnosis of an N-GPU run, never `value`):
+        # until its last result was on the host, and what it then waited for the gathers
+        local_decode_s.append(t_decoded[0] - t0)
+        local_drain_s.append(t_drained - t_decoded[0])
         # every rank sees the same max-reduced times, so they stop together
         if sum(round_s) >= args.min_seconds or len(round_s) >= MAX_ROUNDS:
             break
@@ -374,6 +385,29 @@ def main():
         tot_launch += n_launch.value
         tot_ms += ms.value
         tot_flops += flops.value
+    # The roofline kernel's launch duration, ONE decode in flight: under the headline's two
+    # overlapping decodes the event pair around a launch also times whatever the other stream
+    # runs beside it (config 3: 243 us under two streams, 176 us alone) -- contention, not
+    # the kernel.  `roofline.achieved / frac / avg_launch_us` come from this pass (plain
+    # back-to-back decode() calls on the caller's handle, every 6th launch bracketed), which is
+    # what `rocprofv3 --kernel-trace --stats ... --streams 1` (profiles/) reproduces; the
+    # figures of the timed rounds stay in `roofline.timed_rounds`.
+    timed_launch, timed_ms, timed_flops = tot_launch, tot_ms, tot_flops
+    _lib.check(L.wn_profile_enable(model._h, 1), 'profile')
+    roof_steps = max(4, min(args.steps, 12))
+    for _ in range(2):
+        model.decode([method], feats_dev, lens, beam_size=beam, **decode_kw)
+    _lib.check(L.wn_profile_collect(model._h, ctypes.byref(n_launch), ctypes.byref(ms),
+                                    ctypes.byref(flops)), 'profile')   # drop the warm-up's
+    for _ in range(roof_steps):
+        model.decode([method], feats_dev, lens, beam_size=beam, **decode_kw)
+    torch.cuda.synchronize()
+    _lib.check(L.wn_profile_collect(model._h, ctypes.byref(n_launch), ctypes.byref(ms),
+                                    ctypes.byref(flops)), 'profile')
+    _lib.check(L.wn_profile_enable(model._h, 0), 'profile')
+    if n_launch.value > 0:
+        tot_launch, tot_ms, tot_flops = n_launch.value, ms.value, flops.value
+        prof_name = L.wn_profile_kernel_name(model._h).decode()
     # transparency leg: the same decode with every GEMM on v_mfma_f32 (gemm_x6 = 0), one
     # round of --steps steps; reported beside the headline, never as `value`
     f32_only = None
@@ -436,8 +470,27 @@ def main():
         finally:
             _lib.check(L.wn_tune_set(b'ffn_x6f_var', 0), 'tune')
     pipe.close()
+    gather_ms = list(gatherer.latencies_ms)
     gatherer.close()
     assert len(out) == batch_per_gpu * world, 'result gather lost utterances'
+
+    # per-rank view of the median round (every rank sees the same max-reduced round times, so
+    # they pick the same round): own decode time per step, wait for the gathers at the round's
+    # end, and the latency of ONE result gather (pack + all_gather + unpack on the worker
+    # thread, including the wait for the slowest peer) -- what makes the first real 8-GPU run
+    # diagnosable from this one line
+    med_i = sorted(range(len(round_s)), key=lambda i: round_s[i])[len(round_s) // 2]
+    mine_diag = [local_decode_s[med_i] / args.steps * 1e3, local_drain_s[med_i] * 1e3,
+                 statistics.median(gather_ms) if gather_ms else 0.0,
+                 max(gather_ms) if gather_ms else 0.0]
+    if dist_on:
+        import torch.distributed as dist
+        t = torch.tensor(mine_diag, dtype=torch.float64, device='cpu' if share_gpu else device)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_diag = [x.cpu().tolist() for x in allt]
+    else:
+        rank_diag = [mine_diag]
 
     if rank == 0:
         dt = statistics.median(round_s)
@@ -510,6 +563,20 @@ def main():
                 'note': 'each round = exactly --steps steps between barrier + '
                         'synchronize brackets, max over ranks; value = median round',
             },
+            'ranks': {
+                'decode_ms_per_step': [round(r[0], 3) for r in rank_diag],
+                'decode_ms_per_step_spread': round(max(r[0] for r in rank_diag)
+                                                   - min(r[0] for r in rank_diag), 3),
+                'drain_wait_ms_per_round': [round(r[1], 3) for r in rank_diag],
+                'gather_ms_median': [round(r[2], 3) for r in rank_diag],
+                'gather_ms_max': [round(r[3], 3) for r in rank_diag],
+                'note': 'per rank, median timed round: time until the rank\'s own last result '
+                        'was on the host / --steps; wait for outstanding result gathers at '
+                        'the round\'s end; one result gather (pack + all_gather + unpack on '
+                        'the worker thread, incl. waiting for the slowest peer) over all '
+                        'gathers of the run.  ms_per_step is the max over ranks of the whole '
+                        'round, these are its parts',
+            },
             'roofline': {
                 'bound': 'mfma',
                 'kernel': (f'{prof_name}, M={enc_rows} F={ffn} D={d_model}, hidden split '
@@ -531,6 +598,20 @@ def main():
                 'frac': round(achieved / peak, 4),
                 'launches': tot_launch,
                 'avg_launch_us': round(tot_ms * 1e3 / max(tot_launch, 1), 2),
+                'timing': 'HIP events on the launch stream around every 6th launch of the '
+                          f'kernel, {roof_steps} plain decode() steps with ONE decode in '
+                          'flight right after the timed rounds (reproduce: rocprofv3 '
+                          '--kernel-trace --stats -- python bench.py --streams 1)',
+                'timed_rounds': {
+                    'launches': timed_launch,
+                    'avg_launch_us': round(timed_ms * 1e3 / max(timed_launch, 1), 2),
+                    'achieved': round((timed_flops / (timed_ms * 1e-3)) / 1e12
+                                      if timed_ms > 0 else 0.0, 2),
+                    'frac': round(((timed_flops / (timed_ms * 1e-3)) / 1e12
+                                   if timed_ms > 0 else 0.0) / peak, 4),
+                    'note': 'the same event pairs inside the timed rounds: with --streams > 1 '
+                            'they also time what the other decode runs beside the kernel',
+                },
                 'traffic': None,
                 'whole_decode_tflops': round(whole_flops / world / (ms_per_step * 1e-3)
                                              / 1e12, 2),
@@ -545,21 +626,23 @@ def main():
         }
         # HBM traffic of that kernel from the PMC passes (tools/gpu_pmc.sh; cannot
         # be collected inside a timed run): bytes per launch, committed summary
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_roofline_kernel.json')
-        if args.workload == 'config2' and not reduced and os.path.exists(pmc):
+        # one record per workload and dtype: profiles/pmc_roofline_kernels.json (written by
+        # tools/pmc_table.py --key from the end-of-round PMC passes)
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_roofline_kernels.json')
+        rec = None
+        if os.path.exists(pmc):
             with open(pmc) as f:
-                rec = json.load(f)
+                rec = json.load(f).get(f'{args.workload}:{args.dtype}')
             kind = lambda n: ('ffn_x6f' if 'ffn_x6f' in n else 'ffn_fused' if 'ffn_fused' in n
-                              else 'x6' if 'x6' in n else 'gemm')
-            if kind(rec.get('kernel', '')) != kind(prof_name):
+                              else 'x6' if 'x6' in n else 'lp' if 'gemm_lp' in n else 'gemm')
+            if rec is not None and kind(rec.get('kernel', '')) != kind(prof_name):
                 rec = None     # the committed counters describe another kernel
-        else:
-            rec = None
         if rec is not None:
             line['roofline']['traffic'] = rec['hbm_bytes_per_launch']
             line['roofline']['traffic_unit'] = 'bytes/launch (HBM read + write, PMC)'
-            line['roofline']['traffic_source'] = ('profiles/pmc_roofline_kernel.json, '
-                                                  'visit ' + str(rec.get('visit', 'r01d')))
+            line['roofline']['traffic_source'] = ('profiles/pmc_roofline_kernels.json, '
+                                                  'visit ' + str(rec.get('visit', '?')) +
+                                                  ' (' + str(rec.get('table', '')) + ')')
             if 'ffn_x6f' in prof_name:
                 # fp32 X in once, W_1 + W_2 planes once (6 B / element; every row tile
                 # re-reads them from L2), the hidden-slice partials out; the hidden tensor

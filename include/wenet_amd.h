@@ -124,6 +124,12 @@ int wn_model_clone(const wn_model* src, wn_model** out);
 int wn_model_set_precision(wn_model* m, int32_t precision);
 int32_t wn_model_get_precision(const wn_model* m);
 
+/* Number of utterances of the handle's CURRENT batch (what the last wn_encode /
+ * wn_set_encoder_out / wn_set_ctc_probs installed; 0 before any, -1 for a null handle): the
+ * per-utterance output arrays of the searches and of wn_rescore are sized by it.  No
+ * reference counterpart -- the reference reads encoder_out.size(0) (search.py:385). */
+int32_t wn_batch_size(const wn_model* m);
+
 /* A weight-less handle that only owns a workspace: enough for
  * wn_set_ctc_probs + the two CTC searches, i.e. for calling the reference's
  * free functions search.ctc_greedy_search / ctc_prefix_beam_search on a

@@ -60,13 +60,31 @@ def resample_direct_fp64(x, orig_freq, new_freq, lpw=6, rolloff=0.99):
 def main():
     from wenet_amd import synthetic as S
     outdir = os.path.join(ROOT, 'tests', 'golden')
+    # --from-torchaudio: the REAL third-party implementation the reference calls
+    # (processor.resample -> torchaudio.transforms.Resample(orig, new)(wav), fp32) instead of
+    # the fp64 definition; the files then carry source='torchaudio <version>' and
+    # tests/test_oracle.py reports the pin as a reference run.  Not possible in this image
+    # (torchaudio is not installed and there is no network): until then the resample row
+    # stays "parity unpinned" (README.md).
+    from_ta = '--from-torchaudio' in sys.argv
+    if from_ta:
+        import torch
+        import torchaudio       # noqa: F401 -- fails loudly where it is absent
     for orig, new in CASES:
         n = int(0.2 * orig) + 37                    # odd length: exercises the ceil rule
         x = S.make_audio(n, seed=900 + orig // 100, sample_rate=orig)
-        y = resample_direct_fp64(x, orig, new)
+        if from_ta:
+            xt = torch.from_numpy(np.asarray(x, dtype=np.float32)).unsqueeze(0)
+            y = torchaudio.transforms.Resample(orig_freq=orig, new_freq=new)(xt)[0].numpy()
+            y = y.astype(np.float64)
+            source = 'torchaudio ' + torchaudio.__version__
+        else:
+            y = resample_direct_fp64(x, orig, new)
+            source = 'fp64 definition (parity unpinned)'
         path = os.path.join(outdir, f'resample_{orig}_{new}.npz')
-        np.savez_compressed(path, x=x.astype(np.float32), y=y, orig=orig, new=new)
-        print(path, len(x), '->', len(y))
+        np.savez_compressed(path, x=x.astype(np.float32), y=y, orig=orig, new=new,
+                            source=source)
+        print(path, len(x), '->', len(y), source)
 
 
 if __name__ == '__main__':

@@ -122,3 +122,26 @@ def test_gather_results_rejects_a_wrong_world_size():
     from wenet_amd import dist as wdist
     rec = wdist.pack_results([0], [[1, 2]], [0.5], 1, 4, 'cpu')
     assert wdist.gather_results(rec, 1) == [(0, [1, 2], 0.5)]   # no process group: local path
+
+
+def test_result_gatherer_is_poisoned_by_a_failed_gather():
+    """A gather that failed on this rank may have skipped a collective its peers issued: the
+    worker must not go on to the next queued batch (its all_gather would pair up with the wrong
+    step).  After the failure drain() and submit() raise, every time, and `last` no longer
+    claims to be the newest batch; what was gathered before the failure is counted in
+    `latencies_ms` (bench.py's gather-latency report)."""
+    from wenet_amd import dist as wdist
+    g = wdist.ResultGatherer(1, 2, 4, 'cpu')
+    g.submit([0], [[1, 2]], [0.5])
+    assert g.drain() == [(0, [1, 2], 0.5)]
+    assert len(g.latencies_ms) == 1 and g.latencies_ms[0] >= 0.0
+    g.submit([0, 1, 2], [[1], [2], [3]], [0.1, 0.2, 0.3])   # three records for two slots
+    g.submit([1], [[3]], [0.25])                            # queued behind the failure: dropped
+    with pytest.raises(RuntimeError, match='out of step'):
+        g.drain()
+    assert g.last is None and len(g.latencies_ms) == 1
+    with pytest.raises(RuntimeError, match='out of step'):
+        g.submit([0], [[1]], [0.5])
+    with pytest.raises(RuntimeError, match='out of step'):
+        g.close()
+    assert not g._t.is_alive()

@@ -1420,3 +1420,36 @@ def test_forward_encoder_chunk_batch_aishell_16_sessions():
         att, cnn = natt, ncnn
         offset = [o + ys.size(1) for o in offset]
         cur += 4 * ys.size(1)
+
+
+def test_filter_blank_embedding_of_an_all_blank_batch():
+    """No frame of the batch has a non-blank arg-max: filter_blank_embedding returns an EMPTY
+    selection (B, 0, d) with an all-False (B, 1, 0) mask instead of an opaque view error
+    (round-4 advice; the reference itself fails in index_select here), and decode() with
+    apply_non_blank_embedding says -- attribute + RuntimeWarning -- that it rescored against the
+    unfiltered encoder output."""
+    import warnings
+    configs, sd, model = cached_model('tiny_lite', 0)
+    B, T, V, d = 3, 17, model.vocab_size, configs['encoder_conf']['output_size']
+    logp = torch.full((B, T, V), -20.0)
+    logp[:, :, 0] = -1e-6
+    enc = torch.randn(B, T, d, generator=torch.Generator().manual_seed(3))
+    sel, mask = model.filter_blank_embedding(logp.cuda(), enc.cuda())
+    assert tuple(sel.shape) == (B, 0, d) and tuple(mask.shape) == (B, 1, 0)
+    assert mask.dtype == torch.bool
+    # decode(): a CTC head that always answers blank
+    sd2 = dict(sd)
+    sd2['ctc.ctc_lo.weight'] = torch.zeros_like(sd['ctc.ctc_lo.weight'])
+    b = torch.full_like(sd['ctc.ctc_lo.bias'], -30.0)
+    b[0] = 0.0
+    sd2['ctc.ctc_lo.bias'] = b
+    from gpu_util import make_model
+    from wenet_amd import synthetic as S
+    m2 = make_model(configs, sd2)
+    feats, lens = S.make_features(2, (60, 90), seed=7)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        got = m2.decode(['attention_rescoring'], feats.cuda(), lens, beam_size=3)
+    assert m2.last_non_blank_filter_empty is True
+    assert any(issubclass(x.category, RuntimeWarning) and 'non-blank' in str(x.message) for x in w)
+    assert all(len(r.tokens) == 0 for r in got['attention_rescoring'])

@@ -192,3 +192,50 @@ def test_rescore_edge_shapes_vs_oracle(beam):
     for b in range(4):
         assert free[b].tokens == got[M[1]][b].tokens and free[b].score == got[M[1]][b].score
         assert free[b].all_scores == got[M[1]][b].all_scores
+
+
+def test_rescore_rejects_a_result_list_of_another_batch_size():
+    """wn_rescore writes one record per utterance of the HANDLE's batch (wn_batch_size): a
+    prefix-result list of another length is refused in Python instead of being read / written
+    past its arrays (round-4 advice)."""
+    from wenet_amd import _lib, search as SR, synthetic as S
+    configs, sd, model = cached_model('tiny_causal', 0)
+    feats, lens = S.make_features(4, (80, 260), seed=5)
+    enc, mask = model._forward_encoder(feats.cuda(), lens)
+    enc_lens = mask.squeeze(1).sum(1)
+    assert _lib.lib().wn_batch_size(model._h) == 4
+    pre = model.decode(['ctc_prefix_beam_search'], feats.cuda(), lens,
+                       beam_size=5)['ctc_prefix_beam_search']
+    for r in pre:
+        r.nbest
+    with pytest.raises(ValueError, match='3 prefix beam results for a batch of 4'):
+        SR.attention_rescoring(model, pre[:3], enc, enc_lens, 0.4, 0.0)
+    ok = SR.attention_rescoring(model, pre, enc, enc_lens, 0.4, 0.0)
+    assert len(ok) == 4
+
+
+def test_prefetch_without_the_right_decoder_then_rescoring_with_it():
+    """A C-API caller that prefetches the cross-attention K / V WITHOUT the right-to-left
+    decoder and then rescoring with reverse_weight > 0: the prefetch is unusable, the pass
+    projects in place -- ordered behind the side stream (it still reads the encoder output) --
+    and gives the records of a run without any prefetch."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model('librispeech_bidecoder_large', 0)
+    feats, lens = S.make_features(12, (500, 900), seed=31)
+    kw = dict(beam_size=6, ctc_weight=0.5, reverse_weight=0.3)
+    try:
+        _lib.check(L.wn_tune_set(b'rescore_prefetch', 0), 'tune')
+        ref = model.decode(['attention_rescoring'], feats.cuda(), lens, **kw)['attention_rescoring']
+        _lib.check(L.wn_tune_set(b'rescore_prefetch', 1), 'tune')
+        pre = model.decode(['ctc_prefix_beam_search'], feats.cuda(), lens,
+                           beam_size=6)['ctc_prefix_beam_search']
+        _lib.check(L.wn_rescore_prefetch(model._h, 0, torch.cuda.current_stream().cuda_stream),
+                   'prefetch')
+        got = model._rescore(pre, 0.5, 0.3, raw=model._last_prefix_raw)
+        again = model._rescore(pre, 0.5, 0.3, raw=model._last_prefix_raw)
+    finally:
+        L.wn_tune_set(b'rescore_prefetch', 1)
+    for a, b, c in zip(ref, got, again):
+        assert a.tokens == b.tokens == c.tokens and a.score == b.score == c.score
+        assert a.all_scores == b.all_scores == c.all_scores

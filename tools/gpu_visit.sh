@@ -64,7 +64,16 @@ PY
       timeout 600 rocprofv3 --pmc FETCH_SIZE -d $P/p2 -o pmc --output-format csv -- $CMD > $P/p2.log 2>&1; echo "p2 $?"
       timeout 600 rocprofv3 --pmc WRITE_SIZE -d $P/p3 -o pmc --output-format csv -- $CMD > $P/p3.log 2>&1; echo "p3 $?"
       timeout 600 rocprofv3 --kernel-trace --stats -d $P/kt -o prof -- $CMD > $P/kt.log 2>&1; echo "kt $?"
-      python tools/pmc_table.py $P > $OUT/pmc_table_$a1.md; head -30 $OUT/pmc_table_$a1.md | cut -c1-220
+      # the roofline kernel of the workload (bench.py's roofline.kernel) and its record key
+      dt=fp32; case "$a2" in *bf16*) dt=bf16 ;; *fp8*) dt=fp8 ;; esac
+      case $a1:$dt in
+        config2:fp32) re='ffn_x6f_kernel' ;;
+        config5:fp32|config3:fp32|config4:fp32) re='gemm_x6_kernel<(128|256), 2, [13]' ;;
+        *:bf16) re='gemm_lp_kernel<0, 3' ;;
+        *) re='gemm_lp_kernel<1, 3' ;;
+      esac
+      python tools/pmc_table.py $P "$re" $a1:$dt > $OUT/pmc_table_${a1}_$dt.md; head -30 $OUT/pmc_table_${a1}_$dt.md | cut -c1-220
+      cp $P/pmc_roofline_kernel.json $OUT/pmc_roofline_kernel_${a1}_$dt.json 2>/dev/null
       find $OUT -name "*.db" -size +20M -delete; find $OUT -name "*.csv" -size +8M -delete ;;
     probe)
       # launch-cost probe (tools/probes/launch_probe.hip): which resource shape pays on a slow box

@@ -30,8 +30,28 @@ def load(dirname):
     return agg
 
 
+def merge(rec_path):
+    """python tools/pmc_table.py --merge <dir>/pmc_roofline_kernel.json: file the record under
+    its key in profiles/pmc_roofline_kernels.json (what bench.py reports as roofline.traffic)."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles',
+                        'pmc_roofline_kernels.json')
+    rec = json.load(open(rec_path))
+    table = json.load(open(root)) if os.path.exists(root) else {}
+    table[rec.pop('key')] = rec
+    with open(root, 'w') as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    print('merged into', os.path.normpath(root), sorted(table))
+
+
 def main():
+    """pmc_table.py DIR [ROOFLINE_REGEX KEY]: KEY = '<workload>:<dtype>' of bench.py; the
+    roofline kernel of that workload is the matching kernel with the largest total time."""
+    if sys.argv[1] == '--merge':
+        return merge(sys.argv[2])
     out = sys.argv[1]
+    import re
+    roof_re = re.compile(sys.argv[2]) if len(sys.argv) > 2 else re.compile(re.escape(ROOFLINE_KERNEL))
+    key = sys.argv[3] if len(sys.argv) > 3 else 'config2:fp32'
     p1, p2, p3 = (load(os.path.join(out, d)) for d in ('p1', 'p2', 'p3'))
     dur = {}
     db = glob.glob(os.path.join(out, 'kt', '**', '*.db'), recursive=True)
@@ -60,13 +80,13 @@ def main():
               f'{wr / 1e6:.1f} | {gbs:.0f} |')
     # machine-readable record of the roofline kernel: bench.py reports it as
     # roofline.traffic (copy it to profiles/pmc_roofline_kernel.json)
-    for k, n, avg, tot, util, rd, wr, gbs in rows:
-        if ROOFLINE_KERNEL in k and rd == rd and wr == wr:
-            rec = dict(kernel=ROOFLINE_KERNEL, launches=n, avg_us=round(avg, 2),
+    for k, n, avg, tot, util, rd, wr, gbs in rows:      # rows are sorted by total time
+        if roof_re.search(k) and rd == rd and wr == wr:
+            rec = dict(key=key, kernel=k[:160], launches=n, avg_us=round(avg, 2),
                        mfma_busy=round(util, 4), hbm_read_bytes_per_launch=int(rd),
                        hbm_write_bytes_per_launch=int(wr),
                        hbm_bytes_per_launch=int(rd + wr),
-                       visit=os.path.basename(os.path.normpath(out)),
+                       visit=os.path.basename(os.path.dirname(os.path.normpath(out))),
                        method='rocprofv3 --pmc, separate passes for FETCH_SIZE and '
                               'WRITE_SIZE (KiB; FETCH_SIZE x2 on gfx950), --streams 1')
             with open(os.path.join(out, 'pmc_roofline_kernel.json'), 'w') as f:

@@ -56,6 +56,16 @@ __device__ __forceinline__ float vmax16(const V16& v) {
   return vmax(vmax3(a, b, c), vmax3(d, e, v[15]));
 }
 
+// The asm maxima above are invisible to the compiler's hazard recogniser: a VALU read of an MFMA
+// result needs the XDL write-back wait states (s_nop 11 after v_mfma_f32_32x32x16_bf16, what the
+// compiler itself puts in front of a plain VALU read).  Every softmax takes its scores through
+// this first: the asm "redefines" the accumulator tuple, so all later reads -- asm or not --
+// are ordered behind the wait.
+template <typename V16>
+__device__ __forceinline__ void mfma_settle(V16& v) {
+  asm("s_nop 11" : "+v"(v));
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -296,6 +306,7 @@ __global__ __launch_bounds__(NW * 64, (RELPOS || NW == 2) ? 2 : 4) void attentio
       // subtract and the window select: the loop is bound by this VALU work (16 scores per
       // lane and 32-key tile against 8 MFMAs), not by the matrix pipe.  Interior tiles of an
       // unmasked sequence take the branch without any per-key window test (uniform).
+      mfma_settle(sc);
       const bool full = a.mask_mode == 0 && j0 + KT <= kvlen;
       float psum = 0.f, alpha;
       if (full) {
@@ -564,6 +575,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
     }
     auto softmax_tile = [&](f32x16& sc, int j0, float& alpha) {
       float psum;
+      mfma_settle(sc);
       if (j0 + KT <= kvlen) {
         const float tmax = pair_max(vmax16(sc));
         float m_new = vmax(m_run, tmax);
@@ -730,6 +742,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bf16_dma_kernel(AttnArgs
       }
       // ---- online softmax on this lane's query (see the register-staged kernel) ----------
       float psum, alpha;
+      mfma_settle(sc);
       if (j0 + KT <= kvlen) {
         const float tmax = pair_max(vmax16(sc));
         const float m_new = vmax(m_run, tmax);

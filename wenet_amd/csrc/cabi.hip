@@ -566,6 +566,8 @@ int32_t wn_model_get_precision(const wn_model* m) {
   return m ? (m->fp8_ffn ? (int32_t)PREC_FP8 : m->prec) : -1;
 }
 
+int32_t wn_batch_size(const wn_model* m) { return m ? m->B : -1; }
+
 int wn_profile_enable(wn_model* m, int32_t on) {
   WN_CHECK(m, "wn_profile_enable: null model");
   m->prof_on = on != 0;
@@ -1940,11 +1942,19 @@ int wn_rescore(wn_model* m, int32_t beam, const int32_t* n_hyps_host,
     // cross-attention K | V projected while the prefix beam search ran (wn_rescore_prefetch)?
     const float* kv_l = nullptr;
     const float* kv_r = nullptr;
-    if (m->kv_ready && m->kv_rows == m->rows && m->kv_nl == (int)m->left.layers.size() &&
-        (!use_r2l || m->kv_nr == (int)m->right.layers.size())) {
+    if (m->kv_ready) {
+      // an outstanding prefetch is ALWAYS ordered in front of this pass and consumed here:
+      // usable or not (e.g. prefetched without the right-to-left decoder, rescored with it),
+      // its GEMMs on the side stream read m->enc and write r_kv_all while the decoder pass
+      // below would run beside them (round-4 advice)
       WN_HIP(hipStreamWaitEvent(s, m->side.e1, 0));
-      kv_l = m->r_kv_all.as<float>();
-      kv_r = kv_l + (size_t)m->kv_nl * m->rows * 2 * d;
+      if (m->kv_rows == m->rows && m->kv_nl == (int)m->left.layers.size() &&
+          (!use_r2l || m->kv_nr == (int)m->right.layers.size())) {
+        kv_l = m->r_kv_all.as<float>();
+        kv_r = kv_l + (size_t)m->kv_nl * m->rows * 2 * d;
+      } else {
+        m->kv_ready = false;
+      }
     }
     WN_TRY(run_decoder(m, m->left, R, n_seq, max_q, m->r_tok.as<int>(), m->r_tgt.as<int>(), o_l,
                        s, kv_l, cg));

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 
 #include "tune.h"
@@ -37,6 +38,23 @@ void set_error(const std::string& msg);
   do {                                                                       \
     int _r = (expr);                                                         \
     if (_r != 0) return _r;                                                  \
+  } while (0)
+
+// hipFuncSetAttribute is per DEVICE: a process may hold handles on several GPUs
+// (wn_model_create takes a device), so the "already done" memo of a launcher is a bit per
+// device of the calling thread, not one flag (round-4 advice).  Setting the attribute twice is
+// harmless, so two threads racing here both set it before either launches.
+#define WN_MAX_DYN_LDS(kern, bytes)                                                          \
+  do {                                                                                       \
+    static std::atomic<uint64_t> _mask{0};                                                   \
+    int _dev = 0;                                                                            \
+    WN_HIP(hipGetDevice(&_dev));                                                             \
+    const uint64_t _bit = 1ull << (_dev & 63);                                               \
+    if (!(_mask.load(std::memory_order_acquire) & _bit)) {                                   \
+      WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      _mask.fetch_or(_bit, std::memory_order_release);                                       \
+    }                                                                                        \
   } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

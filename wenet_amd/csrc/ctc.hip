@@ -1178,13 +1178,7 @@ int ctc_logsoftmax_topk(const CtcRowArgs& a, hipStream_t s) {
   }
   const size_t lds = (size_t)a.V * sizeof(float);
   WN_CHECK(lds <= 120 * 1024, "ctc: vocabulary too large for the LDS row buffer");
-  static size_t attr = 0;
-  if (lds > attr) {
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_row_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-    attr = lds;
-  }
+  WN_MAX_DYN_LDS(ctc_row_kernel, 120 * 1024);
   hipLaunchKernelGGL(ctc_row_kernel, dim3(a.M), dim3(256), lds, s, a);
   WN_HIP(hipGetLastError());
   return 0;
@@ -1265,12 +1259,7 @@ template <int NCH, bool CTX, bool LPOOL>
 static int launch_pb(const PrefixBeamArgs& a, size_t pool_bytes, hipStream_t s) {
   auto kern = prefix_beam_kernel<NCH, CTX, LPOOL>;
   if (LPOOL) {
-    static bool done = false;
-    if (!done) {
-      WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)PB_LPOOL_BYTES));
-      done = true;
-    }
+    WN_MAX_DYN_LDS(kern, PB_LPOOL_BYTES);
   }
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(PB_THREADS), pool_bytes, s, a);
   return 0;

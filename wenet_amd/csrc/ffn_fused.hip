@@ -393,12 +393,7 @@ int launch_ffn(const FfnArgs& a, hipStream_t s) {
   const size_t lds = (size_t)4 * STG + HC_BYTES;
   const dim3 grid(cdiv(a.M, FBM) * a.S), blk(512);
   auto kern = ffn_fused_kernel<ND, ACT, 4>;
-  static bool done = false;
-  if (!done) {
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    done = true;
-  }
+  WN_MAX_DYN_LDS(kern, lds);
   hipLaunchKernelGGL(kern, grid, blk, lds, s, a);
   WN_HIP(hipGetLastError());
   return 0;

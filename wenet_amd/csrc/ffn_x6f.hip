@@ -615,12 +615,7 @@ int launch_x6f(const FfnX6Args& a, hipStream_t s) {
                    : a.S <= 8 ? cdiv(tiles_m, 8 / a.S) * 8
                               : tiles_m * a.S;
   auto kern = ffn_x6f_kernel<ACT, RING, VAR>;
-  static bool done = false;
-  if (!done) {
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  WN_MAX_DYN_LDS(kern, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, tiles_m, pairmap);
   WN_HIP(hipGetLastError());
   return 0;

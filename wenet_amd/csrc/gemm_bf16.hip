@@ -184,13 +184,7 @@ int launch(const GemmArgs& a, hipStream_t stream) {
   const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
   const size_t lds = 2 * (BM + BN) * (BKT + 8) * sizeof(__bf16);
   auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, ACT, RESID, GLU, CONV, BKT>;
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-    attr_done = true;
-  }
+  WN_MAX_DYN_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WGM * WGN * 64), lds,
                      stream, a, tiles_m, tiles_n);
   WN_HIP(hipGetLastError());

@@ -575,12 +575,7 @@ int launch_p(const GemmArgs& a, const void* Wq, hipStream_t stream) {
   size_t lds = 2 * TILE_BYTES + (ET == 1 ? 2 * SCALE_BYTES : 0);
   if (CM != 2 && lds < (size_t)8 * EPI_WAVE) lds = (size_t)8 * EPI_WAVE;
   auto kern = gemm_lp_kernel<ET, ACT, RESID, CM, VAR>;
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  WN_MAX_DYN_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, stream, a, Wq, tiles_m,
                      tiles_n);
   WN_HIP(hipGetLastError());

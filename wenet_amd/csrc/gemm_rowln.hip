@@ -183,12 +183,7 @@ int gemm_rowln(const RowLnArgs& a, hipStream_t s) {
   WN_CHECK(a.A && a.W && a.x_out && a.y && a.ln_w && a.ln_b, "gemm_rowln: null argument");
   WN_CHECK(a.N == RN && a.K % 32 == 0 && a.K >= 96 && a.lda % 4 == 0, "gemm_rowln: shape");
   const size_t lds = (size_t)RRING * RSTG + (8 * 32 + 32) * sizeof(float);
-  static bool done = false;
-  if (!done) {
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowln_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    done = true;
-  }
+  WN_MAX_DYN_LDS(gemm_rowln_kernel, lds);
   hipLaunchKernelGGL(gemm_rowln_kernel, dim3(cdiv(a.M, RBM)), dim3(512), lds, s, a);
   WN_HIP(hipGetLastError());
   return 0;

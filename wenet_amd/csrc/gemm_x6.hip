@@ -487,12 +487,7 @@ int launch_x6(const X6Args& a, hipStream_t s) {
   const size_t lds = (size_t)(NW == 4 ? 2 : BM == 128 ? 4 : 3) *
                      ((BM / 32) * (AF32 ? 2048 : TILE3) + 8 * TILE3);
   auto kern = gemm_x6_kernel<BM, EPI, ACT, CONV, AF32, NW>;
-  static bool done = false;
-  if (!done) {
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    done = true;
-  }
+  WN_MAX_DYN_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * a.ksplit), dim3(NW * 64), lds, s, a, tiles_m,
                      tiles_n);
   WN_HIP(hipGetLastError());

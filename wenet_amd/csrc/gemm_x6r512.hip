@@ -740,12 +740,7 @@ template <int EPI>
 int launch_x6r512w(const X6RArgs& a, hipStream_t s) {
   const size_t lds = (size_t)XROWS + QPATCH;
   auto kern = x6r512w_kernel<EPI>;
-  static bool done = false;                     // per instantiation
-  if (!done) {
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    done = true;
-  }
+  WN_MAX_DYN_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(cdiv(a.M, WROWS)), dim3(256), lds, s, a);
   WN_HIP(hipGetLastError());
   return 0;
@@ -755,12 +750,7 @@ template <int EPI>
 int launch_x6r512(const X6RArgs& a, hipStream_t s) {
   const size_t lds = (size_t)XIMG + HPATCH;
   auto kern = x6r512_kernel<EPI>;
-  static bool done = false;                     // per instantiation
-  if (!done) {
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    done = true;
-  }
+  WN_MAX_DYN_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 32)), dim3(256), lds, s, a);
   WN_HIP(hipGetLastError());
   return 0;

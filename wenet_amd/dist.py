@@ -11,6 +11,7 @@ with a single all_gather (RCCL over xGMI on GPUs, gloo in the CPU tests).
 """
 import queue
 import threading
+import time
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -92,6 +93,7 @@ class ResultGatherer:
         self.world, self.max_utts, self.max_len = world_size, max_utts, max_len
         self.device = torch.device(device)
         self.last = None
+        self.latencies_ms = []          # one entry per gathered batch (worker-thread wall time)
         self._q = queue.SimpleQueue()
         self._err = None
         self._pending = 0
@@ -108,25 +110,42 @@ class ResultGatherer:
             item = self._q.get()
             if item is None:
                 return
-            try:
-                indices, tokens, scores = item
-                if self._stream is not None:
-                    with torch.cuda.stream(self._stream):
+            if self._err is None:
+                try:
+                    t0 = time.perf_counter()
+                    indices, tokens, scores = item
+                    if self._stream is not None:
+                        with torch.cuda.stream(self._stream):
+                            rec = pack_results(indices, tokens, scores, self.max_utts,
+                                               self.max_len, self.device)
+                            out = gather_results(rec, self.world)
+                    else:
                         rec = pack_results(indices, tokens, scores, self.max_utts,
                                            self.max_len, self.device)
                         out = gather_results(rec, self.world)
-                else:
-                    rec = pack_results(indices, tokens, scores, self.max_utts, self.max_len,
-                                       self.device)
-                    out = gather_results(rec, self.world)
-                self.last = out
-            except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
-                self._err = e
+                    self.last = out
+                    # pack + all_gather + unpack of ONE batch as this rank saw it (includes
+                    # the wait for the slowest peer to reach the same collective)
+                    self.latencies_ms.append((time.perf_counter() - t0) * 1e3)
+                except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
+                    # POISONED from here on: this rank may not have issued the collective its
+                    # peers issued, so any later all_gather of this group would pair up with
+                    # the wrong step (or hang).  Everything still queued is dropped, `last`
+                    # no longer means "the newest batch", submit() and drain() raise.
+                    self._err = e
+                    self.last = None
             with self._cv:
                 self._pending -= 1
                 self._cv.notify_all()
 
+    def _raise_if_poisoned(self):
+        if self._err is not None:
+            raise RuntimeError('ResultGatherer: a previous gather failed on this rank; the '
+                               'process group is out of step -- tear the job down'
+                               ) from self._err
+
     def submit(self, indices: Sequence[int], tokens, scores) -> None:
+        self._raise_if_poisoned()
         with self._cv:
             self._pending += 1
         self._q.put((list(indices), list(tokens), list(scores)))
@@ -135,12 +154,12 @@ class ResultGatherer:
         with self._cv:
             while self._pending > 0:
                 self._cv.wait()
-        if self._err is not None:
-            e, self._err = self._err, None
-            raise e
+        self._raise_if_poisoned()
         return self.last
 
     def close(self):
-        self.drain()
-        self._q.put(None)
-        self._t.join()
+        try:
+            self.drain()
+        finally:
+            self._q.put(None)
+            self._t.join()

@@ -760,7 +760,16 @@ class ASRModel:
             if self.apply_non_blank_embedding:
                 # asr_model.py:337-342: the decoder's memory becomes the frames whose CTC
                 # arg-max is not blank (+ the zero padding the reference leaves in)
-                self._filter_blank_current(B)
+                _, t_sel = self._filter_blank_current(B)
+                # a batch without a single non-blank frame: the reference raises in
+                # filter_blank_embedding; here the batch is rescored against the UNFILTERED
+                # encoder output (deviations) and the caller can see that it was
+                self.last_non_blank_filter_empty = t_sel == 0
+                if t_sel == 0:
+                    import warnings
+                    warnings.warn('apply_non_blank_embedding: no non-blank frame in the whole '
+                                  'batch; rescored against the unfiltered encoder output',
+                                  RuntimeWarning, stacklevel=2)
             results['attention_rescoring'] = self._rescore(
                 prefix, ctc_weight, reverse_weight, raw=self._last_prefix_raw)
         return results
@@ -796,6 +805,13 @@ class ASRModel:
             'wn_set_ctc_probs')
         out = torch.empty((B, T, encoder_out.shape[2]), dtype=torch.float32, device=self.device)
         n_keep, t_sel = self._filter_blank_current(B, out)
+        if t_sel == 0:
+            # every frame of every utterance is blank: nothing selected.  (The reference fails
+            # here -- index_select with an empty float index; an empty selection with an
+            # all-False mask is the value its code would have produced.)
+            return (torch.zeros((B, 0, encoder_out.shape[2]), dtype=torch.float32,
+                                device=self.device),
+                    torch.zeros((B, 1, 0), dtype=torch.bool, device=self.device))
         sel = out.view(-1)[:B * t_sel * encoder_out.shape[2]].view(B, t_sel, -1)
         mask = (torch.arange(t_sel).unsqueeze(0) < torch.from_numpy(n_keep).unsqueeze(1))
         return sel, mask.unsqueeze(1).to(self.device)

@@ -265,6 +265,12 @@ def rescore_nbest(model, n_hyps, hyp_lens, hyp_tokens, hyp_scores, times_of, ctc
     otherwise the arrays are uploaded.  `times_of(b, i)` -> nbest_times[i] of utterance b."""
     B, beam = hyp_lens.shape
     max_len = hyp_tokens.shape[2]
+    # wn_rescore writes one entry per utterance of the HANDLE's batch: a prefix-result list of
+    # another length would be read / written past these arrays
+    hb = int(_lib.lib().wn_batch_size(model._h))
+    if hb != B:
+        raise ValueError(f'attention_rescoring: {B} prefix beam results for a batch of {hb} '
+                         'utterances')
     best = np.zeros((B, ), dtype=np.int32)
     score = np.zeros((B, ), dtype=np.float32)
     conf = np.zeros((B, ), dtype=np.float64)
