@@ -130,6 +130,16 @@ int32_t wn_model_get_precision(const wn_model* m);
  * reference counterpart -- the reference reads encoder_out.size(0) (search.py:385). */
 int32_t wn_batch_size(const wn_model* m);
 
+/* One-shot: the NEXT wn_encode on this handle waits for `event` (a hipEvent_t already
+ * recorded by the caller, e.g. "the previous batch's encoder is finished" on another handle's
+ * stream) BEHIND its front end -- GlobalCMVN + subsampling conv1 (cmvn.py:36-47,
+ * subsampling.py:188-189), the one HBM-bound kernel of the encoder (10 MB of features ->
+ * a ~1-GB operand image) -- instead of the caller waiting in front of the whole call: the
+ * front end of batch i+1 then runs beside the matrix-bound encoder of batch i, everything
+ * behind it after it (wenet_amd/pipeline.py).  Encoders without that front end wait first.
+ * No reference counterpart (the reference decodes one batch at a time, recognize.py:289). */
+int wn_model_set_encode_gate(wn_model* m, void* event);
+
 /* A weight-less handle that only owns a workspace: enough for
  * wn_set_ctc_probs + the two CTC searches, i.e. for calling the reference's
  * free functions search.ctc_greedy_search / ctc_prefix_beam_search on a

@@ -569,4 +569,4 @@ def test_bf16_attention_large_score_range(config, dma):
         print(f'{config} dma={dma} utt {b}: max rel err {err:.3e}')
         # peaked softmax rows: a probability on a bf16 rounding boundary moves a whole value
         # vector's weight by one bf16 ulp per layer
-        assert err < 3e-2, (config, dma, b, err)
+        assert err < 1.2e-2, (config, dma, b, err)   # measured 1.1e-3 (abs-pos) / 4.2e-3 (rel-pos)

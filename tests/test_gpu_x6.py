@@ -179,6 +179,7 @@ def ffn_form(request):
     (128, 256, 128, 1), (700, 256, 2048, 3), (7932, 256, 2048, 1), (1000, 512, 2048, 2),
     (16231, 512, 2048, 1), (7932, 256, 2048, 2), (33, 256, 64, 1), (3000, 256, 1024, 1),
     (130, 256, 2048, 2), (12000, 256, 2048, 1),     # (12000 rows: two hidden slices)
+    (295, 256, 2048, 1),      # one 11.8-s utterance: 3 row tiles x 32 hidden slices (round 5)
 ])
 def test_ffn_x6_vs_fp64(M, D, F, act, ffn_form):
     from wenet_amd import _lib

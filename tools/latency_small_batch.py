@@ -16,6 +16,10 @@ sys.path.insert(0, ROOT)
 from wenet_amd import synthetic as S  # noqa: E402
 from wenet_amd.model import ASRModel  # noqa: E402
 
+from wenet_amd import _lib  # noqa: E402
+for kv in filter(None, os.environ.get('WN_TUNE', '').split(',')):     # WN_TUNE=key=value,...
+    k, v = kv.split('=')
+    _lib.check(_lib.lib().wn_tune_set(k.encode(), int(v)), 'tune')
 wlname = sys.argv[1] if len(sys.argv) > 1 else 'config2'
 sizes = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8, 16, 32]
 wl = S.BENCH_WORKLOADS[wlname]

@@ -30,7 +30,7 @@ class WnTensor(Structure):
 # every symbol include/wenet_amd.h declares
 EXPORTS = [
     'wn_last_error', 'wn_version', 'wn_model_create', 'wn_model_destroy', 'wn_model_clone',
-    'wn_model_set_precision', 'wn_model_get_precision', 'wn_batch_size', 'wn_op_gemm_bf16',
+    'wn_model_set_precision', 'wn_model_get_precision', 'wn_batch_size', 'wn_model_set_encode_gate', 'wn_op_gemm_bf16',
     'wn_op_gemm_bf16_stored',
     'wn_attention_beam_search', 'wn_encode_chunk_batch', 'wn_op_gemm_lowp', 'wn_op_mx_quantize', 'wn_op_ffn_fused', 'wn_op_gemm_x6', 'wn_op_ffn_x6', 'wn_op_gemm_x6r', 'wn_op_gemm_x6r512', 'wn_profile_kernel_name', 'wn_profile_ffn_split', 'wn_profile_ffn_clocks', 'wn_profile_gemm_clocks', 'wn_filter_blank_embedding',
     'wn_workspace_create', 'wn_resample_length', 'wn_resample', 'wn_fbank', 'wn_log_mel', 'wn_encode', 'wn_encode_chunk', 'wn_set_encoder_out',
@@ -119,6 +119,7 @@ def lib():
     L.wn_model_get_precision.argtypes = [vp]
     L.wn_batch_size.argtypes = [vp]
     L.wn_batch_size.restype = i32
+    L.wn_model_set_encode_gate.argtypes = [vp, vp]
     L.wn_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
     L.wn_op_log_add.argtypes = [vp, vp, vp, i32, vp]
     L.wn_debug_set.argtypes = [vp, c_char_p, i32]

@@ -568,6 +568,12 @@ int32_t wn_model_get_precision(const wn_model* m) {
 
 int32_t wn_batch_size(const wn_model* m) { return m ? m->B : -1; }
 
+int wn_model_set_encode_gate(wn_model* m, void* event) {
+  WN_CHECK(m, "wn_model_set_encode_gate: null handle");
+  m->enc_gate = (hipEvent_t)event;
+  return 0;
+}
+
 int wn_profile_enable(wn_model* m, int32_t on) {
   WN_CHECK(m, "wn_profile_enable: null model");
   m->prof_on = on != 0;
@@ -683,6 +689,7 @@ int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host
              "chunk decoding is not implemented for the transformer encoder");
     WN_CHECK(T >= 1, "wn_encode: empty features");
     WN_HIP(hipSetDevice(m->device));
+    WN_TRY(encode_gate_wait(m, (hipStream_t)stream));
     return encode_transformer(m, feats_dev, feat_lens_host, B, T, enc_out_dev,
                               enc_lens_host, (hipStream_t)stream);
   }
@@ -693,6 +700,7 @@ int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host
   const int d = c.d_model;
   const int Tp = ((T - 1) / 2 - 1) / 2;
   WN_TRY(subsample_conv2d4(m, feats_dev, feat_lens_host, B, T, enc_lens_host, 0, s));
+  WN_TRY(encode_gate_wait(m, s));     // (paths that did not consume the gate behind conv1)
   const int M = m->rows;
   if (M > 0) {
     WN_TRY(encoder_layers(m, chunk, left, s));

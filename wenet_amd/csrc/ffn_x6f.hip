@@ -638,12 +638,15 @@ int x6_split_perm(const float* src, int R, int K, int ld, void* dst, hipStream_t
   return 0;
 }
 
-// hidden slices: the largest S in {1, 2, 4, 8, 16} with tiles_m x S blocks on the 256 CUs
-// (one block per CU) and whole 64-unit chunks per slice
+// hidden slices: the largest S in {1, 2, 4, .., 32} with tiles_m x S blocks on the 256 CUs
+// (one block per CU) and whole 64-unit chunks per slice.  S = 32 (one 64-unit chunk per block at
+// F = 2048) is the small-batch end: a single utterance (M ~ 300 rows = 3 row tiles) then runs
+// on 96 CUs for prologue + ONE chunk instead of on 48 for two (round 5: 23 -> 17 us per module
+// at B = 1; the v_mfma_f32 pair it replaced there took 58 us).
 int ffn_x6f_split(int M, int F) {
   const int tiles_m = cdiv(M, 128);
   int S = 1;
-  while (S < 16 && tiles_m * (S * 2) <= 256 && F % (S * 2 * 64) == 0) S *= 2;
+  while (S < 32 && tiles_m * (S * 2) <= 256 && F % (S * 2 * 64) == 0) S *= 2;
   return S;
 }
 
@@ -653,13 +656,16 @@ bool ffn_x6f_supported(int M, int D, int F, int act) {
   const int S = ffn_x6f_split(M, F);
   if (F % (S * 64) != 0 || F / S > 2048) return false;
   if ((int64_t)cdiv(M, 32) * X3_TILE * XKB >= ((int64_t)1 << 40)) return false;
-  // (fewer blocks than half the CUs: the GEMM pair fills the chip better; 2 = tests force it)
-  return tune().ffn_x6f == 2 || cdiv(M, 128) * S >= 128;
+  // (round 4 kept batches that fill less than half the CUs on the GEMM pair / the v_mfma_f32
+  // kernels; measured in round 5 the fused kernel wins at every size -- B = 1: 3.80 -> 3.08 ms
+  // per decode, B = 2: 3.79 -> 3.14 -- because what such a batch pays for is launches and
+  // dependent phases, not matrix-pipe time.  ffn_x6f = 3 restores the old rule for the A/B.)
+  return tune().ffn_x6f != 3 || cdiv(M, 128) * S >= 128;
 }
 
 int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
   WN_CHECK(a.X && a.ldx % 4 == 0 && a.W13 && a.W2p && a.b1 && a.P && a.M > 0 && a.D == XD && a.S > 0 &&
-               a.F % (a.S * 64) == 0 && a.F / a.S <= 2048 && (a.S & (a.S - 1)) == 0 && a.S <= 16,
+               a.F % (a.S * 64) == 0 && a.F / a.S <= 2048 && (a.S & (a.S - 1)) == 0 && a.S <= 32,
            "ffn_x6f: bad arguments");
 #define WN_X6F(RING, VAR)                                            \
   switch (a.act) {                                                   \

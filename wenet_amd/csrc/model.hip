@@ -351,12 +351,18 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
   const int d = m->cfg.d_model, M = m->rows, F = w1.out;
   // (d: the widths ffn_reduce_ln takes)
   if (t_gemm_prec != PREC_F32 || tune().gemm_x6 == 0 || !m->x6_at || w1.out != w2.in ||
-      !(d == 256 || d == 512) || F % 16 != 0 || (M < 512 && tune().gemm_x6 != 2))
+      !(d == 256 || d == 512) || F % 16 != 0)
     return 0;
+  // batches under 512 rows: only the fused kernel (the tile-GEMM pair is all prologue and
+  // epilogue there; 2 = tests force it)
+  const bool small = M < 512 && tune().gemm_x6 != 2;
+  const bool fused_ok = tune().ffn_x6f != 0 && tune().x6_af32 == 0 && m->x6p_at &&
+                        ffn_x6f_supported(M, d, F, act) && !(small && tune().ffn_x6f == 3);
+  if (small && !fused_ok) return 0;
   auto i1 = m->x6_at->find(w1.w), i2 = m->x6_at->find(w2.w);
   if (i1 == m->x6_at->end() || i2 == m->x6_at->end()) return 0;
   static thread_local int tick = 0;
-  if (tune().ffn_x6f != 0 && tune().x6_af32 == 0 && m->x6p_at && ffn_x6f_supported(M, d, F, act)) {
+  if (fused_ok) {
     // hidden tensor on chip (ffn_x6f.hip)
     auto ip = m->x6p_at->find(w2.w);
     if (ip != m->x6p_at->end()) {
@@ -557,6 +563,17 @@ int sub_out_linear(wn_model* m, int M, int F2, hipStream_t s) {
 // (B, T, F) feature batch: sets the row layout and leaves x = embed(xs) in m->x
 // (encoder.py:155-157, subsampling.py:203-228, embedding.py:134-147).  `pos0` is
 // the position of the first output frame (streaming offset).
+// consume the handle's encode gate (wn_model_set_encode_gate): everything queued on `s` after
+// this point waits for the event; idempotent
+int encode_gate_wait(wn_model* m, hipStream_t s) {
+  if (m->enc_gate) {
+    hipEvent_t e = m->enc_gate;
+    m->enc_gate = nullptr;
+    WN_HIP(hipStreamWaitEvent(s, e, 0));
+  }
+  return 0;
+}
+
 int subsample_conv2d4(wn_model* m, const float* feats_dev,
                       const int32_t* feat_lens_host, int B, int T,
                       int32_t* enc_lens_host, int pos0, hipStream_t s) {
@@ -643,6 +660,9 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
                          m->d_row_utt.as<int>(), m->d_off.as<int>(), m->d_off1.as<int>(), M,
                          F1, F2, 1, pix);
       WN_HIP(hipGetLastError());
+      // the front end (HBM-bound: 10 MB of features -> the ~1-GB plane image) may run beside
+      // the previous decode's matrix-bound encoder; conv2 and everything behind it may not
+      WN_TRY(encode_gate_wait(m, s));
       X6Args g;
       g.A3 = m->c1.as<char>(); g.B3 = w6; g.M = M * F2; g.N = d; g.K = 9 * d;
       g.epi = 0; g.bias = m->conv2.b; g.act = ACT_RELU; g.C = m->c2.as<float>(); g.ldc = d;

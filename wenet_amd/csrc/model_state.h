@@ -391,6 +391,9 @@ struct wn_model {
   // encoder output they were projected from
   DevBuf r_kv_all, r_enc3;
   bool kv_ready = false;
+  // wn_model_set_encode_gate: one-shot event the next wn_encode waits for BEHIND its front end
+  // (CMVN + conv1): chained encoders of several handles overlap only that HBM-bound kernel
+  hipEvent_t enc_gate = nullptr;
   int kv_rows = 0, kv_nl = 0, kv_nr = 0;
   Stager stage;
   // optional HIP-event bracket around the FFN w_1 GEMM launches (the kernel
@@ -524,6 +527,7 @@ int set_layout(wn_model* m, int B, int Tp, const std::vector<int>& off,
                const std::vector<int>& len, int rows, hipStream_t s);
 int subsample_conv2d4(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host, int B,
                       int T, int32_t* enc_lens_host, int pos0, hipStream_t s);
+int encode_gate_wait(wn_model* m, hipStream_t s);
 int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s);
 int encoder_layers_chunk(wn_model* m, int n_sess, int R, const int* offsets,
                          std::vector<ChunkSess>& sess, float* out, hipStream_t s);

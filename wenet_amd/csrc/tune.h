@@ -59,7 +59,7 @@ namespace wn {
      phase stamps (gemm_x6r.hip); WN_ABLATION builds: 1 no MFMAs, 2 no DMA */                  \
   X(x6_probe, 0)                                                                                \
   /* fused six-product FFN (ffn_x6f.hip, d_model 256): 0 = the two six-product GEMMs (A/B,     \
-     tests), 2 = force */                                                                       \
+     tests), 3 = round 4's rule (only batches that fill half the CUs; A/B) */                   \
   X(ffn_x6f, 1)                                                                                 \
   /* WN_ABLATION builds: 4..6 = the older DMA stages of 24 records */                           \
   X(ffn_x6f_ring, 3)                                                                            \

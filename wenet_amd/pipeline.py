@@ -28,12 +28,14 @@ gets status -4 instead of corrupting it.
 """
 import concurrent.futures
 import gc
+import os
 import queue
 import threading
 from typing import List
 
 import torch
 
+from wenet_amd import _lib
 from wenet_amd.model import ASRModel
 
 
@@ -67,6 +69,7 @@ class DecodePipeline:
         # encoder chain: launch order == execution order of the encoders
         self._enc_lock = threading.Lock()
         self._enc_done = None
+        self.gate_front_end = os.environ.get('WN_PIPE_GATE', '1') != '0'
 
     def _run(self, ready: torch.cuda.Event, methods, speech, speech_lengths, kw):
         i = self._free.get()
@@ -82,7 +85,14 @@ class DecodePipeline:
             with torch.cuda.stream(stream):
                 with self._enc_lock:
                     if self._enc_done is not None:
-                        stream.wait_event(self._enc_done)
+                        if self.gate_front_end:
+                            # the wait goes BEHIND this decode's front end (CMVN + conv1, the
+                            # encoder's one HBM-bound kernel): it runs beside the previous
+                            # decode's matrix-bound layers, the rest of the encoder after them
+                            _lib.check(_lib.lib().wn_model_set_encode_gate(
+                                self.models[i]._h, self._enc_done.cuda_event), 'encode gate')
+                        else:
+                            stream.wait_event(self._enc_done)
                     st = self.models[i]._decode_begin(methods, speech,
                                                       speech_lengths, **kw)
                     done = torch.cuda.Event()
