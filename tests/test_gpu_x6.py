@@ -243,6 +243,41 @@ def test_encoder_with_x6_ffn_matches_the_f32_mfma_path(config, B, frames, chunk)
     assert 0 < err < 1e-4
 
 
+@pytest.mark.parametrize('config,B,frames,chunk', [('aishell_u2pp', 4, (400, 700), -1),
+                                                   ('aishell_u2pp', 32, (800, 1200), -1),
+                                                   ('aishell_u2pp', 3, (607, 911), 16),
+                                                   ('aishell_u2pp', 1, (1181, 1181), -1),
+                                                   # d_model 512: the GEMM pair takes the image
+                                                   # (no x6_split launch); 32- and 64-row blocks
+                                                   ('wenetspeech_u2pp', 5, (500, 830), 16),
+                                                   ('librispeech_bidecoder_large', 50,
+                                                    (900, 1100), -1)])
+def test_ffn_input_as_a_plane_image_is_bit_identical(config, B, frames, chunk):
+    """Round 5: the producers of LN(x) in front of a fused feed-forward module (the row-block
+    pointwise_conv2 GEMM's LayerNorm epilogue, the partial reduction in front of the next layer's
+    macaron module) write its X3 plane image and the fused kernel loads operand fragments, instead
+    of fp32 rows that each of the S hidden-slice blocks loads, turns and splits (tune ffn_ximg).
+    The split is exact and done on the same fp32 values, so the whole encoder must return the
+    SAME BITS either way -- a wrong record address, a wrong half-wave exchange or a ragged last
+    row tile shows up here.  (Row counts: ragged tiles of 32 and of 8 rows.)"""
+    from gpu_util import cached_model
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=83, feat_dim=configs['input_dim'])
+    try:
+        _lib.check(L.wn_tune_set(b'ffn_ximg', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        ref = ref.cpu()
+        _lib.check(L.wn_tune_set(b'ffn_ximg', 1), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+    finally:
+        L.wn_tune_set(b'ffn_ximg', 1)
+    assert torch.isfinite(ref).all()
+    assert torch.equal(got.cpu(), ref) and torch.equal(got2.cpu(), ref)
+
+
 @pytest.mark.parametrize('ring', [3, 4, 5])
 def test_ffn_on_chip_equals_itself_for_every_ring_depth(ring):
     """The DMA ring depth changes only when operands arrive, never what is multiplied: the

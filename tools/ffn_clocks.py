@@ -28,6 +28,9 @@ def main():
     lw, lb = torch.ones(D, device='cuda'), torch.zeros(D, device='cuda')
     y = torch.empty(M, D, device='cuda')
     _lib.check(L.wn_tune_set(b'ffn_x6f', 1), 'tune')
+    # FFN_XIMG=1: X handed to the kernel as its plane image (round 5) instead of fp32 rows
+    if os.environ.get('FFN_XIMG') == '1':
+        _lib.check(L.wn_tune_set(b'ffn_ximg', 2), 'tune')
     out = np.zeros((4, 24), dtype=np.uint64)
     for var, what in ((8704, 'stage DMA as one burst behind the barrier (r03 first form)'), (25088, 'default kernel (DMA spread over the stage)'), (90624, 'three of the six products'), (8768, 'no fragment reads'),
                       (8708, 'no pieces'), (8706, 'no DMA'), (8782, 'MFMAs only')):

@@ -2137,6 +2137,11 @@ int wn_op_ffn_x6(const float* X, const float* W1, const float* b1, const float* 
     WN_TRY(x6_split_perm(W2, D, F, F, w23.as<char>(), s));
     a.X = X; a.ldx = D; a.W13 = w13.as<char>(); a.W2p = w23.as<char>(); a.b1 = b1;
     a.P = part.as<float>(); a.M = M; a.D = D; a.F = F; a.act = act;
+    if (tune().ffn_ximg == 2) {     // tests / tools: X handed over as its plane image
+      WN_TRY(x3.ensure(x6_bytes(M, D)));
+      WN_TRY(x6_split(X, M, D, D, x3.as<char>(), s));
+      a.X3 = x3.as<char>(); a.X = nullptr;
+    }
     for (int r = 0; r < (reps > 0 ? reps : 1); ++r) WN_TRY(ffn_x6f(a, s));
     return ffn_reduce_ln(x, part.as<float>(), a.S, b2, alpha, ln_w, ln_b, nullptr, nullptr, y, M,
                          D, eps, 0, s);

@@ -32,6 +32,7 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "kernels.h"
+#include "x6.h"
 
 namespace wn {
 
@@ -370,6 +371,110 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(
   }
 }
 
+// MODE 1 of ffn_reduce_ln_kernel with y2 = LN(y; w2, b2) leaving as its X3 PLANE IMAGE
+// (x6.h: records [k block][row tile][plane] of 32 rows x 16 k, the operand order of the
+// six-product kernels) instead of fp32 rows: the consumer -- the fused feed-forward module of the
+// next layer, ffn_x6f.hip -- loads ready-made fragments.  The row arithmetic is the kernel
+// above, statement for statement (a wave per row, the same sums in the same order: the image
+// holds the exact split of the same fp32 values; tests/test_gpu_x6.py checks the bits).
+// A block = 8 consecutive rows (two per wave): a (k block, half, plane) piece of the image is
+// 16 bytes per row, so eight rows make one whole 128-byte line; the planes are turned through
+// LDS and leave as 96 such lines per block.
+template <int E>
+__global__ __launch_bounds__(256) void ffn_reduce_ln_img_kernel(
+    float* __restrict__ x, const float* __restrict__ P, int S, const float* __restrict__ b2,
+    float alpha, const float* __restrict__ w, const float* __restrict__ b,
+    const float* __restrict__ w2, const float* __restrict__ bb2, char* __restrict__ y3,
+    int M, float eps) {
+  static_assert(E % 4 == 0, "4 columns per lane and chunk");
+  constexpr int D = E * 64;
+  constexpr int NP = D / 8;                // 16-byte pieces of a row and plane: (k block, half)
+  constexpr int SEG = 144;                 // LDS stride of a piece row (8 rows x 16 B + pad)
+  __shared__ __attribute__((aligned(16))) char planes[3 * NP * SEG];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 8;
+  for (int rr = 0; rr < 2; ++rr) {
+    const int rl = wave * 2 + rr;          // row inside the block
+    const int row = m0 + rl;
+    if (row >= M) continue;                // (wave-uniform)
+    float v[E];
+#pragma unroll
+    for (int j = 0; j < E / 4; ++j) {
+      const int c = j * 256 + lane * 4;
+      f32x4 acc = *reinterpret_cast<const f32x4*>(b2 + c);
+      int s = 0;
+      for (; s + 8 <= S; s += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          t[u] = *reinterpret_cast<const f32x4*>(P + ((int64_t)(s + u) * M + row) * D + c);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+      }
+      for (; s < S; ++s)
+        acc += *reinterpret_cast<const f32x4*>(P + ((int64_t)s * M + row) * D + c);
+      const f32x4 xo = *reinterpret_cast<const f32x4*>(x + (int64_t)row * D + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * j + e] = xo[e] + alpha * acc[e];
+    }
+    auto norm = [&](const float* gw, const float* gb) {
+      float sm = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) sm += v[e];
+      const float mean = wave_sum(sm) * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float d = v[e] - mean;
+        q = __builtin_fmaf(d, d, q);
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+      for (int j = 0; j < E / 4; ++j) {
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(gw + j * 256 + lane * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(gb + j * 256 + lane * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * j + e] = (v[4 * j + e] - mean) * rstd * ww[e] + bv[e];
+      }
+    };
+    norm(w, b);
+#pragma unroll
+    for (int j = 0; j < E / 4; ++j)
+      *reinterpret_cast<f32x4*>(x + (int64_t)row * D + j * 256 + lane * 4) =
+          f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+    norm(w2, bb2);
+    // chunk j, lane l hold columns 256 j + 4 l .. + 3 = k block 16 j + l / 4, half (l / 2) & 1,
+    // elements 4 (l & 1) .. + 3 of the half's eight
+#pragma unroll
+    for (int j = 0; j < E / 4; ++j) {
+      bf16x4 h0, h1, h2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const Split3 sp = split3(v[4 * j + e]);
+        h0[e] = sp.h0; h1[e] = sp.h1; h2[e] = sp.h2;
+      }
+      const int piece = (j * 16 + (lane >> 2)) * 2 + ((lane >> 1) & 1);   // (k block, half)
+      char* o = planes + piece * SEG + rl * 16 + (lane & 1) * 8;
+      *reinterpret_cast<bf16x4*>(o) = h0;
+      *reinterpret_cast<bf16x4*>(o + NP * SEG) = h1;
+      *reinterpret_cast<bf16x4*>(o + 2 * NP * SEG) = h2;
+    }
+  }
+  __syncthreads();
+  const int tiles = (M + 31) >> 5, tile = m0 >> 5, r32 = m0 & 31;
+#pragma unroll
+  for (int it = 0; it < 3 * NP * 8 / 256; ++it) {
+    const int q = it * 256 + threadIdx.x;      // pieces of 16 B: (plane, k block, half, row)
+    const int rl = q & 7, ph = q >> 3;         // ph = plane * NP + (k block * 2 + half)
+    const int pl = ph / NP, kh = ph - pl * NP;
+    if (m0 + rl < M) {
+      const f32x4 val = *reinterpret_cast<const f32x4*>(planes + ph * SEG + rl * 16);
+      *reinterpret_cast<f32x4*>(y3 + ((int64_t)(kh >> 1) * tiles + tile) * X3_TILE + pl * X3_REC +
+                                (kh & 1) * 512 + (r32 + rl) * 16) = val;
+    }
+  }
+}
+
 }  // namespace
 
 
@@ -441,6 +546,20 @@ int ffn_reduce_ln(float* x, const float* P, int S, const float* b2, float alpha,
     if (mode == 0) WN_RL(8, 0); else if (mode == 1) WN_RL(8, 1); else WN_RL(8, 2);
   }
 #undef WN_RL
+  WN_HIP(hipGetLastError());
+  return 0;
+}
+
+int ffn_reduce_ln_img(float* x, const float* P, int S, const float* b2, float alpha,
+                      const float* w, const float* b, const float* w2, const float* bb2,
+                      void* y3, int M, int D, float eps, hipStream_t s) {
+  WN_CHECK(M > 0 && (D == 256 || D == 512) && y3 && w2 && bb2, "ffn_reduce_ln_img: shape");
+  if (D == 256)
+    hipLaunchKernelGGL(ffn_reduce_ln_img_kernel<4>, dim3(cdiv(M, 8)), dim3(256), 0, s, x, P, S,
+                       b2, alpha, w, b, w2, bb2, reinterpret_cast<char*>(y3), M, eps);
+  else
+    hipLaunchKernelGGL(ffn_reduce_ln_img_kernel<8>, dim3(cdiv(M, 8)), dim3(256), 0, s, x, P, S,
+                       b2, alpha, w, b, w2, bb2, reinterpret_cast<char*>(y3), M, eps);
   WN_HIP(hipGetLastError());
   return 0;
 }

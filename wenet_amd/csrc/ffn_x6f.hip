@@ -229,11 +229,26 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
   // stage RING - 1 starts behind the first barrier): a wave-private 32 x (256 + 16)-byte patch,
   // row stride 68 dwords = conflict-free ds_read_b128 for lane = row.
   constexpr bool XT = (VAR & 16384) != 0;
+  // VAR & 32768: X arrives as its plane image (FfnX6Args::X3): the wave's 32 rows are row tile
+  // 4 tm + wave, every (k block, plane) record of it one 1-KB load -- 48 loads straight into
+  // the fragment registers, no turn through LDS, no split (6.6 k of the prologue's 13.8 k
+  // cycles, done once by the producer instead of by each of the S slice blocks)
+  constexpr bool XI = (VAR & 32768) != 0;
   bf16x8 X[XKB][3];
   const int xrow = min(tm * 128 + wave * 32 + li, p.M - 1);
   f32x4 xa[XKB], xb[XKB];
   f32x4 xr[4][8];
-  if constexpr (XT) {
+  if constexpr (XI) {
+    const int tiles = (p.M + 31) >> 5;
+    const int tile = min(tm * 4 + wave, tiles - 1);   // (a tile past the end: rows never stored)
+    const char* xi = reinterpret_cast<const char*>(p.X3) + (int64_t)tile * X3_TILE + lane * 16;
+    const int64_t kstr = (int64_t)tiles * X3_TILE;
+#pragma unroll
+    for (int ks = 0; ks < XKB; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        X[ks][pl] = *reinterpret_cast<const bf16x8*>(xi + ks * kstr + pl * REC);
+  } else if constexpr (XT) {
     const int r4 = lane >> 4, c16 = lane & 15;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -262,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
   if constexpr ((VAR & 8192) != 0) { __builtin_amdgcn_sched_barrier(0); clk[15] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
   // exact three-way bf16 split of the rows in registers (x6.h): the operand fragments of
   // phase A for the whole launch; no plane image of LN(x) is ever written
-  if constexpr (XT) {
+  if constexpr (XT && !XI) {
     char* patch = smem_g + (RING - 1) * STG + wave * (32 * 272);
     const int r4 = lane >> 4, c16 = lane & 15;
 #pragma unroll
@@ -279,13 +294,15 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next pass overwrites the patch
     }
   }
+  if constexpr (!XI) {
 #pragma unroll
-  for (int ks = 0; ks < XKB; ++ks) {
+    for (int ks = 0; ks < XKB; ++ks) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const Split3 sa = split3(xa[ks][e]), sb = split3(xb[ks][e]);
-      X[ks][0][e] = sa.h0; X[ks][1][e] = sa.h1; X[ks][2][e] = sa.h2;
-      X[ks][0][4 + e] = sb.h0; X[ks][1][4 + e] = sb.h1; X[ks][2][4 + e] = sb.h2;
+      for (int e = 0; e < 4; ++e) {
+        const Split3 sa = split3(xa[ks][e]), sb = split3(xb[ks][e]);
+        X[ks][0][e] = sa.h0; X[ks][1][e] = sa.h1; X[ks][2][e] = sa.h2;
+        X[ks][0][4 + e] = sb.h0; X[ks][1][4 + e] = sb.h1; X[ks][2][4 + e] = sb.h2;
+      }
     }
   }
   if constexpr ((VAR & 8192) != 0) { __builtin_amdgcn_sched_barrier(0); clk[16] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
@@ -664,7 +681,7 @@ bool ffn_x6f_supported(int M, int D, int F, int act) {
 }
 
 int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
-  WN_CHECK(a.X && a.ldx % 4 == 0 && a.W13 && a.W2p && a.b1 && a.P && a.M > 0 && a.D == XD && a.S > 0 &&
+  WN_CHECK((a.X3 || (a.X && a.ldx % 4 == 0)) && a.W13 && a.W2p && a.b1 && a.P && a.M > 0 && a.D == XD && a.S > 0 &&
                a.F % (a.S * 64) == 0 && a.F / a.S <= 2048 && (a.S & (a.S - 1)) == 0 && a.S <= 32,
            "ffn_x6f: bad arguments");
 #define WN_X6F(RING, VAR)                                            \
@@ -675,7 +692,10 @@ int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
   }
   // the default kernel with shader-clock stamps (same results; bench.py samples the clock the
   // kernel ran at through it, tools/ffn_clocks.py)
-  if (tune().ffn_x6f_var == 25088 && a.act == ACT_SILU) return launch_x6f<ACT_SILU, 3, 25088>(a, s);
+  if (tune().ffn_x6f_var == 25088 && a.act == ACT_SILU) {
+    if (a.X3) return launch_x6f<ACT_SILU, 3, 25088 + 32768>(a, s);
+    return launch_x6f<ACT_SILU, 3, 25088>(a, s);
+  }
 #ifdef WN_ABLATION
   // measurement builds only (python -m wenet_amd.build with WN_ABLATION=1): variants that leave
   // out a part of the kernel -- WRONG RESULTS BY DESIGN -- and the older stage shapes
@@ -712,7 +732,8 @@ int ffn_x6f(const FfnX6Args& a, hipStream_t s) {
   else if (tune().ffn_x6f_ring == 5) { WN_X6F(5, 0) }
   else if (tune().ffn_x6f_ring >= 6) { WN_X6F(6, 0) }
 #endif
-  // three stages of 48 records
+  // three stages of 48 records; X as its plane image where the producer wrote one
+  if (a.X3) { WN_X6F(3, 16896 + 32768) }
   WN_X6F(3, 16896)
 #undef WN_X6F
   set_error("ffn_x6f: unsupported activation");

@@ -557,9 +557,19 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[t][g][e] = (v[t][g][e] - mean) * rstd * w[e] + b[e];
       }
-    if (EPI == 1 || p.y != nullptr) {
+    if (p.y != nullptr) {
       put(v);
       store_rows(p.y, p.ldy);
+    }
+    if constexpr (EPI == 1) {
+      if (p.y3 != nullptr) {
+        // y as its X3 plane image (x6.h x3_store_tile): the consumer -- the fused feed-forward
+        // module -- sees the same fragments it would have made of the fp32 rows
+        const int tiles_m = (p.M + 31) >> 5;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          x3_store_tile(v[t], p.y3, (col0 + t * 32) >> 4, tiles_m, blockIdx.x, hi, li);
+      }
     }
     if constexpr (EPI == 3) {
       // ---- chained: C = GLU(y W2^T + bias2), N2 = 512 (encoder_layer.py:240-251 /
@@ -696,12 +706,12 @@ int gemm_x6r(const X6RArgs& a, hipStream_t s) {
     WN_CHECK(a.epi == 1 && a.N == 256 && a.W3 && a.M > 0 && a.dw.D == 256 && a.dw.M == a.M &&
                  a.dw.x && a.dw.ldx % 4 == 0 && a.dw.wt && a.dw.bias && a.dw.cpad && a.dw.ln_w &&
                  a.dw.ln_b && a.dw.row_utt && a.dw.off && a.dw.len && a.dw.K >= 1 &&
-                 a.resid && a.x_out && a.ln_w && a.ln_b && a.y && a.ldr % 4 == 0 &&
+                 a.resid && a.x_out && a.ln_w && a.ln_b && (a.y || a.y3) && a.ldr % 4 == 0 &&
                  a.ldx % 4 == 0 && a.ldy % 4 == 0, "gemm_x6r: depthwise-conv prologue arguments");
     return launch_x6r<2, 1, 3, 2>(a, s);
   }
   if (a.epi == 1) {
-    WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && a.y && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
+    WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && (a.y || a.y3) && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
                  a.ldy % 4 == 0, "gemm_x6r: row-LN epilogue arguments");
     return launch_x6r<2, 1, 3>(a, s);
   }

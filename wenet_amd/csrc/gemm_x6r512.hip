@@ -296,9 +296,17 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[t][g][e] = (v[t][g][e] - mean) * rstd * w[e] + b[e];
       }
-    if (EPI == 1 || p.y != nullptr) {
+    if (p.y != nullptr) {
       put(v);
       store_rows(p.y, p.ldy, col0);
+    }
+    if constexpr (EPI == 1) {
+      if (p.y3 != nullptr) {      // y as its X3 plane image (x6.h x3_store_tile)
+        const int tiles_m = (p.M + 31) >> 5;
+#pragma unroll
+        for (int t = 0; t < NT5; ++t)
+          x3_store_tile(v[t], p.y3, (col0 + t * 32) >> 4, tiles_m, m0 >> 5, hi, li);
+      }
     }
     if constexpr (EPI == 3) {
       // ---- chained: C = GLU(y W3b^T + bias2), N2 = 1024: the LayerNorm rows never leave the CU.
@@ -671,11 +679,23 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
           for (int e = 0; e < 4; ++e)
             v[rt][t][g][e] = (v[rt][t][g][e] - mean[rt]) * rstd[rt] * w[e] + b[e];
       }
-    if (EPI == 1 || p.y != nullptr) {
+    if (p.y != nullptr) {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int t = 0; t < NT5; ++t) tile_out(v[rt][t], p.y, p.ldy, m0 + rt * 32, col0 + t * 32);
+    }
+    if constexpr (EPI == 1) {
+      if (p.y3 != nullptr) {      // y as its X3 plane image (x6.h x3_store_tile)
+        const int tiles_m = (p.M + 31) >> 5;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+          if ((m0 >> 5) + rt < tiles_m) {
+#pragma unroll
+            for (int t = 0; t < NT5; ++t)
+              x3_store_tile(v[rt][t], p.y3, (col0 + t * 32) >> 4, tiles_m, (m0 >> 5) + rt, hi, li);
+          }
+      }
     }
     if constexpr (EPI == 3) {
       // ---- chained: C = GLU(y W3b^T + bias2), N2 = 1024: the LayerNorm rows go back into the
@@ -779,7 +799,7 @@ int gemm_x6r512(const X6RArgs& a, hipStream_t s) {
            "gemm_x6r512: shape");
   const bool wide = x6r512_wide(a);
   if (a.epi == 1) {
-    WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && a.y && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
+    WN_CHECK(a.resid && a.x_out && a.ln_w && a.ln_b && (a.y || a.y3) && a.ldr % 4 == 0 && a.ldx % 4 == 0 &&
                  a.ldy % 4 == 0, "gemm_x6r512: row-LN epilogue arguments");
     return wide ? launch_x6r512w<1>(a, s) : launch_x6r512<1>(a, s);
   }

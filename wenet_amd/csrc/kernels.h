@@ -110,6 +110,12 @@ int ffn_fused(const FfnArgs& a, hipStream_t s);
 int ffn_reduce_ln(float* x, const float* P, int S, const float* b2, float alpha,
                   const float* w, const float* b, const float* w2, const float* bb2, float* y,
                   int M, int D, float eps, int mode, hipStream_t s);
+// mode 1 with y leaving as the X3 plane image (M x 256) instead of fp32 rows: the same
+// arithmetic per row, eight rows per block, the planes turned through LDS into whole
+// 128-byte pieces of the image
+int ffn_reduce_ln_img(float* x, const float* P, int S, const float* b2, float alpha,
+                      const float* w, const float* b, const float* w2, const float* bb2,
+                      void* y3, int M, int D, float eps, hipStream_t s);
 
 // fp32 GEMM as six bf16 plane products (gemm_x6.hip).  Operands are "X3" images:
 // x6_bytes(R, K) bytes for an R x K matrix, made by x6_split or by a GEMM's EPI 2.
@@ -152,6 +158,11 @@ int gemm_x6(const X6Args& a, hipStream_t s);
 struct FfnX6Args {
   const float* X = nullptr;    // X = LayerNorm(x): [M][ldx] fp32 (split into planes in registers)
   int ldx = 0;
+  // instead of X (round 5): the X3 plane image of LN(x) (M x 256, records [k block][row tile]
+  // [plane]) written by the producer of LN(x) -- the epilogue of the pointwise_conv2 row-block
+  // GEMM, ffn_reduce_ln_img -- so that the S hidden-slice blocks of a row tile load ready-made
+  // operand fragments instead of each loading, turning and splitting the fp32 rows
+  const void* X3 = nullptr;
   const void* W13 = nullptr;   // X3 image of W1: F x 256
   const void* W2p = nullptr;   // k-slot-permuted image of W2 (x6_split_perm): 256 x F
   const float* b1 = nullptr;   // [F]
@@ -192,6 +203,9 @@ struct X6RArgs {
   float* x_out = nullptr; int ldx = 0;
   const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
   float* y = nullptr; int ldy = 0;           // may alias A (a block reads its rows first)
+  // epi 1, K = 256: additionally / instead (y may be null then) the X3 plane image of y (M x N,
+  // ceil(M / 32) row tiles) for a six-product consumer that wants fragments, not rows
+  void* y3 = nullptr;
   // epi 3 = epi 1 chained with C = GLU(y W3b^T + bias2): W3b = X3 image of a 2 K x K weight
   // (rows [32 values | 32 gates] per 64), C [M][K]; y is stored only if set
   const void* W3b = nullptr; const float* bias2 = nullptr;

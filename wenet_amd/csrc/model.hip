@@ -347,9 +347,13 @@ int ffn_x6_split(int M, int F) {
 // fp32 feed-forward module on the bf16 matrix cores (gemm_x6.hip): t1 = LN(x) is in place;
 // split it into planes, w_1 + activation straight into the plane image of the hidden
 // tensor, w_2 as K-slice partials in m->ffn_part.  Returns the slice count (0: not taken).
-int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStream_t s) {
+// Which form will ffn_x6_try run for this module on the current batch?  0 = none (the caller's
+// v_mfma_f32 paths), 1 = the fused kernel (ffn_x6f.hip, d_model 256), 2 = the six-product GEMM
+// pair with the hidden tensor as a plane image.  Forms 1 and 2 (without tune().x6_af32) read
+// LN(x) as an X3 plane image: the producers of LN(x) ask before they decide to write that image
+// instead of fp32 rows (t1_image_for) -- ONE predicate, so producer and consumer cannot disagree.
+int ffn_x6_route(wn_model* m, const Linear& w1, const Linear& w2, int act) {
   const int d = m->cfg.d_model, M = m->rows, F = w1.out;
-  // (d: the widths ffn_reduce_ln takes)
   if (t_gemm_prec != PREC_F32 || tune().gemm_x6 == 0 || !m->x6_at || w1.out != w2.in ||
       !(d == 256 || d == 512) || F % 16 != 0)
     return 0;
@@ -359,17 +363,44 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
   const bool fused_ok = tune().ffn_x6f != 0 && tune().x6_af32 == 0 && m->x6p_at &&
                         ffn_x6f_supported(M, d, F, act) && !(small && tune().ffn_x6f == 3);
   if (small && !fused_ok) return 0;
+  if (m->x6_at->count(w1.w) == 0 || m->x6_at->count(w2.w) == 0) return 0;
+  if (fused_ok && m->x6p_at->count(w2.w) != 0) return 1;
+  return 2;
+}
+
+// the image buffer of t1 = LN(x) when the next feed-forward module will take it, else null
+void* t1_image_for(wn_model* m, const Linear& w1, const Linear& w2, int act) {
+  if (tune().ffn_ximg == 0) return nullptr;
+  const int r = ffn_x6_route(m, w1, w2, act);
+  if (r == 0 || (r == 2 && tune().x6_af32 != 0)) return nullptr;
+  if (m->t1_img.ensure(x6_bytes(m->rows, m->cfg.d_model)) != 0) return nullptr;
+  return m->t1_img.p;
+}
+
+int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStream_t s) {
+  const int d = m->cfg.d_model, M = m->rows, F = w1.out;
+  const bool ximg = m->t1_img_ok;      // t1 exists ONLY as its plane image
+  m->t1_img_ok = false;
+  // (d: the widths ffn_reduce_ln takes)
+  const int route = ffn_x6_route(m, w1, w2, act);
+  if (route == 0) {
+    if (ximg) {
+      set_error("ffn_x6_try: LN(x) was left as a plane image but no six-product form takes it");
+      return -1;
+    }
+    return 0;
+  }
   auto i1 = m->x6_at->find(w1.w), i2 = m->x6_at->find(w2.w);
-  if (i1 == m->x6_at->end() || i2 == m->x6_at->end()) return 0;
   static thread_local int tick = 0;
-  if (fused_ok) {
+  if (route == 1) {
     // hidden tensor on chip (ffn_x6f.hip)
     auto ip = m->x6p_at->find(w2.w);
-    if (ip != m->x6p_at->end()) {
+    {
       FfnX6Args a;
       a.S = ffn_x6f_split(M, F);
       if (m->ffn_part.ensure((size_t)a.S * M * d * sizeof(float)) != 0) return -1;
       a.X = m->t1.as<float>(); a.ldx = d; a.W13 = i1->second; a.W2p = ip->second; a.b1 = w1.b;
+      if (ximg) { a.X3 = m->t1_img.p; a.X = nullptr; }
       a.P = m->ffn_part.as<float>(); a.M = M; a.D = d; a.F = F; a.act = act;
       const bool br = m->prof_on && (tick++ % 6) == 0;
       if (br) {
@@ -400,9 +431,17 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
   X6Args g1;
   g1.B3 = i1->second; g1.M = M; g1.N = F; g1.K = d; g1.bias = w1.b; g1.act = act;
   if (af32) {
+    if (ximg) {
+      set_error("ffn_x6_try: LN(x) was left as a plane image, x6_af32 wants fp32 rows");
+      return -1;
+    }
     if (m->hbuf.ensure((size_t)M * F * sizeof(float)) != 0) return -1;
     g1.A = m->t1.as<float>(); g1.lda = d; g1.a_bytes = (int64_t)M * d * 4;
     g1.epi = 0; g1.C = m->hbuf.as<float>(); g1.ldc = F;
+  } else if (ximg) {
+    // the producer of LN(x) already wrote its plane image (round 5): no x6_split launch
+    if (m->x6_h.ensure(x6_bytes(M, F)) != 0) return -1;
+    g1.A3 = m->t1_img.as<char>(); g1.epi = 2; g1.C3 = m->x6_h.as<char>();
   } else {
     if (m->x6_a.ensure(x6_bytes(M, d)) != 0 || m->x6_h.ensure(x6_bytes(M, F)) != 0) return -1;
     if (x6_split(m->t1.as<float>(), M, d, d, m->x6_a.as<char>(), s) != 0) return -1;
@@ -742,6 +781,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
   // attention context (t2) hold bf16; the GLU output / depthwise-conv tensors
   // stay fp32 (the depthwise kernel is fp32)
   const bool h16 = bf16_store_active();
+  m->t1_img_ok = false;
   for (int li = 0; li < n_run; ++li) {
     const EncLayer& L = m->layers[li];
     // x += 0.5 * FFN_macaron(LN(x))                 encoder_layer.py:220-228
@@ -824,7 +864,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     // kernel exists at that width)
     const bool rowx = rowln || (!h16 && t_gemm_prec == PREC_F32 && d == 512);
     auto x6r_rowln = [&](const Linear& l, const float* A, const Norm& nrm,
-                         const DwConvArgs* dwc = nullptr) -> int {
+                         const DwConvArgs* dwc = nullptr, void* y_img = nullptr) -> int {
       if (!(rowx && tune().x6r != 0 && tune().gemm_x6 != 0 && t_x6 && M >= 512 &&
             gemm_x6r_supported(M, d, l.in, 1)))
         return 1;
@@ -835,7 +875,10 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       g.A = A; g.lda = d; g.K = d; g.W3 = it->second; g.bias = l.b; g.M = M; g.N = d; g.epi = 1;
       g.resid = x; g.ldr = d; g.alpha = 1.0f; g.x_out = x; g.ldx = d;
       g.ln_w = nrm.w; g.ln_b = nrm.b; g.eps = eps; g.y = t1; g.ldy = d;
-      return gemm_x6r(g, s) == 0 ? 0 : -1;
+      if (y_img) { g.y3 = y_img; g.y = nullptr; }     // LN(x) leaves as its plane image only
+      if (gemm_x6r(g, s) != 0) return -1;
+      m->t1_img_ok = y_img != nullptr;
+      return 0;
     };
     // out-projection + residual + LN_conv chained with pointwise_conv1 + GLU in ONE launch
     // (gemm_x6r.hip epi 3): LN_conv(x) never reaches HBM
@@ -897,7 +940,13 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     const bool dwc = tune().x6r_dwc != 0 && d == 256 && rowx && tune().x6r != 0 && tune().gemm_x6 != 0 && t_x6 &&
                      M >= 512 && t_x6->count(L.pw2.w) != 0 && gemm_x6r_supported(M, d, L.pw2.in, 1);
     if (!dwc) WN_TRY(dwconv_ln_silu(dw, s));
-    xr = x6r_rowln(L.pw2, t1, L.norm_ff, dwc ? &dw : nullptr);
+    // (the feed-forward module behind it takes LN_ff(x) as a plane image where it runs fused:
+    // asked BEFORE the launch, the row-block kernel is the only producer that can write one)
+    void* ff_img = nullptr;
+    if (!h16 && rowx && tune().x6r != 0 && tune().gemm_x6 != 0 && t_x6 && M >= 512 &&
+        gemm_x6r_supported(M, d, L.pw2.in, 1) && t_x6->count(L.pw2.w) != 0)
+      ff_img = t1_image_for(m, L.ff1, L.ff2, ACT_SILU);
+    xr = x6r_rowln(L.pw2, t1, L.norm_ff, dwc ? &dw : nullptr, ff_img);
     if (xr < 0) return -2;
     const bool ln_ff_done = xr == 0 || rowln;       // t1 = LN_ff(x) came out of the GEMM's epilogue
     if (xr == 0) {
@@ -921,9 +970,17 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       // partial reduction + residual + norm_final (+ the next layer's norm_ff_macaron)
       if (li + 1 < n_run) {
         const EncLayer& Ln = m->layers[li + 1];
-        WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ff2.b, 0.5f, L.norm_final.w,
-                             L.norm_final.b, Ln.norm_ff_mac.w, Ln.norm_ff_mac.b, t1, M, d, eps,
-                             1, s));
+        void* mac_img = t1_image_for(m, Ln.ffm1, Ln.ffm2, ACT_SILU);
+        if (mac_img) {
+          WN_TRY(ffn_reduce_ln_img(x, m->ffn_part.as<float>(), fS, L.ff2.b, 0.5f, L.norm_final.w,
+                                   L.norm_final.b, Ln.norm_ff_mac.w, Ln.norm_ff_mac.b, mac_img,
+                                   M, d, eps, s));
+          m->t1_img_ok = true;
+        } else {
+          WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ff2.b, 0.5f, L.norm_final.w,
+                               L.norm_final.b, Ln.norm_ff_mac.w, Ln.norm_ff_mac.b, t1, M, d, eps,
+                               1, s));
+        }
       } else {
         WN_TRY(ffn_reduce_ln(x, m->ffn_part.as<float>(), fS, L.ff2.b, 0.5f, L.norm_final.w,
                              L.norm_final.b, nullptr, nullptr, nullptr, M, d, eps, 2, s));

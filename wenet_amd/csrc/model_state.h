@@ -390,6 +390,10 @@ struct wn_model {
   // projected ahead of the rescoring pass (wn_rescore_prefetch), and the plane image of the
   // encoder output they were projected from
   DevBuf r_kv_all, r_enc3;
+  // X3 plane image of t1 = LN(x) for the fused six-product FFN (tune().ffn_ximg): valid while
+  // t1_img_ok (set by the producer launch, cleared by the consumer)
+  DevBuf t1_img;
+  bool t1_img_ok = false;
   bool kv_ready = false;
   // wn_model_set_encode_gate: one-shot event the next wn_encode waits for BEHIND its front end
   // (CMVN + conv1): chained encoders of several handles overlap only that HBM-bound kernel

@@ -61,6 +61,10 @@ namespace wn {
   /* fused six-product FFN (ffn_x6f.hip, d_model 256): 0 = the two six-product GEMMs (A/B,     \
      tests), 3 = round 4's rule (only batches that fill half the CUs; A/B) */                   \
   X(ffn_x6f, 1)                                                                                 \
+  /* fused FFN input: 1 = the producers of LN(x) (pointwise_conv2 row-block GEMM, the partial   \
+     reduction in front of the next layer) write its X3 plane image and the kernel loads         \
+     fragments; 0 = fp32 rows split by every slice block (A/B, tests: bit-identical) */          \
+  X(ffn_ximg, 1)                                                                                \
   /* WN_ABLATION builds: 4..6 = the older DMA stages of 24 records */                           \
   X(ffn_x6f_ring, 3)                                                                            \
   /* 25088 = the clock-stamp form; WN_ABLATION builds: the other VAR variants */                \

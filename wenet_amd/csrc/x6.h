@@ -29,4 +29,50 @@ __device__ __forceinline__ int64_t x3_piece(int kb, int tiles, int row, int h) {
   return ((int64_t)kb * tiles + (row >> 5)) * X3_TILE + h * 512 + (row & 31) * 16;
 }
 
+#ifdef __HIPCC__
+// One 32-column tile of a matrix held the way the operand-swapped MFMA leaves it -- lane = row
+// (li = lane & 31 of row tile `tile`), v[g] = columns 8 g + 4 hi .. + 3 of the tile, hi =
+// lane >> 5 -- stored as its pieces of the X3 image `img` (`tiles` row tiles): exact split,
+// then one half-wave exchange (v_permlane32_swap) so that the low lane holds columns 0-15 (k
+// block kb0), the high lane 16-31 (k block kb0 + 1) of its row as whole 16-byte pieces: 512
+// contiguous bytes per half-wave and store.  (gemm_x6.hip's EPI 2, shared by the row-block
+// kernels that hand LN(x) to a six-product consumer as fragments, round 5.)
+__device__ __forceinline__ void x3_store_tile(const f32x4 (&v)[4], void* img, int kb0, int tiles,
+                                              int tile, int hi, int li) {
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x2 q[3][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bf16x4 h0, h1, h2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const Split3 sp = split3(v[g][e]);
+      h0[e] = sp.h0; h1[e] = sp.h1; h2[e] = sp.h2;
+    }
+    q[0][g] = __builtin_bit_cast(i32x2, h0);
+    q[1][g] = __builtin_bit_cast(i32x2, h1);
+    q[2][g] = __builtin_bit_cast(i32x2, h2);
+  }
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      auto s0 = __builtin_amdgcn_permlane32_swap(q[pl][0][d], q[pl][2][d], false, false);
+      auto s1 = __builtin_amdgcn_permlane32_swap(q[pl][1][d], q[pl][3][d], false, false);
+      q[pl][0][d] = s0[0]; q[pl][2][d] = s0[1];
+      q[pl][1][d] = s1[0]; q[pl][3][d] = s1[1];
+    }
+  char* o = reinterpret_cast<char*>(img) + ((int64_t)(kb0 + hi) * tiles + tile) * X3_TILE + li * 16;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    // half 0: columns 0-7 of the k block = (own g0 | partner's g0), half 1: g1
+    *reinterpret_cast<i32x4*>(o + pl * X3_REC) =
+        i32x4{q[pl][0][0], q[pl][0][1], q[pl][2][0], q[pl][2][1]};
+    *reinterpret_cast<i32x4*>(o + pl * X3_REC + 512) =
+        i32x4{q[pl][1][0], q[pl][1][1], q[pl][3][0], q[pl][3][1]};
+  }
+}
+#endif
+
 }  // namespace wn
