@@ -231,8 +231,10 @@ def test_bench_batch_config5_vs_reference_at_the_configured_shape():
 # operand rounding on both sides (what differs is the fp32 summation order, which moves values
 # across bf16 / e4m3 rounding boundaries, 32 blocks deep) -- measured (visit r06k, printed by the
 # test): bf16 1.6e-2, 2 of 24000 frames with another arg-max (golden margins <= 0.004); MXFP8 FFN
-# 1.2e-1, 10 frames (margins <= 0.23).  The per-frame margins are 5 x / 4 x those errors.
-LOWP_FRAME_EPS = {'bf16': 0.08, 'fp8': 0.5}
+# 1.2e-1, 10 frames (margins <= 0.23); re-measured unchanged in round 5 (r10l: strict frames
+# 0.999 / 0.996).  The per-frame margins are 2 x those errors (round 4: 5 x / 4 x), at least 99 %
+# of the frames must be compared strictly (round 4: 80 %).
+LOWP_FRAME_EPS = {'bf16': 0.032, 'fp8': 0.24}
 
 
 @pytest.mark.parametrize('mode', ['bf16', 'fp8'])
@@ -292,8 +294,8 @@ def test_config5_reduced_modes_token_level_vs_the_oracle_under_the_same_rounding
         same += int(list(res[b].tokens) == meta['greedy'][b])
     print(f'[config5 {mode}] strict frames {n_strict} / {n_frames} ({n_strict / n_frames:.3f}), flips '
           f'{n_flips}, identical token lists {same}/{B}')
-    assert err < eps / 2, err
-    assert n_strict >= 0.8 * n_frames
+    assert err < 0.75 * eps, err
+    assert n_strict >= 0.99 * n_frames
 
 
 def test_bench_verify_helper_matches_goldens():
