@@ -156,6 +156,39 @@ def test_encoder_with_folded_relpos_attention_matches_the_two_contraction_form(c
     assert 0 < err < 1e-4 and 0 < err2 < 1e-4
 
 
+@pytest.mark.parametrize('config,B,frames,chunk', [('aishell_u2pp', 4, (400, 700), -1),
+                                                   ('aishell_u2pp', 32, (800, 1200), -1),
+                                                   ('librispeech_bidecoder_large', 9, (900, 1310), -1),
+                                                   ('wenetspeech_u2pp', 6, (600, 900), 16),
+                                                   ('aishell_u2pp', 7, (130, 900), 16)])
+def test_six_product_attention_matches_the_f32_mfma_attention(config, B, frames, chunk):
+    """attention_x6.hip (both contractions of the folded rel-pos self attention as six bf16
+    plane products of exactly split fp32 operands: key-tile images by a pack pass, then the
+    kernel) against attention_kernel on v_mfma_f32: whole encoder, ragged lengths whose last key
+    tile is partial, full context (the default route) and chunk masks (attn_x6 = 2).  The two do
+    the same mathematics with other fp32 summation orders: 12 layers deep the encoder outputs
+    differ by reordering noise only, and the six-product form is deterministic."""
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=87)
+    try:
+        _lib.check(L.wn_tune_set(b'attn_x6', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        ref = ref.cpu()
+        _lib.check(L.wn_tune_set(b'attn_x6', 2), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got = got.cpu()
+    finally:
+        L.wn_tune_set(b'attn_x6', 1)
+    assert torch.equal(got, got2.cpu())            # race screen
+    err = (got - ref).abs().max().item()
+    print(f'\n[{config} B={B} chunk {chunk}] six-product attention vs v_mfma_f32: max |d enc| '
+          f'{err:.2e}')
+    assert 0 < err < 5e-5
+
+
 @pytest.mark.parametrize('M,N,epi', [(7932, 256, 1), (7932, 768, 0), (7932, 512, 0), (33, 256, 1),
                                      (1000, 256, 0), (31, 768, 0), (4097, 256, 1)])
 def test_gemm_x6r_vs_fp64(M, N, epi):

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, '..', 'build', 'obj')
 LIB = os.path.join(HERE, 'libwenet_amd.so')
-SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_bf16s.hip', 'gemm_bf16p.hip', 'ffn_fused.hip', 'gemm_rowln.hip', 'gemm_x6.hip', 'ffn_x6f.hip', 'gemm_x6r.hip', 'gemm_x6r512.hip', 'attn_search.hip', 'encoder_kernels.hip', 'attention_bf16.hip', 'ctc.hip', 'fbank.hip',
+SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_bf16s.hip', 'gemm_bf16p.hip', 'ffn_fused.hip', 'gemm_rowln.hip', 'gemm_x6.hip', 'ffn_x6f.hip', 'gemm_x6r.hip', 'gemm_x6r512.hip', 'attn_search.hip', 'encoder_kernels.hip', 'attention_bf16.hip', 'attention_x6.hip', 'ctc.hip', 'fbank.hip',
            'logmel.hip', 'model.hip', 'cabi.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-fno-gpu-rdc', '-Wno-unused-result']

@@ -970,6 +970,9 @@ int attention(const AttnArgs& a, hipStream_t s) {
            "attention: strides must be multiples of 4 floats");
   WN_CHECK(a.mask_mode != 2 || a.chunk_size > 0, "attention: chunk size");
   if (t_gemm_prec == PREC_BF16 && tune().attn_bf16 != 0) return attention_bf16(a, s);
+  if (t_gemm_prec == PREC_F32 && tune().attn_x6 != 0 && (a.mask_mode == 0 || tune().attn_x6 == 2) &&
+      attention_x6_supported(a))
+    return attention_x6(a, s);
   constexpr int NW = 2;
   dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 64);
   // key split for the encoder's self attention over long sequences: twice the

@@ -82,8 +82,15 @@ struct AttnArgs {
   int mask_mode = 0;   // 0: keys < kv_len; 1: causal; 2: chunk window
   int chunk_size = 0, left_chunks = -1;
   float scale = 0.125f;
+  // scratch for the six-product form (attention_x6.hip): the key-tile images of this launch;
+  // x6_rows = rows of the K / V matrix (all sequences)
+  void* x6_img = nullptr; size_t x6_img_bytes = 0; int x6_rows = 0;
 };
 int attention(const AttnArgs& a, hipStream_t s);
+// rel-pos self attention as six bf16 plane products (attention_x6.hip): pack pass + kernel
+size_t attention_x6_image_bytes(int rows, int n_seq, int n_heads);
+bool attention_x6_supported(const AttnArgs& a);
+int attention_x6(const AttnArgs& a, hipStream_t s);
 int relpos_fold(float* K, int ldk, const float* P, int ldp, const float* bias_u,
                 const float* bias_v, const int* row_utt, const int* off, const int* p_off,
                 float* kbias, int n_heads, int M, int D, hipStream_t s);

@@ -856,6 +856,13 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     a.n_seq = m->B; a.n_heads = c.n_heads; a.max_q_len = max_len;
     a.mask_mode = mask_mode; a.chunk_size = cs; a.left_chunks = lc;
     a.scale = 1.0f / sqrtf(64.0f);
+    if (a.fold && tune().attn_x6 != 0 && !h16 && t_gemm_prec == PREC_F32 && M >= 512) {
+      // the six-product form wants a scratch image of the key tiles (attention_x6.hip)
+      const size_t need = attention_x6_image_bytes(M, m->B, c.n_heads);
+      if (m->attn_img.ensure(need) == 0) {
+        a.x6_img = m->attn_img.p; a.x6_img_bytes = m->attn_img.cap; a.x6_rows = M;
+      }
+    }
     WN_TRY(attention(a, s));
     // x += out_proj(context); t1 = LN_conv(x)       encoder_layer.py:236-240
     const bool rowln = !h16 && t_gemm_prec == PREC_F32 && gemm_rowln_supported(M, d, d);

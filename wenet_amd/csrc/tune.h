@@ -84,6 +84,10 @@ namespace wn {
   X(gemm_rowln, 1)                                                                              \
   /* depthwise convolution: 1 = four rows per wave; 0 = one row per wave (A/B, tests) */        \
   X(dwconv_tiled, 1)                                                                            \
+  /* rel-pos self attention of the fp32 mode over full-context batches: 1 = six bf16 plane      \
+     products (attention_x6.hip: pack pass + kernel), 0 = the v_mfma_f32 kernel (A/B, tests);   \
+     2 = also under chunk masks (measured slightly slower there) */                             \
+  X(attn_x6, 1)                                                                                 \
   /* rel-pos attention: 0 = two contractions per score, 2 = the fold as a separate pass */      \
   X(attn_fold, 1)                                                                               \
   /* 0 = cross attention of the rescoring decoder per hypothesis (A/B, tests) */                \
