@@ -647,8 +647,11 @@ def main():
                 # fp32 X in once, W_1 + W_2 planes once (6 B / element; every row tile
                 # re-reads them from L2), the hidden-slice partials out; the hidden tensor
                 # itself never leaves the registers
+                # (round 5: X arrives as its plane image, 6 B / element, written by the producer
+                # of LN(x); each XCD pair of slice blocks fetches it once)
                 line['roofline']['algorithmic_bytes'] = int(
-                    4 * enc_rows * d_model * (1 + ffn_split) + 6 * 2 * ffn * d_model)
+                    6 * enc_rows * d_model + 4 * enc_rows * d_model * ffn_split
+                    + 6 * 2 * ffn * d_model)
             elif x6:
                 # A planes in (6 B / element), W planes (L2-resident across row tiles),
                 # hidden-tensor planes out
