@@ -741,6 +741,40 @@ def test_pipeline_two_streams_matches_sequential_decode():
                         assert list(a.nbest_scores) == list(b.nbest_scores)
 
 
+@pytest.mark.parametrize('gate', [True, False])
+def test_pipeline_encode_gate_keeps_results_and_survives_a_failed_decode(gate):
+    """wn_model_set_encode_gate (round 5): with two decodes in flight the wait for the previous
+    decode's encoder sits BEHIND the next decode's CMVN + conv1, which then runs beside that
+    encoder -- on its own workspace, so every result must equal the sequential decode()'s, on
+    batches of different shapes back to back (a front end that ran too early or an encoder that
+    did not wait shows up as another batch's numbers).  A decode that fails in front of
+    wn_encode must not leave its gate on the handle."""
+    from wenet_amd import synthetic as S
+    from wenet_amd.pipeline import DecodePipeline
+    configs, sd, model = cached_model('aishell_u2pp', 0)
+    batches = []
+    for i in range(6):
+        feats, lens = S.make_features(6 + 5 * (i % 3), (300, 900), seed=300 + i)
+        batches.append((feats.cuda(), lens))
+    M = ['ctc_prefix_beam_search']
+    seq = [model.decode(M, f, l, beam_size=6) for f, l in batches]
+    with DecodePipeline(model, n_streams=2) as pipe:
+        pipe.gate_front_end = gate
+        par = pipe.decode_many(M, batches, beam_size=6)
+        # a decode that raises before its encoder is queued (decoding_chunk_size = 0,
+        # asr_model.py:310), then the same batches again in the other order
+        with pytest.raises(AssertionError):
+            pipe.submit(M, batches[0][0], batches[0][1], beam_size=6,
+                        decoding_chunk_size=0).result()
+        par2 = pipe.decode_many(M, batches[::-1], beam_size=6)[::-1]
+    for got_all in (par, par2):
+        for want, got in zip(seq, got_all):
+            for a, b in zip(want[M[0]], got[M[0]]):
+                assert list(a.tokens) == list(b.tokens) and a.score == b.score
+                assert [list(x) for x in a.nbest] == [list(x) for x in b.nbest]
+                assert list(a.nbest_scores) == list(b.nbest_scores)
+
+
 # --------------------------------------------------------------------------
 # context biasing (ContextGraph, search.py:127-249 with context_graph)
 

@@ -84,8 +84,10 @@ class DecodePipeline:
             kw.pop('infos', None)
             with torch.cuda.stream(stream):
                 with self._enc_lock:
+                    gated = False
                     if self._enc_done is not None:
                         if self.gate_front_end:
+                            gated = True
                             # the wait goes BEHIND this decode's front end (CMVN + conv1, the
                             # encoder's one HBM-bound kernel): it runs beside the previous
                             # decode's matrix-bound layers, the rest of the encoder after them
@@ -93,8 +95,15 @@ class DecodePipeline:
                                 self.models[i]._h, self._enc_done.cuda_event), 'encode gate')
                         else:
                             stream.wait_event(self._enc_done)
-                    st = self.models[i]._decode_begin(methods, speech,
-                                                      speech_lengths, **kw)
+                    try:
+                        st = self.models[i]._decode_begin(methods, speech,
+                                                          speech_lengths, **kw)
+                    except BaseException:
+                        # wn_encode may not have been reached: a gate left on the handle would
+                        # make its NEXT encode wait for an event that no longer exists
+                        if gated:
+                            _lib.lib().wn_model_set_encode_gate(self.models[i]._h, None)
+                        raise
                     done = torch.cuda.Event()
                     done.record(stream)
                     self._enc_done = done
