@@ -72,8 +72,12 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// SiLU of the convolution module (convolution.py:146: x * sigmoid(x)) on v_exp_f32 / v_rcp_f32 --
+// ~1 ulp each, the form the fused feed-forward kernels always used (gemm_epilogue.h silu_fast) --
+// instead of the exact expf and the IEEE division sequence: 7.5 k of the depthwise-conv prologue's
+// 19 k cycles went into those (round 4 stamps); round 5.
 __device__ __forceinline__ float silu_f(float x) {
-  return x / (1.0f + expf(-x));
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 __device__ __forceinline__ float sigmoid_f(float x) {
   return 1.0f / (1.0f + expf(-x));
