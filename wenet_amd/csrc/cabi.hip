@@ -678,6 +678,9 @@ int wn_encode(wn_model* m, const float* feats_dev, const int32_t* feat_lens_host
               float* enc_out_dev, int32_t* enc_lens_host, void* stream) {
   WN_CHECK(m && feats_dev && feat_lens_host, "wn_encode: null argument");
   WN_ENTER(m);
+  // the encode gate is one-shot: whatever way this call ends (an argument check included), it
+  // does not stay on the handle for a later call to wait on an event that may be gone by then
+  struct GateDrop { wn_model* m; ~GateDrop() { m->enc_gate = nullptr; } } gate_drop{m};
   m->pb_valid = false;
   PrecisionScope prec_scope(m);
   WN_CHECK(!m->layers.empty() || !m->tf_layers.empty(),
