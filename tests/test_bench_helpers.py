@@ -87,3 +87,38 @@ def test_freeze_host_heap_keeps_the_collector_enabled():
     finally:
         gc.unfreeze()
     assert gc.get_freeze_count() == 0
+
+
+def test_pmc_roofline_records_are_keyed_by_workload_and_dtype(tmp_path, monkeypatch):
+    """profiles/pmc_roofline_kernels.json (bench.py's `roofline.traffic`): one record per
+    '<workload>:<dtype>', filed by `tools/pmc_table.py --merge`; every committed record carries
+    the fields bench.py reads and names the kernel family bench.py reports for that workload."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    table = json.load(open(os.path.join(root, 'profiles', 'pmc_roofline_kernels.json')))
+    want = {'config2:fp32': 'ffn_x6f_kernel', 'config3:fp32': 'gemm_x6_kernel',
+            'config4:fp32': 'gemm_x6_kernel', 'config5:bf16': 'gemm_lp_kernel<0',
+            'config5:fp8': 'gemm_lp_kernel<1'}
+    for key, fam in want.items():
+        rec = table[key]
+        assert fam in rec['kernel'], (key, rec['kernel'])
+        assert rec['hbm_bytes_per_launch'] == rec['hbm_read_bytes_per_launch'] + \
+            rec['hbm_write_bytes_per_launch']
+        assert 0.0 < rec['mfma_busy'] < 1.0 and rec['avg_us'] > 0 and rec['visit']
+    # --merge files a record under its key and leaves the others alone
+    spec = importlib.util.spec_from_file_location('pmc_table', os.path.join(root, 'tools',
+                                                                           'pmc_table.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    (tmp_path / 'tools').mkdir()
+    (prof / 'pmc_roofline_kernels.json').write_text(json.dumps({'config2:fp32': {'kernel': 'a'}}))
+    rec = tmp_path / 'rec.json'
+    rec.write_text(json.dumps({'key': 'config9:bf16', 'kernel': 'b', 'avg_us': 1.0}))
+    monkeypatch.setattr(mod, '__file__', str(tmp_path / 'tools' / 'pmc_table.py'))
+    mod.merge(str(rec))
+    merged = json.loads((prof / 'pmc_roofline_kernels.json').read_text())
+    assert merged == {'config2:fp32': {'kernel': 'a'}, 'config9:bf16': {'kernel': 'b',
+                                                                        'avg_us': 1.0}}
