@@ -69,6 +69,14 @@ def test_bench_eight_ranks_on_one_gpu_equals_the_reference_per_utterance(workloa
     assert d['verified'] is True, d['verify']
     assert d['verify']['utterances'] == 256
     assert d['verify']['identical'] + d['verify']['near_tie'] == 256
+    # the per-rank diagnosis of the N-GPU line (round 5): one entry per rank, own decode time
+    # per step below the max-reduced step time, every rank saw its result gathers
+    rk = d['ranks']
+    assert len(rk['decode_ms_per_step']) == 8 and len(rk['gather_ms_median']) == 8
+    assert all(0.0 < x <= d['rounds']['ms_per_step_max'] * 1.001 for x in rk['decode_ms_per_step'])
+    assert all(x > 0.0 for x in rk['gather_ms_median']) and all(x >= 0.0 for x in
+                                                                rk['drain_wait_ms_per_round'])
+    assert rk['decode_ms_per_step_spread'] >= 0.0
 
 
 def test_bench_rccl_process_group_of_one_rank():
