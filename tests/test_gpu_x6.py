@@ -278,6 +278,38 @@ def test_ffn_input_as_a_plane_image_is_bit_identical(config, B, frames, chunk):
     assert torch.equal(got.cpu(), ref) and torch.equal(got2.cpu(), ref)
 
 
+@pytest.mark.parametrize('config,B,frames,chunk', [('aishell_u2pp', 32, (800, 1200), -1),
+                                                   ('aishell_u2pp', 24, (900, 1500), -1),
+                                                   ('wenetspeech_u2pp', 20, (700, 1100), 16)])
+def test_conv2_tile_forms_agree(config, B, frames, chunk):
+    """tune x6_conv_bm (round 5): the subsampling conv2 as ONE launch of 128-row tiles on four
+    waves (the default: it loses least to the prefix beam search it shares the chip with when
+    decodes are in flight) against 256-row tiles on eight waves with the last round as K slices.
+    Every output element of a full tile is accumulated over the same k blocks in the same order
+    by both tile shapes; only the rows of the K-sliced last round are summed in another order
+    (N <= 256) -- reordering noise at most, and nothing at all where that tail does not exist."""
+    from gpu_util import cached_model
+    from wenet_amd import _lib, synthetic as S
+    L = _lib.lib()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=91)
+    try:
+        _lib.check(L.wn_tune_set(b'x6_conv_bm', 0), 'tune')
+        ref, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        _lib.check(L.wn_tune_set(b'x6_conv_bm', 128), 'tune')
+        got, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+        got2, _ = model._forward_encoder(feats.cuda(), lens, chunk, -1)
+    finally:
+        L.wn_tune_set(b'x6_conv_bm', 128)
+    assert torch.isfinite(ref).all() and torch.equal(got.cpu(), got2.cpu())
+    err = (got - ref).abs().max().item()
+    print(f'\n[{config} B={B}] conv2 128-row one launch vs 256-row + K-slice tail: max |d enc| {err:.2e}')
+    if configs['encoder_conf']['output_size'] > 256:
+        assert err == 0.0       # no K-slice tail at N = 512: the same bits
+    else:
+        assert err < 2e-5
+
+
 @pytest.mark.parametrize('ring', [3, 4, 5])
 def test_ffn_on_chip_equals_itself_for_every_ring_depth(ring):
     """The DMA ring depth changes only when operands arrive, never what is multiplied: the

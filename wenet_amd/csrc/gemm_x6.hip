@@ -604,6 +604,16 @@ int gemm_x6(const X6Args& args, hipStream_t s) {
       return rows == 256 ? launch_x6<256, 0, ACT_RELU, true>(x, s)
                          : launch_x6<128, 0, ACT_RELU, true, false, 4>(x, s);
     };
+    // tune().x6_conv_bm = 128 (round 5, the default): the WHOLE conv2 as ONE launch of 128-row
+    // tiles on four waves, two blocks per CU.  With two decodes in flight conv2 runs beside the
+    // previous decode's prefix beam search, which holds 32 CUs for ~0.9 ms: the 256-row form's
+    // second launch below -- the last round as K slices, 231 blocks meant for 256 free CUs --
+    // then spills into a second round and doubles, its full rounds lose 12.5 %; the finer tiles
+    // of one launch lose 51 us where the three launches lose ~137 (r12l: +2.3 % per step).  Alone
+    // the one-launch form is 3 % slower (844 vs 822 us: -0.4 % on a plain decode()); it is the
+    // default for every caller so that DecodePipeline and decode() return the same bits (the
+    // K-slice tail sums in another order).  0 = the 256-row form (A/B).
+    if (a.bm == 0 && tune().x6_conv_bm == 128 && !af32) return run(a, 128);
     if (a.bm == 0 && a.N <= XBN && full > 0 && t256 - full > 0 && t256 - full <= ncu / 2) {
       X6Args main = a, rest = a;
       main.M = full * 256;

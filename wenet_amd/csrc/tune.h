@@ -55,6 +55,11 @@ namespace wn {
   /* 0 = activations reach gemm_x6 as plane images; 1 = as fp32 rows split in registers.       \
      Measured (r02ag): the split costs more than the plane bytes it saves */                    \
   X(x6_af32, 0)                                                                                 \
+  /* subsampling conv2 (six-product implicit GEMM): 128 = one launch of 128-row tiles on four   \
+     waves, two blocks per CU (loses least to the prefix beam search it shares the chip with     \
+     when decodes are in flight); 0 = 256-row tiles on eight waves + the last round as K         \
+     slices (3 % faster alone; A/B) */                                                          \
+  X(x6_conv_bm, 128)                                                                            \
   /* gemm_x6: 4 = clock stamps; 8 = wn_profile_gemm_clocks returns the row-block kernel's      \
      phase stamps (gemm_x6r.hip); WN_ABLATION builds: 1 no MFMAs, 2 no DMA */                  \
   X(x6_probe, 0)                                                                                \
