@@ -21,9 +21,13 @@ def main(path):
                       'order by start').fetchall()
     beams = [r for r in rows if 'prefix_beam' in r[0]]
     d = [(beams[i + 1][3] - beams[i][3]) / 1e6 for i in range(len(beams) - 1)]
-    wins = [(beams[i][3], beams[i + 1][3]) for i in range(len(d)) if 5.3 < d[i] < 6.0]
+    # steady two-stream intervals: consecutive beam searches `lo`..`hi` ms apart (argv[2:4];
+    # a plain decode() leg in the same trace -- bench.py's roofline pass -- is ~0.7 ms longer)
+    lo = float(sys.argv[2]) if len(sys.argv) > 2 else 4.7
+    hi = float(sys.argv[3]) if len(sys.argv) > 3 else 5.6
+    wins = [(beams[i][3], beams[i + 1][3]) for i in range(len(d)) if lo < d[i] < hi]
     if not wins:
-        raise SystemExit('no steady two-stream intervals (beam searches 5.3-6.0 ms apart)')
+        raise SystemExit(f'no steady two-stream intervals (beam searches {lo}-{hi} ms apart)')
     n = len(wins)
     print(f'{n} steady intervals, {statistics.mean((b - a) / 1e6 for a, b in wins):.3f} ms '
           'per decode')
