@@ -343,8 +343,15 @@ def main():
 
     out = run_steps(args.warmup)
     L = _lib.lib()
+    # (one bracketed launch of the roofline kernel per decode inside the timed rounds: every event
+    # pair idles the GPU for ~10 us around the launch -- four per decode were 0.8 % of a step in
+    # the two-stream timeline, r13b; the roofline figures come from the single-stream pass below,
+    # which brackets every 6th launch)
+    ffn_launches_per_decode = 2 * configs['encoder_conf']['num_blocks']
     for mdl in pipe.models:
-        _lib.check(L.wn_profile_enable(mdl._h, 1), 'profile')
+        _lib.check(L.wn_profile_enable(
+            mdl._h, int(os.environ.get('WN_BENCH_PROF_STRIDE', max(6, ffn_launches_per_decode)))),
+            'profile')
     # The host's cyclic GC walks every tracked object (torch modules, state dicts, the
     # goldens: a large, static heap) on each full collection -- measured 25 % slower rounds
     # about once a second and 4 % on the median (r02ax).  After warm-up the objects alive so

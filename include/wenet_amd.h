@@ -498,7 +498,8 @@ int wn_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev,
  * FFN w_1 GEMM, positionwise_feed_forward.py:58; every 6th launch, because each
  * event pair idles the GPU for ~10 us) with HIP events on the launch stream.  wn_profile_collect waits for them and returns the number of
  * launches, their summed duration and their summed algorithmic FLOPs
- * (2*M*N*K each) since the last enable/collect. */
+ * (2*M*N*K each) since the last enable/collect.  on = 1: every 6th launch; on = N > 1: every
+ * N-th (bench.py's timed rounds use one bracket per decode, its single-stream roofline pass 6). */
 int wn_profile_enable(wn_model* m, int32_t on);
 int wn_profile_collect(wn_model* m, int32_t* n_launches, double* total_ms,
                        double* total_flops);

@@ -577,6 +577,7 @@ int wn_model_set_encode_gate(wn_model* m, void* event) {
 int wn_profile_enable(wn_model* m, int32_t on) {
   WN_CHECK(m, "wn_profile_enable: null model");
   m->prof_on = on != 0;
+  m->prof_stride = on > 1 ? (unsigned)on : 6u;   // on = 1: every 6th launch; on = N > 1: every N-th
   m->prof_used = 0;
   m->prof_flops = 0.0;
   return 0;

@@ -122,7 +122,7 @@ int ffn_w1(wn_model* m, const Linear& l, const float* A, float* C, int M,
   // every hipEventRecord pair costs ~10 us of idle GPU around the launch
   // (measured in the rocprofv3 trace), so only every 6th launch is bracketed:
   // an unbiased sample of the average launch duration (4 per 12-layer pass)
-  if (!m->prof_on || (m->prof_seq++ % 6) != 0)
+  if (!m->prof_on || (m->prof_seq++ % m->prof_stride) != 0)
     return linear(l, A, l.in, C, l.out, M, s, act, nullptr, 0, 1.0f, false, h16, h16);
   if (m->prof_used + 2 > m->prof_ev.size()) {
     for (int i = 0; i < 64; ++i) {
@@ -193,7 +193,7 @@ int ffn_module(wn_model* m, const Norm& nrm, const Linear& w1, const Linear& w2,
   g.a_scale = m->mx_sa.as<unsigned>(); g.a_scale_pitch = pitch;
   g.w_scale = q1->scale; g.w_scale_pitch = w1.out;
   g.c_scale = m->mx_sh.as<unsigned>(); g.c_scale_pitch = pitch;
-  const bool bracket = m->prof_on && (m->prof_seq++ % 6) == 0;
+  const bool bracket = m->prof_on && (m->prof_seq++ % m->prof_stride) == 0;
   if (bracket) {
     if (m->prof_used + 2 > m->prof_ev.size())
       for (int i = 0; i < 64; ++i) {
@@ -402,7 +402,7 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
       a.X = m->t1.as<float>(); a.ldx = d; a.W13 = i1->second; a.W2p = ip->second; a.b1 = w1.b;
       if (ximg) { a.X3 = m->t1_img.p; a.X = nullptr; }
       a.P = m->ffn_part.as<float>(); a.M = M; a.D = d; a.F = F; a.act = act;
-      const bool br = m->prof_on && (tick++ % 6) == 0;
+      const bool br = m->prof_on && (tick++ % m->prof_stride) == 0;
       if (br) {
         if (m->prof_used + 2 > m->prof_ev.size())
           for (int i = 0; i < 64; ++i) {
@@ -447,7 +447,7 @@ int ffn_x6_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipStre
     if (x6_split(m->t1.as<float>(), M, d, d, m->x6_a.as<char>(), s) != 0) return -1;
     g1.A3 = m->x6_a.as<char>(); g1.epi = 2; g1.C3 = m->x6_h.as<char>();
   }
-  const bool bracket = m->prof_on && (tick++ % 6) == 0;
+  const bool bracket = m->prof_on && (tick++ % m->prof_stride) == 0;
   if (bracket) {
     if (m->prof_used + 2 > m->prof_ev.size())
       for (int i = 0; i < 64; ++i) {
@@ -520,7 +520,7 @@ int ffn_fused_try(wn_model* m, const Linear& w1, const Linear& w2, int act, hipS
   a.M = M; a.D = d; a.F = w1.out; a.S = ffn_fused_split(M, d, w1.out); a.act = act;
   if (m->ffn_part.ensure((size_t)a.S * M * d * sizeof(float)) != 0) return -1;
   a.P = m->ffn_part.as<float>();
-  const bool bracket = m->prof_on && (m->prof_seq++ % 6) == 0;
+  const bool bracket = m->prof_on && (m->prof_seq++ % m->prof_stride) == 0;
   if (bracket) {
     if (m->prof_used + 2 > m->prof_ev.size())
       for (int i = 0; i < 64; ++i) {

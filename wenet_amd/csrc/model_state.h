@@ -407,6 +407,7 @@ struct wn_model {
   size_t prof_used = 0;
   bool prof_on = false;
   unsigned prof_seq = 0;
+  unsigned prof_stride = 6;   // every prof_stride-th launch of the kernel is bracketed
   double prof_flops = 0.0;
   const char* prof_kernel = "gemm (FFN w_1)";  // what the bracketed launches were
   int prof_split = 1;        // hidden slices / K slices of the feed-forward module last run
