@@ -640,6 +640,11 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
     WN_TRY(upload_desc(m, m->d_off1, off1, s));
     WN_TRY(upload_desc(m, m->d_len1, len1, s));
     WN_TRY(m->stage.end(s));
+    // encode gate, position 0 (the default): the wait for the previous decode sits BEHIND this
+    // call's descriptor uploads -- five small host -> device copies, ~22 us of copy kernels plus
+    // their launch gaps that otherwise stand in the encoder chain (two-stream timeline r13b) --
+    // and in front of conv1
+    if (tune().enc_gate_pos == 0) WN_TRY(encode_gate_wait(m, s));
     WN_TRY(m->c1.ensure((size_t)M1 * F1 * d * sizeof(float)));
     WN_TRY(m->c2.ensure((size_t)M * F2 * d * sizeof(float)));
     WN_TRY(m->x.ensure((size_t)M * d * sizeof(float)));

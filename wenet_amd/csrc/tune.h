@@ -55,6 +55,10 @@ namespace wn {
   /* 0 = activations reach gemm_x6 as plane images; 1 = as fp32 rows split in registers.       \
      Measured (r02ag): the split costs more than the plane bytes it saves */                    \
   X(x6_af32, 0)                                                                                 \
+  /* wn_model_set_encode_gate: where wn_encode waits for the event: 0 = behind its descriptor   \
+     uploads, in front of conv1; 1 = behind CMVN + conv1 (that kernel then runs beside the       \
+     previous decode's layers: +0.7 % with the 256-row conv2, -0.6 % with the 128-row one) */   \
+  X(enc_gate_pos, 0)                                                                            \
   /* subsampling conv2 (six-product implicit GEMM): 128 = one launch of 128-row tiles on four   \
      waves, two blocks per CU (loses least to the prefix beam search it shares the chip with     \
      when decodes are in flight); 0 = 256-row tiles on eight waves + the last round as K         \

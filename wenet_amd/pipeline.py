@@ -69,14 +69,19 @@ class DecodePipeline:
         # encoder chain: launch order == execution order of the encoders
         self._enc_lock = threading.Lock()
         self._enc_done = None
-        # wn_model_set_encode_gate: the next decode's CMVN + conv1 beside this decode's encoder.
-        # +0.7 % while conv2 ran as 256-row tiles (r10b); with conv2 as one launch of 128-row tiles
-        # the better order is conv1 + conv2 (0.97 ms) UNDER the previous decode's prefix beam
-        # search (0.95 ms) -- the HBM-bound conv1 does not care about the 32 CUs the search
-        # holds, and the search is over when the single-round kernels behind conv2 start
-        # (`sub_out`: 102 us alone, 185 us under the search) -- gate off: +0.6 % (r12p).
-        # WN_PIPE_GATE=1 turns it on (A/B).
-        self.gate_front_end = os.environ.get('WN_PIPE_GATE', '0') == '1'
+        # The wait for the previous decode's encoder is handed to the library
+        # (wn_model_set_encode_gate), which places it BEHIND its own descriptor uploads (five
+        # small host -> device copies that otherwise stand in the encoder chain) and in front of
+        # conv1 (tune enc_gate_pos = 0).  WN_PIPE_GATE=0: plain stream wait in front of the whole
+        # call; WN_PIPE_GATE=2: behind CMVN + conv1 (+0.7 % while conv2 ran as 256-row tiles,
+        # r10b; -0.6 % with conv2 as one launch of 128-row tiles: conv1 + conv2 = 0.97 ms then fit
+        # under the previous decode's prefix beam search, 0.95 ms, which is over when the
+        # single-round kernels behind conv2 start, r12p).
+        gate_mode = os.environ.get('WN_PIPE_GATE', '1')
+        self.gate_front_end = gate_mode != '0'
+        if gate_mode == '2':
+            for m in self.models:
+                m.tune('enc_gate_pos', 1)
 
     def _run(self, ready: torch.cuda.Event, methods, speech, speech_lengths, kw):
         i = self._free.get()
