@@ -132,11 +132,12 @@ int32_t wn_batch_size(const wn_model* m);
 
 /* One-shot: the NEXT wn_encode on this handle waits for `event` (a hipEvent_t already
  * recorded by the caller, e.g. "the previous batch's encoder is finished" on another handle's
- * stream) BEHIND its front end -- GlobalCMVN + subsampling conv1 (cmvn.py:36-47,
- * subsampling.py:188-189), the one HBM-bound kernel of the encoder (10 MB of features ->
- * a ~1-GB operand image) -- instead of the caller waiting in front of the whole call: the
- * front end of batch i+1 then runs beside the matrix-bound encoder of batch i, everything
- * behind it after it (wenet_amd/pipeline.py).  Encoders without that front end wait first.
+ * stream) INSIDE the call instead of the caller waiting in front of it -- behind the call's own
+ * descriptor uploads and in front of GlobalCMVN + subsampling conv1 (the default, tune
+ * enc_gate_pos = 0: the small host -> device copies of batch i+1 no longer stand in the chain of
+ * encoders), or behind CMVN + conv1 (enc_gate_pos = 1: cmvn.py:36-47, subsampling.py:188-189,
+ * the encoder's one HBM-bound kernel, then runs beside batch i's matrix-bound layers).  Used by
+ * wenet_amd/pipeline.py; whatever way the call ends, the gate does not stay on the handle.
  * No reference counterpart (the reference decodes one batch at a time, recognize.py:289). */
 int wn_model_set_encode_gate(wn_model* m, void* event);
 
