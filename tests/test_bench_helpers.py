@@ -103,8 +103,9 @@ def test_pmc_roofline_records_are_keyed_by_workload_and_dtype(tmp_path, monkeypa
     for key, fam in want.items():
         rec = table[key]
         assert fam in rec['kernel'], (key, rec['kernel'])
-        assert rec['hbm_bytes_per_launch'] == rec['hbm_read_bytes_per_launch'] + \
-            rec['hbm_write_bytes_per_launch']
+        # (the three fields are truncations of float averages: the sum may be off by one)
+        assert abs(rec['hbm_bytes_per_launch'] - rec['hbm_read_bytes_per_launch'] -
+                   rec['hbm_write_bytes_per_launch']) <= 1
         assert 0.0 < rec['mfma_busy'] < 1.0 and rec['avg_us'] > 0 and rec['visit']
     # --merge files a record under its key and leaves the others alone
     spec = importlib.util.spec_from_file_location('pmc_table', os.path.join(root, 'tools',

@@ -85,7 +85,7 @@ def main():
             rec = dict(key=key, kernel=k[:160], launches=n, avg_us=round(avg, 2),
                        mfma_busy=round(util, 4), hbm_read_bytes_per_launch=int(rd),
                        hbm_write_bytes_per_launch=int(wr),
-                       hbm_bytes_per_launch=int(rd + wr),
+                       hbm_bytes_per_launch=int(rd) + int(wr),
                        visit=os.path.basename(os.path.dirname(os.path.normpath(out))),
                        method='rocprofv3 --pmc, separate passes for FETCH_SIZE and '
                               'WRITE_SIZE (KiB; FETCH_SIZE x2 on gfx950), --streams 1')
