@@ -2,9 +2,9 @@
 """Headline benchmark: audio-seconds per second (RTF^-1) of the 12-layer
 Conformer decode path on MI355X (BASELINE.json `metric`).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        # N > 1: starts its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...   # or under a launcher
 
 One step = one `ASRModel.decode()` pass over one batch of synthetic fbank
 features that are already resident in HBM: BASELINE.json configs[1]
@@ -155,47 +155,79 @@ def cpu_baseline(configs, sd, feats, lens, method, kw, beam):
     return out
 
 
-def end_to_end_leg(model, lens, device, total_audio, ms_per_step):
-    """PCM -> tokens variant: the same utterance lengths
-    as 16 kHz waveforms resident in HBM go through wn_fbank (Kaldi fbank on the
-    GPU) before the decode.  The fbank pass is timed on its own (it is a separate
-    C-ABI call on the same stream) and added to the measured decode step."""
+def end_to_end_leg(model, pipe, finish, drain, barrier, lens, device, total_audio, steps,
+                   method, beam, decode_kw, depth):
+    """PCM -> tokens in ONE timed region (the reference's
+    runtime/core/bin/decoder_main.cc:52,64-70 times wav -> text the same way): the same
+    utterance lengths as 16 kHz waveforms resident in HBM; every step runs wn_fbank (Kaldi
+    fbank on the GPU, the caller's stream) into a feature buffer and hands that buffer to the
+    same two-decodes-in-flight pipeline as the headline; the round is bracketed by barrier +
+    synchronize like the headline's.  At most `depth` steps are submitted ahead and the
+    feature buffers form a ring of depth + 1, so a buffer is only rewritten after the decode
+    that read it has returned."""
+    import collections
     n_samp = [(int(t) - 1) * 160 + 400 for t in lens.tolist()]
     g = torch.Generator().manual_seed(99)
     waves = [(torch.rand(n, generator=g) * 0.6 - 0.3).numpy() for n in n_samp]
-    model.compute_fbank(waves)  # warm-up (+ host->device copy of the PCM)
     offs = np.zeros((len(waves) + 1, ), dtype=np.int64)
     offs[1:] = np.cumsum(n_samp)
     pcm = torch.from_numpy(np.concatenate(waves)).to(device)
     tmax = int(max(lens.tolist()))
-    feats = torch.empty((len(waves), tmax, 80), dtype=torch.float32, device=device)
+    ring = [torch.empty((len(waves), tmax, 80), dtype=torch.float32, device=device)
+            for _ in range(depth + 1)]
     nfr = np.zeros((len(waves), ), dtype=np.int32)
     L = _lib_mod.lib()
     stream = torch.cuda.current_stream(device).cuda_stream
-    # median of five event-bracketed groups of four calls (one bracket of ten once caught an
-    # 88-ms stall of the box right behind the test suite, r13a: 8.8 ms "per batch")
-    reps, groups = 20, []
+
+    def fbank_into(buf):
+        _lib_mod.check(L.wn_fbank(model._h, pcm.data_ptr(), _lib_mod.i64p(offs), len(waves),
+                                  buf.data_ptr(), tmax, _lib_mod.i32p(nfr), stream), 'wn_fbank')
+
+    def steps_pcm(n):
+        pending, last = collections.deque(), None
+        for i in range(n):
+            if len(pending) >= depth:
+                last = pending.popleft().result()[method]
+                finish(last)
+            buf = ring[i % len(ring)]
+            fbank_into(buf)
+            pending.append(pipe.submit([method], buf, lens, beam_size=beam, **decode_kw))
+        while pending:
+            last = pending.popleft().result()[method]
+            finish(last)
+        drain()
+        return last
+
+    steps_pcm(max(2, depth))       # warm-up
+    assert nfr.tolist() == [int(t) for t in lens.tolist()], 'fbank frame counts'
+    barrier()
+    t0 = time.perf_counter()
+    last = steps_pcm(steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    # the fbank pass alone, for the record (median of five event-bracketed groups of four)
+    groups = []
     for _ in range(5):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(4):
-            _lib_mod.check(L.wn_fbank(model._h, pcm.data_ptr(), _lib_mod.i64p(offs),
-                                      len(waves), feats.data_ptr(), tmax,
-                                      _lib_mod.i32p(nfr), stream), 'wn_fbank')
+            fbank_into(ring[0])
         e1.record()
         torch.cuda.synchronize()
         groups.append(e0.elapsed_time(e1) / 4)
-    fb_ms = statistics.median(groups)
     return {
-        'value': round(total_audio / ((ms_per_step + fb_ms) * 1e-3), 1),
+        'value': round(total_audio * steps / dt, 1),
         'unit': 'audio_s/s',
-        'fbank_ms_per_batch': round(fb_ms, 3),
-        'note': 'PCM resident in HBM -> wn_fbank -> decode; fbank timed separately '
-                f'(median of 5 groups of 4 calls, HIP events) and added to ms_per_step.  16-kHz PCM: no '
-                'resampling in this leg -- wn_resample (other sample rates) is pinned to an '
-                'fp64 evaluation of torchaudio\'s published definition only: PARITY '
-                'UNPINNED (torchaudio absent from the image, oracle/gen_golden_resample.py)',
+        'ms_per_step': round(dt / steps * 1e3, 3),
+        'fbank_ms_per_batch_alone': round(statistics.median(groups), 3),
+        'tokens_last_step': int(sum(len(r.tokens) for r in last)),
+        'note': 'ONE timed region per round of --steps steps: 16-kHz PCM resident in HBM -> '
+                'wn_fbank -> decode (the headline\'s pipeline) -> token lists on the host, '
+                'barrier + synchronize brackets.  No resampling in this leg -- wn_resample '
+                '(other sample rates) is pinned to an fp64 evaluation of torchaudio\'s '
+                'published definition only: PARITY UNPINNED (torchaudio absent from the image, '
+                'oracle/gen_golden_resample.py)',
     }
 
 
@@ -226,6 +258,8 @@ def main():
                          'roofline kernel')
     ap.add_argument('--no-nbest-leg', action='store_true',
                     help='skip the extra round that materialises every n-best list')
+    ap.add_argument('--no-e2e-leg', action='store_true',
+                    help='skip the extra round that starts from PCM (wn_fbank inside the round)')
     ap.add_argument('--no-plain-leg', action='store_true',
                     help='skip the extra round of plain back-to-back decode() calls')
     ap.add_argument('--tune', default='',
@@ -239,15 +273,33 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with '
-                         f'--nproc-per-node {args.gpus} (WORLD_SIZE={world})')
     # WN_BENCH_SHARE_GPU=1: self-test of the N > 1 code path on a 1-GPU box
     # (every rank on cuda:0, results gathered over gloo); never a measurement.
     share_gpu = os.environ.get('WN_BENCH_SHARE_GPU') == '1'
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks, one per GPU (the
+        # reference's tools/decode.sh:65-83 loop over `nj` jobs, wenet/bin/recognize.py:43-46);
+        # under torch.distributed.run the variables are there and this is skipped
+        from wenet_amd.dist import launch_local_ranks
+        if not share_gpu and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f'--gpus {args.gpus}: this node shows '
+                             f'{torch.cuda.device_count()} GPU(s)')
+        raise SystemExit(launch_local_ranks([os.path.abspath(__file__)] + sys.argv[1:],
+                                            args.gpus))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} under a launcher that started {world} rank(s) '
+                         f'(WORLD_SIZE={world}): start it with --nproc-per-node {args.gpus}, '
+                         'or without a launcher (bench.py starts its own ranks)')
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
+    # each rank's host threads (decode thread, the pipeline's workers, the result gatherer)
+    # on its own slice of the cores next to its GPU; WN_BENCH_PIN=0: leave the scheduler alone
+    pinned = []
+    if world > 1 and os.environ.get('WN_BENCH_PIN', '1') != '0':
+        from wenet_amd.dist import pin_rank_to_local_cores
+        pinned = pin_rank_to_local_cores(local_rank, world,
+                                         [0] * world if share_gpu else None)
     # WN_BENCH_FORCE_DIST=1: a process group (RCCL) even for one rank, so that the backend,
     # the device-tensor all_gather / all_reduce / barrier of the N > 1 path execute on a
     # 1-GPU box (tests/test_gpu_dist.py); the collectives of one rank are no-ops in time
@@ -480,6 +532,11 @@ def main():
                 clock_ghz = float((cyc / ns).mean())
         finally:
             _lib.check(L.wn_tune_set(b'ffn_x6f_var', 0), 'tune')
+    e2e = None
+    if world == 1 and not whisper and not args.no_e2e_leg:
+        e2e = end_to_end_leg(model, pipe, finish, gatherer.drain, barrier, lens, device,
+                             total_audio, args.steps, method, beam, decode_kw,
+                             max(1, args.streams))
     pipe.close()
     gather_ms = list(gatherer.latencies_ms)
     gatherer.close()
@@ -493,7 +550,9 @@ def main():
     med_i = sorted(range(len(round_s)), key=lambda i: round_s[i])[len(round_s) // 2]
     mine_diag = [local_decode_s[med_i] / args.steps * 1e3, local_drain_s[med_i] * 1e3,
                  statistics.median(gather_ms) if gather_ms else 0.0,
-                 max(gather_ms) if gather_ms else 0.0]
+                 max(gather_ms) if gather_ms else 0.0,
+                 float(len(pinned)), float(min(pinned)) if pinned else -1.0,
+                 float(max(pinned)) if pinned else -1.0]
     if dist_on:
         import torch.distributed as dist
         t = torch.tensor(mine_diag, dtype=torch.float64, device='cpu' if share_gpu else device)
@@ -581,6 +640,11 @@ def main():
                 'drain_wait_ms_per_round': [round(r[1], 3) for r in rank_diag],
                 'gather_ms_median': [round(r[2], 3) for r in rank_diag],
                 'gather_ms_max': [round(r[3], 3) for r in rank_diag],
+                'host_cpus_pinned': [{'n': int(r[4]), 'first': int(r[5]), 'last': int(r[6])}
+                                     for r in rank_diag],
+                'launcher': ('bench.py (wenet_amd.dist.launch_local_ranks)'
+                             if os.environ.get('WN_SELF_LAUNCHED') == '1' else
+                             'torch.distributed.run' if world > 1 or dist_on else None),
                 'note': 'per rank, median timed round: time until the rank\'s own last result '
                         'was on the host / --steps; wait for outstanding result gathers at '
                         'the round\'s end; one result gather (pack + all_gather + unpack on '
@@ -655,12 +719,15 @@ def main():
                                                   'visit ' + str(rec.get('visit', '?')) +
                                                   ' (' + str(rec.get('table', '')) + ')')
             if 'ffn_x6f' in prof_name:
-                # fp32 X in once, W_1 + W_2 planes once (6 B / element; every row tile
-                # re-reads them from L2), the hidden-slice partials out; the hidden tensor
-                # itself never leaves the registers
-                # (round 5: X arrives as its plane image, 6 B / element, written by the producer
-                # of LN(x); each XCD pair of slice blocks fetches it once)
+                # the ALGORITHM's bytes: X planes in once (6 B / element: LN(x) arrives as
+                # its plane image), W_1 + W_2 planes once, the result Y out once (fp32); the
+                # hidden tensor never leaves the registers.  What this launch geometry adds
+                # -- Y leaves as `ffn_split` hidden-slice partials instead of once -- is NOT
+                # algorithmic: it is listed beside it as launch_geometry_bytes
                 line['roofline']['algorithmic_bytes'] = int(
+                    6 * enc_rows * d_model + 4 * enc_rows * d_model
+                    + 6 * 2 * ffn * d_model)
+                line['roofline']['launch_geometry_bytes'] = int(
                     6 * enc_rows * d_model + 4 * enc_rows * d_model * ffn_split
                     + 6 * 2 * ffn * d_model)
             elif x6:
@@ -675,6 +742,9 @@ def main():
             else:
                 line['roofline']['algorithmic_bytes'] = int(
                     4 * (enc_rows * d_model + ffn * d_model + enc_rows * ffn))
+        if line['roofline'].get('traffic') and line['roofline'].get('algorithmic_bytes'):
+            line['roofline']['traffic_over_algorithmic'] = round(
+                line['roofline']['traffic'] / line['roofline']['algorithmic_bytes'], 2)
         if clock_ghz is not None:
             line['roofline']['shader_clock_ghz_sampled'] = round(clock_ghz, 3)
             line['roofline']['frac_at_sampled_clock'] = round(
@@ -729,9 +799,8 @@ def main():
                                       'this mode is per frame against the oracle under the same '
                                       'operand rounding at this shape (tests/golden/'
                                       'bench_config5_{bf16,fp8}.npz, tests/test_gpu_bench_parity.py)')
-        if world == 1 and not whisper:
-            line['end_to_end'] = end_to_end_leg(model, lens, device, total_audio,
-                                                ms_per_step)
+        if e2e is not None:
+            line['end_to_end'] = e2e
         if not args.no_cpu_baseline and world == 1 and not whisper:
             line['cpu_baseline'] = cpu_baseline(configs, sd, feats, lens, method,
                                                 decode_kw, beam)

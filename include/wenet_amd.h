@@ -98,8 +98,12 @@ int wn_model_clone(const wn_model* src, wn_model** out);
 /* Operand precision of the handle's contractions: the reference's
  * `recognize.py --dtype {fp32,bf16}` (wenet/bin/recognize.py:52-56,250-255: torch
  * autocast around model.decode).
- *   WN_PREC_F32  (default) fp32 operands on the fp32 matrix-core path: the parity
- *                mode (identical greedy tokens, rescoring scores within 1e-3);
+ *   WN_PREC_F32  (default) fp32 operands, fp32 accumulation: the parity mode (identical
+ *                greedy tokens, rescoring scores within 1e-3).  Large contractions run
+ *                as six products of the operands' three exact bf16 planes on the bf16
+ *                matrix cores (error against fp64 not above v_mfma_f32's:
+ *                tests/test_gpu_x6.py); small ones, and everything under
+ *                wn_tune_set("gemm_x6", 0), on v_mfma_f32_32x32x2_f32;
  *   WN_PREC_BF16 every Linear / pointwise-conv / subsampling-conv contraction
  *                rounds its two operands to bf16 (round to nearest even) and
  *                accumulates in fp32; the attention products likewise; LayerNorm,

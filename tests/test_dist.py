@@ -145,3 +145,93 @@ def test_result_gatherer_is_poisoned_by_a_failed_gather():
     with pytest.raises(RuntimeError, match='out of step'):
         g.close()
     assert not g._t.is_alive()
+
+
+# ---- the one-command N-rank launch (bench.py --gpus N without torchrun) and the per-rank
+# ---- core pinning: reference tools/decode.sh:65-83 (a shell loop over `nj` jobs)
+
+_RANK_SCRIPT = '''
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from wenet_amd import dist as wdist
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+assert os.environ['LOCAL_RANK'] == os.environ['RANK'] and os.environ['WN_SELF_LAUNCHED'] == '1'
+if len(sys.argv) > 2 and int(sys.argv[2]) == rank:
+    sys.exit(7)                      # a failing rank: the launcher must not hang on the others
+dist.init_process_group('gloo', rank=rank, world_size=world)
+mine = wdist.shard_indices(list(range(100, 110)), world, rank)
+rec = wdist.pack_results(mine, [[g, g + 1] for g in mine], [float(g) for g in mine], 8, 4, 'cpu')
+res = wdist.gather_results(rec, world)
+assert [g for g, _, _ in res] == list(range(10))
+if rank == 0:
+    open(sys.argv[1], 'w').write('ok %d' % world)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_launch_local_ranks_runs_n_ranks_and_returns_zero(tmp_path):
+    from wenet_amd import dist as wdist
+    script = tmp_path / 'rank.py'
+    script.write_text(_RANK_SCRIPT.format(root=ROOT))
+    out = tmp_path / 'out.txt'
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    assert wdist.launch_local_ranks([str(script), str(out)], 3, env=env) == 0
+    assert out.read_text() == 'ok 3'
+
+
+def test_launch_local_ranks_propagates_a_failing_rank(tmp_path):
+    from wenet_amd import dist as wdist
+    script = tmp_path / 'rank.py'
+    script.write_text(_RANK_SCRIPT.format(root=ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    import time
+    t0 = time.time()
+    assert wdist.launch_local_ranks([str(script), str(tmp_path / 'o'), '1'], 2, env=env) == 7
+    assert time.time() - t0 < 120     # rank 0 (waiting in the rendezvous) was terminated
+    assert not (tmp_path / 'o').exists()
+
+
+def test_cpulist_parse_and_format_round_trip():
+    from wenet_amd import dist as wdist
+    assert wdist.parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    assert wdist.parse_cpulist('') == []
+    assert wdist.format_cpulist([11, 0, 1, 2, 3, 8, 10]) == '0-3,8,10-11'
+
+
+def test_rank_core_plan_is_a_partition_of_whole_cores():
+    """Two sockets x 8 cores x 2 threads (cpu c and c + 16 are siblings); GPUs 0-3 hang off
+    socket 0, GPUs 4-7 off socket 1: every rank gets two whole cores of its GPU's socket, no
+    cpu twice, hyper-thread pairs together."""
+    from wenet_amd import dist as wdist
+    allowed = list(range(32))
+    sib = {c: [c % 16, c % 16 + 16] for c in allowed}
+    node0 = list(range(0, 8)) + list(range(16, 24))
+    node1 = list(range(8, 16)) + list(range(24, 32))
+    lists = [node0] * 4 + [node1] * 4
+    plans = [wdist.plan_rank_cpus(r, 8, allowed, lists, sib) for r in range(8)]
+    flat = [c for p in plans for c in p]
+    assert sorted(flat) == allowed                      # a partition of the machine
+    for r, p in enumerate(plans):
+        assert len(p) == 4 and set(p) <= set(node0 if r < 4 else node1)
+        assert all((c + 16) % 32 in p for c in p)       # whole cores
+    # no locality information: an even split of what the process may run on
+    plans = [wdist.plan_rank_cpus(r, 4, allowed, [None] * 4, sib) for r in range(4)]
+    assert sorted(c for p in plans for c in p) == allowed and all(len(p) == 8 for p in plans)
+    # a cgroup that leaves fewer than two cpus per rank: nothing is pinned
+    assert wdist.plan_rank_cpus(0, 8, [0, 1, 2, 3], [None] * 8, {}) == []
+    # the GPU's node lies outside the allowed set: fall back to the even split
+    got = wdist.plan_rank_cpus(1, 2, list(range(8)), [[40, 41], [40, 41]], {})
+    assert got == [4, 5, 6, 7]
+
+
+def test_pin_rank_to_local_cores_on_this_host():
+    from wenet_amd import dist as wdist
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        got = wdist.pin_rank_to_local_cores(1, 2)
+        if got:
+            assert sorted(os.sched_getaffinity(0)) == got and set(got) < set(before)
+    finally:
+        os.sched_setaffinity(0, before)

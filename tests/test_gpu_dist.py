@@ -79,6 +79,43 @@ def test_bench_eight_ranks_on_one_gpu_equals_the_reference_per_utterance(workloa
     assert rk['decode_ms_per_step_spread'] >= 0.0
 
 
+def test_bench_starts_its_own_eight_ranks_without_a_launcher():
+    """`python bench.py --gpus 8` the way the driver types it at N = 1 -- no torchrun around it:
+    bench.py becomes the launcher (wenet_amd.dist.launch_local_ranks), starts 8 ranks, each pins
+    its host threads, rank 0 prints the ONE line; 256 / 256 against the real reference's
+    8-rank golden (tests/golden/bench_config2_w8.npz).  Reference: tools/decode.sh:65-83."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(WN_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '8', '--steps', '2'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, 'exactly one JSON line (rank 0)'
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['global_batch'] == 256
+    assert d['verified'] is True and d['verify']['utterances'] == 256
+    assert d['verify']['identical'] + d['verify']['near_tie'] == 256
+    rk = d['ranks']
+    assert rk['launcher'].startswith('bench.py') and len(rk['decode_ms_per_step']) == 8
+    pins = rk['host_cpus_pinned']
+    assert len(pins) == 8
+    if all(p['n'] > 0 for p in pins):       # enough cores on this box: disjoint slices
+        spans = sorted((p['first'], p['last']) for p in pins)
+        assert len(set(spans)) == 8
+
+
+def test_bench_gpus_n_on_a_node_with_fewer_gpus_says_so():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'WN_BENCH_SHARE_GPU')}
+    if torch.cuda.device_count() >= 8:
+        pytest.skip('an 8-GPU node')
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '8', '--steps', '2'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'this node shows' in r.stderr
+
+
 def test_bench_rccl_process_group_of_one_rank():
     """The `nccl` (= RCCL) branch of the N > 1 path executed on this 1-GPU box: bench.py with a
     process group of ONE rank -- backend initialisation on the device, the result all_gather,

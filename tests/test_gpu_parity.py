@@ -744,8 +744,10 @@ def test_pipeline_two_streams_matches_sequential_decode():
 @pytest.mark.parametrize('gate', [True, False])
 def test_pipeline_encode_gate_keeps_results_and_survives_a_failed_decode(gate):
     """wn_model_set_encode_gate (round 5): with two decodes in flight the wait for the previous
-    decode's encoder sits BEHIND the next decode's CMVN + conv1, which then runs beside that
-    encoder -- on its own workspace, so every result must equal the sequential decode()'s, on
+    decode's encoder is placed by the library -- behind wn_encode's descriptor uploads and in
+    front of conv1 by default (tune enc_gate_pos = 0; 1 = behind CMVN + conv1, which then runs
+    beside that encoder).  It only orders work for performance: each decode has its own
+    workspace, so every result must equal the sequential decode()'s, on
     batches of different shapes back to back (a front end that ran too early or an encoder that
     did not wait shows up as another batch's numbers).  A decode that fails in front of
     wn_encode must not leave its gate on the handle."""

@@ -362,10 +362,11 @@ int ffn_x6_route(wn_model* m, const Linear& w1, const Linear& w2, int act) {
   const bool small = M < 512 && tune().gemm_x6 != 2;
   const bool fused_ok = tune().ffn_x6f != 0 && tune().x6_af32 == 0 && m->x6p_at &&
                         ffn_x6f_supported(M, d, F, act) && !(small && tune().ffn_x6f == 3);
-  if (small && !fused_ok) return 0;
   if (m->x6_at->count(w1.w) == 0 || m->x6_at->count(w2.w) == 0) return 0;
-  if (fused_ok && m->x6p_at->count(w2.w) != 0) return 1;
-  return 2;
+  const bool fused = fused_ok && m->x6p_at->count(w2.w) != 0;
+  // small batches never take the tile-GEMM pair: the fused kernel or the v_mfma_f32 paths
+  if (small) return fused ? 1 : 0;
+  return fused ? 1 : 2;
 }
 
 // the image buffer of t1 = LN(x) when the next feed-forward module will take it, else null

@@ -396,8 +396,12 @@ struct wn_model {
   DevBuf t1_img;
   bool t1_img_ok = false;
   bool kv_ready = false;
-  // wn_model_set_encode_gate: one-shot event the next wn_encode waits for BEHIND its front end
-  // (CMVN + conv1): chained encoders of several handles overlap only that HBM-bound kernel
+  // wn_model_set_encode_gate: one-shot event the next wn_encode waits for.  Where: behind its
+  // descriptor uploads and in front of conv1 (tune enc_gate_pos = 0, default), or behind
+  // CMVN + conv1 (= 1: chained encoders of several handles overlap that HBM-bound kernel);
+  // conv paths that never reach either position wait once conv2 is queued (model.hip).  The
+  // gate orders work for performance only -- each handle has its own workspace, no result
+  // depends on it
   hipEvent_t enc_gate = nullptr;
   int kv_rows = 0, kv_nl = 0, kv_nr = 0;
   Stager stage;

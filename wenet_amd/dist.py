@@ -9,10 +9,14 @@ rank decodes its shard with no data-path collective, and the fixed-shape
 results (token ids, lengths, scores -- a few KB) are gathered once per batch
 with a single all_gather (RCCL over xGMI on GPUs, gloo in the CPU tests).
 """
+import os
 import queue
+import socket
+import subprocess
+import sys
 import threading
 import time
-from typing import List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -163,3 +167,169 @@ class ResultGatherer:
         finally:
             self._q.put(None)
             self._t.join()
+
+
+# --------------------------------------------------------------------------------------------
+# One command -> N ranks on the GPUs of this node.  The reference does this in shell
+# (tools/decode.sh:65-83: a loop over `nj` jobs, one `--gpu` each, results `cat`ed);
+# here `launch_local_ranks` starts one Python process per GPU with the torch.distributed
+# rendezvous variables set (the same ones `python -m torch.distributed.run` exports, so a
+# script runs unchanged under either), and every rank pins its host threads to its own
+# slice of the cores next to its GPU (`pin_rank_to_local_cores`).
+
+
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' (the kernel's cpulist format) -> [0, 1, 2, 3, 8, 10, 11]."""
+    cpus = []
+    for part in text.strip().split(','):
+        part = part.strip()
+        if not part:
+            continue
+        if '-' in part:
+            a, b = part.split('-')
+            cpus.extend(range(int(a), int(b) + 1))
+        else:
+            cpus.append(int(part))
+    return sorted(set(cpus))
+
+
+def format_cpulist(cpus: Sequence[int]) -> str:
+    cpus = sorted(set(int(c) for c in cpus))
+    out, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f'{cpus[i]}-{cpus[j]}')
+        i = j + 1
+    return ','.join(out)
+
+
+def split_cores(cpus: Sequence[int], siblings: Dict[int, Sequence[int]], n: int,
+                k: int) -> List[int]:
+    """Share `k` of `n` of the cpu set `cpus`: whole physical cores (a cpu and its
+    hyper-thread siblings stay on one rank), contiguous, sizes within one core."""
+    cpus = sorted(set(cpus))
+    seen, cores = set(), []
+    for c in cpus:
+        if c in seen:
+            continue
+        grp = sorted(set(s for s in siblings.get(c, (c, )) if s in cpus) | {c})
+        seen.update(grp)
+        cores.append(grp)
+    lo, hi = (len(cores) * k) // n, (len(cores) * (k + 1)) // n
+    return sorted(c for grp in cores[lo:hi] for c in grp)
+
+
+def _thread_siblings(cpus: Sequence[int]) -> Dict[int, List[int]]:
+    sib = {}
+    for c in cpus:
+        try:
+            with open(f'/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list') as f:
+                sib[c] = parse_cpulist(f.read())
+        except (OSError, ValueError):
+            sib[c] = [c]
+    return sib
+
+
+def gpu_local_cpus(dev_index: int) -> Optional[List[int]]:
+    """The cpus of the NUMA node GPU `dev_index` hangs off (its PCI function's
+    `local_cpulist`); None when the platform does not say."""
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bdf = f'{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0'
+        with open(f'/sys/bus/pci/devices/{bdf}/local_cpulist') as f:
+            cpus = parse_cpulist(f.read())
+        return cpus or None
+    except Exception:  # noqa: BLE001 -- attribute, sysfs or parse: no locality information
+        return None
+
+
+def plan_rank_cpus(local_rank: int, nproc: int, allowed: Sequence[int],
+                   local_lists: Sequence[Optional[Sequence[int]]],
+                   siblings: Dict[int, Sequence[int]]) -> List[int]:
+    """The cpus rank `local_rank` of `nproc` pins itself to.  `local_lists[r]` = the cpus
+    next to rank r's GPU (None = unknown).  Ranks whose GPUs share a NUMA node split that
+    node's cores among themselves; with no locality information the allowed cpus are
+    split evenly.  Returns [] when a rank would be left with fewer than two cpus (then
+    nothing is pinned: a starved rank is worse than a wandering one)."""
+    allowed = sorted(set(allowed))
+    mine = local_lists[local_rank] if local_rank < len(local_lists) else None
+    if mine is not None:
+        node = [c for c in mine if c in set(allowed)]
+        peers = [r for r in range(nproc) if local_lists[r] is not None
+                 and sorted(local_lists[r]) == sorted(mine)]
+        if node and local_rank in peers:
+            got = split_cores(node, siblings, len(peers), peers.index(local_rank))
+            if len(got) >= 2:
+                return got
+    got = split_cores(allowed, siblings, nproc, local_rank)
+    return got if len(got) >= 2 else []
+
+
+def pin_rank_to_local_cores(local_rank: int, nproc: int,
+                            device_of_rank: Optional[Sequence[int]] = None) -> List[int]:
+    """Pin this process (and the threads it starts from here on: the decode pipeline's
+    workers, the result gatherer) to its slice of the cores next to its GPU.  Every rank
+    evaluates the same plan for all ranks, so the slices are disjoint without a
+    rendezvous.  Returns the cpus it was pinned to ([] = left alone)."""
+    if not hasattr(os, 'sched_setaffinity'):
+        return []
+    allowed = sorted(os.sched_getaffinity(0))
+    devs = list(device_of_rank) if device_of_rank is not None else list(range(nproc))
+    lists = [gpu_local_cpus(d) if torch.cuda.is_available() else None for d in devs]
+    cpus = plan_rank_cpus(local_rank, nproc, allowed, lists, _thread_siblings(allowed))
+    if cpus:
+        os.sched_setaffinity(0, cpus)
+    return cpus
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_local_ranks(argv: Sequence[str], nproc: int, env: Optional[dict] = None,
+                       poll_s: float = 0.2) -> int:
+    """Run `python argv...` as `nproc` ranks of one node (RANK / LOCAL_RANK / WORLD_SIZE /
+    LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT exported like torch.distributed.run
+    does; rendezvous on 127.0.0.1).  The ranks share this process's stdout / stderr, so
+    rank 0's one result line comes out where the caller reads it.  When a rank fails the
+    others are terminated (by their pids) and its exit code is returned; 0 = all ranks
+    exited 0."""
+    base = dict(os.environ if env is None else env)
+    base.setdefault('MASTER_ADDR', '127.0.0.1')
+    base.setdefault('MASTER_PORT', str(free_port()))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    base['WORLD_SIZE'] = base['LOCAL_WORLD_SIZE'] = str(nproc)
+    base['WN_SELF_LAUNCHED'] = '1'
+    procs = []
+    for r in range(nproc):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK='0')
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(poll_s)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+            if rc != 0:
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc

@@ -250,6 +250,10 @@ class ASRModel:
         self.reverse_weight = mc.get('reverse_weight', 0.0)
         # asr_model.py:46,337-342: attention_rescoring sees only the non-blank frames
         self.apply_non_blank_embedding = bool(mc.get('apply_non_blank_embedding', False))
+        # True when the last attention_rescoring decode found no non-blank frame in the whole
+        # batch and rescored against the unfiltered encoder output (deviations);
+        # reset by every decode, copied back to the caller's model by DecodePipeline
+        self.last_non_blank_filter_empty = False
         self.special_tokens = (configs.get('tokenizer_conf') or {}).get(
             'special_tokens')
         L = _lib.lib()
@@ -727,6 +731,7 @@ class ASRModel:
         methods, B, enc_lens = st['methods'], st['B'], st['enc_lens']
         beam_size, blank_id = st['beam_size'], st['blank_id']
         results = {}
+        self.last_non_blank_filter_empty = False
         max_len = int(enc_lens.max()) if B > 0 else 0
         if 'attention' in methods:
             if self._cfg.dec_layers <= 0:

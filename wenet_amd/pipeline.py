@@ -58,6 +58,7 @@ class DecodePipeline:
     def __init__(self, model: ASRModel, n_streams: int = 2):
         assert n_streams >= 1
         self.device = model.device
+        self._owner = model
         self.models: List[ASRModel] = [model.clone() for _ in range(n_streams)]
         self.streams = [torch.cuda.Stream(device=self.device)
                         for _ in range(n_streams)]
@@ -100,9 +101,11 @@ class DecodePipeline:
                     if self._enc_done is not None:
                         if self.gate_front_end:
                             gated = True
-                            # the wait goes BEHIND this decode's front end (CMVN + conv1, the
-                            # encoder's one HBM-bound kernel): it runs beside the previous
-                            # decode's matrix-bound layers, the rest of the encoder after them
+                            # the library places the wait behind wn_encode's descriptor
+                            # uploads and in front of conv1 (tune enc_gate_pos = 0, the
+                            # default; 1 = behind CMVN + conv1).  The gate only ORDERS work
+                            # for performance: every handle has its own workspace, so no
+                            # result depends on it
                             _lib.check(_lib.lib().wn_model_set_encode_gate(
                                 self.models[i]._h, self._enc_done.cuda_event), 'encode gate')
                         else:
@@ -119,8 +122,12 @@ class DecodePipeline:
                     done = torch.cuda.Event()
                     done.record(stream)
                     self._enc_done = done
-                return self.models[i]._decode_end(st, ctc_weight, reverse_weight,
-                                                  length_penalty)
+                res = self.models[i]._decode_end(st, ctc_weight, reverse_weight,
+                                                 length_penalty)
+                # per-decode status the caller reads on ITS model (the clones are private)
+                self._owner.last_non_blank_filter_empty = \
+                    self.models[i].last_non_blank_filter_empty
+                return res
         finally:
             self._free.put(i)
 
