@@ -71,3 +71,62 @@ def test_as_dict_and_pickle_carry_the_reference_field_names():
     for q in (pickle.loads(blob), copy.deepcopy(r)):
         assert q.as_dict() == d and q._lazy is None
         assert q.nbest == r.nbest and q.tokens == (5, 6) and q.all_scores == [0.25]
+
+
+def _naive(arrs):
+    n_hyps, hyp_lens, hyp_tlens, hyp_tokens, hyp_times, hyp_scores = arrs
+    out = []
+    for b in range(len(n_hyps)):
+        n = int(n_hyps[b])
+        out.append(([tuple(hyp_tokens[b, i, :hyp_lens[b, i]].tolist()) for i in range(n)],
+                    hyp_scores[b, :n].tolist(),
+                    [hyp_times[b, i, :hyp_tlens[b, i]].tolist() for i in range(n)]))
+    return out
+
+
+def test_whole_batch_builders_agree_c_helper_numpy_pass_and_per_hypothesis_slicing():
+    """Round 6: the three n-best list families of a WHOLE batch in one pass -- the C helper
+    (wenet_amd/cext/nbest_lists.c) and the numpy pass it falls back to both give exactly what
+    slicing every hypothesis out of the arrays gives (types included: token tuples, float
+    scores, lists of frame indices), for ragged n_hyps, empty hypotheses, token lengths that
+    differ from the time lengths, values beyond the helper's small-int table, non-contiguous
+    views."""
+    from wenet_amd import search
+    from wenet_amd import build
+    build.build_host_ext()
+    import importlib
+    importlib.reload(search) if search._nbest_lists is None else None
+    assert search._nbest_lists is not None, 'host helper not built'
+    for seed, (B, beam, T) in enumerate([(5, 4, 9), (32, 10, 60), (1, 1, 1), (3, 64, 7)]):
+        arrs = list(_batch(B, beam, T, seed))
+        rng = np.random.default_rng(100 + seed)
+        arrs[0] = rng.integers(0, beam + 1, (B, )).astype(np.int32)     # n_hyps incl. 0
+        arrs[2] = rng.integers(0, T + 1, (B, beam)).astype(np.int32)    # tlens != lens
+        arrs[3] = arrs[3] * 977                                          # ids above 8192
+        want = _naive(arrs)
+        got_c = search._NBestBatch(*arrs).all_utterances()
+        got_np = search._NBestBatch(*arrs)._build_numpy()
+        assert [tuple(x) for x in got_c] == [tuple(x) for x in want]
+        assert [tuple(x) for x in got_np] == [tuple(x) for x in want]
+        for rec in (got_c, got_np):
+            for nb, ns, nt in rec:
+                assert all(type(h) is tuple for h in nb) and all(type(t) is list for t in nt)
+                assert all(type(s) is float for s in ns)
+                assert all(type(v) is int for h in nb for v in h)
+        # a sliced (non-contiguous) token array, as a caller's view may be
+        wide = np.zeros((B, beam, T + 3), dtype=np.int32)
+        wide[:, :, :T] = arrs[3]
+        view = list(arrs)
+        view[3] = wide[:, :, :T]
+        assert [tuple(x) for x in search._NBestBatch(*view).all_utterances()] == \
+            [tuple(x) for x in want]
+
+
+def test_c_helper_rejects_short_buffers():
+    import pytest
+    from wenet_amd import search
+    if search._nbest_lists is None:
+        pytest.skip('helper not built')
+    a = _batch(2, 3, 4)
+    with pytest.raises(ValueError):
+        search._nbest_lists.build(a[0], a[1], a[2], a[3], a[4], a[5], 2, 3, 5)

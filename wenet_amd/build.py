@@ -43,6 +43,27 @@ def _hipcc():
     raise RuntimeError('hipcc not found')
 
 
+def build_host_ext(force: bool = False) -> str:
+    """The CPython helper that turns the n-best arrays of a batch into the reference's list
+    fields (cext/nbest_lists.c; host code, gcc).  Lands next to this file like the HIP
+    library."""
+    import sysconfig
+    src = os.path.join(HERE, 'cext', 'nbest_lists.c')
+    out = os.path.join(HERE, '_nbest_lists' + sysconfig.get_config_var('EXT_SUFFIX'))
+    if (not force and os.path.exists(out)
+            and os.path.getmtime(out) >= os.path.getmtime(src)):
+        return out
+    cc = shutil.which('gcc') or shutil.which('cc')
+    if cc is None:
+        raise RuntimeError('gcc not found')
+    cmd = [cc, '-O2', '-shared', '-fPIC', '-I' + sysconfig.get_paths()['include'], src,
+           '-o', out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'gcc failed for nbest_lists.c:\n{r.stderr}')
+    return out
+
+
 def _stamp(paths):
     h = hashlib.sha256()
     for p in sorted(paths):
@@ -56,6 +77,7 @@ def _stamp(paths):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    build_host_ext(force)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
                if f.endswith('.h')]
     headers.append(os.path.join(HERE, '..', 'include', 'wenet_amd.h'))

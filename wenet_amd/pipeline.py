@@ -78,6 +78,9 @@ class DecodePipeline:
         # r10b; -0.6 % with conv2 as one launch of 128-row tiles: conv1 + conv2 = 0.97 ms then fit
         # under the previous decode's prefix beam search, 0.95 ms, which is over when the
         # single-round kernels behind conv2 start, r12p).
+        # WN_PIPE_CHAIN=0 (experiment): no chaining at all -- the encoders of the decodes in
+        # flight share the chip freely
+        self.chain = os.environ.get('WN_PIPE_CHAIN', '1') != '0'
         gate_mode = os.environ.get('WN_PIPE_GATE', '1')
         self.gate_front_end = gate_mode != '0'
         if gate_mode == '2':
@@ -98,7 +101,7 @@ class DecodePipeline:
             with torch.cuda.stream(stream):
                 with self._enc_lock:
                     gated = False
-                    if self._enc_done is not None:
+                    if self._enc_done is not None and self.chain:
                         if self.gate_front_end:
                             gated = True
                             # the library places the wait behind wn_encode's descriptor
