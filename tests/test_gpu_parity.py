@@ -1253,6 +1253,32 @@ def test_attention_key_split_vs_oracle(config, B, frames, chunk, left):
     assert (outs[1] - outs[2]).abs().max() < 5e-4
 
 
+@pytest.mark.parametrize('config,B,frames,chunk,left', [
+    ('aishell_u2pp', 9, (300, 1200), -1, -1),     # the six-product kernel (full context)
+    ('aishell_u2pp', 5, (500, 1100), 16, -1),     # the v_mfma_f32 kernel under chunk masks
+    ('tiny_causal', 7, (30, 700), -1, -1),
+    ('tiny_causal', 1, (260, 260), 8, 1),
+])
+def test_attention_xcd_block_order_is_bit_identical(config, B, frames, chunk, left):
+    """Round 6: the fp32 attention kernels decode their (sequence, head, query block) from an
+    XCD-aware 1-D block order (all query blocks of a (sequence, head) share one XCD's L2) --
+    the same blocks doing the same arithmetic in another launch order: the encoder output is
+    bit-identical to the plain 3-D grid's (tune attn_xcd = 0)."""
+    from wenet_amd import _lib, synthetic as S
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=77)
+    L = _lib.lib()
+    outs = {}
+    try:
+        for mode in (1, 0):
+            _lib.check(L.wn_tune_set(b'attn_xcd', mode), 'tune')
+            enc, _ = model._forward_encoder(feats.cuda(), lens, chunk, left)
+            outs[mode] = enc.cpu()
+    finally:
+        L.wn_tune_set(b'attn_xcd', 1)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_recognize_cli_shard_list_equals_raw_list(tmp_path):
     """--data_type shard (tar shards of <key>.wav / <key>.txt, one plain and one
     gzip-compressed) writes the same result files as --data_type raw on the same

@@ -33,6 +33,8 @@
 //                     order of the V^T image); 2 k blocks x 2 dim halves x 6 products.  O stays
 //                     transposed (lane = query): rescale and 1 / l are the lane's own scalars.
 #include "kernels.h"
+#include "gemm_epilogue.h"
+#include "tune.h"
 #include "x6.h"
 
 namespace wn {
@@ -157,10 +159,22 @@ __global__ __launch_bounds__(256) void attn_x6_pack_kernel(AttnArgs a, char* img
 }
 
 // ---- launch 2 ----------------------------------------------------------------------------------
-template <int NW>
+// ABL (WN_ABLATION builds only, tune attn_x6_var; wrong results by design -- they attribute the
+// kernel's time): 1 = tiles staged once, 2 = no MFMAs, 4 = no softmax arithmetic (exp2 / split3),
+// 8 = no barriers in the loop (with 1)
+template <int NW, int ABL = 0>
 __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a, const char* img) {
-  const int s = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * (NW * 32);
+  int s = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
+  if (a.xcd_nqb > 0) {
+    // all query blocks of one (sequence, head) on the same XCD: its 4-5 blocks re-read the same
+    // key-tile images (24 KB per tile), which then come from HBM / the fabric into ONE L2
+    // instead of five (round 6: the launch fetched 126 MB for a 26-MB image)
+    const int bid = xcd_block_order(blockIdx.x, gridDim.x);
+    qb = bid % a.xcd_nqb;
+    h = (bid / a.xcd_nqb) % a.n_heads;
+    s = bid / (a.xcd_nqb * a.n_heads);
+  }
+  const int q0 = qb * (NW * 32);
   const int qlen = a.q_len[s];
   if (q0 >= qlen) return;
   const int kvlen = a.kv_len[s];
@@ -261,8 +275,8 @@ __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a
     const int kt = t_lo + kh * n_it + it;   // this wave's tile (may be >= t_hi)
     const int j0 = kt * KT;
     // no register prefetch: three waves per SIMD (<= 168 VGPRs) cover the load latency
-    stage(it);
-    __syncthreads();   // both halves' tiles visible
+    if (!(ABL & 1) || it == 0) stage(it);
+    if (!(ABL & 8) || it == 0) __syncthreads();   // both halves' tiles visible
     if (kt < t_hi) {
       // ---- S^T tile -------------------------------------------------------------------
       f32x16 sc;
@@ -276,9 +290,14 @@ __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
             fk[pl] = *reinterpret_cast<const bf16x8*>(kf + pl * KPL + kk * 16);
+          if constexpr (ABL & 2) {
 #pragma unroll
-          for (int q = 0; q < 6; ++q)
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[PA[q]], qp[PB[q]][kk], sc, 0, 0, 0);
+            for (int pl = 0; pl < 3; ++pl) sc[pl] += (float)fk[pl][0] * (float)qp[pl][kk][0];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+              sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[PA[q]], qp[PB[q]][kk], sc, 0, 0, 0);
+          }
         }
       }
       // the per-key scalar: keys (r&3) + 8(r>>2) + 4hi -> four 16-byte reads
@@ -291,7 +310,10 @@ __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a
       // ---- online softmax on this lane's query -------------------------------------
       const bool full = a.mask_mode == 0 && j0 + KT <= kvlen;
       float psum = 0.f, alpha;
-      if (full) {
+      if constexpr (ABL & 4) {
+        alpha = 1.0f;
+        psum = sc[0];
+      } else if (full) {
         const float t0 = vmax3(sc[0], sc[1], sc[2]), t1 = vmax3(sc[3], sc[4], sc[5]);
         const float t2 = vmax3(sc[6], sc[7], sc[8]), t3 = vmax3(sc[9], sc[10], sc[11]);
         const float t4 = vmax3(sc[12], sc[13], sc[14]);
@@ -338,10 +360,15 @@ __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         bf16x8 pa[3];
+        if constexpr (ABL & 4) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const Split3 t = split3(sc[8 * j + e]);
-          pa[0][e] = t.h0; pa[1][e] = t.h1; pa[2][e] = t.h2;
+          for (int e = 0; e < 8; ++e) pa[0][e] = pa[1][e] = pa[2][e] = (__bf16)sc[8 * j + e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const Split3 t = split3(sc[8 * j + e]);
+            pa[0][e] = t.h0; pa[1][e] = t.h1; pa[2][e] = t.h2;
+          }
         }
         bf16x8 v0[3], v1[3];
 #pragma unroll
@@ -349,14 +376,22 @@ __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a
           v0[pl] = *reinterpret_cast<const bf16x8*>(sV + pl * VPL + vt_off(li, j * 16 + hi * 8));
           v1[pl] = *reinterpret_cast<const bf16x8*>(sV + pl * VPL + vt_off(32 + li, j * 16 + hi * 8));
         }
+        if constexpr (ABL & 2) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0[PA[q]], pa[PB[q]], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1[PA[q]], pa[PB[q]], o1, 0, 0, 0);
+          for (int pl = 0; pl < 3; ++pl) {
+            o0[pl] += (float)v0[pl][0] * (float)pa[pl][0];
+            o1[pl] += (float)v1[pl][0] * (float)pa[pl][0];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0[PA[q]], pa[PB[q]], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1[PA[q]], pa[PB[q]], o1, 0, 0, 0);
+          }
         }
       }
     }
-    __syncthreads();   // every wave is done with the tiles
+    if (!(ABL & 8)) __syncthreads();   // every wave is done with the tiles
   }
   float l_tot = l_run + __shfl_xor(l_run, 32, 64);
 
@@ -424,7 +459,25 @@ int attention_x6(const AttnArgs& a, hipStream_t s) {
   dim3 gp(cdiv(a.max_q_len, KT), a.n_heads, a.n_seq);
   hipLaunchKernelGGL(attn_x6_pack_kernel, gp, dim3(256), 0, s, a, img);
   dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 2 * 64);
-  hipLaunchKernelGGL((attention_x6_kernel<NW>), g, t, 0, s, a, img);
+  AttnArgs b = a;
+  if (tune().attn_xcd != 0) {
+    b.xcd_nqb = g.x;
+    g = dim3(g.x * g.y * g.z);
+  }
+#ifdef WN_ABLATION
+  switch (tune().attn_x6_var) {
+    case 1: hipLaunchKernelGGL((attention_x6_kernel<NW, 1>), g, t, 0, s, b, img); break;
+    case 2: hipLaunchKernelGGL((attention_x6_kernel<NW, 2>), g, t, 0, s, b, img); break;
+    case 4: hipLaunchKernelGGL((attention_x6_kernel<NW, 4>), g, t, 0, s, b, img); break;
+    case 6: hipLaunchKernelGGL((attention_x6_kernel<NW, 6>), g, t, 0, s, b, img); break;
+    case 7: hipLaunchKernelGGL((attention_x6_kernel<NW, 7>), g, t, 0, s, b, img); break;
+    case 9: hipLaunchKernelGGL((attention_x6_kernel<NW, 9>), g, t, 0, s, b, img); break;
+    case 15: hipLaunchKernelGGL((attention_x6_kernel<NW, 15>), g, t, 0, s, b, img); break;
+    default: hipLaunchKernelGGL((attention_x6_kernel<NW>), g, t, 0, s, b, img);
+  }
+#else
+  hipLaunchKernelGGL((attention_x6_kernel<NW>), g, t, 0, s, b, img);
+#endif
   WN_HIP(hipGetLastError());
   return 0;
 }

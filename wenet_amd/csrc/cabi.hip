@@ -828,14 +828,18 @@ int wn_ctc_logprobs(wn_model* m, int32_t topk, int32_t blank_id,
   m->ctc_rows = M; m->ctc_k = k;
   int ldv = V;
   if (M > 0) {
-    // logits rows at a pitch of V rounded up to 4 floats (16-B aligned rows; what the
-    // six-product GEMM needs to store them)
-    const int V4 = (V + 3) / 4 * 4;
+    // logits rows at a pitch of V rounded up to 32 floats: whole 128-byte lines per row, so
+    // that the GEMM's column tiles (multiples of 128 columns) never share a line -- at a pitch
+    // of V rounded up to 4 (round 5) the tile edges fell inside lines written by two blocks on
+    // two XCDs, and the counters showed the read-modify-write: 140 MB READ + 168 MB written
+    // by a GEMM whose operands are 19 MB and whose result is 134 MB (r13b)
+    const int V4 = (V + 31) / 32 * 32;
     ldv = V4;
     WN_TRY(m->logits.ensure((size_t)M * V4 * sizeof(float)));
     WN_TRY(m->topk_val.ensure((size_t)M * k * sizeof(float)));
     WN_TRY(m->topk_idx.ensure((size_t)M * k * sizeof(int)));
-    WN_TRY(vocab_linear(m, m->ctc, m->enc.as<float>(), c.d_model, m->logits.as<float>(), M, s));
+    WN_TRY(vocab_linear(m, m->ctc, m->enc.as<float>(), c.d_model, m->logits.as<float>(), V4, M,
+                        s));
     CtcRowArgs r;
     r.logits = m->logits.as<float>(); r.ld = V4; r.M = M; r.V = V; r.k = k;
     r.blank = blank_id; r.blank_penalty = blank_penalty > 0.f ? blank_penalty : 0.f;
@@ -1280,7 +1284,7 @@ int run_decoder(wn_model* m, const Decoder& D, int R, int n_seq, int max_q,
   float* t1 = m->r_t1.as<float>();
   WN_TRY(ln(D.after, m->r_x.as<float>(), t1, R, d, c.norm_eps, s));
   // (the caller sized r_logits for a pitch of V rounded up to 4)
-  WN_TRY(vocab_linear(m, D.out, t1, d, m->r_logits.as<float>(), R, s));
+  WN_TRY(vocab_linear(m, D.out, t1, d, m->r_logits.as<float>(), (V + 3) / 4 * 4, R, s));
   hipLaunchKernelGGL(row_logp_at_kernel, dim3(R), dim3(256), 0, s,
                      m->r_logits.as<float>(), (V + 3) / 4 * 4, V, d_tgt, out_dev);
   WN_HIP(hipGetLastError());

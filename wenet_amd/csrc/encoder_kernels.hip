@@ -2,6 +2,7 @@
 // conv, the depthwise-conv core of the Conformer conv module, and the
 // relative-position multi-head attention (online softmax, fp32 MFMA).
 #include "kernels.h"
+#include "gemm_epilogue.h"
 #include "x6.h"
 #include "mxfp8.h"
 #include "rowregs.h"
@@ -446,8 +447,14 @@ constexpr int KSTR = 68;        // LDS row stride (floats): 64 + 4 pad
 template <int NW, bool RELPOS, int KS, bool FOLD = false>
 __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kernel(AttnArgs a) {
   constexpr bool GLB = FOLD && KS == 2;
-  const int s = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * (NW * 32);
+  int s = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
+  if (a.xcd_nqb > 0) {   // XCD-aware block order (kernels.h AttnArgs::xcd_nqb)
+    const int bid = xcd_block_order(blockIdx.x, gridDim.x);
+    qb = bid % a.xcd_nqb;
+    h = (bid / a.xcd_nqb) % a.n_heads;
+    s = bid / (a.xcd_nqb * a.n_heads);
+  }
+  const int q0 = qb * (NW * 32);
   const int qlen = a.q_len[s];
   if (q0 >= qlen) return;
   const int kvlen = a.kv_len[s];
@@ -975,6 +982,11 @@ int attention(const AttnArgs& a, hipStream_t s) {
     return attention_x6(a, s);
   constexpr int NW = 2;
   dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 64);
+  AttnArgs ax = a;
+  if (tune().attn_xcd != 0) {
+    ax.xcd_nqb = g.x;
+    g = dim3(g.x * g.y * g.z);
+  }
   // key split for the encoder's self attention over long sequences: twice the
   // waves for the same tiles (tune().attn_split: 0 auto, 1 off, 2 on)
   const bool split = tune().attn_split == 2 ||
@@ -984,17 +996,17 @@ int attention(const AttnArgs& a, hipStream_t s) {
   if (split) {
     dim3 t2(NW * 2 * 64);
     if (fold)
-      hipLaunchKernelGGL((attention_kernel<NW, false, 2, true>), g, t2, 0, s, a);
+      hipLaunchKernelGGL((attention_kernel<NW, false, 2, true>), g, t2, 0, s, ax);
     else if (a.P)
-      hipLaunchKernelGGL((attention_kernel<NW, true, 2>), g, t2, 0, s, a);
+      hipLaunchKernelGGL((attention_kernel<NW, true, 2>), g, t2, 0, s, ax);
     else
-      hipLaunchKernelGGL((attention_kernel<NW, false, 2>), g, t2, 0, s, a);
+      hipLaunchKernelGGL((attention_kernel<NW, false, 2>), g, t2, 0, s, ax);
   } else if (fold)
-    hipLaunchKernelGGL((attention_kernel<NW, false, 1, true>), g, t, 0, s, a);
+    hipLaunchKernelGGL((attention_kernel<NW, false, 1, true>), g, t, 0, s, ax);
   else if (a.P)
-    hipLaunchKernelGGL((attention_kernel<NW, true, 1>), g, t, 0, s, a);
+    hipLaunchKernelGGL((attention_kernel<NW, true, 1>), g, t, 0, s, ax);
   else
-    hipLaunchKernelGGL((attention_kernel<NW, false, 1>), g, t, 0, s, a);
+    hipLaunchKernelGGL((attention_kernel<NW, false, 1>), g, t, 0, s, ax);
   WN_HIP(hipGetLastError());
   return 0;
 }

@@ -85,6 +85,11 @@ struct AttnArgs {
   // scratch for the six-product form (attention_x6.hip): the key-tile images of this launch;
   // x6_rows = rows of the K / V matrix (all sequences)
   void* x6_img = nullptr; size_t x6_img_bytes = 0; int x6_rows = 0;
+  // set by the launchers (tune attn_xcd): > 0 = the grid is 1-D and block b stands for logical
+  // block xcd_block_order(b): all query blocks of a (sequence, head) on ONE XCD, whose L2 then
+  // fetches that pair's keys / values once instead of once per query block; the value is the
+  // number of query blocks per (sequence, head)
+  int xcd_nqb = 0;
 };
 int attention(const AttnArgs& a, hipStream_t s);
 // rel-pos self attention as six bf16 plane products (attention_x6.hip): pack pass + kernel

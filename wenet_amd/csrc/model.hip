@@ -42,6 +42,10 @@ int tune_check(const std::string& key, int32_t value, const char* who) {
               "(25088) need a WN_ABLATION build");
     return -1;
   }
+  if (key == "attn_x6_var" && value != 0) {
+    set_error(std::string(who) + ": attn_x6_var needs a WN_ABLATION build");
+    return -1;
+  }
   if (key == "ffn_x6f_ring" && value != 3) {
     set_error(std::string(who) + ": ffn_x6f_ring needs a WN_ABLATION build");
     return -1;
@@ -306,12 +310,13 @@ int build_x6_images(wn_model* m) {
   return 0;
 }
 
-// A vocabulary-sized layer (N = V, any V) into a logits buffer whose rows have a pitch of V
-// rounded up to 4: the six-product GEMM when the layer has a plane image (and, for V % 4 !=
+// A vocabulary-sized layer (N = V, any V) into a logits buffer whose rows have the pitch ldc
+// (>= V rounded up to 4): the six-product GEMM when the layer has a plane image (and, for V % 4 !=
 // 0, a padded bias), else linear().
-int vocab_linear(wn_model* m, const Linear& l, const float* A, int lda, float* C, int M,
-                 hipStream_t s) {
+int vocab_linear(wn_model* m, const Linear& l, const float* A, int lda, float* C, int ldc,
+                 int M, hipStream_t s) {
   const int V = l.out, V4 = (V + 3) / 4 * 4;
+  WN_CHECK(ldc >= V4 && ldc % 4 == 0, "vocab_linear: pitch");
   const void* w6 = nullptr;
   const float* bias = l.b;
   if (t_gemm_prec == PREC_F32 && tune().gemm_x6 != 0 && tune().x6_linear != 0 && m->x6_at &&
@@ -327,12 +332,12 @@ int vocab_linear(wn_model* m, const Linear& l, const float* A, int lda, float* C
       if (!bias) w6 = nullptr;
     }
   }
-  if (!w6) return linear(l, A, lda, C, V4, M, s);
+  if (!w6) return linear(l, A, lda, C, ldc, M, s);
   WN_TRY(m->x6_lin.ensure(x6_bytes(M, l.in)));
   WN_TRY(x6_split(A, M, l.in, lda, m->x6_lin.as<char>(), s));
   X6Args x;
   x.A3 = m->x6_lin.as<char>(); x.B3 = w6; x.M = M; x.N = V4; x.K = l.in;
-  x.epi = 0; x.bias = bias; x.C = C; x.ldc = V4;
+  x.epi = 0; x.bias = bias; x.C = C; x.ldc = ldc;
   return gemm_x6(x, s);
 }
 

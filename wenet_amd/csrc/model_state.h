@@ -528,7 +528,7 @@ int linear(const Linear& l, const float* A, int lda, float* C, int ldc, int M, h
 int ln(const Norm& n, const float* x, float* y, int M, int D, float eps, hipStream_t s,
        bool y_bf16 = false);
 int build_x6_images(wn_model* m);
-int vocab_linear(wn_model* m, const Linear& l, const float* A, int lda, float* C, int M,
+int vocab_linear(wn_model* m, const Linear& l, const float* A, int lda, float* C, int ldc, int M,
                  hipStream_t s);
 int ffn_x6_split(int M, int F);
 int ffn_x6_pair(wn_model* m, const Linear& w1, const Linear& w2, int act, const float* A, int M,

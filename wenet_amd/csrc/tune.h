@@ -97,6 +97,11 @@ namespace wn {
      products (attention_x6.hip: pack pass + kernel), 0 = the v_mfma_f32 kernel (A/B, tests);   \
      2 = also under chunk masks (measured slightly slower there) */                             \
   X(attn_x6, 1)                                                                                 \
+  /* fp32 attention kernels: 1 = XCD-aware block order (the query blocks of a (sequence, head)  \
+     share one XCD's L2), 0 = the plain 3-D grid (A/B, tests: bit-identical) */                 \
+  X(attn_xcd, 1)                                                                                \
+  /* WN_ABLATION builds: attention_x6_kernel without parts of itself (attention_x6.hip ABL) */  \
+  X(attn_x6_var, 0)                                                                             \
   /* rel-pos attention: 0 = two contractions per score, 2 = the fold as a separate pass */      \
   X(attn_fold, 1)                                                                               \
   /* 0 = cross attention of the rescoring decoder per hypothesis (A/B, tests) */                \
