@@ -30,6 +30,7 @@ from gpu_util import (cached_model, compare_nbest, frame_margins, greedy_frame_c
                       nbest_check, rescoring_check)
 
 pytestmark = pytest.mark.gpu
+_GALIGN_DEFAULT = 2      # wn_tune_set's process default of attn_x6_galign (csrc/tune.h)
 
 METHODS = ['ctc_greedy_search', 'ctc_prefix_beam_search', 'attention_rescoring']
 
@@ -1277,6 +1278,42 @@ def test_attention_xcd_block_order_is_bit_identical(config, B, frames, chunk, le
     finally:
         L.wn_tune_set(b'attn_xcd', 1)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('config,B,frames', [
+    ('aishell_u2pp', 9, (300, 1200)),
+    ('aishell_u2pp', 32, (800, 1200)),
+    ('tiny_causal', 7, (130, 700)),
+])
+def test_attention_x6_global_tile_alignment_vs_oracle(config, B, frames):
+    """Round 6: the key-tile images of the six-product attention aligned to the GLOBAL 32-row
+    blocks of the packed K / V matrix (tune attn_x6_galign = 1: the slots of a boundary tile
+    that belong to the neighbouring sequence are masked) and, = 2, written by the QKV
+    projection's epilogue instead of the pack pass.  Against the oracle within the encoder
+    tolerance; 2 vs 1 BIT-identical (same planes, same scalars, same kernel); 1 vs 0 differs
+    only by the grouping of the online softmax (far inside the tolerance)."""
+    from wenet_amd import _lib, synthetic as S
+    O = _oracle()
+    configs, sd, model = cached_model(config, 0)
+    feats, lens = S.make_features(B, frames, seed=31)
+    with torch.no_grad():
+        ref, mask = O.encoder_forward(configs, sd, feats, lens, -1, -1)
+    ref_lens = mask.squeeze(1).sum(1).numpy()
+    L = _lib.lib()
+    outs = {}
+    try:
+        for mode in (0, 1, 2):
+            _lib.check(L.wn_tune_set(b'attn_x6_galign', mode), 'tune')
+            enc, _ = model._forward_encoder(feats.cuda(), lens, -1, -1)
+            outs[mode] = enc.cpu()
+            for b in range(B):
+                nb = int(ref_lens[b])
+                err = (outs[mode][b, :nb] - ref[b, :nb]).abs().max().item()
+                assert err < 2e-3, (config, 'galign', mode, 'utt', b, err)
+    finally:
+        L.wn_tune_set(b'attn_x6_galign', _GALIGN_DEFAULT)
+    assert (outs[1] - outs[0]).abs().max() < 5e-4
+    assert torch.equal(outs[2], outs[1])
 
 
 def test_recognize_cli_shard_list_equals_raw_list(tmp_path):

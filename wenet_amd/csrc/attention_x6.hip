@@ -33,6 +33,7 @@
 //                     order of the V^T image); 2 k blocks x 2 dim halves x 6 products.  O stays
 //                     transposed (lane = query): rescale and 1 / l are the lane's own scalars.
 #include "kernels.h"
+#include "attn_x6_img.h"
 #include "gemm_epilogue.h"
 #include "tune.h"
 #include "x6.h"
@@ -43,29 +44,23 @@ namespace {
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int KT = 32;               // keys per tile
-constexpr int KSTR = 72;             // K' plane row stride (bf16): 64 dims + 16 B pad
-constexpr int VSTR = 32;             // V^T plane row stride (bf16): 32 key slots = four 16-B groups,
+constexpr int KT = AX_KT;            // keys per tile
+constexpr int KSTR = 72;             // K' plane row stride (bf16) in LDS: 64 dims + 16 B pad
+constexpr int VSTR = AX_VSTR;        // V^T plane row stride (bf16): 32 key slots = four 16-B groups,
                                      // no pad: group g of dim row d lies at g ^ ((d >> 2) & 3)
 constexpr int KPL = KT * KSTR;       // one K' plane (bf16 elements)
-constexpr int VPL = 64 * VSTR;       // one V^T plane
+constexpr int VPL = AX_VPL;          // one V^T plane
 constexpr int HALF = 3 * KPL + 3 * VPL;   // one key half's tile: 26112 B; a block: 52.5 KB,
                                           // three blocks per CU -- the 531 blocks of config 2
                                           // then run in ONE round (with two per CU = 512 slots the
                                           // last 19 started when the first ones ended: 43 us)
-// the tile image in HBM: K' planes as [32][64] rows of 128 B (no pad), V^T planes exactly as in
-// LDS, then the per-key scalars
-constexpr int IMG_K = KT * 64 * 2;                  // 4096 B per K' plane
-constexpr int IMG_V = VPL * 2;                      // 4096 B per V^T plane
-constexpr int IMG_BIAS = 3 * IMG_K + 3 * IMG_V;     // byte offset of the 32 scalars
-constexpr int IMG_TILE = IMG_BIAS + 256;            // 24832 B
+// the tile image in HBM (attn_x6_img.h): K' planes as [32][64] rows of 128 B (no pad), V^T planes
+// exactly as in LDS, then the per-key scalars
+constexpr int IMG_K = AX_IMG_K, IMG_V = AX_IMG_V, IMG_BIAS = AX_IMG_BIAS, IMG_TILE = AX_IMG_TILE;
 // first tile of sequence s in the image: every sequence adds at most one partial tile
 __device__ __forceinline__ int64_t img_tile0(int kvoff, int s) { return (kvoff >> 5) + s; }
 
-// element offset of key slot `slot` (0..31) of dim row d inside a V^T plane
-__device__ __forceinline__ int vt_off(int d, int slot) {
-  return d * VSTR + ((((slot >> 3) ^ (d >> 2)) & 3) << 3) + (slot & 7);
-}
+__device__ __forceinline__ int vt_off(int d, int slot) { return ax_vt_off(d, slot); }
 
 __device__ __forceinline__ float vmax(float a, float b) {   // bare v_max_f32 (attention_bf16.hip)
   float r;
@@ -83,33 +78,48 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
 // float4 chunks, natural mapping (coalesced rows); V: 16 key pairs x 16 float4 chunks: an item
 // loads the same 4 dims of keys 2m, 2m + 1 (adjacent slots of V^T) and writes 4 packed bf16 pairs
 // per plane.  The image is assembled in LDS and leaves as 16-byte chunks.
+// GAL: tiles = the global 32-row blocks of the K / V matrix (AttnArgs::x6_galign): grid (row
+// blocks, heads); a row's position row is its index inside ITS sequence (row_utt)
+template <bool GAL>
 __global__ __launch_bounds__(256) void attn_x6_pack_kernel(AttnArgs a, char* img) {
-  const int s = blockIdx.z, h = blockIdx.y, t = blockIdx.x;
-  const int kvlen = a.kv_len[s];
-  if (t * KT >= kvlen) return;
-  const int kvoff = a.kv_off[s];
-  const int p_off = a.p_off ? a.p_off[s] : 0;
+  const int s = GAL ? 0 : blockIdx.z, h = blockIdx.y, t = blockIdx.x;
+  const int kvlen = GAL ? 0 : a.kv_len[s];
+  if (!GAL && t * KT >= kvlen) return;
+  const int kvoff = GAL ? 0 : a.kv_off[s];
+  const int p_off = (!GAL && a.p_off) ? a.p_off[s] : 0;
   const int tid = threadIdx.x;
   __shared__ __attribute__((aligned(16))) char tile[IMG_TILE];
   const f32x4 fu = *reinterpret_cast<const f32x4*>(a.bias_u + h * 64 + (tid & 15) * 4);
   const f32x4 fv = *reinterpret_cast<const f32x4*>(a.bias_v + h * 64 + (tid & 15) * 4);
   f32x4 rK[2], rP[2], rV0, rV1;
+  // row of the K / V matrix and row of the position table of tile-local key r
+  auto krow = [&](int r, int* prow) {
+    if constexpr (GAL) {
+      const int g = min(t * KT + r, a.x6_rows - 1);
+      const int u = a.row_utt[g];
+      *prow = g - a.kv_off[u] + (a.p_off ? a.p_off[u] : 0);
+      return g;
+    } else {
+      const int j = min(t * KT + r, kvlen - 1);
+      *prow = j + p_off;
+      return kvoff + j;
+    }
+  };
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = tid + i * 256;
     const int r = c >> 4, c4 = c & 15;
-    int j = t * KT + r;
-    if (j > kvlen - 1) j = kvlen - 1;
-    rK[i] = *reinterpret_cast<const f32x4*>(a.K + (int64_t)(kvoff + j) * a.ldk + h * 64 + c4 * 4);
-    rP[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)(j + p_off) * a.ldp + h * 64 + c4 * 4);
+    int pr;
+    const int g = krow(r, &pr);
+    rK[i] = *reinterpret_cast<const f32x4*>(a.K + (int64_t)g * a.ldk + h * 64 + c4 * 4);
+    rP[i] = *reinterpret_cast<const f32x4*>(a.P + (int64_t)pr * a.ldp + h * 64 + c4 * 4);
   }
   {
     const int m = tid & 15, c4 = tid >> 4;
-    int j0 = t * KT + 2 * m, j1 = j0 + 1;
-    if (j0 > kvlen - 1) j0 = kvlen - 1;
-    if (j1 > kvlen - 1) j1 = kvlen - 1;
-    rV0 = *reinterpret_cast<const f32x4*>(a.V + (int64_t)(kvoff + j0) * a.ldv + h * 64 + c4 * 4);
-    rV1 = *reinterpret_cast<const f32x4*>(a.V + (int64_t)(kvoff + j1) * a.ldv + h * 64 + c4 * 4);
+    int pr;
+    const int g0 = krow(2 * m, &pr), g1 = krow(2 * m + 1, &pr);
+    rV0 = *reinterpret_cast<const f32x4*>(a.V + (int64_t)g0 * a.ldv + h * 64 + c4 * 4);
+    rV1 = *reinterpret_cast<const f32x4*>(a.V + (int64_t)g1 * a.ldv + h * 64 + c4 * 4);
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -117,8 +127,7 @@ __global__ __launch_bounds__(256) void attn_x6_pack_kernel(AttnArgs a, char* img
     const int r = c >> 4, c4 = c & 15;
     const f32x4 p = rP[i];
     f32x4 k = rK[i];
-    float d = fu[0] * k[0] + fu[1] * k[1] + fu[2] * k[2] + fu[3] * k[3] +
-              fv[0] * p[0] + fv[1] * p[1] + fv[2] * p[2] + fv[3] * p[3];
+    float d = x6_key_scalar4(fu, k, fv, p);
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
     if (c4 == 0) reinterpret_cast<float*>(tile + IMG_BIAS)[r] = d;
@@ -136,8 +145,7 @@ __global__ __launch_bounds__(256) void attn_x6_pack_kernel(AttnArgs a, char* img
   }
   {
     const int m = tid & 15, c4 = tid >> 4;
-    const int k = 2 * m, k16 = k & 15;                 // tile-local key of rV0 (even)
-    const int slot = (k >> 4) * 16 + ((k16 >> 2) & 1) * 8 + (k16 & 3) + 4 * (k16 >> 3);
+    const int slot = ax_key_slot(2 * m);               // tile-local key of rV0 (even)
     __bf16* vt = reinterpret_cast<__bf16*>(tile + 3 * IMG_K);   // key k + 1: slot + 1
 #pragma unroll
     for (int dd = 0; dd < 4; ++dd) {
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_x6_pack_kernel(AttnArgs a, char* img
     }
   }
   __syncthreads();
-  char* dst = img + ((img_tile0(kvoff, s) + t) * a.n_heads + h) * IMG_TILE;
+  char* dst = img + (((GAL ? 0 : img_tile0(kvoff, s)) + t) * a.n_heads + h) * IMG_TILE;
   for (int c = tid; c < IMG_TILE / 16; c += 256)
     *reinterpret_cast<f32x4*>(dst + c * 16) = *reinterpret_cast<const f32x4*>(tile + c * 16);
 }
@@ -227,9 +235,12 @@ __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a
         blo = max((q0 / a.chunk_size - a.left_chunks) * a.chunk_size, 0);
     }
   }
-  const int t_lo = blo / KT, t_hi = (bhi + KT - 1) / KT;
+  // x6_galign: tile t = global rows 32 t .. of the K / V matrix; key j of this sequence sits in
+  // tile (kvoff + j) / 32, slots outside [0, kvlen) belong to the neighbours and are masked
+  const int gsh = a.x6_galign ? kvoff : 0;
+  const int t_lo = (blo + gsh) / KT, t_hi = (bhi + gsh + KT - 1) / KT;
   const int n_it = (t_hi - t_lo + 1) / 2;   // half kh works on tile t_lo + kh * n_it + it
-  const int t_last = (kvlen - 1) / KT;      // (a tile past the sequence: its last one again)
+  const int t_last = (kvlen - 1 + gsh) / KT;   // (a tile past the sequence: its last one again)
 
   f32x16 o0, o1;
 #pragma unroll
@@ -239,7 +250,8 @@ __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a
   // ---- staging: the two halves' images as 16-byte chunks; thread tid moves chunk tid of every
   // plane of both halves (K' rows get their 16-byte pad on the way, the V^T planes and the
   // scalars are copied as they lie): addresses are two tile pointers + compile-time offsets
-  const char* img0 = img + ((img_tile0(kvoff, s) * a.n_heads) + h) * (int64_t)IMG_TILE;
+  const char* img0 =
+      img + (((a.x6_galign ? 0 : img_tile0(kvoff, s)) * a.n_heads) + h) * (int64_t)IMG_TILE;
   const int64_t tile_stride = (int64_t)a.n_heads * IMG_TILE;
   char* lds0 = reinterpret_cast<char*>(stile);
   const int k_dst = (tid >> 3) * (KSTR * 2) + (tid & 7) * 16;
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a
   const __bf16* sV = sK + 3 * KPL;
   for (int it = 0; it < n_it; ++it) {
     const int kt = t_lo + kh * n_it + it;   // this wave's tile (may be >= t_hi)
-    const int j0 = kt * KT;
+    const int j0 = kt * KT - gsh;           // sequence-local key of the tile's slot 0 (< 0: a neighbour's)
     // no register prefetch: three waves per SIMD (<= 168 VGPRs) cover the load latency
     if (!(ABL & 1) || it == 0) stage(it);
     if (!(ABL & 8) || it == 0) __syncthreads();   // both halves' tiles visible
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a
         for (int e = 0; e < 4; ++e) sc[4 * g + e] += b[e];
       }
       // ---- online softmax on this lane's query -------------------------------------
-      const bool full = a.mask_mode == 0 && j0 + KT <= kvlen;
+      const bool full = a.mask_mode == 0 && j0 >= 0 && j0 + KT <= kvlen;
       float psum = 0.f, alpha;
       if constexpr (ABL & 4) {
         alpha = 1.0f;
@@ -449,15 +461,22 @@ bool attention_x6_supported(const AttnArgs& a) {
   // attention), with a scratch image from the caller; everything else stays on attention_kernel
   return a.P != nullptr && a.fold && a.bias_u && a.bias_v && a.kbias == nullptr &&
          a.max_q_len >= 128 && !a.o_bf16 && !a.qkv_bf16 && a.ldo % 4 == 0 && a.x6_img != nullptr &&
-         a.q_off == a.kv_off && a.q_len == a.kv_len &&
+         a.q_off == a.kv_off && a.q_len == a.kv_len && (!a.x6_galign || a.row_utt != nullptr) &&
+         (!a.x6_img_ready || a.x6_galign) &&
          a.x6_img_bytes >= attention_x6_image_bytes(a.x6_rows, a.n_seq, a.n_heads);
 }
 
 int attention_x6(const AttnArgs& a, hipStream_t s) {
   constexpr int NW = 2;
   char* img = reinterpret_cast<char*>(a.x6_img);
-  dim3 gp(cdiv(a.max_q_len, KT), a.n_heads, a.n_seq);
-  hipLaunchKernelGGL(attn_x6_pack_kernel, gp, dim3(256), 0, s, a, img);
+  if (a.x6_galign) {
+    if (!a.x6_img_ready)
+      hipLaunchKernelGGL(attn_x6_pack_kernel<true>, dim3(cdiv(a.x6_rows, KT), a.n_heads),
+                         dim3(256), 0, s, a, img);
+  } else {
+    dim3 gp(cdiv(a.max_q_len, KT), a.n_heads, a.n_seq);
+    hipLaunchKernelGGL(attn_x6_pack_kernel<false>, gp, dim3(256), 0, s, a, img);
+  }
   dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 2 * 64);
   AttnArgs b = a;
   if (tune().attn_xcd != 0) {

@@ -487,6 +487,7 @@ int wn_model_clone(const wn_model* src, wn_model** out) {
   m->weights_mx = src->weights_mx; m->mx_at = src->mx_at; m->fp8_ffn = src->fp8_ffn;
   m->weights_x6 = src->weights_x6; m->x6_at = src->x6_at;
   m->weights_x6p = src->weights_x6p; m->x6p_at = src->x6p_at; m->bias4_buf = src->bias4_buf; m->bias4 = src->bias4;
+  m->weights_x6q = src->weights_x6q; m->x6q_at = src->x6q_at;
   m->pos_tabs = src->pos_tabs;
   m->fb_tab_i = src->fb_tab_i;
   m->w = src->w;

@@ -33,11 +33,17 @@
 #include "common.h"
 #include "kernels.h"
 #include "rowregs.h"
+#include "attn_x6_img.h"
 #include "x6.h"
 
 namespace wn {
 
 namespace {
+
+// wave-private LDS patches are written and read back by the SAME wave without a barrier (the
+// LDS executes a wave's accesses in order); where the two sides use different vector types the
+// compiler must not move one across the other either
+#define WAVE_LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 constexpr int RK = 256;              // K of this kernel
 constexpr int RKB = RK / 16;         // 16 k blocks
@@ -475,6 +481,124 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
       }
     put(v);
     store_rows(p.C, p.ldc);
+  } else if constexpr (EPI == 4) {
+    // ---- QKV of a layer whose attention reads global-row-aligned key tiles (kernels.h, epi 4):
+    // wave = head; tiles 0-1 Q_h, 2-3 K_h, 4-5 V_h of this block's 32 rows = key tile blockIdx.x
+    static_assert(EPI != 4 || NT == 6, "epi 4: [Q | K | V] x 64 columns of one head per wave");
+    const int head = wave;
+    const int u_l = p.at_row_utt[rowc];
+    const int prow = rowc - p.at_off[u_l] + (p.at_p_off ? p.at_p_off[u_l] : 0);
+    f32x4 fu[2][4], fv[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        fu[t][g] = *reinterpret_cast<const f32x4*>(p.at_u + head * 64 + t * 32 + 8 * g + 4 * hi);
+        fv[t][g] = *reinterpret_cast<const f32x4*>(p.at_v + head * 64 + t * 32 + 8 * g + 4 * hi);
+      }
+    // Q_h: fp32 rows through the patch (lane = row -> whole 256-byte row segments)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(wp + li * PST + (t * 32 + 8 * g + 4 * hi) * 4) =
+            f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]} +
+            ebias[t][g];
+    WAVE_LDS_ORDER();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int q = it * 64 + lane, r = q >> 4, pc = q & 15;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wp + r * PST + pc * 16);
+      if (m0 + r < p.M)
+        *reinterpret_cast<f32x4*>(p.C + (int64_t)(m0 + r) * p.ldc + head * 64 + pc * 4) = v;
+    }
+    WAVE_LDS_ORDER();
+    // the position rows of the block's keys, this head's 64 dims: coalesced -> patch -> lane = row
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int q = it * 64 + lane, r = q >> 4, pc = q & 15;
+      const int pr = __shfl(prow, r, 64);
+      *reinterpret_cast<f32x4*>(wp + r * PST + pc * 16) =
+          *reinterpret_cast<const f32x4*>(p.at_P + (int64_t)pr * p.at_ldp + head * 64 + pc * 4);
+    }
+    WAVE_LDS_ORDER();
+    f32x4 pv[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        pv[t][g] = *reinterpret_cast<const f32x4*>(wp + li * PST + (t * 32 + 8 * g + 4 * hi) * 4);
+    WAVE_LDS_ORDER();
+    // K_h: the per-key scalar u.k + v.p (the pack pass's pieces of 4 dims and its butterfly
+    // order: piece c = 8 t + 2 g + hi; xor 8 = t, xor 4 / 2 = g, xor 1 = the partner lane), then
+    // K' = k + p split into planes
+    float sc[2][4];
+    bf16x4 kp[3][2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 k4 = f32x4{acc[2 + t][4 * g], acc[2 + t][4 * g + 1], acc[2 + t][4 * g + 2],
+                         acc[2 + t][4 * g + 3]} + ebias[2 + t][g];
+        sc[t][g] = x6_key_scalar4(fu[t][g], k4, fv[t][g], pv[t][g]);
+        k4 = k4 + pv[t][g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const Split3 sp = split3(k4[e]);
+          kp[0][t][g][e] = sp.h0; kp[1][t][g][e] = sp.h1; kp[2][t][g][e] = sp.h2;
+        }
+      }
+    float dsum = ((sc[0][0] + sc[1][0]) + (sc[0][2] + sc[1][2])) +
+                 ((sc[0][1] + sc[1][1]) + (sc[0][3] + sc[1][3]));
+    dsum += __shfl_xor(dsum, 32, 64);
+    char* dst = reinterpret_cast<char*>(p.at_img) +
+                ((int64_t)blockIdx.x * 4 + head) * AX_IMG_TILE;
+    if (hi == 0) *reinterpret_cast<float*>(dst + AX_IMG_BIAS + li * 4) = dsum;
+    // K' planes: [32 keys][64 dims] bf16 in the patch (row stride 144 B), out as 16-byte pieces
+    constexpr int KROW = 144, KPLB = 32 * KROW;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<bf16x4*>(wp + pl * KPLB + li * KROW + (t * 32 + 8 * g + 4 * hi) * 2) =
+              kp[pl][t][g];
+    WAVE_LDS_ORDER();
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int q = it * 64 + lane, r = q >> 3, pc = q & 7;
+        *reinterpret_cast<f32x4*>(dst + pl * AX_IMG_K + q * 16) =
+            *reinterpret_cast<const f32x4*>(wp + pl * KPLB + r * KROW + pc * 16);
+      }
+    WAVE_LDS_ORDER();
+    // V_h^T planes: [64 dims][32 key slots], the image's slot order and group swizzle
+    {
+      __bf16* vt = reinterpret_cast<__bf16*>(wp);
+      const int slot = ax_key_slot(li);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v4 = f32x4{acc[4 + t][4 * g], acc[4 + t][4 * g + 1], acc[4 + t][4 * g + 2],
+                                 acc[4 + t][4 * g + 3]} + ebias[4 + t][g];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const Split3 sp = split3(v4[e]);
+            const int o = ax_vt_off(t * 32 + 8 * g + 4 * hi + e, slot);
+            vt[o] = sp.h0; vt[AX_VPL + o] = sp.h1; vt[2 * AX_VPL + o] = sp.h2;
+          }
+        }
+      WAVE_LDS_ORDER();
+#pragma unroll
+      for (int it = 0; it < 3 * AX_IMG_V / 1024; ++it) {
+        const int q = it * 64 + lane;
+        *reinterpret_cast<f32x4*>(dst + 3 * AX_IMG_K + q * 16) =
+            *reinterpret_cast<const f32x4*>(wp + q * 16);
+      }
+    }
   } else if constexpr (EPI == 2) {
     // GLU (convolution.py:117-118) over a weight whose rows are permuted per 64 as [32 a | 32
     // gate] (wn_model_create): tile 2 u of the wave = values, tile 2 u + 1 = their gates; the
@@ -662,7 +786,7 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   k4 = __builtin_readcyclecounter();
   if (stamp) {
-    unsigned long long* o = g_x6r_clk[EPI + (PRO != 0 ? 4 : 0)];
+    unsigned long long* o = g_x6r_clk[(EPI == 4 ? 0 : EPI) + (PRO != 0 ? 4 : 0)];
     o[0] = k0; o[1] = k1; o[2] = k2; o[3] = k3; o[4] = k4; o[5] = kp;
     o[6] = rt0; o[7] = __builtin_amdgcn_s_memrealtime();
   }
@@ -688,6 +812,7 @@ bool gemm_x6r_supported(int M, int N, int K, int epi) {
   if (K != RK || M <= 0) return false;
   if (epi == 1 || epi == 3) return N == 256;
   if (epi == 2) return N == 512;
+  if (epi == 4) return N == 768;
   return N == 256 || N == 512 || N == 768;
 }
 
@@ -695,13 +820,18 @@ int gemm_x6r(const X6RArgs& a, hipStream_t s) {
   if (a.K == 512) return gemm_x6r512(a, s);
   WN_CHECK(a.K == RK, "gemm_x6r: K must be 256 or 512");
   if (a.pro_P) {
-    WN_CHECK(a.epi == 0 && a.N == 768 && a.W3 && a.M > 0 && a.pro_S >= 1 && a.pro_b2 && a.pro_x &&
-                 a.ln_w && a.ln_b && a.C && a.ldc % 4 == 0,
+    WN_CHECK((a.epi == 0 || a.epi == 4) && a.N == 768 && a.W3 && a.M > 0 && a.pro_S >= 1 &&
+                 a.pro_b2 && a.pro_x && a.ln_w && a.ln_b && a.C && a.ldc % 4 == 0,
              "gemm_x6r: prologue fold arguments");
+    if (a.epi == 4) {
+      WN_CHECK(a.at_img && a.at_P && a.at_ldp % 4 == 0 && a.at_u && a.at_v && a.at_row_utt &&
+                   a.at_off && a.bias, "gemm_x6r: key-tile image arguments (epi 4)");
+      return launch_x6r<6, 4, 1, 1>(a, s);
+    }
     return launch_x6r<6, 0, 1, 1>(a, s);
   }
-  WN_CHECK((a.A || a.dw_on) && a.W3 && a.lda % 4 == 0 && gemm_x6r_supported(a.M, a.N, RK, a.epi),
-           "gemm_x6r: shape");
+  WN_CHECK((a.A || a.dw_on) && a.W3 && a.lda % 4 == 0 && a.epi != 4 &&
+               gemm_x6r_supported(a.M, a.N, RK, a.epi), "gemm_x6r: shape");
   if (a.dw_on) {
     WN_CHECK(a.epi == 1 && a.N == 256 && a.W3 && a.M > 0 && a.dw.D == 256 && a.dw.M == a.M &&
                  a.dw.x && a.dw.ldx % 4 == 0 && a.dw.wt && a.dw.bias && a.dw.cpad && a.dw.ln_w &&

@@ -90,6 +90,15 @@ struct AttnArgs {
   // fetches that pair's keys / values once instead of once per query block; the value is the
   // number of query blocks per (sequence, head)
   int xcd_nqb = 0;
+  // six-product form, key-tile images aligned to the GLOBAL 32-row blocks of the packed K / V
+  // matrix (tile t = rows 32 t .. 32 t + 31, whatever sequences they belong to; the kernel
+  // masks the slots outside its own sequence) instead of to each sequence's first key: the
+  // tiles are then exactly the row blocks of the QKV projection, whose epilogue can write
+  // them (x6_img_ready: the image is already there, no pack pass).  row_utt [x6_rows]: the
+  // sequence of every row (pack pass with x6_galign)
+  int x6_galign = 0;
+  bool x6_img_ready = false;
+  const int* row_utt = nullptr;
 };
 int attention(const AttnArgs& a, hipStream_t s);
 // rel-pos self attention as six bf16 plane products (attention_x6.hip): pack pass + kernel
@@ -232,6 +241,19 @@ struct X6RArgs {
   // them from dw.x (dw.y is ignored: the rows never reach HBM)
   int dw_on = 0;
   DwConvArgs dw;
+  // epi 4 (K = 256, N = 768, with the prologue fold): the QKV projection of a layer whose self
+  // attention runs as six plane products over GLOBAL-row-aligned key tiles (attention_x6.hip,
+  // AttnArgs::x6_galign): W3 / bias hold the rows permuted per head ([Q_h | K_h | V_h] x 64,
+  // h = 0..3 -- wave h of a block owns head h), Q goes to C (columns h 64 ..) as fp32 rows, and
+  // the block's 32 rows ARE key tile blockIdx.x: K' = k + p planes, V^T planes and the per-key
+  // scalars u.k + v.p of the four heads are written straight into the tile image (at_img),
+  // the pack pass's arithmetic in its order -- bit-identical, one launch and 42 MB of traffic
+  // per layer less.  at_P [T][at_ldp] = the layer's projected position table, at_u / at_v
+  // [4][64], at_row_utt [M] / at_off [n_seq] / at_p_off (or null) give a row its position
+  void* at_img = nullptr;
+  const float* at_P = nullptr; int at_ldp = 0;
+  const float* at_u = nullptr; const float* at_v = nullptr;
+  const int* at_row_utt = nullptr; const int* at_off = nullptr; const int* at_p_off = nullptr;
 };
 int gemm_x6r_clocks(unsigned long long* out);   // phase stamps of the last x6r_kernel launch (gemm_x6r.hip)
 bool gemm_x6r_supported(int M, int N, int K, int epi);

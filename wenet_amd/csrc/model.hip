@@ -285,6 +285,43 @@ int build_x6_images(wn_model* m) {
   }
   m->weights_x6p = pbuf;
   m->x6p_at = pat;
+  // QKV projections of 4-head / d_model-256 encoders, rows regrouped per head (gemm_x6r.hip
+  // epi 4: wave h of a row block owns [Q_h | K_h | V_h]): new row h 192 + part 64 + j = old row
+  // part 256 + h 64 + j.  One fp32 staging copy, then the ordinary split
+  auto qbuf = std::make_shared<DevBuf>();
+  auto qat = std::make_shared<std::map<const float*, std::pair<const void*, const float*>>>();
+  if (m->cfg.d_model == 256 && m->cfg.n_heads == 4) {
+    size_t n_q = 0;
+    for (const auto& L : m->layers)
+      if (L.qkv.w && L.qkv.b && L.qkv.out == 768 && L.qkv.in == 256 && L.pos_tab) ++n_q;
+    if (n_q > 0) {
+      const size_t img = x6_bytes(768, 256), per = img + 768 * sizeof(float);
+      DevBuf stage;
+      WN_TRY(stage.ensure((size_t)768 * 256 * sizeof(float)));
+      WN_TRY(qbuf->ensure(n_q * per));
+      char* q = qbuf->as<char>();
+      for (const auto& L : m->layers) {
+        if (!(L.qkv.w && L.qkv.b && L.qkv.out == 768 && L.qkv.in == 256 && L.pos_tab) ||
+            qat->count(L.qkv.w))
+          continue;
+        float* qb = reinterpret_cast<float*>(q + img);
+        for (int h = 0; h < 4; ++h)
+          for (int part = 0; part < 3; ++part) {
+            const size_t nr = (size_t)h * 192 + part * 64, orow = (size_t)part * 256 + h * 64;
+            WN_HIP(hipMemcpyAsync(stage.as<float>() + nr * 256, L.qkv.w + orow * 256,
+                                  64 * 256 * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+            WN_HIP(hipMemcpyAsync(qb + nr, L.qkv.b + orow, 64 * sizeof(float),
+                                  hipMemcpyDeviceToDevice, nullptr));
+          }
+        WN_TRY(x6_split(stage.as<float>(), 768, 256, 256, q, nullptr));
+        (*qat)[L.qkv.w] = {q, qb};
+        q += per;
+      }
+      WN_HIP(hipStreamSynchronize(nullptr));   // `stage` goes away with this scope
+    }
+  }
+  m->weights_x6q = qbuf;
+  m->x6q_at = qat;
   // the six-product kernel stores 16-B pieces: the vocabulary-sized layers run with N = V
   // rounded up to 4 (the image rows past V are zero, their bias too) and their logits rows
   // get that pitch
@@ -828,11 +865,31 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       // x += MHA(LN(x))                               encoder_layer.py:230-238
       WN_TRY(ln(L.norm_mha, x, t1, M, d, eps, s, h16));
     }
+    // The six-product attention over key tiles aligned to the global 32-row blocks (tune
+    // attn_x6_galign): decided HERE, in front of the QKV projection, because with = 2 that
+    // projection writes the tile images itself (epi 4) and leaves no K / V rows behind
+    const bool ax6 = !h16 && t_gemm_prec == PREC_F32 && tune().attn_x6 != 0 &&
+                     tune().attn_fold == 1 && mask_mode == 0 && M >= 512 && max_len >= 128 &&
+                     L.pos_tab && L.bias_u && L.bias_v;
+    bool ax6_img = false;
+    if (ax6 && m->attn_img.ensure(attention_x6_image_bytes(M, m->B, c.n_heads)) == 0)
+      ax6_img = true;
+    const std::pair<const void*, const float*>* qkv_q = nullptr;
+    if (ax6_img && pro && tune().attn_x6_galign == 2 && m->x6q_at) {
+      auto it = m->x6q_at->find(L.qkv.w);
+      if (it != m->x6q_at->end()) qkv_q = &it->second;
+    }
     bool qkv_done = false;
     if (qkv_w6) {
       X6RArgs g;
       g.A = t1; g.lda = d; g.K = d; g.W3 = qkv_w6; g.bias = L.qkv.b; g.M = M; g.N = 3 * d;
       g.epi = 0; g.C = qkv; g.ldc = 3 * d;
+      if (qkv_q) {
+        g.epi = 4; g.W3 = qkv_q->first; g.bias = qkv_q->second;
+        g.at_img = m->attn_img.p; g.at_P = L.pos_tab; g.at_ldp = d;
+        g.at_u = L.bias_u; g.at_v = L.bias_v;
+        g.at_row_utt = m->d_row_utt.as<int>(); g.at_off = m->d_off.as<int>();
+      }
       if (pro) {
         g.pro_P = m->ffn_part.as<float>(); g.pro_S = fS; g.pro_b2 = L.ffm2.b; g.pro_alpha = 0.5f;
         g.pro_x = x; g.ln_w = L.norm_mha.w; g.ln_b = L.norm_mha.b; g.eps = eps;
@@ -867,14 +924,29 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     a.n_seq = m->B; a.n_heads = c.n_heads; a.max_q_len = max_len;
     a.mask_mode = mask_mode; a.chunk_size = cs; a.left_chunks = lc;
     a.scale = 1.0f / sqrtf(64.0f);
-    if (a.fold && tune().attn_x6 != 0 && !h16 && t_gemm_prec == PREC_F32 && M >= 512) {
-      // the six-product form wants a scratch image of the key tiles (attention_x6.hip)
+    if (ax6_img) {
+      a.x6_img = m->attn_img.p; a.x6_img_bytes = m->attn_img.cap; a.x6_rows = M;
+      if (tune().attn_x6_galign != 0) {
+        a.x6_galign = 1;
+        a.row_utt = m->d_row_utt.as<int>();
+      }
+    } else if (a.fold && tune().attn_x6 != 0 && !h16 && t_gemm_prec == PREC_F32 && M >= 512) {
+      // (chunk-masked batches with attn_x6 = 2: the sequence-aligned image)
       const size_t need = attention_x6_image_bytes(M, m->B, c.n_heads);
       if (m->attn_img.ensure(need) == 0) {
         a.x6_img = m->attn_img.p; a.x6_img_bytes = m->attn_img.cap; a.x6_rows = M;
       }
     }
-    WN_TRY(attention(a, s));
+    if (qkv_q) {
+      // the tiles are in the image already and K / V exist nowhere else: this launch MUST be
+      // the six-product kernel
+      a.x6_img_ready = true;
+      WN_CHECK(a.fold && attention_x6_supported(a),
+               "encoder: QKV wrote the key-tile images but the six-product attention declines");
+      WN_TRY(attention_x6(a, s));
+    } else {
+      WN_TRY(attention(a, s));
+    }
     // x += out_proj(context); t1 = LN_conv(x)       encoder_layer.py:236-240
     const bool rowln = !h16 && t_gemm_prec == PREC_F32 && gemm_rowln_supported(M, d, d);
     // the same fusion as six bf16 plane products on the row-block kernels (gemm_x6r.hip: A rows

@@ -319,6 +319,11 @@ struct wn_model {
   DevBuf nb_map, nb_keep, nb_enc, nb_off_old;   // filter_blank_embedding scratch
   std::shared_ptr<DevBuf> weights_x6p;      // k-slot-permuted FFN w_2 images (ffn_x6f.hip)
   std::shared_ptr<std::map<const float*, const void*>> x6p_at;
+  // QKV weights with the rows permuted per head ([Q_h | K_h | V_h] x 64) as X3 images + the
+  // biases in the same order: the QKV projection that writes the attention's key-tile images
+  // itself (gemm_x6r.hip epi 4); fp32 weight pointer -> (image, bias)
+  std::shared_ptr<DevBuf> weights_x6q;
+  std::shared_ptr<std::map<const float*, std::pair<const void*, const float*>>> x6q_at;
   DevBuf x6_a, x6_h;                     // images of the GEMM input rows / the FFN hidden tensor
   DevBuf x6_lin;                         // image of linear()'s A operand (large fp32 GEMMs)
   // biases of the vocabulary-sized layers (CTC head, decoder output layers) padded with zeros

@@ -100,6 +100,10 @@ namespace wn {
   /* fp32 attention kernels: 1 = XCD-aware block order (the query blocks of a (sequence, head)  \
      share one XCD's L2), 0 = the plain 3-D grid (A/B, tests: bit-identical) */                 \
   X(attn_xcd, 1)                                                                                \
+  /* six-product attention: 1 = key-tile images aligned to the global 32-row blocks of the      \
+     packed K / V matrix (the row blocks of the QKV projection); 2 = ... and written by that     \
+     projection's epilogue, no pack pass; 0 = aligned to each sequence's first key (A/B) */      \
+  X(attn_x6_galign, 2)                                                                          \
   /* WN_ABLATION builds: attention_x6_kernel without parts of itself (attention_x6.hip ABL) */  \
   X(attn_x6_var, 0)                                                                             \
   /* rel-pos attention: 0 = two contractions per score, 2 = the fold as a separate pass */      \

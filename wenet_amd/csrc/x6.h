@@ -24,6 +24,22 @@ __device__ __forceinline__ Split3 split3(float x) {
   return s;
 }
 
+// One 4-dim piece of the per-key scalar u . k + v . p of the folded rel-pos attention
+// (attention_x6.hip): ONE explicit order, shared by the pack pass and the QKV epilogue that
+// replaces it, so that both give the same bits
+__device__ __forceinline__ float x6_key_scalar4(const f32x4& fu, const f32x4& k, const f32x4& fv,
+                                                const f32x4& p) {
+  float d = fu[0] * k[0];
+  d = __builtin_fmaf(fu[1], k[1], d);
+  d = __builtin_fmaf(fu[2], k[2], d);
+  d = __builtin_fmaf(fu[3], k[3], d);
+  d = __builtin_fmaf(fv[0], p[0], d);
+  d = __builtin_fmaf(fv[1], p[1], d);
+  d = __builtin_fmaf(fv[2], p[2], d);
+  d = __builtin_fmaf(fv[3], p[3], d);
+  return d;
+}
+
 // byte offset of the 16-B piece (k half h) of image row `row`, k block kb, plane 0
 __device__ __forceinline__ int64_t x3_piece(int kb, int tiles, int row, int h) {
   return ((int64_t)kb * tiles + (row >> 5)) * X3_TILE + h * 512 + (row & 31) * 16;
