@@ -705,7 +705,8 @@ int subsample_conv2d4(wn_model* m, const float* feats_dev,
       auto it = m->x6_at->find(m->conv2.w);
       if (it != m->x6_at->end()) w6 = it->second;
     }
-    if (w6 && tune().x6_af32 != 0 && (int64_t)M1 * F1 * d * 4 < ((int64_t)1 << 31)) {
+    if (w6 && (tune().x6_af32 != 0 || tune().x6_conv_af32 != 0) &&
+        (int64_t)M1 * F1 * d * 4 < ((int64_t)1 << 31)) {
       // conv1 as always (fp32, channels last); conv2 gathers its A rows from it, 64 B per
       // pixel and k block, and splits them in registers
       WN_TRY(m->c1.ensure((size_t)M1 * F1 * d * sizeof(float)));

@@ -55,6 +55,9 @@ namespace wn {
   /* 0 = activations reach gemm_x6 as plane images; 1 = as fp32 rows split in registers.       \
      Measured (r02ag): the split costs more than the plane bytes it saves */                    \
   X(x6_af32, 0)                                                                                 \
+  /* subsampling only: 1 = conv1 writes fp32 pixels (4 B / element instead of the 6-B plane     \
+     image) and conv2 splits them while it stages its A operand (A/B; r14k: slower) */          \
+  X(x6_conv_af32, 0)                                                                            \
   /* wn_model_set_encode_gate: where wn_encode waits for the event: 0 = behind its descriptor   \
      uploads, in front of conv1; 1 = behind CMVN + conv1 (that kernel then runs beside the       \
      previous decode's layers: +0.7 % with the 256-row conv2, -0.6 % with the 128-row one) */   \
