@@ -219,8 +219,9 @@ def test_rank_core_plan_is_a_partition_of_whole_cores():
     # no locality information: an even split of what the process may run on
     plans = [wdist.plan_rank_cpus(r, 4, allowed, [None] * 4, sib) for r in range(4)]
     assert sorted(c for p in plans for c in p) == allowed and all(len(p) == 8 for p in plans)
-    # a cgroup that leaves fewer than two cpus per rank: nothing is pinned
+    # a cgroup that leaves fewer than four cpus per rank: nothing is pinned
     assert wdist.plan_rank_cpus(0, 8, [0, 1, 2, 3], [None] * 8, {}) == []
+    assert wdist.plan_rank_cpus(0, 8, list(range(16)), [None] * 8, {}) == []
     # the GPU's node lies outside the allowed set: fall back to the even split
     got = wdist.plan_rank_cpus(1, 2, list(range(8)), [[40, 41], [40, 41]], {})
     assert got == [4, 5, 6, 7]

@@ -245,14 +245,18 @@ def gpu_local_cpus(dev_index: int) -> Optional[List[int]]:
         return None
 
 
+MIN_RANK_CPUS = 4
+
+
 def plan_rank_cpus(local_rank: int, nproc: int, allowed: Sequence[int],
                    local_lists: Sequence[Optional[Sequence[int]]],
                    siblings: Dict[int, Sequence[int]]) -> List[int]:
     """The cpus rank `local_rank` of `nproc` pins itself to.  `local_lists[r]` = the cpus
     next to rank r's GPU (None = unknown).  Ranks whose GPUs share a NUMA node split that
     node's cores among themselves; with no locality information the allowed cpus are
-    split evenly.  Returns [] when a rank would be left with fewer than two cpus (then
-    nothing is pinned: a starved rank is worse than a wandering one)."""
+    split evenly.  Returns [] when a rank would be left with fewer than MIN_RANK_CPUS cpus
+    (then nothing is pinned: a rank runs its decode thread(s), the result gatherer and the
+    HIP runtime's helpers -- starved of cores it is worse off than wandering)."""
     allowed = sorted(set(allowed))
     mine = local_lists[local_rank] if local_rank < len(local_lists) else None
     if mine is not None:
@@ -261,10 +265,10 @@ def plan_rank_cpus(local_rank: int, nproc: int, allowed: Sequence[int],
                  and sorted(local_lists[r]) == sorted(mine)]
         if node and local_rank in peers:
             got = split_cores(node, siblings, len(peers), peers.index(local_rank))
-            if len(got) >= 2:
+            if len(got) >= MIN_RANK_CPUS:
                 return got
     got = split_cores(allowed, siblings, nproc, local_rank)
-    return got if len(got) >= 2 else []
+    return got if len(got) >= MIN_RANK_CPUS else []
 
 
 def pin_rank_to_local_cores(local_rank: int, nproc: int,
