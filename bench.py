@@ -667,6 +667,11 @@ def main():
                            f'{4 * enc_rows * ffn * d_model / 1e9:.2f} GFLOP per launch'
                            if 'fused' in prof_name else
                            f'{prof_name} (FFN w_1, M={enc_rows} N={ffn} K={d_model})'),
+                'regime': 'achieved / frac / avg_launch_us: ONE decode in flight (a pass of plain '
+                          'decode() steps right after the timed rounds -- the kernel alone on the '
+                          'chip, what rocprofv3 --streams 1 reproduces); the same event pairs '
+                          'inside the headline\'s rounds (two decodes in flight) are under '
+                          'timed_rounds',
                 'achieved': round(achieved, 2),
                 'peak': peak,
                 'unit': 'TFLOP/s',

@@ -1314,6 +1314,14 @@ def test_attention_x6_global_tile_alignment_vs_oracle(config, B, frames):
         L.wn_tune_set(b'attn_x6_galign', _GALIGN_DEFAULT)
     assert (outs[1] - outs[0]).abs().max() < 5e-4
     assert torch.equal(outs[2], outs[1])
+    # the block list (full blocks first, light ones last; dead query groups skip their work):
+    # the same blocks in another dispatch order -- bit-identical to the plain grid
+    try:
+        _lib.check(L.wn_tune_set(b'attn_x6_order', 0), 'tune')
+        enc, _ = model._forward_encoder(feats.cuda(), lens, -1, -1)
+    finally:
+        L.wn_tune_set(b'attn_x6_order', 1)
+    assert torch.equal(enc.cpu(), outs[2])
 
 
 def test_recognize_cli_shard_list_equals_raw_list(tmp_path):

@@ -173,7 +173,10 @@ __global__ __launch_bounds__(256) void attn_x6_pack_kernel(AttnArgs a, char* img
 template <int NW, int ABL = 0>
 __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a, const char* img) {
   int s = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
-  if (a.xcd_nqb > 0) {
+  if (a.blk_tab) {
+    const int e = a.blk_tab[blockIdx.x];
+    s = e >> 16; h = (e >> 8) & 255; qb = e & 255;
+  } else if (a.xcd_nqb > 0) {
     // all query blocks of one (sequence, head) on the same XCD: its 4-5 blocks re-read the same
     // key-tile images (24 KB per tile), which then come from HBM / the fabric into ONE L2
     // instead of five (round 6: the launch fetched 126 MB for a 26-MB image)
@@ -246,6 +249,10 @@ __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;   // running maximum of the RAW scores, running sum
+  // a query group past the sequence's end (the last block of a sequence with an odd number of
+  // 32-query tiles) only stages and meets the barriers: its SIMD time goes to the other
+  // blocks of the CU (round 6: such a block cost as much as a full one)
+  const bool wave_live = q0 + wave * 32 < qlen;
 
   // ---- staging: the two halves' images as 16-byte chunks; thread tid moves chunk tid of every
   // plane of both halves (K' rows get their 16-byte pad on the way, the V^T planes and the
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(NW * 2 * 64, 3) void attention_x6_kernel(AttnArgs a
     // no register prefetch: three waves per SIMD (<= 168 VGPRs) cover the load latency
     if (!(ABL & 1) || it == 0) stage(it);
     if (!(ABL & 8) || it == 0) __syncthreads();   // both halves' tiles visible
-    if (kt < t_hi) {
+    if (kt < t_hi && wave_live) {
       // ---- S^T tile -------------------------------------------------------------------
       f32x16 sc;
 #pragma unroll
@@ -479,7 +486,9 @@ int attention_x6(const AttnArgs& a, hipStream_t s) {
   }
   dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 2 * 64);
   AttnArgs b = a;
-  if (tune().attn_xcd != 0) {
+  if (a.blk_tab && a.n_blk > 0) {
+    g = dim3(a.n_blk);
+  } else if (tune().attn_xcd != 0) {
     b.xcd_nqb = g.x;
     g = dim3(g.x * g.y * g.z);
   }

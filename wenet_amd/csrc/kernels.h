@@ -97,6 +97,10 @@ struct AttnArgs {
   // them (x6_img_ready: the image is already there, no pack pass).  row_utt [x6_rows]: the
   // sequence of every row (pack pass with x6_galign)
   int x6_galign = 0;
+  // six-product form: the launch's blocks in dispatch order, (sequence << 16 | head << 8 |
+  // query block of 64) -- full blocks first, the light last blocks of odd sequences behind
+  // them (model.hip set_layout); null = the (query block, head, sequence) grid
+  const int* blk_tab = nullptr; int n_blk = 0;
   bool x6_img_ready = false;
   const int* row_utt = nullptr;
 };

@@ -2,6 +2,7 @@
 // (subsampling, Conformer / Transformer layers, streaming chunks), the GEMM routing
 // (v_mfma_f32 / six-product / bf16 / MXFP8 kernels) and the weight plane images.  The state
 // it works on is model_state.h; the C ABI over it is cabi.hip.
+#include <algorithm>
 #include "model_state.h"
 
 namespace wn {
@@ -596,7 +597,36 @@ int set_layout(wn_model* m, int B, int Tp, const std::vector<int>& off,
   std::vector<int> row_utt(std::max(rows, 1), -1);
   for (int b = 0; b < B; ++b)
     for (int t = 0; t < len[b]; ++t) row_utt[off[b] + t] = b;
-  WN_TRY(m->stage.begin((size_t)(rows + 4 * B + 64) * sizeof(int) + 1024));
+  // Block list of the six-product self attention (attention_x6.hip, 64 queries per block),
+  // appended to the row_utt upload: (sequence << 16 | head << 8 | query block), the blocks with
+  // two live 32-query groups first, the "light" last blocks of sequences with an odd number of
+  // query tiles behind them, longer sequences first inside each class.  The dispatcher deals
+  // blocks to the CUs in this order, so the ones a CU gets on top of its two full blocks are
+  // the cheap ones (round 6: 531 equal-looking blocks on 256 CUs -- the CUs with three set the
+  // kernel's time).
+  m->attn_blk_off = (int)((row_utt.size() + 15) / 16 * 16);
+  m->attn_n_blk = 0;
+  {
+    const int H = m->cfg.n_heads;
+    std::vector<int> order(B);
+    for (int b = 0; b < B; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return len[x] > len[y]; });
+    std::vector<int> tab;
+    if (B < 65536 && H < 256)
+      for (int light = 0; light < 2; ++light)
+        for (int b : order) {
+          const int nqb = (len[b] + 63) / 64;
+          for (int qb = 0; qb < nqb && qb < 256; ++qb) {
+            const bool is_light = len[b] - qb * 64 <= 32;
+            if ((int)is_light != light) continue;
+            for (int h = 0; h < H; ++h) tab.push_back((b << 16) | (h << 8) | qb);
+          }
+        }
+    row_utt.resize(m->attn_blk_off + tab.size(), -1);
+    std::copy(tab.begin(), tab.end(), row_utt.begin() + m->attn_blk_off);
+    m->attn_n_blk = (int)tab.size();
+  }
+  WN_TRY(m->stage.begin((size_t)(row_utt.size() + 4 * B + 64) * sizeof(int) + 1024));
   WN_TRY(upload_desc(m, m->d_off, off, s));
   WN_TRY(upload_desc(m, m->d_len, len, s));
   WN_TRY(upload_desc(m, m->d_row_utt, row_utt, s));
@@ -927,6 +957,10 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     a.scale = 1.0f / sqrtf(64.0f);
     if (ax6_img) {
       a.x6_img = m->attn_img.p; a.x6_img_bytes = m->attn_img.cap; a.x6_rows = M;
+      if (tune().attn_x6_order != 0 && m->attn_n_blk > 0) {
+        a.blk_tab = m->d_row_utt.as<int>() + m->attn_blk_off;
+        a.n_blk = m->attn_n_blk;
+      }
       if (tune().attn_x6_galign != 0) {
         a.x6_galign = 1;
         a.row_utt = m->d_row_utt.as<int>();
@@ -1328,6 +1362,7 @@ int encode_transformer(wn_model* m, const float* feats_dev,
       for (int b = 0; b < B; ++b)
         for (int t = 0; t < len2[b]; ++t) row_utt[off2[b] + t] = b;
       WN_TRY(upload_desc(m, m->d_row_utt, row_utt, s));
+      m->attn_n_blk = 0;      // (no block list behind this row_utt)
     }
     WN_TRY(upload_desc(m, m->d_off1, seg, s));
     WN_TRY(upload_desc(m, m->d_len1, lens, s));

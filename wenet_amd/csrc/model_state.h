@@ -398,6 +398,7 @@ struct wn_model {
   // X3 plane image of t1 = LN(x) for the fused six-product FFN (tune().ffn_ximg): valid while
   // t1_img_ok (set by the producer launch, cleared by the consumer)
   DevBuf attn_img;      // key-tile images of the six-product attention (attention_x6.hip)
+  int attn_blk_off = 0, attn_n_blk = 0;   // its block list inside d_row_utt (set_layout)
   DevBuf t1_img;
   bool t1_img_ok = false;
   bool kv_ready = false;

@@ -107,6 +107,10 @@ namespace wn {
      packed K / V matrix (the row blocks of the QKV projection); 2 = ... and written by that     \
      projection's epilogue, no pack pass; 0 = aligned to each sequence's first key (A/B) */      \
   X(attn_x6_galign, 2)                                                                          \
+  /* six-product attention of the encoder: 1 = its blocks are dispatched from a list -- two     \
+     live query groups first, the light last blocks of odd sequences behind them -- 0 = the      \
+     (query block, head, sequence) grid (A/B, tests: bit-identical) */                           \
+  X(attn_x6_order, 1)                                                                           \
   /* WN_ABLATION builds: attention_x6_kernel without parts of itself (attention_x6.hip ABL) */  \
   X(attn_x6_var, 0)                                                                             \
   /* rel-pos attention: 0 = two contractions per score, 2 = the fold as a separate pass */      \
