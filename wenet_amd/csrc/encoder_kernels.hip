@@ -448,7 +448,10 @@ template <int NW, bool RELPOS, int KS, bool FOLD = false>
 __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kernel(AttnArgs a) {
   constexpr bool GLB = FOLD && KS == 2;
   int s = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
-  if (a.xcd_nqb > 0) {   // XCD-aware block order (kernels.h AttnArgs::xcd_nqb)
+  if (a.blk_tab) {       // the launch's block list (kernels.h AttnArgs::blk_tab)
+    const int e = a.blk_tab[blockIdx.x];
+    s = e >> 16; h = (e >> 8) & 255; qb = e & 255;
+  } else if (a.xcd_nqb > 0) {   // XCD-aware block order (kernels.h AttnArgs::xcd_nqb)
     const int bid = xcd_block_order(blockIdx.x, gridDim.x);
     qb = bid % a.xcd_nqb;
     h = (bid / a.xcd_nqb) % a.n_heads;
@@ -527,6 +530,8 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
+  // (a query group past the sequence's end only stages and meets the barriers: attention_x6.hip)
+  const bool wave_live = q0 + wave * 32 < qlen;
 
   // ---- tile staging: global -> registers (issued a whole iteration ahead, so
   // the HBM / L2 latency hides under the MFMAs) -> LDS.  With KS == 2 one
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 2 ? 3 : 1) void attention_kerne
       gload(it + 1);
     }
 
-    if (KS == 1 || kt < t_hi) {
+    if ((KS == 1 || kt < t_hi) && wave_live) {
     // ---- S^T tile -------------------------------------------------------------
     f32x16 sc;
 #pragma unroll
@@ -983,7 +988,9 @@ int attention(const AttnArgs& a, hipStream_t s) {
   constexpr int NW = 2;
   dim3 g(cdiv(a.max_q_len, NW * 32), a.n_heads, a.n_seq), t(NW * 64);
   AttnArgs ax = a;
-  if (tune().attn_xcd != 0) {
+  if (a.blk_tab && a.n_blk > 0) {
+    g = dim3(a.n_blk);       // (a list of 64-query blocks: NW = 2)
+  } else if (tune().attn_xcd != 0) {
     ax.xcd_nqb = g.x;
     g = dim3(g.x * g.y * g.z);
   }

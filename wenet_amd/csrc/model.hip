@@ -957,10 +957,7 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     a.scale = 1.0f / sqrtf(64.0f);
     if (ax6_img) {
       a.x6_img = m->attn_img.p; a.x6_img_bytes = m->attn_img.cap; a.x6_rows = M;
-      if (tune().attn_x6_order != 0 && m->attn_n_blk > 0) {
-        a.blk_tab = m->d_row_utt.as<int>() + m->attn_blk_off;
-        a.n_blk = m->attn_n_blk;
-      }
+
       if (tune().attn_x6_galign != 0) {
         a.x6_galign = 1;
         a.row_utt = m->d_row_utt.as<int>();
@@ -971,6 +968,12 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
       if (m->attn_img.ensure(need) == 0) {
         a.x6_img = m->attn_img.p; a.x6_img_bytes = m->attn_img.cap; a.x6_rows = M;
       }
+    }
+    // the encoder's self attention is dispatched from the batch's block list (set_layout) --
+    // both fp32 kernels decode it
+    if (!h16 && t_gemm_prec == PREC_F32 && tune().attn_x6_order != 0 && m->attn_n_blk > 0) {
+      a.blk_tab = m->d_row_utt.as<int>() + m->attn_blk_off;
+      a.n_blk = m->attn_n_blk;
     }
     if (qkv_q) {
       // the tiles are in the image already and K / V exist nowhere else: this launch MUST be
