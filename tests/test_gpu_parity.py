@@ -1283,6 +1283,8 @@ def test_attention_xcd_block_order_is_bit_identical(config, B, frames, chunk, le
 @pytest.mark.parametrize('config,B,frames', [
     ('aishell_u2pp', 9, (300, 1200)),
     ('aishell_u2pp', 32, (800, 1200)),
+    ('aishell_u2pp', 24, (8, 900)),      # 1 .. 224 encoder frames: tiles that span 3+ sequences
+    ('aishell_u2pp', 40, (8, 640)),
     ('tiny_causal', 7, (130, 700)),
 ])
 def test_attention_x6_global_tile_alignment_vs_oracle(config, B, frames):
