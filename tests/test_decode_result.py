@@ -91,12 +91,16 @@ def test_whole_batch_builders_agree_c_helper_numpy_pass_and_per_hypothesis_slici
     scores, lists of frame indices), for ragged n_hyps, empty hypotheses, token lengths that
     differ from the time lengths, values beyond the helper's small-int table, non-contiguous
     views."""
+    import pytest
     from wenet_amd import search
     from wenet_amd import build
-    build.build_host_ext()
+    try:
+        build.build_host_ext()
+    except Exception as e:  # noqa: BLE001 -- no C compiler / Python headers on this host
+        pytest.skip(f'host helper cannot be built here: {e}')
     import importlib
     importlib.reload(search) if search._nbest_lists is None else None
-    assert search._nbest_lists is not None, 'host helper not built'
+    assert search._nbest_lists is not None, 'host helper built but not importable'
     for seed, (B, beam, T) in enumerate([(5, 4, 9), (32, 10, 60), (1, 1, 1), (3, 64, 7)]):
         arrs = list(_batch(B, beam, T, seed))
         rng = np.random.default_rng(100 + seed)

@@ -77,7 +77,12 @@ def _stamp(paths):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    build_host_ext(force)
+    try:
+        build_host_ext(force)
+    except Exception as e:  # noqa: BLE001 -- host-side list building only: search.py then
+        # uses its numpy pass (same lists); the HIP library below is what must build
+        print(f'warning: host helper not built ({e}); wenet_amd.search falls back to numpy',
+              file=sys.stderr)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
                if f.endswith('.h')]
     headers.append(os.path.join(HERE, '..', 'include', 'wenet_amd.h'))
