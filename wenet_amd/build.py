@@ -26,6 +26,11 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
 # shapes; the product build has none of them (wn_tune_set refuses their keys / values)
 if os.environ.get('WN_ABLATION') == '1':
     FLAGS.append('-DWN_ABLATION')
+# WN_EXACT=1 python -m wenet_amd.build: a VALIDATION build whose SiLU / GLU gates and CTC
+# log-softmax sums run on the exact expf / exp2f / IEEE division instead of v_exp_f32 /
+# v_rcp_f32 (csrc/common.h); never the product library
+if os.environ.get('WN_EXACT') == '1':
+    FLAGS.append('-DWN_EXACT_TRANSCENDENTALS')
 # per-source extras: the one-wave-per-SIMD kernel pins its VALU slices between MFMA pairs;
 # SLP-packed f32 ops (v_pk_*) would undo the spacing (MI355X_MICROARCH.md: an anti-lever
 # beside MFMAs)

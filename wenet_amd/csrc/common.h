@@ -76,8 +76,23 @@ __device__ __forceinline__ float wave_max(float v) {
 // ~1 ulp each, the form the fused feed-forward kernels always used (gemm_epilogue.h silu_fast) --
 // instead of the exact expf and the IEEE division sequence: 7.5 k of the depthwise-conv prologue's
 // 19 k cycles went into those (round 4 stamps); round 5.
+// WN_EXACT_TRANSCENDENTALS (a validation build: WN_EXACT=1 python -m wenet_amd.build): the
+// exponentials and reciprocals of the SiLU / GLU gates and of the CTC log-softmax sum run on the
+// exact library routines (expf, exp2f, IEEE division) -- the reference's own operations --
+// instead of v_exp_f32 / v_rcp_f32.  The product library is never built this way; the build
+// exists so that the 1-2 ulp the fast forms move can be measured end to end (DESIGN.md,
+// deviations).  The attention softmaxes are not part of it: their exp always ran on v_exp_f32.
+#ifdef WN_EXACT_TRANSCENDENTALS
+__device__ __forceinline__ float wn_exp(float x) { return expf(x); }
+__device__ __forceinline__ float wn_exp2(float x) { return exp2f(x); }
+__device__ __forceinline__ float wn_rcp(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ float wn_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float wn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float wn_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
 __device__ __forceinline__ float silu_f(float x) {
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+  return x * wn_rcp(1.0f + wn_exp(-x));
 }
 __device__ __forceinline__ float sigmoid_f(float x) {
   return 1.0f / (1.0f + expf(-x));

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(CtcRowArgs a) {
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float sm = 0.f;
-  for (int i = tid; i < a.V; i += 256) sm += __expf(srow[i] - mx);
+  for (int i = tid; i < a.V; i += 256) sm += wn_exp(srow[i] - mx);
   sm = wave_sum(sm);
   if (lane == 0) red[4 + wave] = sm;
   __syncthreads();
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, EPL <= 72 ? 3 : 2) void ctc_row_wave2_kernel(C
   float sm4[4] = {0.f, 0.f, 0.f, 0.f};      // (the wave kernel's summation order)
 #pragma unroll
   for (int e = 0; e < EPL; ++e)
-    if (e * 64 + lane < a.V) sm4[e & 3] += __expf(v[e] - mx);
+    if (e * 64 + lane < a.V) sm4[e & 3] += wn_exp(v[e] - mx);
   const float lsum = logf(wave_sum(sm4[0]) + wave_sum(sm4[1]) + wave_sum(sm4[2]) +
                           wave_sum(sm4[3]));
   float gv[NG];

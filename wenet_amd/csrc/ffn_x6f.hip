@@ -382,13 +382,13 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
         if (ACT == ACT_SILU) {
           asm volatile("" : "+v"(pt0), "+v"(pv1));
           pt1 = pv1 * -1.4426950408889634f;
-          pt0 = __builtin_amdgcn_exp2f(pt0);
+          pt0 = wn_exp2(pt0);
         }
         break;
       case 4:
         if (ACT == ACT_SILU) {
           asm volatile("" : "+v"(pt0), "+v"(pt1));
-          pt1 = __builtin_amdgcn_exp2f(pt1);
+          pt1 = wn_exp2(pt1);
           pt0 = 1.0f + pt0;
         }
         break;
@@ -396,14 +396,14 @@ __global__ __launch_bounds__(256, 1) void ffn_x6f_kernel(FfnX6Args p, int tiles_
         if (ACT == ACT_SILU) {
           asm volatile("" : "+v"(pt0), "+v"(pt1));
           pt1 = 1.0f + pt1;
-          pt0 = __builtin_amdgcn_rcpf(pt0);
+          pt0 = wn_rcp(pt0);
         }
         break;
       case 6:
         asm volatile("" : "+v"(pv0));
         if (ACT == ACT_SILU) {
           asm volatile("" : "+v"(pt0), "+v"(pt1));
-          pt1 = __builtin_amdgcn_rcpf(pt1);
+          pt1 = wn_rcp(pt1);
           pv0 *= pt0;
         }
         if (ACT == ACT_RELU) pv0 = fmaxf(pv0, 0.0f);

@@ -12,7 +12,7 @@ namespace {
 __device__ __forceinline__ float silu_fast(float x) {
   // x * sigmoid(x) on v_exp_f32 / v_rcp_f32 (each ~1 ulp); __frcp_rn would be
   // the correctly rounded division sequence (v_div_scale / fmas / fixup)
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+  return x * wn_rcp(1.0f + wn_exp(-x));
 }
 
 // CH: C is a bf16 matrix (p.C reinterpreted, p.ldc in bf16 elements) -- the
@@ -43,7 +43,7 @@ __device__ __forceinline__ void gemm_epilogue(
       for (int r = 0; r < 16; ++r) {
         const float a = acc[i][0][r] + ba;
         const float g = acc[i][1][r] + bg;
-        v[r] = a * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+        v[r] = a * wn_rcp(1.0f + wn_exp(-g));
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

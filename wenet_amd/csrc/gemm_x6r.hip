@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
         gt += ebias[2 * u + 1][g];
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
+        for (int e = 0; e < 4; ++e) o[e] = a[e] * wn_rcp(1.0f + wn_exp(-gt[e]));
         *reinterpret_cast<f32x4*>(wp + li * PST + (u * 32 + 8 * g + 4 * hi) * 4) = o;
       }
 #pragma unroll
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(256, 1) void x6r_kernel(X6RArgs p) {
           gt += ebias2[2 * u + 1][g];
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
+          for (int e = 0; e < 4; ++e) o[e] = a[e] * wn_rcp(1.0f + wn_exp(-gt[e]));
           *reinterpret_cast<f32x4*>(wp2 + li * 272 + (u * 32 + 8 * g + 4 * hi) * 4) = o;
         }
 #pragma unroll

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void x6r512_kernel(X6RArgs p) {
             gt += eb2[2 * u + 1][g];
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
+            for (int e = 0; e < 4; ++e) o[e] = a[e] * wn_rcp(1.0f + wn_exp(-gt[e]));
             *reinterpret_cast<f32x4*>(wp2 + li * 272 + (u * 32 + 8 * g + 4 * hi) * 4) = o;
           }
 #pragma unroll
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256, 1) void x6r512w_kernel(X6RArgs p) {
               gt += ebw2[2 * u + 1][g];
 #pragma unroll
               for (int e = 0; e < 4; ++e)
-                o[g][e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gt[e]));
+                o[g][e] = a[e] * wn_rcp(1.0f + wn_exp(-gt[e]));
             }
             tile_out(o, p.C, p.ldc, m0 + rt * 32, c2 / 2 + u * 32);
           }
