@@ -957,7 +957,6 @@ int encoder_layers(wn_model* m, int chunk, int left, hipStream_t s) {
     a.scale = 1.0f / sqrtf(64.0f);
     if (ax6_img) {
       a.x6_img = m->attn_img.p; a.x6_img_bytes = m->attn_img.cap; a.x6_rows = M;
-
       if (tune().attn_x6_galign != 0) {
         a.x6_galign = 1;
         a.row_utt = m->d_row_utt.as<int>();
