@@ -200,11 +200,16 @@ def end_to_end_leg(model, pipe, finish, drain, barrier, lens, device, total_audi
 
     steps_pcm(max(2, depth))       # warm-up
     assert nfr.tolist() == [int(t) for t in lens.tolist()], 'fbank frame counts'
-    barrier()
-    t0 = time.perf_counter()
-    last = steps_pcm(steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    # median of three rounds (one round of a single-round leg once caught a stall of the box:
+    # 48.7 k beside 65.9 k, r18a)
+    dts = []
+    for _ in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        last = steps_pcm(steps)
+        barrier()
+        dts.append(time.perf_counter() - t0)
+    dt = statistics.median(dts)
     # the fbank pass alone, for the record (median of five event-bracketed groups of four)
     groups = []
     for _ in range(5):
@@ -222,7 +227,8 @@ def end_to_end_leg(model, pipe, finish, drain, barrier, lens, device, total_audi
         'ms_per_step': round(dt / steps * 1e3, 3),
         'fbank_ms_per_batch_alone': round(statistics.median(groups), 3),
         'tokens_last_step': int(sum(len(r.tokens) for r in last)),
-        'note': 'ONE timed region per round of --steps steps: 16-kHz PCM resident in HBM -> '
+        'rounds_ms_per_step': [round(x / steps * 1e3, 3) for x in dts],
+        'note': 'ONE timed region per round of --steps steps (median of three rounds): 16-kHz PCM resident in HBM -> '
                 'wn_fbank -> decode (the headline\'s pipeline) -> token lists on the host, '
                 'barrier + synchronize brackets.  No resampling in this leg -- wn_resample '
                 '(other sample rates) is pinned to an fp64 evaluation of torchaudio\'s '
@@ -240,8 +246,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--min-seconds', type=float, default=MIN_TIMED_SECONDS,
                     help='rounds of --steps steps are repeated until they cover this')
-    ap.add_argument('--streams', type=int, default=2,
-                    help='decodes kept in flight per GPU (wenet_amd/pipeline.py); '
+    ap.add_argument('--streams', type=int, default=6,
+                    help='decodes kept in flight per GPU (wenet_amd/pipeline.py: up to two '
+                         'the encoders are chained by events, above they run free -- r17c: '
+                         '64.3 k at 2, 66.7 k at 4, 69.3 k at 6, 69.1 k at 8 on one box); '
                          '1 = plain back-to-back ASRModel.decode() calls')
     ap.add_argument('--workload', default='config2', choices=sorted(S.BENCH_WORKLOADS),
                     help='config2 = BASELINE.json configs[1] (the metric\'s '
@@ -260,6 +268,9 @@ def main():
                     help='skip the extra round that materialises every n-best list')
     ap.add_argument('--no-e2e-leg', action='store_true',
                     help='skip the extra round that starts from PCM (wn_fbank inside the round)')
+    ap.add_argument('--no-two-stream-leg', action='store_true',
+                    help='skip the extra round with two chained decodes in flight (the headline '
+                         'form of rounds 2-5)')
     ap.add_argument('--no-plain-leg', action='store_true',
                     help='skip the extra round of plain back-to-back decode() calls')
     ap.add_argument('--tune', default='',
@@ -501,6 +512,26 @@ def main():
         plain_steps(args.steps)
         barrier()
         plain = max_over_ranks(time.perf_counter() - t0)
+    # transparency leg: the headline of rounds 2-5 -- TWO decodes in flight, their encoders chained
+    # by events -- for continuity with the earlier rounds' numbers; one round of --steps steps
+    two_chained = None
+    if args.streams > 2 and not args.no_two_stream_leg:
+        pipe2 = DecodePipeline(model, n_streams=2)
+        try:
+            def two_steps(n):
+                futs = [pipe2.submit([method], feats_dev, lens, beam_size=beam, **decode_kw)
+                        for _ in range(n)]
+                for f in futs:
+                    finish(f.result()[method])
+                return gatherer.drain()
+            two_steps(max(2, args.warmup // 2))
+            barrier()
+            t0 = time.perf_counter()
+            two_steps(args.steps)
+            barrier()
+            two_chained = max_over_ranks(time.perf_counter() - t0)
+        finally:
+            pipe2.close()
     # transparency leg: the same pipelined steps with the n-best lists of EVERY result
     # materialised inside the timed round (Python lists of the reference's DecodeResult fields;
     # the headline reads tokens / score only and leaves them lazy)
@@ -670,7 +701,7 @@ def main():
                 'regime': 'achieved / frac / avg_launch_us: ONE decode in flight (a pass of plain '
                           'decode() steps right after the timed rounds -- the kernel alone on the '
                           'chip, what rocprofv3 --streams 1 reproduces); the same event pairs '
-                          'inside the headline\'s rounds (two decodes in flight) are under '
+                          'inside the headline\'s rounds (--streams decodes in flight) are under '
                           'timed_rounds',
                 'achieved': round(achieved, 2),
                 'peak': peak,
@@ -790,6 +821,15 @@ def main():
                         'in flight, as wenet/bin/recognize.py:289 drives the reference), one '
                         'round of --steps steps; the headline keeps --streams decodes in '
                         'flight (wenet_amd.pipeline.DecodePipeline)',
+            }
+        if two_chained is not None:
+            line['two_in_flight_chained'] = {
+                'value': round(total_audio * args.steps / two_chained, 1),
+                'ms_per_step': round(two_chained / args.steps * 1e3, 3),
+                'note': 'the headline form of rounds 2-5: two decodes in flight, encoder i + 1 '
+                        'starts when encoder i has finished (DecodePipeline(n_streams=2)); one '
+                        'round of --steps steps.  The headline keeps --streams decodes in flight '
+                        'with free-running encoders (wenet_amd/pipeline.py)',
             }
         if nbest_leg is not None:
             line['nbest_materialised'] = {

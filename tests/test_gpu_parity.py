@@ -742,6 +742,38 @@ def test_pipeline_two_streams_matches_sequential_decode():
                         assert list(a.nbest_scores) == list(b.nbest_scores)
 
 
+def test_pipeline_six_free_running_streams_match_sequential_decode():
+    """Round 6: above two streams DecodePipeline lets the encoders run free (no event chain;
+    the bench's headline keeps six decodes in flight): on the full-size model, batches of
+    different shapes decoded six at a time return exactly what back-to-back decode() calls do
+    -- every decode has its own workspace handle, nothing depends on the order the GPU
+    interleaves them in."""
+    from wenet_amd import synthetic as S
+    from wenet_amd.pipeline import DecodePipeline
+    configs, sd, model = cached_model('aishell_u2pp', 0)
+    batches = []
+    for i in range(9):
+        feats, lens = S.make_features(6 + 3 * (i % 3), (200 + 100 * (i % 4), 900), seed=300 + i)
+        batches.append((feats.cuda(), lens))
+    kw = dict(beam_size=10)
+    methods = ['ctc_greedy_search', 'ctc_prefix_beam_search']
+    seq = [model.decode(methods, f, l, **kw) for f, l in batches]
+    with DecodePipeline(model, n_streams=6) as pipe:
+        assert pipe.chain is False or os.environ.get('WN_PIPE_CHAIN') == '1'
+        par = pipe.decode_many(methods, batches, **kw)
+        par2 = pipe.decode_many(methods, batches[::-1], **kw)[::-1]
+    for got_all in (par, par2):
+        for want, got in zip(seq, got_all):
+            for m in methods:
+                assert len(want[m]) == len(got[m])
+                for a, b in zip(want[m], got[m]):
+                    assert list(a.tokens) == list(b.tokens)
+                    assert a.score == b.score
+                    if a.nbest is not None:
+                        assert [list(x) for x in a.nbest] == [list(x) for x in b.nbest]
+                        assert list(a.nbest_scores) == list(b.nbest_scores)
+
+
 @pytest.mark.parametrize('gate', [True, False])
 def test_pipeline_encode_gate_keeps_results_and_survives_a_failed_decode(gate):
     """wn_model_set_encode_gate (round 5): with two decodes in flight the wait for the previous

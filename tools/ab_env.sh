@@ -3,7 +3,7 @@
 # -> gpurun_out/TAG/ab_<VAR>.txt (value, ms_per_step, plain per run)
 TAG=$1; VAR=$2; A=$3; B=$4; shift 4
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-ARGS="--no-cpu-baseline --no-f32-mfma-leg --no-nbest-leg --no-e2e-leg --no-clock-sample $*"
+ARGS="--no-cpu-baseline --no-f32-mfma-leg --no-nbest-leg --no-e2e-leg --no-two-stream-leg --no-clock-sample $*"
 for rep in 1 2 3; do
   for v in $A $B; do
     env $VAR=$v timeout 600 python bench.py $ARGS > $OUT/ab_${VAR}_${v}_$rep.json 2>> $OUT/ab.err

@@ -20,7 +20,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ulimit -c 0
-SHORT="--steps 5 --warmup 2 --no-cpu-baseline --no-f32-mfma-leg --no-clock-sample --no-plain-leg --no-nbest-leg --no-e2e-leg --min-seconds 0.2"
+SHORT="--steps 5 --warmup 2 --no-cpu-baseline --no-f32-mfma-leg --no-clock-sample --no-plain-leg --no-nbest-leg --no-e2e-leg --no-two-stream-leg --min-seconds 0.2"
 n=0
 for step in "$@"; do
   n=$((n + 1))
@@ -58,7 +58,7 @@ PY
       python tools/rocpd_stats.py $OUT/kt${st}_$a1/prof_results.db $OUT/kernel_stats_${a1}_streams$st.md | head -34 | cut -c1-220
       find $OUT -name "*.db" -size +20M -delete ;;
     pmc)
-      CMD="python bench.py --workload $a1 --steps 2 --warmup 1 --no-cpu-baseline --no-clock-sample --no-f32-mfma-leg --no-plain-leg --no-nbest-leg --no-e2e-leg --streams 1 --min-seconds 0.1 $a2"
+      CMD="python bench.py --workload $a1 --steps 2 --warmup 1 --no-cpu-baseline --no-clock-sample --no-f32-mfma-leg --no-plain-leg --no-nbest-leg --no-e2e-leg --no-two-stream-leg --streams 1 --min-seconds 0.1 $a2"
       P=$OUT/pmc_$a1; mkdir -p $P
       timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $P/p1 -o pmc --output-format csv -- $CMD > $P/p1.log 2>&1; echo "p1 $?"
       timeout 600 rocprofv3 --pmc FETCH_SIZE -d $P/p2 -o pmc --output-format csv -- $CMD > $P/p2.log 2>&1; echo "p2 $?"

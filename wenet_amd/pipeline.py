@@ -8,12 +8,15 @@ and the host cannot queue the next batch's ~200 launches until the results are
 back.  `DecodePipeline` runs `n_streams` decodes concurrently, each on its own
 HIP stream and its own workspace handle (`wn_model_clone`: the weights are
 shared), so the search / result copy of batch i overlaps the encoder of batch
-i+1.  The encoders themselves are chained with HIP events (encoder i+1 starts
-on the GPU when encoder i has finished): the MFMA-bound GEMMs of two batches
-never share the chip -- they would only slow each other -- while the
-latency-bound search always has a full encoder to hide under.  Results are
-identical to `ASRModel.decode()`: every batch runs the same kernels in the same
-order on its stream.
+i+1.  With one or two streams the encoders are chained with HIP events (encoder
+i+1 starts on the GPU when encoder i has finished): the MFMA-bound GEMMs of two
+batches started together only slow each other, while the latency-bound search
+always has a full encoder to hide under.  With more streams (round 6: four to
+eight) the encoders run free: enough decodes are in flight that their phases
+drift apart and the chip always holds a mix of matrix-bound, HBM-bound and
+latency-bound kernels -- +7.7 % at six streams over the chained pair (see
+`__init__`).  Results are identical to `ASRModel.decode()` either way: every
+batch runs the same kernels in the same order on its stream.
 
 One host thread per stream drives the C ABI (ctypes drops the GIL inside the
 calls); the reference's own multi-process sharding (tools/decode.sh:65-83) is
@@ -78,9 +81,18 @@ class DecodePipeline:
         # r10b; -0.6 % with conv2 as one launch of 128-row tiles: conv1 + conv2 = 0.97 ms then fit
         # under the previous decode's prefix beam search, 0.95 ms, which is over when the
         # single-round kernels behind conv2 start, r12p).
-        # WN_PIPE_CHAIN=0 (experiment): no chaining at all -- the encoders of the decodes in
-        # flight share the chip freely
-        self.chain = os.environ.get('WN_PIPE_CHAIN', '1') != '0'
+        # Chained or free-running encoders (round 6, r17b-r17d).  With TWO decodes in flight the
+        # event chain wins (+2.4 %: two identical kernel sequences started together only fight
+        # for the same CUs in the same phases).  From FOUR on the free-running form wins and
+        # keeps winning up to ~6 (config 2, same box: 64.3 k chained at any depth; unchained
+        # 66.7 k at 4, 67.8 k at 5, 69.3 k at 6, 69.1 k at 8): the decodes drift apart, and at
+        # any moment the chip holds a mix of phases -- the power-limited matrix kernels of one
+        # decode beside the HBM- and latency-bound phases of the others (reduce / LayerNorm
+        # passes, row-block prologues and epilogues, the search) -- instead of every CU being in
+        # the same phase.  Default: chained up to two streams, free-running above;
+        # WN_PIPE_CHAIN=0 / 1 forces either.
+        chain_env = os.environ.get('WN_PIPE_CHAIN')
+        self.chain = (n_streams <= 2) if chain_env is None else chain_env != '0'
         gate_mode = os.environ.get('WN_PIPE_GATE', '1')
         self.gate_front_end = gate_mode != '0'
         if gate_mode == '2':
