@@ -314,6 +314,8 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
     depth = max(2, 2 * args.streams)  # batches of wav data read ahead
     readers = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, args.num_workers))
 
+    model.stage_pool = readers      # the PCM staging copies of a batch run on the reader pool too
+
     def load(bi):
         return [readers.submit(read16k, wav) for _, wav in batches[bi]]
 
@@ -343,52 +345,88 @@ def recognize(model, tokenizer, batches: List[List[Tuple[str, str]]], my_batches
                     emit(bi, mode, line)
             stat['detokenize'] += clock() - t0
 
+    # Two host threads (round 6): the FEEDER waits for the wav readers, stages the PCM, launches
+    # the feature kernel and submits the batch (numpy's bulk copies and the C calls drop the
+    # GIL); the calling thread takes the results in order, detokenizes and emits.  One thread
+    # doing both spent 2.5-2.9 ms per batch in `features` and ~0.9 ms in `detokenize` back to
+    # back -- more than the ~4.7 ms the GPU needs for a batch once its waits are added (r15e /
+    # r18d: wav -> text 52-54 k against 66-69 k with resident features).
+    import queue
+    import threading
+    handoff = queue.Queue(maxsize=max(1, args.streams))   # bounds the batches in flight
+    feeder_err = []
+
+    def feed(pipe):
+        try:
+            torch.cuda.set_device(model.device)
+            for pos, bi in enumerate(order):
+                t0 = clock()
+                raw = [f.result() for f in pending_wavs.pop(bi)]
+                t1 = clock()
+                stat['wav_wait'] += t1 - t0
+                stat['audio_s'] += sum(len(w) / float(sr) for w, sr in raw)
+                stat['utts'] += len(raw)
+                stat['batches'] += 1
+                waves = [w if sr == 16000 else model.resample(w, sr, 16000) for w, sr in raw]
+                t2 = clock()
+                stat['resample'] += t2 - t1
+                if pos + depth < len(order):
+                    nxt = order[pos + depth]
+                    pending_wavs[nxt] = load(nxt)
+                if frames_of is not None:
+                    # longest first (processor.padding) on the host, then ONE feature launch
+                    # straight into the padded batch tensor
+                    perm = padding_order([frames_of(len(w)) for w in waves])
+                    waves = [waves[i] for i in perm]
+                    t3 = clock()
+                    stat['pad_sort'] += t3 - t2
+                    feats, lens = compute_features(waves)
+                    t4 = clock()
+                    stat['features'] += t4 - t3
+                else:
+                    feats, n_frames = compute_features(waves)
+                    t3 = clock()
+                    stat['features'] += t3 - t2
+                    perm = padding_order(n_frames.tolist())
+                    idx = torch.as_tensor(perm, dtype=torch.long)
+                    feats = feats.index_select(0, idx.to(feats.device))
+                    lens = n_frames.index_select(0, idx)
+                    tmax = int(lens.max()) if len(perm) else 0
+                    feats = feats[:, :tmax].contiguous()
+                    t4 = clock()
+                    stat['pad_sort'] += t4 - t3
+                keys = [batches[bi][i][0] for i in perm]
+                fut = pipe.submit(args.modes, feats, lens, **kw)
+                t5 = clock()
+                stat['submit'] += t5 - t4
+                handoff.put((bi, keys, fut))          # blocks while `streams` batches wait
+                stat['feeder_blocked'] = stat.get('feeder_blocked', 0.0) + clock() - t5
+        except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
+            feeder_err.append(e)
+        finally:
+            handoff.put(None)
+
     with DecodePipeline(model, n_streams=args.streams) as pipe:
-        for pos, bi in enumerate(order):
+        feeder = threading.Thread(target=feed, args=(pipe, ), name='wn-feed', daemon=True)
+        feeder.start()
+        n_done = 0
+        while True:
             t0 = clock()
-            raw = [f.result() for f in pending_wavs.pop(bi)]
-            t1 = clock()
-            stat['wav_wait'] += t1 - t0
-            stat['audio_s'] += sum(len(w) / float(sr) for w, sr in raw)
-            stat['utts'] += len(raw)
-            stat['batches'] += 1
-            waves = [w if sr == 16000 else model.resample(w, sr, 16000) for w, sr in raw]
-            t2 = clock()
-            stat['resample'] += t2 - t1
-            if pos + depth < len(order):
-                nxt = order[pos + depth]
-                pending_wavs[nxt] = load(nxt)
-            if frames_of is not None:
-                # longest first (processor.padding) on the host, then ONE feature launch
-                # straight into the padded batch tensor
-                perm = padding_order([frames_of(len(w)) for w in waves])
-                waves = [waves[i] for i in perm]
-                t3 = clock()
-                stat['pad_sort'] += t3 - t2
-                feats, lens = compute_features(waves)
-                t4 = clock()
-                stat['features'] += t4 - t3
-            else:
-                feats, n_frames = compute_features(waves)
-                t3 = clock()
-                stat['features'] += t3 - t2
-                perm = padding_order(n_frames.tolist())
-                idx = torch.as_tensor(perm, dtype=torch.long)
-                feats = feats.index_select(0, idx.to(feats.device))
-                lens = n_frames.index_select(0, idx)
-                tmax = int(lens.max()) if len(perm) else 0
-                feats = feats[:, :tmax].contiguous()
-                t4 = clock()
-                stat['pad_sort'] += t4 - t3
-            keys = [batches[bi][i][0] for i in perm]
-            inflight.append((bi, keys, pipe.submit(args.modes, feats, lens, **kw)))
-            stat['submit'] += clock() - t4
-            drain(args.streams)
-            if pos == 2:
+            item = handoff.get()
+            if item is None:
+                break
+            inflight.append(item)
+            stat['result_wait'] += clock() - t0      # (waiting for the feeder)
+            drain(0)
+            n_done += 1
+            if n_done == 3:
                 # the process is up: stop the cyclic collector from re-walking the model's
                 # static heap on every full collection (pipeline.freeze_host_heap)
                 freeze_host_heap()
-        drain(0)
+        feeder.join()
+        if feeder_err:
+            raise feeder_err[0]
+    model.stage_pool = None
     readers.shutdown(wait=True)
     stat['wall_s'] = clock() - t_begin
     return stat

@@ -843,11 +843,27 @@ class ASRModel:
         elif ring['events'][i] is not None:
             ring['events'][i].synchronize()       # the copy that last used this buffer is done
         view = buf.numpy()
-        pos = 0
-        for w in waveforms:
-            n = len(w)
-            view[pos:pos + n] = w
-            pos += n
+        pool = getattr(self, 'stage_pool', None)
+        if pool is not None and len(waveforms) >= 8:
+            # the bulk copies of a batch (20 MB for 32 x 10 s) on the caller's thread pool: numpy
+            # drops the GIL in them (wenet_amd/bin/recognize.py sets `stage_pool`)
+            offs = np.zeros((len(waveforms) + 1, ), dtype=np.int64)
+            offs[1:] = np.cumsum([len(w) for w in waveforms])
+
+            def put(lo, hi):
+                for i in range(lo, hi):
+                    view[offs[i]:offs[i + 1]] = waveforms[i]
+            step = (len(waveforms) + 3) // 4
+            futs = [pool.submit(put, lo, min(lo + step, len(waveforms)))
+                    for lo in range(0, len(waveforms), step)]
+            for f in futs:
+                f.result()
+        else:
+            pos = 0
+            for w in waveforms:
+                n = len(w)
+                view[pos:pos + n] = w
+                pos += n
         with torch.cuda.device(self.device):
             pcm = buf[:total].to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
